@@ -1,0 +1,165 @@
+/*
+ * wfa_hip.h -- C-ABI of libwfahip.so: the MI355X (gfx950) wavefront-alignment hot path behind
+ * the shenwei356/wfa Aligner API.
+ *
+ * Every entry point is `extern "C"`, takes plain pointers and sizes, and is what a cgo binding of
+ * the reference's Go package would call in place of its pure-Go path (INTEGRATION.md shows the
+ * binding).  Citations are file:line into the reference checkout.
+ *
+ *   reference interface (Go)                                    replaced by
+ *   ----------------------------------------------------------  ---------------------------------
+ *   wfa.New(p *Penalties, opt *Options)            wfa.go:120    wfahip_create + wfahip_params
+ *   (*Aligner).AdaptiveReduction(ad)               wfa.go:134    wfahip_params.adaptive/min_wf_len/...
+ *   (*Aligner).Align / AlignPointers(q, t)         wfa.go:196,201  wfahip_align_batch (n_pairs = 1 or N)
+ *   ErrEmptySeq / ErrSeqTooLong / MaxSeqLen        wfa.go:186-193  per-pair status WFAHIP_PAIR_EMPTY / _TOO_LONG
+ *   AlignmentResult{Ops,Score,TBegin,...}          wfa_cigar.go:30-48  wfahip_results (struct of arrays)
+ *   RecycleAlignmentResult                         wfa_cigar.go:92   wfahip_results_free
+ *   RecycleAligner                                 wfa.go:102    wfahip_destroy
+ *
+ * Threading: one wfahip_ctx may be used by one thread at a time; different contexts may be used
+ * concurrently (mirrors "one Aligner per goroutine", wfa.go:73-78).
+ */
+#ifndef WFA_HIP_H
+#define WFA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WFAHIP_VERSION 100 /* 0.1.0 */
+
+/* whole-call return codes (0 = success, negative = failure) */
+enum {
+    WFAHIP_OK              = 0,
+    WFAHIP_ERR_NO_DEVICE   = -1,
+    WFAHIP_ERR_BAD_ARG     = -2,
+    WFAHIP_ERR_OOM         = -3,
+    WFAHIP_ERR_HIP         = -4,
+    WFAHIP_ERR_UNSUPPORTED = -5, /* degenerate penalties (mismatch == 0 or gap_ext == 0) */
+    WFAHIP_ERR_INTERNAL    = -6
+};
+
+/* per-pair status (wfahip_results.status) */
+enum {
+    WFAHIP_PAIR_OK        = 0,
+    WFAHIP_PAIR_EMPTY     = 1, /* ErrEmptySeq,   wfa.go:204-206 */
+    WFAHIP_PAIR_TOO_LONG  = 2, /* ErrSeqTooLong, wfa.go:207-209 */
+    WFAHIP_PAIR_NO_MEMORY = 4  /* wavefront arena could not be grown enough for this pair */
+};
+
+/* wfa.go:190 MaxSeqLen */
+#define WFAHIP_MAX_SEQ_LEN ((1u << 29) - 1u)
+
+/* Penalties (wfa.go:32-36) + Options (wfa.go:64-66) + AdaptiveReductionOption (wfa.go:46-50) */
+typedef struct {
+    uint32_t mismatch, gap_open, gap_ext;
+    uint8_t  global_alignment; /* Options.GlobalAlignment */
+    uint8_t  adaptive;         /* 0: AdaptiveReduction was never called (algn.ad == nil) */
+    uint8_t  reserved[2];
+    uint32_t min_wf_len, max_dist_diff, cutoff_step; /* cutoff_step is unused by the reference too (wfa.go:49) */
+} wfahip_params;
+
+/* AlignmentResult as a struct of arrays, one element per pair (wfa_cigar.go:30-48).
+ * ops holds, for pair i, ops_len[i] entries starting at ops[ops_off[i]], each `op<<32 | n`
+ * (wfa_cigar.go:118-124), already reversed and merged the way AlignmentResult.process() leaves
+ * them (wfa_cigar.go:136-214).  All arrays are malloc'd by the library. */
+typedef struct {
+    uint64_t  n;
+    int32_t  *status;
+    uint32_t *score;
+    int32_t  *tbegin, *tend, *qbegin, *qend;
+    uint32_t *align_len, *matches, *gaps, *gap_regions;
+    uint64_t *ops_off;
+    uint32_t *ops_len;
+    uint64_t *ops;
+    uint64_t  n_ops;
+} wfahip_results;
+
+/* device-side result record: 16 x u32 per pair, one 64-byte line */
+enum {
+    WFAHIP_REC_STATUS = 0, WFAHIP_REC_SCORE, WFAHIP_REC_TBEGIN, WFAHIP_REC_TEND, WFAHIP_REC_QBEGIN,
+    WFAHIP_REC_QEND, WFAHIP_REC_ALIGN_LEN, WFAHIP_REC_MATCHES, WFAHIP_REC_GAPS, WFAHIP_REC_GAP_REGIONS,
+    WFAHIP_REC_OPS_LEN, WFAHIP_REC_OPS_OFF_LO, WFAHIP_REC_OPS_OFF_HI,
+    WFAHIP_REC_CELLS_LO, WFAHIP_REC_CELLS_HI, /* non-zero wavefront words stored (M+I+D) */
+    WFAHIP_REC_N_SCORES,
+    WFAHIP_REC_WORDS = 16
+};
+
+/* timing / accounting of the most recent wfahip_align_batch* call on a context */
+typedef struct {
+    double   kernel_ms;        /* sum of the alignment kernels' durations (hipEvent, on their stream) */
+    double   total_ms;         /* whole device-side call: first launch -> last kernel done */
+    uint32_t n_launches;       /* alignment kernel launches (1 + retries for bigger arenas / byte path) */
+    uint32_t n_retried_pairs;  /* pairs that needed a second configuration */
+    uint64_t cells_stored;     /* sum over pairs of non-zero wavefront words stored */
+    uint64_t ops_written;      /* CIGAR ops written */
+    uint64_t arena_bytes;      /* arena footprint allocated */
+    double   main_kernel_ms;   /* duration of the first (dominant) alignment kernel launch */
+} wfahip_timing;
+
+typedef struct wfahip_ctx wfahip_ctx;
+
+int         wfahip_version(void);
+const char *wfahip_strerror(int code);
+int         wfahip_device_count(void);
+
+/* One context per GPU (one process per GPU in multi-GPU jobs).  device_id < 0 = current device. */
+int  wfahip_create(int device_id, wfahip_ctx **out);
+void wfahip_destroy(wfahip_ctx *ctx);
+
+/* The cgo entry: host inputs, host outputs, synchronous.  seq_blob holds all sequences; pair i is
+ * query seq_blob[q_off[i] .. +q_len[i]) vs target seq_blob[t_off[i] .. +t_len[i]).  Inputs are
+ * borrowed for the duration of the call only.  out is filled with malloc'd arrays; release with
+ * wfahip_results_free.  Replaces Aligner.Align (wfa.go:196). */
+int  wfahip_align_batch(wfahip_ctx *ctx, const wfahip_params *p, const uint8_t *seq_blob,
+                        uint64_t blob_bytes, const uint64_t *q_off, const uint32_t *q_len,
+                        const uint64_t *t_off, const uint32_t *t_len, uint64_t n_pairs,
+                        wfahip_results *out);
+void wfahip_results_free(wfahip_results *r);
+
+/* Device-resident variant: every pointer is a device address on the context's GPU (caller-owned).
+ * d_rec receives n_pairs records of WFAHIP_REC_WORDS u32; d_ops receives the CIGAR ops
+ * (capacity ops_cap entries; record fields OPS_OFF/OPS_LEN index into it).  max_len = an upper
+ * bound of every q_len/t_len (0 = let the library compute it).  stream = hipStream_t to launch on
+ * (NULL = the context's own stream).  Synchronous: returns when results are complete.
+ * If ops_cap is too small the call returns WFAHIP_ERR_OOM and *ops_needed (if non-NULL) holds
+ * the required capacity. */
+int  wfahip_align_batch_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_seq_blob,
+                               uint64_t blob_bytes, const void *d_q_off, const void *d_q_len,
+                               const void *d_t_off, const void *d_t_len, uint64_t n_pairs,
+                               uint32_t max_len, void *d_rec, void *d_ops, uint64_t ops_cap,
+                               uint64_t *ops_needed, void *stream);
+
+int  wfahip_last_timing(const wfahip_ctx *ctx, wfahip_timing *out);
+
+/* Tuning knobs (optional): key = "arena_bytes_per_slot", "slots", "threads_per_pair". */
+int  wfahip_set_option(wfahip_ctx *ctx, const char *key, int64_t value);
+
+/* Debug / parity aid: align ONE pair and return every stored wavefront row.  rows[] receives
+ * n_rows descriptors {score, lo, width, offset into words}; words[] holds, per row, the M, I and D
+ * raw words (offset<<3|tag, 0 = absent; wfa_wavefront.go:93) for k = lo .. lo+width-1,
+ * 3*width words per row.  Caller frees both with wfahip_free. */
+typedef struct { uint32_t score; int32_t lo; uint32_t width; uint64_t word_off; } wfahip_row;
+int  wfahip_debug_wavefronts(wfahip_ctx *ctx, const wfahip_params *p, const uint8_t *q, uint32_t n,
+                             const uint8_t *t, uint32_t m, wfahip_row **rows, uint64_t *n_rows,
+                             uint32_t **words, uint64_t *n_words, wfahip_results *res);
+void wfahip_free(void *p);
+
+/* Synthetic input generator (host): the seeded dataset spec of DESIGN.md (mirrors what
+ * WFA's generate_dataset, used by README.md:298-306, produces: random ACGT pattern of length
+ * `length`, text = pattern with round(length*error_rate) random edits).  Pair i uses
+ * splitmix64(seed ^ (first_index+i)*0x9E3779B97F4A7C15).  query = pattern, target = text
+ * (wfa-go/wfa-go.go:166-178).  blob must hold n_pairs*stride bytes with
+ * stride = wfahip_gen_stride(length, error_rate); offsets/lengths arrays hold n_pairs entries. */
+uint64_t wfahip_gen_stride(uint32_t length, double error_rate);
+int      wfahip_generate_pairs(uint64_t seed, uint64_t first_index, uint64_t n_pairs, uint32_t length,
+                               double error_rate, int n_threads, uint8_t *blob, uint64_t *q_off,
+                               uint32_t *q_len, uint64_t *t_off, uint32_t *t_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

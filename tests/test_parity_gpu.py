@@ -1,0 +1,258 @@
+"""GPU: the HIP path (through the C-ABI) against the oracle and the golden fixtures.  Bit-exact: score,
+CIGAR ops, match region, statistics."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ("score", "tbegin", "tend", "qbegin", "qend", "align_len", "matches", "gaps", "gap_regions", "ops_len")
+
+
+def _aligner(global_alignment=True, adaptive=(10, 50, 1), penalties=(4, 6, 2)):
+    import wfa_amd as w
+    al = w.New(w.Penalties(*penalties), w.Options(GlobalAlignment=global_alignment), device=0)
+    if adaptive is not None:
+        assert al.AdaptiveReduction(w.AdaptiveReductionOption(*adaptive)) is None
+    return al
+
+
+def _oracle_params(global_alignment=True, adaptive=(10, 50, 1), penalties=(4, 6, 2)):
+    from oracle import oracle as O
+    return O.make_params(*penalties, global_alignment=global_alignment, adaptive=adaptive)
+
+
+def assert_batch_equal(got, want, what=""):
+    assert np.array_equal(got.status, want.status), what
+    for f in FIELDS:
+        a, b = getattr(got, f), getattr(want, f)
+        if not np.array_equal(a, b):
+            bad = np.nonzero(a != b)[0]
+            raise AssertionError(f"{what}: field {f} differs at {len(bad)} pairs, first {bad[:5]}: "
+                                 f"{a[bad[:5]]} vs {b[bad[:5]]}")
+    # ops: both are packed in pair order
+    if not np.array_equal(got.ops, want.ops):
+        for i in range(len(got.status)):
+            if not np.array_equal(got.pair_ops(i), want.pair_ops(i)):
+                raise AssertionError(f"{what}: CIGAR differs at pair {i}")
+
+
+def test_known_answers(built, known_answers):
+    for ka in known_answers["vectors"]:
+        al = _aligner(ka["mode"] == "global", tuple(ka["adaptive"]))
+        r = al.Align(ka["q"].encode(), ka["t"].encode())
+        if ka.get("cigar_exact", True):
+            assert r.CIGAR(False) == ka["cigar"], ka["id"]
+        for f, g in (("score", "Score"), ("qbegin", "QBegin"), ("qend", "QEnd"), ("tbegin", "TBegin"),
+                     ("tend", "TEnd"), ("align_len", "AlignLen"), ("matches", "Matches"), ("gaps", "Gaps"),
+                     ("gap_regions", "GapRegions")):
+            if f in ka:
+                assert getattr(r, g) == ka[f], (ka["id"], f)
+        if "text" in ka:
+            Q, A, T = r.AlignmentText(ka["q"].encode(), ka["t"].encode(), False)
+            assert (Q.decode(), A.decode().rstrip(), T.decode()) == (ka["text"][0], ka["text"][1].rstrip(),
+                                                                     ka["text"][2])
+        al.close()
+
+
+def test_reference_test_pairs_all_option_sets(built, ref_pairs, oracle_vectors):
+    """Every input pair of wfa_test.go / seqs.txt under 4 option sets vs the committed oracle vectors."""
+    opts = {"global+adaptive": (True, (10, 50, 1)), "global": (True, None),
+            "semiglobal+adaptive": (False, (10, 50, 1)), "semiglobal": (False, None)}
+    qs = [p["q"].upper().encode() for p in ref_pairs]
+    ts = [p["t"].upper().encode() for p in ref_pairs]
+    for name, (g, ad) in opts.items():
+        al = _aligner(g, ad)
+        results, errors = al.AlignBatch(qs, ts)
+        exp = [e for e in oracle_vectors["results"] if e["options"] == name]
+        assert len(exp) == len(qs)
+        for e in exp:
+            r = results[e["pair"]]
+            assert errors[e["pair"]] is None
+            got = (r.Score, r.CIGAR(False), r.QBegin, r.QEnd, r.TBegin, r.TEnd, r.AlignLen, r.Matches, r.Gaps,
+                   r.GapRegions)
+            want = (e["score"], e["cigar"], e["qbegin"], e["qend"], e["tbegin"], e["tend"], e["align_len"],
+                    e["matches"], e["gaps"], e["gap_regions"])
+            assert got == want, (name, ref_pairs[e["pair"]]["source"])
+        al.close()
+
+
+def test_wavefront_dumps_match_oracle(built, known_answers, oracle_vectors):
+    """Internal state: every stored M/I/D word of KA1 and KA2 equals the oracle's final wavefronts."""
+    for d in oracle_vectors["dumps"]:
+        ka = [k for k in known_answers["vectors"] if k["id"] == d["id"]][0]
+        al = _aligner(ka["mode"] == "global", tuple(ka["adaptive"]))
+        wf, res = al.debug_wavefronts(ka["q"].encode(), ka["t"].encode())
+        # the device stops at the same final score; rows above the backtrace start score exist in both
+        for comp in "MID":
+            want = {int(s): {int(k): v for k, v in row.items()} for s, row in d["final"][comp].items()}
+            want = {s: r for s, r in want.items() if r}
+            assert wf[comp] == want, (d["id"], comp)
+        al.close()
+
+
+@pytest.mark.parametrize("length,err,n", [(150, 0.02, 4000), (1000, 0.05, 3000), (1000, 0.2, 300), (37, 0.1, 2000)])
+@pytest.mark.parametrize("glob,adaptive", [(True, (10, 50, 1)), (True, None), (False, (10, 50, 1)), (False, None)])
+def test_synthetic_batches(built, length, err, n, glob, adaptive):
+    import wfa_amd as w
+    from oracle import oracle as O
+    if not glob and length >= 1000:
+        n = max(50, n // 10)  # semi-global seeds make the oracle slow
+    data = w.generate_pairs(seed=length * 7 + int(err * 100), n_pairs=n, length=length, error_rate=err)
+    al = _aligner(glob, adaptive)
+    got = al.align_arrays(*data)
+    want = O.align_batch(_oracle_params(glob, adaptive), *data, n_threads=8)
+    assert_batch_equal(got, want, f"L={length} e={err} glob={glob} ad={adaptive}")
+    al.close()
+
+
+@pytest.mark.parametrize("pen", [(4, 6, 2), (1, 1, 1), (2, 3, 1), (5, 0, 3), (3, 7, 2), (6, 5, 4), (2, 12, 1)])
+def test_other_penalties(built, pen):
+    import wfa_amd as w
+    from oracle import oracle as O
+    data = w.generate_pairs(seed=sum(pen), n_pairs=600, length=200, error_rate=0.08)
+    for glob in (True, False):
+        for ad in (None, (10, 50, 1), (4, 5, 1)):
+            al = _aligner(glob, ad, pen)
+            got = al.align_arrays(*data)
+            want = O.align_batch(_oracle_params(glob, ad, pen), *data, n_threads=8)
+            assert_batch_equal(got, want, f"pen={pen} glob={glob} ad={ad}")
+            al.close()
+
+
+def test_ragged_and_edge_inputs(built):
+    """Empty / 1-base / very unequal lengths / non-ACGT bytes / lowercase, mixed in one batch."""
+    import wfa_amd as w
+    from oracle import oracle as O
+    rng = np.random.default_rng(5)
+    qs, ts = [], []
+    alpha = b"ACGT"
+    for i in range(400):
+        n, m = int(rng.integers(1, 120)), int(rng.integers(1, 120))
+        q = bytes(alpha[j] for j in rng.integers(0, 4, n))
+        if i % 3 == 0:  # related sequences
+            t = bytearray(q)
+            for _ in range(int(rng.integers(0, 6))):
+                p = int(rng.integers(0, len(t)))
+                t[p] = alpha[int(rng.integers(0, 4))]
+            t = bytes(t[:m]) if len(t) > m else bytes(t)
+        else:
+            t = bytes(alpha[j] for j in rng.integers(0, 4, m))
+        qs.append(q), ts.append(t)
+    qs += [b"", b"ACGT", b"", b"A", b"A", b"acgtacgt", b"ACGTNNACGT", b"Bioinformatics helps Biology", b"C", b"CG",
+           b"A" * 300, b"ACGT" * 50]
+    ts += [b"ACGT", b"", b"", b"A", b"CA", b"ACGTACGT", b"ACGTACGT", b"We learn bioinformatics to help biologists",
+           b"C", b"C", b"A", b"TGCA" * 50]
+    for glob in (True, False):
+        for ad in (None, (10, 50, 1)):
+            al = _aligner(glob, ad)
+            blob, q_off, q_len, t_off, t_len = w.make_blob(qs, ts)
+            got = al.align_arrays(blob, q_off, q_len, t_off, t_len)
+            want = O.align_batch(_oracle_params(glob, ad), blob, q_off, q_len, t_off, t_len, n_threads=4)
+            assert_batch_equal(got, want, f"ragged glob={glob} ad={ad}")
+            results, errors = al.AlignBatch(qs[-12:-9], ts[-12:-9])
+            assert errors[0] is w.ErrEmptySeq and errors[1] is w.ErrEmptySeq and errors[2] is w.ErrEmptySeq
+            with pytest.raises(w.WfaError):
+                al.Align(b"", b"A")
+            al.close()
+
+
+def test_unaligned_blob_offsets(built):
+    """Sequences at arbitrary byte offsets (the staging loop uses aligned dword loads + funnel shifts)."""
+    import wfa_amd as w
+    from oracle import oracle as O
+    rng = np.random.default_rng(11)
+    n = 300
+    parts, q_off, q_len, t_off, t_len = [], [], [], [], []
+    pos = 0
+    for i in range(n):
+        pad = int(rng.integers(0, 7))
+        parts.append(b"#" * pad)
+        pos += pad
+        L = int(rng.integers(1, 200))
+        q = bytes(b"ACGT"[j] for j in rng.integers(0, 4, L))
+        t = bytearray(q)
+        for _ in range(int(rng.integers(0, 8))):
+            t[int(rng.integers(0, len(t)))] = b"ACGT"[int(rng.integers(0, 4))]
+        if rng.integers(0, 2):
+            t = t[int(rng.integers(0, 3)):]
+        t = bytes(t) or b"A"
+        q_off.append(pos), q_len.append(len(q)), parts.append(q)
+        pos += len(q)
+        t_off.append(pos), t_len.append(len(t)), parts.append(t)
+        pos += len(t)
+    blob = np.frombuffer(b"".join(parts), dtype=np.uint8)
+    args = (blob, np.array(q_off, np.uint64), np.array(q_len, np.uint32), np.array(t_off, np.uint64),
+            np.array(t_len, np.uint32))
+    al = _aligner(True, (10, 50, 1))
+    assert_batch_equal(al.align_arrays(*args), O.align_batch(_oracle_params(), *args), "unaligned")
+    al.close()
+
+
+def test_small_arena_forces_retry_ladder(built):
+    """A deliberately tiny wavefront arena: pairs overflow, are re-run with 8x slots, results unchanged."""
+    import wfa_amd as w
+    from oracle import oracle as O
+    data = w.generate_pairs(seed=21, n_pairs=500, length=400, error_rate=0.1)
+    al = _aligner(True, None)
+    al.set_option("arena_bytes_per_slot", 16 * 1024)
+    got = al.align_arrays(*data)
+    t = al.last_timing()
+    assert t.n_launches >= 2 and t.n_retried_pairs > 0
+    assert_batch_equal(got, O.align_batch(_oracle_params(True, None), *data, n_threads=8), "retry")
+    al.close()
+
+
+def test_multiwave_configuration(built):
+    """256- and 1024-thread workgroups per pair (the long-read configuration) on short inputs."""
+    import wfa_amd as w
+    from oracle import oracle as O
+    data = w.generate_pairs(seed=33, n_pairs=300, length=700, error_rate=0.1)
+    for tpp in (256, 1024):
+        for glob in (True, False):
+            al = _aligner(glob, (10, 50, 1))
+            al.set_option("threads_per_pair", tpp)
+            got = al.align_arrays(*data)
+            assert_batch_equal(got, O.align_batch(_oracle_params(glob), *data, n_threads=8), f"tpp={tpp} glob={glob}")
+            al.close()
+
+
+def test_long_pair_semiglobal(built):
+    """One 20 kbp pair, semi-global + adaptive (wide seeded wavefronts, 256 threads per pair)."""
+    import wfa_amd as w
+    from oracle import oracle as O
+    data = w.generate_pairs(seed=5, n_pairs=2, length=20000, error_rate=0.05)
+    for glob in (True, False):
+        al = _aligner(glob, (10, 50, 1))
+        got = al.align_arrays(*data)
+        assert_batch_equal(got, O.align_batch(_oracle_params(glob), *data, n_threads=2), f"20kbp glob={glob}")
+        al.close()
+
+
+def test_full_size_properties(built):
+    """BASELINE config sizes are too big for the oracle: check size-independent properties on 2e5 x 1 kbp --
+    every CIGAR consumes exactly both sequences, statistics are consistent with the ops, the score equals the
+    CIGAR's gap-affine cost, and a second run is bit-identical (determinism)."""
+    import wfa_amd as w
+    n = 200_000
+    blob, q_off, q_len, t_off, t_len = w.generate_pairs(seed=3, n_pairs=n, length=1000, error_rate=0.05)
+    al = _aligner(True, (10, 50, 1))
+    a = al.align_arrays(blob, q_off, q_len, t_off, t_len)
+    b = al.align_arrays(blob, q_off, q_len, t_off, t_len)
+    assert (a.status == 0).all()
+    for f in FIELDS:
+        assert np.array_equal(getattr(a, f), getattr(b, f)), f
+    assert np.array_equal(a.ops, b.ops)
+    letters = (a.ops >> np.uint64(32)).astype(np.uint8)
+    counts = (a.ops & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    pair_of_op = np.repeat(np.arange(n), a.ops_len)
+    q_used = np.bincount(pair_of_op, weights=counts * np.isin(letters, list(b"MXDH")), minlength=n)
+    t_used = np.bincount(pair_of_op, weights=counts * np.isin(letters, list(b"MXI")), minlength=n)
+    assert np.array_equal(q_used.astype(np.int64), q_len.astype(np.int64))
+    assert np.array_equal(t_used.astype(np.int64), t_len.astype(np.int64))
+    # gap-affine cost from ops == score (global: every op counts)
+    cost = np.bincount(pair_of_op, weights=(letters == ord("X")) * counts * 4
+                       + np.isin(letters, list(b"IDH")) * (6 + 2 * counts), minlength=n)
+    assert np.array_equal(cost.astype(np.int64), a.score.astype(np.int64))
+    matches = np.bincount(pair_of_op, weights=(letters == ord("M")) * counts, minlength=n)
+    assert (a.matches <= matches).all()
+    al.close()

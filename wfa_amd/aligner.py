@@ -1,0 +1,376 @@
+"""Host-side mirror of the reference's Go API (package wfa) over the libwfahip.so C-ABI.
+
+Same names, argument meaning and error behaviour as the reference (file:line into shenwei356/wfa):
+
+    Penalties / DefaultPenalties                     wfa.go:32-43
+    AdaptiveReductionOption / DefaultAdaptiveOption  wfa.go:46-60
+    Options / DefaultOptions                         wfa.go:64-71
+    New, RecycleAligner                              wfa.go:102-131
+    Aligner.AdaptiveReduction                        wfa.go:134-140
+    Aligner.Align / AlignPointers                    wfa.go:196-268
+    ErrEmptySeq, ErrSeqTooLong, MaxSeqLen            wfa.go:186-193
+    AlignmentResult, Op, OpM.., CIGAR, AlignmentText wfa_cigar.go:30-66,236-333
+    RecycleAlignmentResult / RecycleAlignmentText    wfa_cigar.go:92,347
+
+New (not in the reference): Aligner.AlignBatch -- the batch entry a GPU needs.  All alignment work
+happens in the HIP kernels; this module only marshals buffers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib as L
+
+MaxSeqLen = L.MAX_SEQ_LEN
+MaskLower32 = 4294967295
+OpM, OpD, OpI, OpX, OpH = ord("M"), ord("D"), ord("I"), ord("X"), ord("H")
+
+
+class WfaError(Exception):
+    pass
+
+
+ErrEmptySeq = WfaError("wfa: invalid empty sequence")                                 # wfa.go:187
+ErrSeqTooLong = WfaError(f"wfa: sequences longer than {MaxSeqLen} are not supported")  # wfa.go:193
+
+
+@dataclass
+class Penalties:
+    Mismatch: int = 4
+    GapOpen: int = 6
+    GapExt: int = 2
+
+
+@dataclass
+class AdaptiveReductionOption:
+    MinWFLen: int = 10
+    MaxDistDiff: int = 50
+    CutoffStep: int = 1  # not used by the reference either (wfa.go:49)
+
+
+@dataclass
+class Options:
+    GlobalAlignment: bool = True
+
+
+DefaultPenalties = Penalties()
+DefaultAdaptiveOption = AdaptiveReductionOption()
+DefaultOptions = Options()
+
+
+def Op(op: int) -> Tuple[str, int]:
+    """wfa_cigar.go:57-59: split an op word into (letter, count)."""
+    return chr(int(op) >> 32), int(op) & MaskLower32
+
+
+def trimOps(ops: Sequence[int]) -> List[int]:
+    """wfa_cigar.go:217-233 (returns [] where the reference would panic: no M op)."""
+    idx = [i for i, o in enumerate(ops) if (int(o) >> 32) == OpM]
+    if not idx:
+        return []
+    return list(ops[idx[0]:idx[-1] + 1])
+
+
+@dataclass
+class AlignmentResult:
+    """wfa_cigar.go:30-48.  Ops are op<<32|n, already reversed/merged (process(), :136-214)."""
+    Ops: List[int] = field(default_factory=list)
+    Score: int = 0
+    TBegin: int = 0
+    TEnd: int = 0
+    QBegin: int = 0
+    QEnd: int = 0
+    AlignLen: int = 0
+    Matches: int = 0
+    Gaps: int = 0
+    GapRegions: int = 0
+
+    def CIGAR(self, onlyAlignedRegion: bool = False) -> str:  # wfa_cigar.go:236-255
+        ops = trimOps(self.Ops) if onlyAlignedRegion else self.Ops
+        return "".join(f"{int(o) & MaskLower32}{chr(int(o) >> 32)}" for o in ops)
+
+    def AlignmentText(self, q0: bytes, t0: bytes, onlyAlignedRegion: bool = False) -> Tuple[bytes, bytes, bytes]:
+        """wfa_cigar.go:259-333: the three display lines (query, bars, target)."""
+        if not onlyAlignedRegion:
+            q, t, ops = q0, t0, self.Ops
+        else:
+            q, t = q0[self.QBegin - 1:self.QEnd], t0[self.TBegin - 1:self.TEnd]
+            ops = trimOps(self.Ops)
+        Q, A, T = bytearray(), bytearray(), bytearray()
+        v = h = 0
+        for op in ops:
+            letter, n = int(op) >> 32, int(op) & MaskLower32
+            if letter == OpM or letter == OpX:
+                Q += q[v:v + n]
+                A += (b"|" if letter == OpM else b" ") * n
+                T += t[h:h + n]
+                v += n
+                h += n
+            elif letter == OpI:
+                Q += b"-" * n
+                A += b" " * n
+                T += t[h:h + n]
+                h += n
+            elif letter in (OpD, OpH):
+                Q += q[v:v + n]
+                A += b" " * n
+                T += b"-" * n
+                v += n
+        return bytes(Q), bytes(A), bytes(T)
+
+    def key(self):
+        return (0, self.Score, self.CIGAR(False), self.QBegin, self.QEnd, self.TBegin, self.TEnd,
+                self.AlignLen, self.Matches, self.Gaps, self.GapRegions)
+
+
+def RecycleAlignmentResult(r: Optional[AlignmentResult]) -> None:  # wfa_cigar.go:92 (pool return: no-op here)
+    return None
+
+
+def RecycleAlignmentText(Q, A, T) -> None:  # wfa_cigar.go:347
+    return None
+
+
+@dataclass
+class Timing:
+    kernel_ms: float
+    total_ms: float
+    n_launches: int
+    n_retried_pairs: int
+    cells_stored: int
+    ops_written: int
+    arena_bytes: int
+    main_kernel_ms: float
+
+
+def make_blob(qs: Sequence[bytes], ts: Sequence[bytes]):
+    """Flat byte blob + offset/length arrays, the C-ABI input layout (cgo rule: no Go pointers inside)."""
+    n = len(qs)
+    q_len = np.fromiter((len(x) for x in qs), dtype=np.uint32, count=n)
+    t_len = np.fromiter((len(x) for x in ts), dtype=np.uint32, count=n)
+    # 16-byte aligned starts: lets the staging loop use aligned dword loads
+    q_cap = (q_len.astype(np.uint64) + 15) & ~np.uint64(15)
+    t_cap = (t_len.astype(np.uint64) + 15) & ~np.uint64(15)
+    tot = q_cap + t_cap
+    starts = np.zeros(n, dtype=np.uint64)
+    if n > 1:
+        starts[1:] = np.cumsum(tot[:-1])
+    q_off = starts
+    t_off = starts + q_cap
+    total = int(tot.sum()) if n else 0
+    blob = np.zeros(max(total, 1), dtype=np.uint8)
+    for i in range(n):
+        blob[int(q_off[i]):int(q_off[i]) + int(q_len[i])] = np.frombuffer(qs[i], dtype=np.uint8)
+        blob[int(t_off[i]):int(t_off[i]) + int(t_len[i])] = np.frombuffer(ts[i], dtype=np.uint8)
+    return blob, q_off, q_len, t_off, t_len
+
+
+class Aligner:
+    """The aligner object (wfa.go:79-87).  Not safe for concurrent use; one per thread (wfa.go:73-78)."""
+
+    def __init__(self, p: Penalties, opt: Options, device: int = -1):
+        self.p = p
+        self.opt = opt
+        self.ad: Optional[AdaptiveReductionOption] = None
+        self._ctx = C.c_void_p()
+        L.check(L.lib().wfahip_create(device, C.byref(self._ctx)), "wfahip_create")
+
+    # -- reference API ---------------------------------------------------------------------------
+    def AdaptiveReduction(self, ad: AdaptiveReductionOption) -> Optional[Exception]:
+        """wfa.go:134-140: returns an error (not raises) iff MinWFLen == 0, like the Go method."""
+        if ad.MinWFLen == 0:
+            return WfaError("cutoff step should not be 0")
+        self.ad = ad
+        return None
+
+    def Align(self, q: bytes, t: bytes) -> AlignmentResult:
+        """wfa.go:196: raises ErrEmptySeq / ErrSeqTooLong where the Go method returns them."""
+        if len(q) == 0 or len(t) == 0:
+            raise ErrEmptySeq
+        if len(q) > MaxSeqLen or len(t) > MaxSeqLen:
+            raise ErrSeqTooLong
+        results, errors = self.AlignBatch([q], [t])
+        if errors[0] is not None:
+            raise errors[0]
+        return results[0]
+
+    AlignPointers = Align  # wfa.go:201 (pointer arguments have no Python analogue)
+
+    # -- new: batch entry --------------------------------------------------------------------------
+    def _params(self) -> L.Params:
+        p = L.Params(self.p.Mismatch, self.p.GapOpen, self.p.GapExt, 1 if self.opt.GlobalAlignment else 0, 0)
+        if self.ad is not None:
+            p.adaptive = 1
+            p.min_wf_len, p.max_dist_diff, p.cutoff_step = self.ad.MinWFLen, self.ad.MaxDistDiff, self.ad.CutoffStep
+        return p
+
+    def align_arrays(self, blob, q_off, q_len, t_off, t_len) -> "BatchResult":
+        """Batch alignment over the C-ABI layout; returns struct-of-arrays results (numpy copies)."""
+        n = int(len(q_len))
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        q_off = np.ascontiguousarray(q_off, dtype=np.uint64)
+        t_off = np.ascontiguousarray(t_off, dtype=np.uint64)
+        q_len = np.ascontiguousarray(q_len, dtype=np.uint32)
+        t_len = np.ascontiguousarray(t_len, dtype=np.uint32)
+        res = L.Results()
+        prm = self._params()
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        L.check(L.lib().wfahip_align_batch(self._ctx, C.byref(prm), vp(blob), blob.size, vp(q_off), vp(q_len),
+                                           vp(t_off), vp(t_len), n, C.byref(res)), "wfahip_align_batch")
+        try:
+            def arr(ptr, dt, cnt):
+                if cnt == 0:
+                    return np.zeros(0, dtype=dt)
+                return np.ctypeslib.as_array(ptr, shape=(cnt,)).astype(dt, copy=True)
+            out = BatchResult(
+                status=arr(res.status, np.int32, n), score=arr(res.score, np.uint32, n),
+                tbegin=arr(res.tbegin, np.int32, n), tend=arr(res.tend, np.int32, n),
+                qbegin=arr(res.qbegin, np.int32, n), qend=arr(res.qend, np.int32, n),
+                align_len=arr(res.align_len, np.uint32, n), matches=arr(res.matches, np.uint32, n),
+                gaps=arr(res.gaps, np.uint32, n), gap_regions=arr(res.gap_regions, np.uint32, n),
+                ops_off=arr(res.ops_off, np.uint64, n), ops_len=arr(res.ops_len, np.uint32, n),
+                ops=arr(res.ops, np.uint64, int(res.n_ops)))
+        finally:
+            L.lib().wfahip_results_free(C.byref(res))
+        return out
+
+    def AlignBatch(self, qs: Sequence[bytes], ts: Sequence[bytes]):
+        """([]*AlignmentResult, []error): per-pair results and per-pair errors (None = ok)."""
+        if len(qs) != len(ts):
+            raise ValueError("qs and ts differ in length")
+        if not qs:
+            return [], []
+        br = self.align_arrays(*make_blob(qs, ts))
+        results: List[Optional[AlignmentResult]] = []
+        errors: List[Optional[Exception]] = []
+        for i in range(len(qs)):
+            st = int(br.status[i])
+            if st == L.PAIR_OK:
+                results.append(br.result(i))
+                errors.append(None)
+            else:
+                results.append(None)
+                errors.append(ErrEmptySeq if st == L.PAIR_EMPTY else ErrSeqTooLong if st == L.PAIR_TOO_LONG
+                              else WfaError("wfa: out of device memory for this pair"))
+        return results, errors
+
+    # -- diagnostics ----------------------------------------------------------------------------
+    def last_timing(self) -> Timing:
+        t = L.Timing()
+        L.check(L.lib().wfahip_last_timing(self._ctx, C.byref(t)))
+        return Timing(t.kernel_ms, t.total_ms, t.n_launches, t.n_retried_pairs, t.cells_stored, t.ops_written,
+                      t.arena_bytes, t.main_kernel_ms)
+
+    def set_option(self, key: str, value: int) -> None:
+        L.check(L.lib().wfahip_set_option(self._ctx, key.encode(), int(value)), f"set_option({key})")
+
+    def debug_wavefronts(self, q: bytes, t: bytes):
+        """All stored M/I/D rows of one alignment: ({'M': {s: {k: raw}}, 'I': .., 'D': ..}, AlignmentResult)."""
+        rows, words = C.POINTER(L.Row)(), C.POINTER(C.c_uint32)()
+        n_rows, n_words = C.c_uint64(), C.c_uint64()
+        res = L.Results()
+        prm = self._params()
+        L.check(L.lib().wfahip_debug_wavefronts(self._ctx, C.byref(prm), q, len(q), t, len(t), C.byref(rows),
+                                                C.byref(n_rows), C.byref(words), C.byref(n_words), C.byref(res)),
+                "wfahip_debug_wavefronts")
+        try:
+            out = {"M": {}, "I": {}, "D": {}}
+            for i in range(n_rows.value):
+                r = rows[i]
+                for ci, name in enumerate("MID"):
+                    d = {}
+                    for j in range(r.width):
+                        w = words[r.word_off + ci * r.width + j]
+                        if w:
+                            d[r.lo + j] = int(w)
+                    if d:
+                        out[name][int(r.score)] = d
+            br = BatchResult.from_c(res, 1)
+        finally:
+            L.lib().wfahip_free(rows)
+            L.lib().wfahip_free(words)
+            L.lib().wfahip_results_free(C.byref(res))
+        return out, br.result(0)
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            L.lib().wfahip_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+@dataclass
+class BatchResult:
+    status: np.ndarray
+    score: np.ndarray
+    tbegin: np.ndarray
+    tend: np.ndarray
+    qbegin: np.ndarray
+    qend: np.ndarray
+    align_len: np.ndarray
+    matches: np.ndarray
+    gaps: np.ndarray
+    gap_regions: np.ndarray
+    ops_off: np.ndarray
+    ops_len: np.ndarray
+    ops: np.ndarray
+
+    @staticmethod
+    def from_c(res: "L.Results", n: int) -> "BatchResult":
+        def arr(ptr, dt, cnt):
+            if cnt == 0:
+                return np.zeros(0, dtype=dt)
+            return np.ctypeslib.as_array(ptr, shape=(cnt,)).astype(dt, copy=True)
+        return BatchResult(arr(res.status, np.int32, n), arr(res.score, np.uint32, n), arr(res.tbegin, np.int32, n),
+                           arr(res.tend, np.int32, n), arr(res.qbegin, np.int32, n), arr(res.qend, np.int32, n),
+                           arr(res.align_len, np.uint32, n), arr(res.matches, np.uint32, n),
+                           arr(res.gaps, np.uint32, n), arr(res.gap_regions, np.uint32, n),
+                           arr(res.ops_off, np.uint64, n), arr(res.ops_len, np.uint32, n),
+                           arr(res.ops, np.uint64, int(res.n_ops)))
+
+    def pair_ops(self, i: int) -> np.ndarray:
+        return self.ops[int(self.ops_off[i]):int(self.ops_off[i]) + int(self.ops_len[i])]
+
+    def result(self, i: int) -> AlignmentResult:
+        return AlignmentResult(Ops=[int(o) for o in self.pair_ops(i)], Score=int(self.score[i]),
+                               TBegin=int(self.tbegin[i]), TEnd=int(self.tend[i]), QBegin=int(self.qbegin[i]),
+                               QEnd=int(self.qend[i]), AlignLen=int(self.align_len[i]),
+                               Matches=int(self.matches[i]), Gaps=int(self.gaps[i]),
+                               GapRegions=int(self.gap_regions[i]))
+
+
+def New(p: Penalties = DefaultPenalties, opt: Options = DefaultOptions, device: int = -1) -> Aligner:
+    """wfa.go:120."""
+    return Aligner(p, opt, device)
+
+
+def RecycleAligner(algn: Optional[Aligner]) -> None:
+    """wfa.go:102: returns the aligner to the pool; here it releases the device context."""
+    if algn is not None:
+        algn.close()
+
+
+def generate_pairs(seed: int, n_pairs: int, length: int, error_rate: float, first_index: int = 0,
+                   n_threads: int = 8):
+    """Seeded synthetic dataset (include/wfa_hip.h: wfahip_generate_pairs).  Host only, no GPU needed."""
+    stride = int(L.lib().wfahip_gen_stride(length, error_rate))
+    blob = np.zeros(max(n_pairs * stride, 1) + 16, dtype=np.uint8)
+    q_off = np.zeros(n_pairs, dtype=np.uint64)
+    t_off = np.zeros(n_pairs, dtype=np.uint64)
+    q_len = np.zeros(n_pairs, dtype=np.uint32)
+    t_len = np.zeros(n_pairs, dtype=np.uint32)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    if n_pairs:
+        L.check(L.lib().wfahip_generate_pairs(seed, first_index, n_pairs, length, float(error_rate), n_threads,
+                                              vp(blob), vp(q_off), vp(q_len), vp(t_off), vp(t_len)),
+                "wfahip_generate_pairs")
+    return blob, q_off, q_len, t_off, t_len

@@ -1,0 +1,74 @@
+// wfa_common.hpp -- shared definitions of the gfx950 wavefront-alignment kernels.
+//
+// Semantics follow shenwei356/wfa v0.4.0 (citations are file:line into the reference checkout):
+//   * a wavefront word is  offset<<3 | tag , 0 = absent      (wfa_wavefront.go:93,153-159)
+//   * tags 1..6 = InsOpen, InsExt, DelOpen, DelExt, Mismatch, Match   (wfa_backtrace_types.go:27-35)
+//   * offsets count target bases consumed (1-based h); diagonal k = h - v
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace wfa {
+
+enum : uint32_t {
+    TAG_INS_OPEN = 1, TAG_INS_EXT = 2, TAG_DEL_OPEN = 3, TAG_DEL_EXT = 4, TAG_MISMATCH = 5, TAG_MATCH = 6
+};
+constexpr uint32_t TAG_BITS = 3, TAG_MASK = 7;
+
+// internal per-pair status values written to rec[STATUS] while a batch is in flight
+enum : uint32_t {
+    ST_OK = 0, ST_EMPTY = 1, ST_TOO_LONG = 2, ST_NO_MEMORY = 4,
+    ST_PENDING = 0xFFFFFFFFu,  // not processed yet
+    ST_REDO_BYTES = 100,       // non-ACGT byte found: needs the byte-compare path
+    ST_REDO_ARENA = 101,       // wavefront arena too small: needs a bigger slot
+    ST_REDO_LDS   = 102,       // sequences do not fit this launch's LDS budget
+    ST_REDO_BAND  = 103        // register-window kernel: diagonal band left the tile range
+};
+
+constexpr int REC_WORDS = 16;
+enum { REC_STATUS = 0, REC_SCORE, REC_TBEGIN, REC_TEND, REC_QBEGIN, REC_QEND, REC_ALIGN_LEN, REC_MATCHES,
+       REC_GAPS, REC_GAP_REGIONS, REC_OPS_LEN, REC_OPS_OFF_LO, REC_OPS_OFF_HI, REC_CELLS_LO, REC_CELLS_HI,
+       REC_N_SCORES };
+
+// One directory entry per score index (score / g): the M, I and D rows of that score share the
+// diagonal range [lo, lo+w) and sit at arena[base], arena[base+w], arena[base+2w].  w == 0 means no
+// wavefront exists at that score in any component (Component.HasScore false, wfa_component.go:81-86).
+struct alignas(16) DirEnt {
+    uint32_t base;
+    int32_t  lo;
+    int32_t  w;
+    uint32_t pad;
+};
+
+struct KParams {
+    // input (device pointers)
+    const uint8_t  *blob;
+    uint64_t        blob_bytes;
+    const uint64_t *q_off;
+    const uint32_t *q_len;
+    const uint64_t *t_off;
+    const uint32_t *t_len;
+    const uint32_t *work;  // pair ids to process (nullptr = identity 0..n_work-1)
+    uint32_t        n_work;
+    // scheduling
+    uint32_t *queue_head;
+    // per-slot scratch
+    uint32_t *arena;
+    uint64_t  arena_words;  // per slot
+    // penalties / options
+    uint32_t x, o, e, oe, g;
+    uint32_t global_alignment, adaptive, min_wf_len, max_dist_diff;
+    // output
+    uint32_t           *rec;  // [n_pairs][REC_WORDS]
+    uint64_t           *ops;
+    uint64_t            ops_cap;
+    unsigned long long *ops_cursor;
+    uint32_t           *redo_list;  // pairs needing another configuration
+    uint32_t           *redo_count;
+    // LDS budget of this launch: words available for EACH packed sequence (incl. 1 pad word)
+    uint32_t lds_seq_words;
+    // debug: keep slot 0's arena intact and publish its final directory size
+    uint32_t *debug_info;  // [0] = number of directory entries, [1] = final score
+};
+
+}  // namespace wfa

@@ -1,0 +1,491 @@
+// wfa_device.hpp -- device functions shared by the gfx950 alignment kernels.
+//
+// Each function cites the reference code it reproduces (file:line into shenwei356/wfa v0.4.0).
+// Nothing here is GEMM-shaped: it is integer max/compare work on u32 offsets, so no MFMA; the
+// levers are wave64 lane<->diagonal mapping, LDS-resident 2-bit sequences and one coalesced store
+// per finished wavefront row.
+#pragma once
+#include "wfa_common.hpp"
+
+namespace wfa {
+
+#define WFA_DEV __device__ __forceinline__
+
+WFA_DEV uint32_t umax2(uint32_t a, uint32_t b) { return a > b ? a : b; }
+WFA_DEV int      imin2(int a, int b) { return a < b ? a : b; }
+WFA_DEV int      imax2(int a, int b) { return a > b ? a : b; }
+
+// ---------------------------------------------------------------------------------------------
+// wave64 reductions (DPP/ds_swizzle via __shfl_xor; 64 lanes, not 32)
+WFA_DEV int wave_min(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = imin2(v, __shfl_xor(v, o, 64));
+    return v;
+}
+WFA_DEV int wave_max(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = imax2(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sequence access.  MODE 0: 2-bit packed in LDS, 16 bases per u32 (base i at bits 2(i%16)),
+// valid only when both sequences are pure uppercase ACGT.  MODE 1: raw bytes in global memory (any
+// alphabet; the reference compares raw bytes, wfa.go:408-454).
+template <int MODE>
+struct SeqView;
+
+template <>
+struct SeqView<0> {
+    const uint32_t *q, *t;
+    int             n, m;
+    WFA_DEV uint32_t qbase(int i) const { return (q[i >> 4] >> ((i & 15) * 2)) & 3u; }
+    WFA_DEV uint32_t tbase(int i) const { return (t[i >> 4] >> ((i & 15) * 2)) & 3u; }
+    // 16-base window starting at base p (needs one readable pad word after the last data word)
+    static WFA_DEV uint32_t win16(const uint32_t *s, int p) {
+        int w = p >> 4;
+        return __funnelshift_r(s[w], s[w + 1], (uint32_t)(p & 15) * 2u);
+    }
+    // longest common prefix of q[v:], t[h:] (0-based v, h), clamped to the sequence ends.
+    // Equals what the 8-byte block loop + byte tail of wfa.go:410-454 add up to.
+    WFA_DEV int lcp(int v, int h) const {
+        int rem = imin2(n - v, m - h);
+        int tot = 0;
+        while (tot < rem) {
+            uint32_t x = win16(q, v + tot) ^ win16(t, h + tot);
+            if (x) {
+                tot += __builtin_ctz(x) >> 1;
+                break;
+            }
+            tot += 16;
+        }
+        return imin2(tot, rem);
+    }
+};
+
+template <>
+struct SeqView<1> {
+    const uint8_t *q, *t;
+    int            n, m;
+    WFA_DEV uint32_t qbase(int i) const { return q[i]; }
+    WFA_DEV uint32_t tbase(int i) const { return t[i]; }
+    WFA_DEV int      lcp(int v, int h) const {
+        int rem = imin2(n - v, m - h);
+        int tot = 0;
+        while (tot < rem && q[v + tot] == t[h + tot]) tot++;
+        return tot;
+    }
+};
+
+// Pack `len` bytes at blob[off..) into 2-bit words dst[0..ceil(len/16)] (last index = zero pad word).
+// Threads tid, tid+G, ... each produce one word from up to five aligned dword loads (coalesced across
+// the group).  Returns true if this thread saw a byte outside {A,C,G,T}.
+template <int G>
+WFA_DEV bool stage_pack(const uint8_t *blob, uint64_t off, uint32_t len, uint32_t *dst, int tid) {
+    const uint32_t nw  = (len + 15u) >> 4;
+    bool           bad = false;
+    for (uint32_t j = tid; j <= nw; j += G) {
+        uint32_t word = 0;
+        if (j < nw) {
+            const uintptr_t a  = (uintptr_t)(blob + off) + 16ull * j;
+            const uint32_t *p  = (const uint32_t *)(a & ~(uintptr_t)3);
+            const uint32_t  sh = (uint32_t)(a & 3) * 8u;
+            const uint32_t  nb = (len - 16u * j) < 16u ? (len - 16u * j) : 16u;
+            const uint32_t  nd = ((uint32_t)(a & 3) + nb + 3u) >> 2;  // dwords that hold valid bytes: 1..5
+            uint32_t        d[5];
+#pragma unroll
+            for (int i = 0; i < 5; i++) d[i] = ((uint32_t)i < nd) ? p[i] : 0u;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                uint32_t w = __funnelshift_r(d[i], d[i + 1], sh);
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    uint32_t idx = 4u * i + b;
+                    uint32_t c   = (w >> (8 * b)) & 0xFFu;
+                    bool     ok  = (c == 'A') | (c == 'C') | (c == 'G') | (c == 'T');
+                    if (idx < nb) {
+                        bad |= !ok;
+                        word |= ((c >> 1) & 3u) << (2u * idx);
+                    }
+                }
+            }
+        }
+        dst[j] = word;
+    }
+    return bad;
+}
+
+// ---------------------------------------------------------------------------------------------
+// One diagonal of WF_NEXT (wfa.go:572-699).  Inputs are the raw source words (0 = absent):
+//   mo_km1 = M[s-o-e][k-1], ie_km1 = I[s-e][k-1], mo_kp1 = M[s-o-e][k+1], de_kp1 = D[s-e][k+1],
+//   mx_k   = M[s-x][k].   n = len(q), m = len(t).
+struct Cell {
+    uint32_t M, I, D;  // raw words; 0 = nothing stored
+};
+
+WFA_DEV Cell next_cell(uint32_t mo_km1, uint32_t ie_km1, uint32_t mo_kp1, uint32_t de_kp1, uint32_t mx_k,
+                       int k, int n, int m) {
+    Cell c;
+    // insertion (wfa.go:579-609): a source is rejected when its offset is > m (not >=)
+    uint32_t v1 = mo_km1 >> TAG_BITS, v2 = ie_km1 >> TAG_BITS;
+    bool     fM = mo_km1 != 0 && (int)v1 <= m;
+    bool     fI = ie_km1 != 0 && (int)v2 <= m;
+    v1          = fM ? v1 : 0u;
+    v2          = fI ? v2 : 0u;
+    const bool     uI  = fM | fI;
+    const uint32_t Isk = uI ? umax2(v1, v2) + 1u : 0u;
+    const uint32_t tI  = (fM && (!fI || v1 >= v2)) ? TAG_INS_OPEN : TAG_INS_EXT;
+    c.I                = uI ? ((Isk << TAG_BITS) | tI) : 0u;
+
+    // deletion (wfa.go:614-645): rejected when offset - k > n
+    v1 = mo_kp1 >> TAG_BITS;
+    v2 = de_kp1 >> TAG_BITS;
+    fM = mo_kp1 != 0 && (int)v1 - k <= n;
+    bool fD = de_kp1 != 0 && (int)v2 - k <= n;
+    v1      = fM ? v1 : 0u;
+    v2      = fD ? v2 : 0u;
+    const bool     uD  = fM | fD;
+    const uint32_t Dsk = uD ? umax2(v1, v2) : 0u;
+    const uint32_t tD  = (fM && (!fD || v1 >= v2)) ? TAG_DEL_OPEN : TAG_DEL_EXT;
+    c.D                = uD ? ((Dsk << TAG_BITS) | tD) : 0u;
+
+    // mismatch (wfa.go:650-698): rejected when offset > m or offset - k > n; mismatch wins ties,
+    // then insertion, then deletion; M carries I's / D's tag when it comes from them.
+    v1 = mx_k >> TAG_BITS;
+    fM = mx_k != 0 && !((int)v1 > m || (int)v1 - k > n);
+    v1 = fM ? v1 : 0u;
+    const uint32_t Msk = umax2(umax2(Isk, Dsk), v1 + 1u);
+    uint32_t       tM;
+    if (fM && Msk == v1 + 1u)
+        tM = TAG_MISMATCH;
+    else if (uI && (Msk == Isk || !uD))
+        tM = tI;
+    else
+        tM = tD;
+    c.M = (uI | uD | fM) ? ((Msk << TAG_BITS) | tM) : 0u;
+    return c;
+}
+
+// Seeds of initComponents (wfa.go:143-184) that belong to score s, as a raw word for diagonal k
+// (0 if none).  Global: only k = 0.  Semi-global: first row k = 1..m-1 (offset k+1), first column
+// k = -1..-(n-1) (offset 1).  Class: score 0 / Match when the bases agree, else score x / Mismatch.
+template <int MODE>
+WFA_DEV uint32_t seed_word(const SeqView<MODE> &sv, int k, uint32_t s, uint32_t x, bool global_alignment) {
+    if (k != 0 && global_alignment) return 0u;
+    if (k > sv.m - 1 || k < -(sv.n - 1)) return 0u;
+    bool     match = (k >= 0) ? (sv.qbase(0) == sv.tbase(k)) : (sv.qbase(-k) == sv.tbase(0));
+    uint32_t h     = (k >= 0) ? (uint32_t)(k + 1) : 1u;
+    uint32_t cls   = match ? 0u : x;
+    if (cls != s) return 0u;
+    return (h << TAG_BITS) | (match ? TAG_MATCH : TAG_MISMATCH);
+}
+
+// WF_EXTEND for one diagonal (wfa.go:394-455): only cells with 0 < v < n and h < m are extended.
+template <int MODE>
+WFA_DEV uint32_t extend_word(const SeqView<MODE> &sv, uint32_t raw, int k) {
+    if (raw == 0u) return 0u;
+    int h = (int)(raw >> TAG_BITS);
+    int v = h - k;
+    if (v <= 0 || v >= sv.n || h >= sv.m) return raw;
+    return raw + ((uint32_t)sv.lcp(v, h) << TAG_BITS);
+}
+
+// remaining-distance of wf-adaptive (wfa.go:474-494): -1 when absent or past a sequence end
+WFA_DEV int reduce_dist(uint32_t raw, int k, int n, int m) {
+    if (raw == 0u) return -1;
+    int h = (int)(raw >> TAG_BITS);
+    int v = h - k;
+    if (v < 0 || v >= n || h >= m) return -1;
+    return imax2(m - h, n - v);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Arena access used by the end-cell search and the backtrace.  The directory grows downward from the
+// end of the slot: entry i sits at arena + cap - 4*(i+1) words.
+struct ArenaView {
+    const uint32_t *A;
+    uint64_t        cap;    // words
+    uint32_t        g;      // score granularity gcd(x, o+e, e): only multiples of g can exist
+    uint32_t        n_ent;  // directory entries written (scores 0, g, .., (n_ent-1)*g)
+
+    WFA_DEV DirEnt ent(uint32_t idx) const {
+        const uint4 r = *reinterpret_cast<const uint4 *>(A + cap - 4ull * (idx + 1));
+        DirEnt      e;
+        e.base = r.x;
+        e.lo   = (int)r.y;
+        e.w    = (int)r.z;
+        e.pad  = r.w;
+        return e;
+    }
+    // Component.GetRaw (wfa_component.go:150-155 + wfa_wavefront.go:163-169); s may have wrapped
+    // below zero (uint32), which lands beyond the directory like the reference's len check.
+    WFA_DEV uint32_t get_raw(int comp, uint32_t s, int k) const {
+        if (s % g != 0u) return 0u;
+        uint32_t idx = s / g;
+        if (idx >= n_ent) return 0u;
+        DirEnt e = ent(idx);
+        if (e.w <= 0 || k < e.lo || k >= e.lo + e.w) return 0u;
+        return A[(uint64_t)e.base + (uint64_t)comp * (uint32_t)e.w + (uint32_t)(k - e.lo)];
+    }
+};
+
+// AlignmentResult being built by one lane.  Ops are appended in backtrace order into scratch and
+// merged with the previous one when the letter repeats -- merging adjacent equal ops commutes with
+// the reversal done by process() (wfa_cigar.go:136-166).
+struct OpsWriter {
+    uint64_t *buf;
+    uint32_t  cap;
+    uint32_t  n;
+    uint64_t  cur;  // pending op (0 = none)
+    bool      overflow;
+    WFA_DEV void init(uint64_t *b, uint32_t c) {
+        buf = b, cap = c, n = 0, cur = 0, overflow = false;
+    }
+    WFA_DEV void add(uint32_t letter, uint32_t cnt) {  // AddN, wfa_cigar.go:118-124
+        if (cur != 0 && (uint32_t)(cur >> 32) == letter) {
+            cur += cnt;
+            return;
+        }
+        flush();
+        cur = ((uint64_t)letter << 32) | cnt;
+    }
+    WFA_DEV void flush() {
+        if (cur != 0) {
+            if (n < cap)
+                buf[n] = cur;
+            else
+                overflow = true;
+            n++;
+            cur = 0;
+        }
+    }
+};
+
+WFA_DEV uint32_t op_letter(uint32_t tag) {  // wfaOps = ".IIDDXMH" (wfa_backtrace_types.go:37)
+    const uint32_t tbl0 = ('.') | ('I' << 8) | ('I' << 16) | ('D' << 24);
+    const uint32_t tbl1 = ('D') | ('X' << 8) | ('M' << 16) | ('H' << 24);
+    return ((tag < 4 ? tbl0 : tbl1) >> (8 * (tag & 3))) & 0xFFu;
+}
+
+struct TraceOut {
+    uint32_t score;
+    int      tbegin, tend, qbegin, qend;
+};
+
+// backtraceStartPosistion (wfa.go:270-375): semi-global end cell.  Serial, one lane.
+WFA_DEV void backtrace_start(const ArenaView &av, int n, int m, uint32_t s, uint32_t &outS, int &outK) {
+    uint32_t minS = s;
+    const int Ak  = m - n;
+    int      lastK = Ak;
+    for (uint32_t idx = s / av.g + 1; idx-- > 0;) {
+        const uint32_t _s = idx * av.g;
+        DirEnt         e  = av.ent(idx);
+        if (e.w <= 0) continue;  // !M.HasScore(_s)
+        const int lo = e.lo, hi = e.lo + e.w - 1;
+        const uint32_t *row = av.A + e.base;
+        bool hit = false;
+        int  k   = Ak;
+        for (;;) {  // wfa.go:301-326
+            if (k < lo) break;
+            uint32_t raw = (k <= hi) ? row[k - lo] : 0u;
+            if (raw == 0u) {
+                k--;
+                continue;
+            }
+            int h = (int)(raw >> TAG_BITS), v = h - k;
+            if (v <= 0 || v > n || h > m) break;
+            if ((v == n && h >= n) || (h == m && v >= m)) {
+                hit = true;
+                break;
+            }
+            k--;
+        }
+        if (hit && _s <= minS) {
+            lastK = k;
+            minS  = _s;
+        }
+        hit = false;
+        k   = Ak + 1;
+        for (;;) {  // wfa.go:336-361
+            if (k > hi) break;
+            uint32_t raw = (k >= lo) ? row[k - lo] : 0u;
+            if (raw == 0u) {
+                k++;
+                continue;
+            }
+            int h = (int)(raw >> TAG_BITS), v = h - k;
+            if (v <= 0 || v > n || h > m) break;
+            if ((v == n && h >= n) || (h == m && v >= m)) {
+                hit = true;
+                break;
+            }
+            k++;
+        }
+        if (hit && _s <= minS) {
+            lastK = k;
+            minS  = _s;
+        }
+    }
+    outS = minS;
+    outK = lastK;
+}
+
+// backTrace (wfa.go:703-983), one lane.  Source lookups are plain Gets with NO bounds rejection,
+// exactly as the reference recomputes the pre-extension offset.
+WFA_DEV void back_trace(const ArenaView &av, int lenQ, int lenT, uint32_t s, int Ak, bool semiGlobal,
+                        uint32_t px, uint32_t po, uint32_t pe, OpsWriter &ow, TraceOut &out) {
+    out.score  = s;
+    out.tbegin = out.tend = out.qbegin = out.qend = 0;
+
+    int      k = Ak, h, v, h0;
+    uint32_t offset, wfaType;
+    int      qBegin = 0, tBegin = 0;
+    uint32_t v1, v2, Isk = 0, Dsk = 0, offset0 = 0;
+    bool     fromMI, fromMD, fromItself = false, fromM, fromX;
+    uint32_t sMismatch, sGapOpen, sGapExt;
+    bool     previousFromM = true, firstMatch = true;
+    int      nMatches;
+    int      M0 = 0;  // component to read the next tag from: 0 = M, 1 = I, 2 = D
+
+    offset  = av.get_raw(0, s, k);  // wfa.go:738
+    wfaType = offset & TAG_MASK;
+    h       = (int)(offset >> TAG_BITS);
+    v       = h - k;
+
+    if (h < lenT)  // wfa.go:746-750
+        ow.add('I', (uint32_t)lenT - (uint32_t)h);
+    else if (v < lenQ)
+        ow.add('H', (uint32_t)lenQ - (uint32_t)v);
+
+    while (v > 0 && h > 0) {  // wfa.go:753
+        sMismatch = s - px;
+        sGapOpen  = s - po - pe;
+        sGapExt   = s - pe;
+        fromMI = false, fromMD = false;
+        if (wfaType == TAG_INS_EXT) {  // wfa.go:767-777
+            uint32_t r1 = av.get_raw(0, sGapOpen, k - 1), r2 = av.get_raw(1, sGapExt, k - 1);
+            if (r1 != 0 || r2 != 0) {
+                fromMI  = true;
+                offset0 = umax2(r1 >> TAG_BITS, r2 >> TAG_BITS) + 1u;
+            } else {
+                offset0 = 0;
+            }
+            M0 = 1;
+        } else if (wfaType == TAG_DEL_EXT) {  // wfa.go:778-788
+            uint32_t r1 = av.get_raw(0, sGapOpen, k + 1), r2 = av.get_raw(2, sGapExt, k + 1);
+            if (r1 != 0 || r2 != 0) {
+                fromMD  = true;
+                offset0 = umax2(r1 >> TAG_BITS, r2 >> TAG_BITS);
+            } else {
+                offset0 = 0;
+            }
+            M0 = 2;
+        } else {  // wfa.go:789-817
+            uint32_t r1 = av.get_raw(0, sGapOpen, k - 1), r2 = av.get_raw(1, sGapExt, k - 1);
+            uint32_t r3 = av.get_raw(0, sGapOpen, k + 1), r4 = av.get_raw(2, sGapExt, k + 1);
+            uint32_t r5 = av.get_raw(0, sMismatch, k);
+            v1 = r1 >> TAG_BITS, v2 = r2 >> TAG_BITS;
+            if (r1 != 0 || r2 != 0) {
+                fromMI = true;
+                Isk    = umax2(v1, v2) + 1u;
+            } else {
+                Isk = 0;
+            }
+            v1 = r3 >> TAG_BITS, v2 = r4 >> TAG_BITS;
+            if (r3 != 0 || r4 != 0) {
+                fromMD = true;
+                Dsk    = umax2(v1, v2);
+            } else {
+                Dsk = 0;
+            }
+            fromX = r5 != 0;
+            v1    = r5 >> TAG_BITS;
+            if (fromMI || fromMD || fromX) {
+                offset0    = umax2(umax2(Isk, Dsk), v1 + 1u);
+                fromItself = false;
+            } else {
+                fromItself = true;
+            }
+            M0 = 0;
+        }
+        (void)fromM;
+        if (fromItself) break;    // wfa.go:818-821
+        if (offset0 == 0) break;  // wfa.go:822-825
+        h0 = (int)offset0;
+
+        if (previousFromM) {  // wfa.go:833-869
+            nMatches = h - h0;
+            if (nMatches > 0) {
+                if (firstMatch) {
+                    firstMatch = false;
+                    out.tend   = h;
+                    out.qend   = v;
+                }
+                ow.add('M', (uint32_t)nMatches);
+            }
+            h = h0;
+            v = h - k;
+            if (wfaType == TAG_MATCH) {
+                tBegin = h, qBegin = v;
+            } else if (nMatches > 0) {
+                tBegin = h + 1, qBegin = v + 1;
+            }
+            if (h <= 0 || v <= 0) break;
+        }
+
+        ow.add(op_letter(wfaType), 1);  // wfa.go:872-873
+
+        if (semiGlobal && (h == 1 || v == 1)) break;  // wfa.go:876-879
+
+        previousFromM = true;  // wfa.go:885-909
+        bool stop     = false;
+        switch (wfaType) {
+        case TAG_MISMATCH: s = sMismatch; h--; break;
+        case TAG_INS_OPEN: s = sGapOpen; k--; h--; break;
+        case TAG_INS_EXT: s = sGapExt; k--; h--; previousFromM = false; break;
+        case TAG_DEL_OPEN: s = sGapOpen; k++; break;
+        case TAG_DEL_EXT: s = sGapExt; k++; previousFromM = false; break;
+        default: stop = true; break;
+        }
+        if (stop) break;
+        v = h - k;
+
+        offset = av.get_raw(M0, s, k);  // wfa.go:915-920
+        if (offset == 0) break;
+        wfaType = offset & TAG_MASK;
+    }
+
+    if (h > 0 && v > 0) {  // wfa.go:930-968
+        nMatches = imin2(h, v) - 1;
+        if (nMatches > 0) {
+            if (firstMatch) {
+                firstMatch = false;
+                out.tend   = h;
+                out.qend   = v;
+            }
+            ow.add('M', (uint32_t)nMatches);
+            h -= nMatches;
+            v -= nMatches;
+            if (wfaType == TAG_MATCH) {
+                tBegin = h, qBegin = v;
+            } else {
+                tBegin = h + 1, qBegin = v + 1;
+            }
+        } else if (wfaType == TAG_MATCH) {
+            tBegin = h, qBegin = v;
+            if (firstMatch) {
+                firstMatch = false;
+                out.tend   = h;
+                out.qend   = v;
+            }
+        }
+        ow.add(op_letter(wfaType), 1);
+    }
+    if (v > 1) ow.add('H', (uint32_t)(v - 1));  // wfa.go:970-972
+    if (h > 1) ow.add('I', (uint32_t)(h - 1));  // wfa.go:974-976
+    ow.flush();
+    out.tbegin = tBegin;  // wfa.go:979
+    out.qbegin = qBegin;
+}
+
+}  // namespace wfa

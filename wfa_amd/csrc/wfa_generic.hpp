@@ -1,0 +1,309 @@
+// wfa_generic.hpp -- kernel A: the general wavefront-alignment kernel.
+//
+// One workgroup of 64*WAVES threads aligns one pair at a time (persistent: pairs are pulled from a
+// device queue).  Any penalties with mismatch > 0 and gap_ext > 0, any sequence length that fits the
+// slot's arena, global or semi-global, wf-adaptive on or off.  The M/I/D rows of finished scores
+// live in the slot's HBM arena (they are what the backtrace needs) and the sources of WF_NEXT are
+// read back from there (L2-resident: the slot wrote them a few scores ago).
+//
+// Per score s (a multiple of g = gcd(x, o+e, e); other scores cannot exist) the kernel runs the
+// reference's sequence  next(s) -> extend(s) -> termination test -> reduce(s)  (wfa.go:228-251)
+// fused per diagonal, so each cell is produced in registers and stored once.
+#pragma once
+#include "wfa_device.hpp"
+
+namespace wfa {
+
+// LDS words used besides the two packed sequences
+constexpr int GEN_LDS_EXTRA_WORDS = 16;
+
+template <int WAVES, int MODE>
+__global__ __launch_bounds__(64 * WAVES) void wfa_generic_kernel(const KParams P) {
+    constexpr int G = 64 * WAVES;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t *const lq  = lds;
+    uint32_t *const lt  = lds + P.lds_seq_words;
+    int *const      red = reinterpret_cast<int *>(lds + 2 * (MODE == 0 ? P.lds_seq_words : 0));
+    // red[0]=mlo red[1]=mhi red[2]=term red[3]=minDist red[4]=first_ok red[5]=last_ok red[6]=anyfail
+    // red[7]=lead  red[8]=pair broadcast  red[9]=bad  red[10..11] = cells count (lo, hi)
+
+    const int      tid  = threadIdx.x;
+    const int      lane = tid & 63;
+    uint32_t *const A   = P.arena + (uint64_t)blockIdx.x * P.arena_words;
+    const uint64_t cap  = P.arena_words;
+    const uint32_t x = P.x, oe = P.oe, e = P.e, g = P.g;
+
+    for (;;) {
+        // ---- dequeue one pair (thread 0) and broadcast
+        __syncthreads();
+        if (tid == 0) red[8] = (int)atomicAdd(P.queue_head, 1u);
+        __syncthreads();
+        const uint32_t wi = (uint32_t)red[8];
+        if (wi >= P.n_work) break;
+        const uint32_t pair = P.work ? P.work[wi] : wi;
+        uint32_t *const rec = P.rec + (uint64_t)pair * REC_WORDS;
+
+        const uint32_t nq = P.q_len[pair], mt = P.t_len[pair];
+        if (nq == 0 || mt == 0 || nq > 0x1FFFFFFFu || mt > 0x1FFFFFFFu) {  // wfa.go:204-209
+            if (tid < REC_WORDS) rec[tid] = (tid == REC_STATUS) ? ((nq == 0 || mt == 0) ? ST_EMPTY : ST_TOO_LONG) : 0u;
+            continue;
+        }
+        const int n = (int)nq, m = (int)mt, Ak = m - n;
+
+        SeqView<MODE> sv;
+        sv.n = n, sv.m = m;
+        if constexpr (MODE == 0) {
+            // ---- stage + 2-bit pack both sequences into LDS
+            const uint32_t need = ((imax2(n, m) + 15) >> 4) + 1;
+            if (need > P.lds_seq_words) {
+                if (tid == 0) {
+                    rec[REC_STATUS]                          = ST_REDO_LDS;
+                    P.redo_list[atomicAdd(P.redo_count, 1u)] = pair;
+                }
+                continue;
+            }
+            if (tid == 0) red[9] = 0;
+            __syncthreads();
+            bool bad = stage_pack<G>(P.blob, P.q_off[pair], nq, lq, tid);
+            bad |= stage_pack<G>(P.blob, P.t_off[pair], mt, lt, tid);
+            if (__ballot(bad) != 0ull && lane == 0) red[9] = 1;
+            __syncthreads();
+            if (red[9]) {  // non-ACGT byte: the byte-compare configuration must take this pair
+                if (tid == 0) {
+                    rec[REC_STATUS]                          = ST_REDO_BYTES;
+                    P.redo_list[atomicAdd(P.redo_count, 1u)] = pair;
+                }
+                continue;
+            }
+            sv.q = lq, sv.t = lt;
+        } else {
+            sv.q = P.blob + P.q_off[pair];
+            sv.t = P.blob + P.t_off[pair];
+        }
+
+        // ---- score loop
+        const bool     glob    = P.global_alignment != 0;
+        const int      seed_lo = glob ? 0 : -(n - 1), seed_hi = glob ? 0 : m - 1;
+        uint64_t       top     = 0;  // next free arena word
+        uint32_t       n_ent   = 0;  // directory entries written
+        bool           overflow = false, done = false;
+        uint32_t       s_final = 0;
+        uint64_t       my_cells = 0;
+        auto dir_ptr = [&](uint32_t idx) { return reinterpret_cast<uint4 *>(A + cap - 4ull * (idx + 1)); };
+        auto load_ent = [&](uint32_t idx) {
+            const uint4 r = *dir_ptr(idx);
+            DirEnt      d;
+            d.base = r.x, d.lo = (int)r.y, d.w = (int)r.z, d.pad = r.w;
+            return d;
+        };
+        const DirEnt none = {0u, 0, 0, 0u};
+
+        for (uint32_t s = 0;; s += g) {
+            const uint32_t si = s / g;
+            // sources: M[s-x], M[s-o-e], I[s-e] / D[s-e]  (wfa.go:557-560; missing when diff > s)
+            const DirEnt eX = (s >= x) ? load_ent(si - x / g) : none;
+            const DirEnt eO = (s >= oe) ? load_ent(si - oe / g) : none;
+            const DirEnt eE = (s >= e) ? load_ent(si - e / g) : none;
+            const bool   seeded = (s == 0u) || (s == x);
+
+            int lo = INT32_MAX, hi = INT32_MIN;
+            if (eX.w > 0) lo = imin2(lo, eX.lo - 1), hi = imax2(hi, eX.lo + eX.w);
+            if (eO.w > 0) lo = imin2(lo, eO.lo - 1), hi = imax2(hi, eO.lo + eO.w);
+            if (eE.w > 0) lo = imin2(lo, eE.lo - 1), hi = imax2(hi, eE.lo + eE.w);
+            lo = imax2(lo, -(n - 1));  // wfa.go:562-563
+            hi = imin2(hi, m - 1);
+            if (s == 0u) lo = INT32_MAX, hi = INT32_MIN;  // the reference never calls next(0)
+            if (seeded) lo = imin2(lo, seed_lo), hi = imax2(hi, seed_hi);
+
+            // room for 3 rows + this directory entry (+ ops scratch is checked later)
+            const int64_t W = (hi >= lo) ? ((int64_t)hi - lo + 1) : 0;
+            if (top + 3ull * (uint64_t)W + 4ull * (si + 2) > cap || top + 3ull * (uint64_t)W > 0xFFFFFFFFull) {
+                overflow = true;
+                break;
+            }
+            if (W == 0) {
+                if (tid == 0) *dir_ptr(si) = make_uint4(0u, 0u, 0u, 0u);
+                n_ent = si + 1;
+                __syncthreads();  // the entry may be a source of the very next score
+                continue;
+            }
+            const uint32_t base = (uint32_t)top;
+            uint32_t *const rowM = A + base, *const rowI = rowM + W, *const rowD = rowI + W;
+
+            if (tid == 0) {
+                red[0] = INT32_MAX, red[1] = INT32_MIN, red[2] = 0, red[3] = INT32_MAX;
+                red[4] = INT32_MAX, red[5] = INT32_MIN, red[6] = 0, red[7] = INT32_MIN;
+                *dir_ptr(si) = make_uint4(base, (uint32_t)lo, (uint32_t)W, 0u);
+            }
+            __syncthreads();
+
+            auto src = [&](const DirEnt &d, int comp, int k) -> uint32_t {
+                return (d.w > 0 && k >= d.lo && k < d.lo + d.w)
+                           ? A[(uint64_t)d.base + (uint64_t)comp * (uint32_t)d.w + (uint32_t)(k - d.lo)]
+                           : 0u;
+            };
+
+            // ---- P1: next + seeds + extend, store rows, partial reductions
+            int mlo = INT32_MAX, mhi = INT32_MIN, term = 0, mind = INT32_MAX;
+            for (int64_t i = tid; i < W; i += G) {
+                const int k = lo + (int)i;
+                Cell      c = {0u, 0u, 0u};
+                if (s != 0u)
+                    c = next_cell(src(eO, 0, k - 1), src(eE, 1, k - 1), src(eO, 0, k + 1), src(eE, 2, k + 1),
+                                  src(eX, 0, k), k, n, m);
+                if (seeded && c.M == 0u) c.M = seed_word<MODE>(sv, k, s, x, glob);  // Set = last write wins (R2)
+                c.M = extend_word<MODE>(sv, c.M, k);
+                rowM[i] = c.M, rowI[i] = c.I, rowD[i] = c.D;
+                my_cells += (c.M != 0u) + (c.I != 0u) + (c.D != 0u);
+                if (c.M != 0u) {
+                    mlo = imin2(mlo, k), mhi = imax2(mhi, k);
+                    if (k == Ak && (int)(c.M >> TAG_BITS) >= m) term = 1;  // wfa.go:235-239
+                    const int d = reduce_dist(c.M, k, n, m);
+                    if (d >= 0) mind = imin2(mind, d);
+                }
+            }
+            mlo = wave_min(mlo), mhi = wave_max(mhi), mind = wave_min(mind);
+            term = __ballot(term) != 0ull;
+            if (lane == 0) {
+                atomicMin(&red[0], mlo), atomicMax(&red[1], mhi), atomicMin(&red[3], mind);
+                if (term) red[2] = 1;
+            }
+            __syncthreads();
+            mlo = red[0], mhi = red[1], term = red[2], mind = red[3];
+            top += 3ull * (uint64_t)W;
+            n_ent = si + 1;
+            if (term) {
+                done    = true;
+                s_final = s;
+                break;
+            }
+
+            // ---- reduce (wfa.go:461-540) when M exists at s and its Lo..Hi span is wide enough
+            if (P.adaptive && mhi >= mlo && (mhi - mlo + 1) >= (int)P.min_wf_len && mind != INT32_MAX) {
+                const int maxdiff = (int)P.max_dist_diff;
+                int       first_ok = INT32_MAX, last_ok = INT32_MIN, anyfail = 0;
+                for (int64_t i = tid; i < W; i += G) {
+                    const int k = lo + (int)i;
+                    const int d = reduce_dist(rowM[i], k, n, m);
+                    if (d >= 0) {
+                        if (d - mind > maxdiff)
+                            anyfail = 1;
+                        else
+                            first_ok = imin2(first_ok, k), last_ok = imax2(last_ok, k);
+                    }
+                }
+                first_ok = wave_min(first_ok), last_ok = wave_max(last_ok);
+                anyfail  = __ballot(anyfail) != 0ull;
+                if (lane == 0) {
+                    atomicMin(&red[4], first_ok), atomicMax(&red[5], last_ok);
+                    if (anyfail) red[6] = 1;
+                }
+                __syncthreads();
+                first_ok = red[4], last_ok = red[5], anyfail = red[6];
+                if (anyfail) {
+                    // _lo: one past the last valid entry before the first non-failing one (wfa.go:503-516)
+                    int lead = INT32_MIN;
+                    for (int64_t i = tid; i < W; i += G) {
+                        const int k = lo + (int)i;
+                        if (k < first_ok && reduce_dist(rowM[i], k, n, m) >= 0) lead = imax2(lead, k);
+                    }
+                    lead = wave_max(lead);
+                    if (lane == 0) atomicMax(&red[7], lead);
+                    __syncthreads();
+                    lead           = red[7];
+                    const int _lo  = (lead != INT32_MIN) ? lead + 1 : mlo;
+                    const int _hi  = last_ok;  // wfa.go:517-524
+                    for (int64_t i = tid; i < W; i += G) {  // wfa.go:526-535: Delete in M, I and D
+                        const int k = lo + (int)i;
+                        if (k < _lo || k > _hi) {
+                            my_cells -= (rowM[i] != 0u) + (rowI[i] != 0u) + (rowD[i] != 0u);
+                            rowM[i] = 0u, rowI[i] = 0u, rowD[i] = 0u;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+
+        // ---- count stored cells across the group
+        if (tid == 0) red[10] = 0, red[11] = 0;
+        __syncthreads();
+        atomicAdd(reinterpret_cast<unsigned int *>(&red[10]), (unsigned int)(my_cells & 0xFFFFFFFFull));
+        __syncthreads();
+
+        if (overflow || !done) {
+            if (tid == 0) {
+                rec[REC_STATUS]                          = ST_REDO_ARENA;
+                P.redo_list[atomicAdd(P.redo_count, 1u)] = pair;
+            }
+            continue;
+        }
+
+        // ---- end-cell search (semi-global) + backtrace + result record: lane 0 of wave 0
+        __syncthreads();
+        if (tid == 0) {
+            ArenaView av;
+            av.A = A, av.cap = cap, av.g = g, av.n_ent = n_ent;
+            uint32_t minS  = s_final;
+            int      lastK = Ak;
+            if (!glob) backtrace_start(av, n, m, s_final, minS, lastK);  // wfa.go:258-261
+
+            // ops scratch: free arena words between the rows and the directory
+            uint64_t  scratch0 = (top + 1ull) & ~1ull;
+            uint64_t  dir_lo   = cap - 4ull * (uint64_t)n_ent;
+            uint64_t  room     = dir_lo > scratch0 ? (dir_lo - scratch0) / 2ull : 0ull;
+            OpsWriter ow;
+            ow.init(reinterpret_cast<uint64_t *>(A + scratch0), (uint32_t)(room > 0xFFFFFFFFull ? 0xFFFFFFFFull : room));
+            TraceOut to;
+            back_trace(av, n, m, minS, lastK, !glob, x, P.o, e, ow, to);
+
+            if (ow.overflow) {
+                rec[REC_STATUS]                          = ST_REDO_ARENA;
+                P.redo_list[atomicAdd(P.redo_count, 1u)] = pair;
+            } else {
+                // process() (wfa_cigar.go:136-214): the forward list is the scratch list reversed
+                const uint32_t L   = ow.n;
+                const uint64_t off = atomicAdd(P.ops_cursor, (unsigned long long)L);
+                uint32_t begin = 0, end = 0;
+                bool     seenM = false;
+                for (uint32_t i = 0; i < L; i++) {
+                    const uint64_t op = ow.buf[L - 1 - i];
+                    if ((uint32_t)(op >> 32) == 'M') {
+                        if (!seenM) begin = i, seenM = true;
+                        end = i;
+                    }
+                    if (off + i < P.ops_cap) P.ops[off + i] = op;
+                }
+                uint32_t alen = 0, matches = 0, gaps = 0, regions = 0;
+                for (uint32_t i = begin; i <= end && i < L; i++) {
+                    const uint64_t op  = ow.buf[L - 1 - i];
+                    const uint32_t cnt = (uint32_t)op, o = (uint32_t)(op >> 32);
+                    alen += cnt;
+                    if (o == 'M')
+                        matches += cnt;
+                    else if (o == 'I' || o == 'D')
+                        gaps += cnt, regions++;
+                }
+                rec[REC_STATUS]      = ST_OK;
+                rec[REC_SCORE]       = to.score;
+                rec[REC_TBEGIN]      = (uint32_t)to.tbegin;
+                rec[REC_TEND]        = (uint32_t)to.tend;
+                rec[REC_QBEGIN]      = (uint32_t)to.qbegin;
+                rec[REC_QEND]        = (uint32_t)to.qend;
+                rec[REC_ALIGN_LEN]   = alen;
+                rec[REC_MATCHES]     = matches;
+                rec[REC_GAPS]        = gaps;
+                rec[REC_GAP_REGIONS] = regions;
+                rec[REC_OPS_LEN]     = L;
+                rec[REC_OPS_OFF_LO]  = (uint32_t)off;
+                rec[REC_OPS_OFF_HI]  = (uint32_t)(off >> 32);
+                rec[REC_CELLS_LO]    = (uint32_t)red[10];
+                rec[REC_CELLS_HI]    = 0u;
+                rec[REC_N_SCORES]    = s_final;
+            }
+            if (P.debug_info) P.debug_info[0] = n_ent, P.debug_info[1] = s_final;
+        }
+    }
+}
+
+}  // namespace wfa

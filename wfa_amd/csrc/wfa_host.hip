@@ -1,0 +1,636 @@
+// wfa_host.hip -- the C-ABI of libwfahip.so (include/wfa_hip.h): context, workspaces, launch
+// configuration, retry ladder (bigger arena / byte-compare path) and result unpacking.
+//
+// There is NO CPU fallback here: every alignment is produced by the HIP kernels.  Without a GPU the
+// entry points return WFAHIP_ERR_NO_DEVICE.
+#include "../../include/wfa_hip.h"
+#include "wfa_generic.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <numeric>
+#include <string>
+#include <vector>
+
+using namespace wfa;
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess) {                                                                        \
+            std::snprintf(ctx->last_error, sizeof ctx->last_error, "%s:%d %s -> %s", __FILE__, __LINE__, \
+                          #expr, hipGetErrorString(_e));                                               \
+            return (_e == hipErrorOutOfMemory) ? WFAHIP_ERR_OOM : WFAHIP_ERR_HIP;                      \
+        }                                                                                              \
+    } while (0)
+
+namespace {
+
+struct DevBuf {
+    void  *p     = nullptr;
+    size_t bytes = 0;
+};
+
+// ctrl words (device): [0] queue_head [1] redo_count [2,3] ops_cursor (u64) [4,5] debug_info
+constexpr int CTRL_WORDS = 8;
+
+}  // namespace
+
+struct wfahip_ctx {
+    int           device     = 0;
+    int           num_cus    = 256;
+    size_t        total_mem  = 0;
+    hipStream_t   stream     = nullptr;
+    hipEvent_t    ev0 = nullptr, ev1 = nullptr, evA = nullptr, evB = nullptr;
+    DevBuf        arena, ctrl, redo, work;
+    DevBuf        in_blob, in_qoff, in_qlen, in_toff, in_tlen, out_rec, out_ops;  // host-entry staging
+    // options (0 = automatic)
+    int64_t       opt_arena_bytes_per_slot = 0;
+    int64_t       opt_slots                = 0;
+    int64_t       opt_threads_per_pair     = 0;
+    int           force_mode               = -1;  // debug: start the ladder in this mode
+    wfahip_timing timing{};
+    char          last_error[256] = {0};
+};
+
+namespace {
+
+int ensure(wfahip_ctx *ctx, DevBuf &b, size_t bytes) {
+    if (b.bytes >= bytes && b.p) return WFAHIP_OK;
+    if (b.p) {
+        HIP_TRY(hipFree(b.p));
+        b.p = nullptr, b.bytes = 0;
+    }
+    size_t want = std::max<size_t>(bytes, 256);
+    HIP_TRY(hipMalloc(&b.p, want));
+    b.bytes = want;
+    return WFAHIP_OK;
+}
+
+void release(DevBuf &b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr, b.bytes = 0;
+}
+
+uint32_t gcd_u32(uint32_t a, uint32_t b) {
+    while (b) {
+        uint32_t t = a % b;
+        a          = b;
+        b          = t;
+    }
+    return a;
+}
+
+struct LaunchCfg {
+    int      waves;        // 1, 4 or 16 waves per pair
+    int      mode;         // 0 = 2-bit LDS, 1 = bytes in global memory
+    uint32_t lds_seq_words;
+    size_t   lds_bytes;
+    uint64_t arena_words;  // per slot
+    uint32_t slots;
+};
+
+template <int WAVES, int MODE>
+hipError_t launch_one(const KParams &P, const LaunchCfg &c, hipStream_t st) {
+    auto kfn = wfa_generic_kernel<WAVES, MODE>;
+    if (c.lds_bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kfn, dim3(c.slots), dim3(64 * WAVES), c.lds_bytes, st, P);
+    return hipGetLastError();
+}
+
+hipError_t launch_generic(const KParams &P, const LaunchCfg &c, hipStream_t st) {
+    switch (c.waves * 2 + c.mode) {
+    case 1 * 2 + 0: return launch_one<1, 0>(P, c, st);
+    case 1 * 2 + 1: return launch_one<1, 1>(P, c, st);
+    case 4 * 2 + 0: return launch_one<4, 0>(P, c, st);
+    case 4 * 2 + 1: return launch_one<4, 1>(P, c, st);
+    case 16 * 2 + 0: return launch_one<16, 0>(P, c, st);
+    case 16 * 2 + 1: return launch_one<16, 1>(P, c, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+struct Job {
+    int                   mode;
+    int                   level;  // arena size = base * 8^level
+    bool                  all;    // identity work list over all pairs
+    std::vector<uint32_t> pairs;
+};
+
+constexpr size_t LDS_MAX_BYTES = 160 * 1024;
+
+// Launch configuration for one job.
+int make_cfg(wfahip_ctx *ctx, uint32_t max_len, int mode, int level, uint64_t n_work, LaunchCfg &c) {
+    int waves = max_len <= 4096 ? 1 : (max_len <= 65536 ? 4 : 16);
+    if (ctx->opt_threads_per_pair > 0) {
+        int64_t t = ctx->opt_threads_per_pair;
+        waves     = t <= 64 ? 1 : (t <= 256 ? 4 : 16);
+    }
+    c.waves         = waves;
+    c.mode          = mode;
+    c.lds_seq_words = (mode == 0) ? ((max_len + 15) / 16 + 1) : 0;
+    c.lds_bytes     = (2ull * c.lds_seq_words + GEN_LDS_EXTRA_WORDS) * 4ull;
+    if (c.lds_bytes > LDS_MAX_BYTES) return 1;  // caller must use mode 1
+
+    uint64_t base_words = std::max<uint64_t>(64 * 1024, 96ull * max_len);
+    if (ctx->opt_arena_bytes_per_slot > 0) base_words = std::max<uint64_t>(4096, ctx->opt_arena_bytes_per_slot / 4);
+    uint64_t words = base_words;
+    for (int i = 0; i < level; i++) words *= 8;
+    words         = (words + 3) & ~3ull;  // directory entries are 16-byte aligned from the slot end
+    c.arena_words = words;
+
+    // resident workgroups per CU: 32 wave slots, LDS, and keep <= 8 blocks of >=256 threads
+    uint32_t per_cu = 32 / waves;
+    per_cu          = std::min<uint32_t>(per_cu, (uint32_t)(LDS_MAX_BYTES / std::max<size_t>(c.lds_bytes, 1)));
+    per_cu          = std::max<uint32_t>(per_cu, 1);
+    uint64_t slots  = (uint64_t)ctx->num_cus * per_cu;
+    if (ctx->opt_slots > 0) slots = (uint64_t)ctx->opt_slots;
+    // arena budget: at most ~60 % of device memory
+    uint64_t budget = (uint64_t)((double)ctx->total_mem * 0.6);
+    uint64_t fit    = budget / (words * 4ull);
+    if (fit == 0) return 2;  // even one slot does not fit
+    slots   = std::min<uint64_t>(slots, fit);
+    slots   = std::min<uint64_t>(slots, std::max<uint64_t>(n_work, 1));
+    c.slots = (uint32_t)slots;
+    return 0;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------ C-ABI
+extern "C" int wfahip_version(void) { return WFAHIP_VERSION; }
+
+extern "C" const char *wfahip_strerror(int code) {
+    switch (code) {
+    case WFAHIP_OK: return "ok";
+    case WFAHIP_ERR_NO_DEVICE: return "no HIP device available";
+    case WFAHIP_ERR_BAD_ARG: return "bad argument";
+    case WFAHIP_ERR_OOM: return "out of memory (device or ops buffer)";
+    case WFAHIP_ERR_HIP: return "HIP runtime error";
+    case WFAHIP_ERR_UNSUPPORTED: return "unsupported penalties (mismatch and gap_ext must be > 0)";
+    case WFAHIP_ERR_INTERNAL: return "internal error";
+    }
+    return "unknown error";
+}
+
+extern "C" int wfahip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int wfahip_create(int device_id, wfahip_ctx **out) {
+    if (!out) return WFAHIP_ERR_BAD_ARG;
+    *out = nullptr;
+    int n = wfahip_device_count();
+    if (n <= 0) return WFAHIP_ERR_NO_DEVICE;
+    int dev = device_id;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return WFAHIP_ERR_NO_DEVICE;
+    if (dev >= n) return WFAHIP_ERR_BAD_ARG;
+    wfahip_ctx *ctx = new wfahip_ctx();
+    ctx->device     = dev;
+    if (hipSetDevice(dev) != hipSuccess) {
+        delete ctx;
+        return WFAHIP_ERR_HIP;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+        ctx->num_cus   = prop.multiProcessorCount;
+        ctx->total_mem = prop.totalGlobalMem;
+    }
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
+        hipEventCreate(&ctx->evA) != hipSuccess || hipEventCreate(&ctx->evB) != hipSuccess) {
+        delete ctx;
+        return WFAHIP_ERR_HIP;
+    }
+    *out = ctx;
+    return WFAHIP_OK;
+}
+
+extern "C" void wfahip_destroy(wfahip_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    for (DevBuf *b : {&ctx->arena, &ctx->ctrl, &ctx->redo, &ctx->work, &ctx->in_blob, &ctx->in_qoff, &ctx->in_qlen,
+                      &ctx->in_toff, &ctx->in_tlen, &ctx->out_rec, &ctx->out_ops})
+        release(*b);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->evA) (void)hipEventDestroy(ctx->evA);
+    if (ctx->evB) (void)hipEventDestroy(ctx->evB);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int wfahip_set_option(wfahip_ctx *ctx, const char *key, int64_t value) {
+    if (!ctx || !key) return WFAHIP_ERR_BAD_ARG;
+    std::string k(key);
+    if (k == "arena_bytes_per_slot")
+        ctx->opt_arena_bytes_per_slot = value;
+    else if (k == "slots")
+        ctx->opt_slots = value;
+    else if (k == "threads_per_pair")
+        ctx->opt_threads_per_pair = value;
+    else
+        return WFAHIP_ERR_BAD_ARG;
+    return WFAHIP_OK;
+}
+
+extern "C" int wfahip_last_timing(const wfahip_ctx *ctx, wfahip_timing *out) {
+    if (!ctx || !out) return WFAHIP_ERR_BAD_ARG;
+    *out = ctx->timing;
+    return WFAHIP_OK;
+}
+
+extern "C" void wfahip_free(void *p) { std::free(p); }
+
+static int check_params(const wfahip_params *p) {
+    if (!p) return WFAHIP_ERR_BAD_ARG;
+    if (p->mismatch == 0 || p->gap_ext == 0) return WFAHIP_ERR_UNSUPPORTED;
+    if (p->adaptive && p->min_wf_len == 0) return WFAHIP_ERR_BAD_ARG;  // AdaptiveReduction rejects it (wfa.go:134-137)
+    return WFAHIP_OK;
+}
+
+// Core: everything device-resident.  keep_debug: run with one slot and keep ctrl debug words.
+static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_blob, uint64_t blob_bytes,
+                        const void *d_q_off, const void *d_q_len, const void *d_t_off, const void *d_t_len,
+                        uint64_t n_pairs, uint32_t max_len, void *d_rec, void *d_ops, uint64_t ops_cap,
+                        uint64_t *ops_needed, hipStream_t st, bool debug_single) {
+    int rc = check_params(p);
+    if (rc != WFAHIP_OK) return rc;
+    if (n_pairs > 0xFFFFFFF0ull) return WFAHIP_ERR_BAD_ARG;
+    ctx->timing = wfahip_timing{};
+    if (ops_needed) *ops_needed = 0;
+    if (n_pairs == 0) return WFAHIP_OK;
+    if (!d_q_off || !d_q_len || !d_t_off || !d_t_len || !d_rec || (!d_ops && ops_cap)) return WFAHIP_ERR_BAD_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (!st) st = ctx->stream;
+
+    if (max_len == 0) {  // compute the bound from the device-resident length arrays
+        std::vector<uint32_t> ql(n_pairs), tl(n_pairs);
+        HIP_TRY(hipMemcpyAsync(ql.data(), d_q_len, n_pairs * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(tl.data(), d_t_len, n_pairs * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (uint64_t i = 0; i < n_pairs; i++) {
+            if (ql[i] <= WFAHIP_MAX_SEQ_LEN) max_len = std::max(max_len, ql[i]);
+            if (tl[i] <= WFAHIP_MAX_SEQ_LEN) max_len = std::max(max_len, tl[i]);
+        }
+        if (max_len == 0) max_len = 1;
+    }
+
+    rc = ensure(ctx, ctx->ctrl, CTRL_WORDS * 4);
+    if (rc) return rc;
+    rc = ensure(ctx, ctx->redo, n_pairs * 4);
+    if (rc) return rc;
+    uint32_t *d_ctrl = static_cast<uint32_t *>(ctx->ctrl.p);
+
+    KParams P{};
+    P.blob = static_cast<const uint8_t *>(d_blob), P.blob_bytes = blob_bytes;
+    P.q_off = static_cast<const uint64_t *>(d_q_off), P.q_len = static_cast<const uint32_t *>(d_q_len);
+    P.t_off = static_cast<const uint64_t *>(d_t_off), P.t_len = static_cast<const uint32_t *>(d_t_len);
+    P.queue_head = d_ctrl + 0;
+    P.redo_count = d_ctrl + 1;
+    P.ops_cursor = reinterpret_cast<unsigned long long *>(d_ctrl + 2);
+    P.debug_info = debug_single ? d_ctrl + 4 : nullptr;
+    P.redo_list  = static_cast<uint32_t *>(ctx->redo.p);
+    P.x = p->mismatch, P.o = p->gap_open, P.e = p->gap_ext, P.oe = p->gap_open + p->gap_ext;
+    P.g                = gcd_u32(gcd_u32(P.x, P.oe), P.e);
+    P.global_alignment = p->global_alignment ? 1 : 0;
+    P.adaptive = p->adaptive ? 1 : 0, P.min_wf_len = p->min_wf_len, P.max_dist_diff = p->max_dist_diff;
+    P.rec = static_cast<uint32_t *>(d_rec);
+    P.ops = static_cast<uint64_t *>(d_ops), P.ops_cap = ops_cap;
+
+    HIP_TRY(hipMemsetAsync(d_ctrl, 0, CTRL_WORDS * 4, st));
+    HIP_TRY(hipEventRecord(ctx->ev0, st));
+
+    std::deque<Job> jobs;
+    {
+        Job j;
+        j.mode = ctx->force_mode == 1 ? 1 : 0, j.level = 0, j.all = true;
+        jobs.push_back(std::move(j));
+    }
+    std::vector<uint32_t> no_memory;
+    const int             max_level = 6;
+    bool                  first     = true;
+
+    while (!jobs.empty()) {
+        Job job = std::move(jobs.front());
+        jobs.pop_front();
+        const uint64_t n_work = job.all ? n_pairs : job.pairs.size();
+        if (n_work == 0) continue;
+        LaunchCfg cfg;
+        int       cr = make_cfg(ctx, max_len, job.mode, job.level, n_work, cfg);
+        if (cr == 1) {  // sequences do not fit LDS: byte path for the whole job
+            job.mode = 1;
+            cr       = make_cfg(ctx, max_len, 1, job.level, n_work, cfg);
+        }
+        if (debug_single) cfg.slots = 1;
+        if (cr == 2 || job.level > max_level) {
+            if (job.all) {
+                no_memory.resize(n_pairs);
+                std::iota(no_memory.begin(), no_memory.end(), 0u);
+            } else {
+                no_memory.insert(no_memory.end(), job.pairs.begin(), job.pairs.end());
+            }
+            continue;
+        }
+        rc = ensure(ctx, ctx->arena, (size_t)cfg.arena_words * 4ull * cfg.slots);
+        if (rc == WFAHIP_ERR_OOM && cfg.slots > 1) {  // shrink once
+            cfg.slots = std::max<uint32_t>(1, cfg.slots / 4);
+            rc        = ensure(ctx, ctx->arena, (size_t)cfg.arena_words * 4ull * cfg.slots);
+        }
+        if (rc) return rc;
+        ctx->timing.arena_bytes = std::max<uint64_t>(ctx->timing.arena_bytes, (uint64_t)cfg.arena_words * 4ull * cfg.slots);
+
+        P.arena = static_cast<uint32_t *>(ctx->arena.p), P.arena_words = cfg.arena_words;
+        P.lds_seq_words = cfg.lds_seq_words;
+        P.n_work        = (uint32_t)n_work;
+        if (job.all) {
+            P.work = nullptr;
+        } else {
+            rc = ensure(ctx, ctx->work, n_work * 4);
+            if (rc) return rc;
+            HIP_TRY(hipMemcpyAsync(ctx->work.p, job.pairs.data(), n_work * 4, hipMemcpyHostToDevice, st));
+            P.work = static_cast<const uint32_t *>(ctx->work.p);
+        }
+        HIP_TRY(hipMemsetAsync(d_ctrl, 0, 8, st));  // queue_head, redo_count
+        HIP_TRY(hipEventRecord(ctx->evA, st));
+        HIP_TRY(launch_generic(P, cfg, st));
+        HIP_TRY(hipEventRecord(ctx->evB, st));
+        uint32_t hctrl[CTRL_WORDS];
+        HIP_TRY(hipMemcpyAsync(hctrl, d_ctrl, sizeof hctrl, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, ctx->evA, ctx->evB));
+        ctx->timing.kernel_ms += ms;
+        if (first) ctx->timing.main_kernel_ms = ms, first = false;
+        ctx->timing.n_launches++;
+
+        const uint32_t n_redo = hctrl[1];
+        if (n_redo) {
+            ctx->timing.n_retried_pairs += n_redo;
+            std::vector<uint32_t> ids(n_redo), st_words(n_redo);
+            HIP_TRY(hipMemcpy(ids.data(), ctx->redo.p, n_redo * 4ull, hipMemcpyDeviceToHost));
+            std::sort(ids.begin(), ids.end());
+            // fetch each pair's status word (strided gather; redo sets are small)
+            for (uint32_t i = 0; i < n_redo; i++)
+                HIP_TRY(hipMemcpy(&st_words[i], P.rec + (uint64_t)ids[i] * REC_WORDS, 4, hipMemcpyDeviceToHost));
+            Job jb, ja;
+            jb.mode = 1, jb.level = job.level, jb.all = false;
+            ja.mode = job.mode, ja.level = job.level + 1, ja.all = false;
+            for (uint32_t i = 0; i < n_redo; i++) {
+                if (st_words[i] == ST_REDO_BYTES || st_words[i] == ST_REDO_LDS)
+                    jb.pairs.push_back(ids[i]);
+                else
+                    ja.pairs.push_back(ids[i]);
+            }
+            if (!jb.pairs.empty()) jobs.push_back(std::move(jb));
+            if (!ja.pairs.empty()) jobs.push_back(std::move(ja));
+        }
+        if (debug_single) break;
+    }
+    HIP_TRY(hipEventRecord(ctx->ev1, st));
+
+    for (uint32_t pid : no_memory) {
+        uint32_t recw[REC_WORDS] = {0};
+        recw[REC_STATUS]         = ST_NO_MEMORY;
+        HIP_TRY(hipMemcpyAsync(P.rec + (uint64_t)pid * REC_WORDS, recw, sizeof recw, hipMemcpyHostToDevice, st));
+    }
+    uint32_t hctrl[CTRL_WORDS];
+    HIP_TRY(hipMemcpyAsync(hctrl, d_ctrl, sizeof hctrl, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    ctx->timing.total_ms    = ms;
+    const uint64_t cursor   = (uint64_t)hctrl[2] | ((uint64_t)hctrl[3] << 32);
+    ctx->timing.ops_written = cursor;
+    if (ops_needed) *ops_needed = cursor;
+    if (cursor > ops_cap) return WFAHIP_ERR_OOM;
+    return WFAHIP_OK;
+}
+
+extern "C" int wfahip_align_batch_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_seq_blob,
+                                         uint64_t blob_bytes, const void *d_q_off, const void *d_q_len,
+                                         const void *d_t_off, const void *d_t_len, uint64_t n_pairs,
+                                         uint32_t max_len, void *d_rec, void *d_ops, uint64_t ops_cap,
+                                         uint64_t *ops_needed, void *stream) {
+    if (!ctx) return WFAHIP_ERR_BAD_ARG;
+    return align_device(ctx, p, d_seq_blob, blob_bytes, d_q_off, d_q_len, d_t_off, d_t_len, n_pairs, max_len,
+                        d_rec, d_ops, ops_cap, ops_needed, static_cast<hipStream_t>(stream), false);
+}
+
+static void results_zero(wfahip_results *r) { std::memset(r, 0, sizeof *r); }
+
+extern "C" void wfahip_results_free(wfahip_results *r) {
+    if (!r) return;
+    std::free(r->status), std::free(r->score), std::free(r->tbegin), std::free(r->tend), std::free(r->qbegin);
+    std::free(r->qend), std::free(r->align_len), std::free(r->matches), std::free(r->gaps);
+    std::free(r->gap_regions), std::free(r->ops_off), std::free(r->ops_len), std::free(r->ops);
+    results_zero(r);
+}
+
+static int unpack_results(const std::vector<uint32_t> &rec, const std::vector<uint64_t> &ops, uint64_t n,
+                          wfahip_results *out, uint64_t *cells_total) {
+    results_zero(out);
+    out->n = n;
+    size_t cnt = std::max<uint64_t>(n, 1);
+#define ALLOC(field, type)                                            \
+    out->field = static_cast<type *>(std::calloc(cnt, sizeof(type))); \
+    if (!out->field) return WFAHIP_ERR_OOM;
+    ALLOC(status, int32_t) ALLOC(score, uint32_t) ALLOC(tbegin, int32_t) ALLOC(tend, int32_t)
+    ALLOC(qbegin, int32_t) ALLOC(qend, int32_t) ALLOC(align_len, uint32_t) ALLOC(matches, uint32_t)
+    ALLOC(gaps, uint32_t) ALLOC(gap_regions, uint32_t) ALLOC(ops_off, uint64_t) ALLOC(ops_len, uint32_t)
+#undef ALLOC
+    uint64_t total = 0;
+    for (uint64_t i = 0; i < n; i++)
+        if (rec[i * REC_WORDS + REC_STATUS] == ST_OK) total += rec[i * REC_WORDS + REC_OPS_LEN];
+    out->ops = static_cast<uint64_t *>(std::malloc(std::max<uint64_t>(total, 1) * 8));
+    if (!out->ops) return WFAHIP_ERR_OOM;
+    uint64_t pos = 0, cells = 0;
+    for (uint64_t i = 0; i < n; i++) {  // ops are re-packed in pair order (device order is completion order)
+        const uint32_t *r  = &rec[i * REC_WORDS];
+        uint32_t        st = r[REC_STATUS];
+        out->status[i]     = (st == ST_OK || st == ST_EMPTY || st == ST_TOO_LONG) ? (int32_t)st : WFAHIP_PAIR_NO_MEMORY;
+        if (st != ST_OK) continue;
+        out->score[i]       = r[REC_SCORE];
+        out->tbegin[i]      = (int32_t)r[REC_TBEGIN];
+        out->tend[i]        = (int32_t)r[REC_TEND];
+        out->qbegin[i]      = (int32_t)r[REC_QBEGIN];
+        out->qend[i]        = (int32_t)r[REC_QEND];
+        out->align_len[i]   = r[REC_ALIGN_LEN];
+        out->matches[i]     = r[REC_MATCHES];
+        out->gaps[i]        = r[REC_GAPS];
+        out->gap_regions[i] = r[REC_GAP_REGIONS];
+        out->ops_len[i]     = r[REC_OPS_LEN];
+        out->ops_off[i]     = pos;
+        uint64_t src        = (uint64_t)r[REC_OPS_OFF_LO] | ((uint64_t)r[REC_OPS_OFF_HI] << 32);
+        std::memcpy(out->ops + pos, ops.data() + src, (size_t)r[REC_OPS_LEN] * 8);
+        pos += r[REC_OPS_LEN];
+        cells += (uint64_t)r[REC_CELLS_LO] | ((uint64_t)r[REC_CELLS_HI] << 32);
+    }
+    out->n_ops = pos;
+    if (cells_total) *cells_total = cells;
+    return WFAHIP_OK;
+}
+
+extern "C" int wfahip_align_batch(wfahip_ctx *ctx, const wfahip_params *p, const uint8_t *seq_blob,
+                                  uint64_t blob_bytes, const uint64_t *q_off, const uint32_t *q_len,
+                                  const uint64_t *t_off, const uint32_t *t_len, uint64_t n_pairs,
+                                  wfahip_results *out) {
+    if (!ctx || !out) return WFAHIP_ERR_BAD_ARG;
+    results_zero(out);
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (n_pairs == 0) return WFAHIP_OK;
+    if (!q_off || !q_len || !t_off || !t_len || (!seq_blob && blob_bytes)) return WFAHIP_ERR_BAD_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+
+    uint32_t max_len = 1;
+    uint64_t sum_len = 0;
+    for (uint64_t i = 0; i < n_pairs; i++) {
+        if (q_len[i] <= WFAHIP_MAX_SEQ_LEN && t_len[i] <= WFAHIP_MAX_SEQ_LEN && q_len[i] && t_len[i]) {
+            if (q_off[i] + q_len[i] > blob_bytes || t_off[i] + t_len[i] > blob_bytes) return WFAHIP_ERR_BAD_ARG;
+            max_len = std::max(max_len, std::max(q_len[i], t_len[i]));
+            sum_len += (uint64_t)q_len[i] + t_len[i];
+        }
+    }
+    hipStream_t st = ctx->stream;
+    // device staging (+16 bytes so aligned dword loads at the tail stay inside the allocation)
+    if ((rc = ensure(ctx, ctx->in_blob, blob_bytes + 16))) return rc;
+    if ((rc = ensure(ctx, ctx->in_qoff, n_pairs * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->in_toff, n_pairs * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->in_qlen, n_pairs * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->in_tlen, n_pairs * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->out_rec, n_pairs * REC_WORDS * 4))) return rc;
+    if (blob_bytes) HIP_TRY(hipMemcpyAsync(ctx->in_blob.p, seq_blob, blob_bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(ctx->in_qoff.p, q_off, n_pairs * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(ctx->in_toff.p, t_off, n_pairs * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(ctx->in_qlen.p, q_len, n_pairs * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(ctx->in_tlen.p, t_len, n_pairs * 4, hipMemcpyHostToDevice, st));
+
+    // CIGAR ops are merged runs: a first guess of (n+m)/4 + 8 per pair, grown on demand (at most n+m+2 each)
+    uint64_t ops_cap = sum_len / 4 + 8 * n_pairs + 1024;
+    for (int attempt = 0; attempt < 3; attempt++) {
+        if ((rc = ensure(ctx, ctx->out_ops, ops_cap * 8))) return rc;
+        uint64_t needed = 0;
+        rc = align_device(ctx, p, ctx->in_blob.p, blob_bytes, ctx->in_qoff.p, ctx->in_qlen.p, ctx->in_toff.p,
+                          ctx->in_tlen.p, n_pairs, max_len, ctx->out_rec.p, ctx->out_ops.p, ops_cap, &needed, st,
+                          false);
+        if (rc == WFAHIP_ERR_OOM && needed > ops_cap) {
+            ops_cap = needed + 1024;
+            continue;
+        }
+        break;
+    }
+    if (rc) return rc;
+
+    std::vector<uint32_t> rec(n_pairs * REC_WORDS);
+    std::vector<uint64_t> ops(std::max<uint64_t>(ctx->timing.ops_written, 1));
+    HIP_TRY(hipMemcpy(rec.data(), ctx->out_rec.p, rec.size() * 4, hipMemcpyDeviceToHost));
+    if (ctx->timing.ops_written)
+        HIP_TRY(hipMemcpy(ops.data(), ctx->out_ops.p, ctx->timing.ops_written * 8, hipMemcpyDeviceToHost));
+    uint64_t cells = 0;
+    rc             = unpack_results(rec, ops, n_pairs, out, &cells);
+    ctx->timing.cells_stored = cells;
+    if (rc) wfahip_results_free(out);
+    return rc;
+}
+
+extern "C" int wfahip_debug_wavefronts(wfahip_ctx *ctx, const wfahip_params *p, const uint8_t *q, uint32_t n,
+                                       const uint8_t *t, uint32_t m, wfahip_row **rows, uint64_t *n_rows,
+                                       uint32_t **words, uint64_t *n_words, wfahip_results *res) {
+    if (!ctx || !rows || !n_rows || !words || !n_words || !q || !t || n == 0 || m == 0) return WFAHIP_ERR_BAD_ARG;
+    *rows = nullptr, *words = nullptr, *n_rows = 0, *n_words = 0;
+    if (res) results_zero(res);
+    int rc = check_params(p);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+
+    bool acgt = true;
+    for (uint32_t i = 0; i < n && acgt; i++) acgt = q[i] == 'A' || q[i] == 'C' || q[i] == 'G' || q[i] == 'T';
+    for (uint32_t i = 0; i < m && acgt; i++) acgt = t[i] == 'A' || t[i] == 'C' || t[i] == 'G' || t[i] == 'T';
+
+    std::vector<uint8_t> blob((size_t)n + m);
+    std::memcpy(blob.data(), q, n);
+    std::memcpy(blob.data() + n, t, m);
+    uint64_t qo = 0, to = n;
+    if ((rc = ensure(ctx, ctx->in_blob, blob.size() + 16))) return rc;
+    if ((rc = ensure(ctx, ctx->in_qoff, 8))) return rc;
+    if ((rc = ensure(ctx, ctx->in_toff, 8))) return rc;
+    if ((rc = ensure(ctx, ctx->in_qlen, 4))) return rc;
+    if ((rc = ensure(ctx, ctx->in_tlen, 4))) return rc;
+    if ((rc = ensure(ctx, ctx->out_rec, REC_WORDS * 4))) return rc;
+    uint64_t ops_cap = (uint64_t)n + m + 16;
+    if ((rc = ensure(ctx, ctx->out_ops, ops_cap * 8))) return rc;
+    HIP_TRY(hipMemcpyAsync(ctx->in_blob.p, blob.data(), blob.size(), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(ctx->in_qoff.p, &qo, 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(ctx->in_toff.p, &to, 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(ctx->in_qlen.p, &n, 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(ctx->in_tlen.p, &m, 4, hipMemcpyHostToDevice, st));
+
+    // grow the single slot until the pair fits; the byte path is chosen up front for non-ACGT input
+    const int64_t saved = ctx->opt_arena_bytes_per_slot;
+    int64_t       bytes = saved > 0 ? saved : (int64_t)std::max<uint64_t>(256 * 1024, 384ull * std::max(n, m));
+    uint32_t      recw[REC_WORDS];
+    uint32_t      hctrl[CTRL_WORDS];
+    for (int attempt = 0;; attempt++) {
+        ctx->opt_arena_bytes_per_slot = bytes;
+        // debug_single stops after one launch, so the byte path is chosen up front for non-ACGT input
+        ctx->force_mode = acgt ? 0 : 1;
+        rc = align_device(ctx, p, ctx->in_blob.p, blob.size(), ctx->in_qoff.p, ctx->in_qlen.p, ctx->in_toff.p,
+                          ctx->in_tlen.p, 1, std::max(n, m), ctx->out_rec.p, ctx->out_ops.p, ops_cap, nullptr, st,
+                          true);
+        ctx->force_mode               = -1;
+        ctx->opt_arena_bytes_per_slot = saved;
+        if (rc) return rc;
+        HIP_TRY(hipMemcpy(recw, ctx->out_rec.p, sizeof recw, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(hctrl, ctx->ctrl.p, sizeof hctrl, hipMemcpyDeviceToHost));
+        if (recw[REC_STATUS] == ST_REDO_ARENA && attempt < 8) {
+            bytes *= 8;
+            continue;
+        }
+        break;
+    }
+    if (recw[REC_STATUS] != ST_OK) return WFAHIP_ERR_INTERNAL;
+
+    const uint64_t cap   = (uint64_t)(((bytes / 4) + 3) & ~3ll);
+    const uint32_t n_ent = hctrl[4];
+    std::vector<uint32_t> dir((size_t)n_ent * 4);
+    HIP_TRY(hipMemcpy(dir.data(), static_cast<uint32_t *>(ctx->arena.p) + cap - 4ull * n_ent, dir.size() * 4,
+                      hipMemcpyDeviceToHost));
+    uint64_t total = 0, nr = 0;
+    for (uint32_t i = 0; i < n_ent; i++) {
+        const uint32_t *e = &dir[(size_t)(n_ent - 1 - i) * 4];
+        if ((int32_t)e[2] > 0) total += 3ull * e[2], nr++;
+    }
+    *rows  = static_cast<wfahip_row *>(std::malloc(std::max<uint64_t>(nr, 1) * sizeof(wfahip_row)));
+    *words = static_cast<uint32_t *>(std::malloc(std::max<uint64_t>(total, 1) * 4));
+    if (!*rows || !*words) return WFAHIP_ERR_OOM;
+    const uint32_t g = gcd_u32(gcd_u32(p->mismatch, p->gap_open + p->gap_ext), p->gap_ext);
+    uint64_t       pos = 0, ri = 0;
+    for (uint32_t i = 0; i < n_ent; i++) {
+        const uint32_t *e = &dir[(size_t)(n_ent - 1 - i) * 4];
+        if ((int32_t)e[2] <= 0) continue;
+        HIP_TRY(hipMemcpy(*words + pos, static_cast<uint32_t *>(ctx->arena.p) + e[0], 12ull * e[2],
+                          hipMemcpyDeviceToHost));
+        (*rows)[ri++] = wfahip_row{i * g, (int32_t)e[1], e[2], pos};
+        pos += 3ull * e[2];
+    }
+    *n_rows = nr, *n_words = total;
+    if (res) {
+        std::vector<uint32_t> rec(recw, recw + REC_WORDS);
+        std::vector<uint64_t> ops(std::max<uint64_t>(ctx->timing.ops_written, 1));
+        if (ctx->timing.ops_written)
+            HIP_TRY(hipMemcpy(ops.data(), ctx->out_ops.p, ctx->timing.ops_written * 8, hipMemcpyDeviceToHost));
+        rc = unpack_results(rec, ops, 1, res, nullptr);
+    }
+    return rc;
+}
