@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py -- aligned pairs/s of the HIP wavefront-alignment hot path on MI355X.
+
+Workload (BASELINE.json configs[2], the one `metric` is quoted on): 1e6 synthetic 1 kbp DNA pairs at 5 % error
+per GPU, global alignment, wf-adaptive 10/50/1, penalties 4/6/2, seed 3.  A "step" is one pass of the hot path
+over the rank's batch: raw byte sequences already resident in HBM -> result records + CIGAR ops in HBM.
+Multi-GPU (torchrun, one rank per GPU): pairs are sharded over ranks (weak scaling: 1e6 pairs per GPU, rank r
+owns dataset indices [r*n, (r+1)*n)), no data-path collective; the only RCCL traffic is the gather of the
+result records and CIGAR ops onto rank 0 at the end of every step.
+
+Prints ONE JSON line (rank 0).  `value` = pairs aligned by all ranks / max-over-ranks wall time of K steps.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pairs", type=int, default=1_000_000, help="pairs per GPU")
+    ap.add_argument("--length", type=int, default=1000)
+    ap.add_argument("--error", type=float, default=0.05)
+    ap.add_argument("--seed", type=int, default=3)
+    ap.add_argument("--semi-global", action="store_true")
+    ap.add_argument("--no-adaptive", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=60_000, help="pairs timed on one host core (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=1)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+
+    import __graft_entry__ as entry
+    entry.build()
+    import wfa_amd as w
+    from wfa_amd import _lib as L
+
+    n = args.pairs
+    # ---- synthetic input (host generation, then H2D: outside the timed region)
+    blob, q_off, q_len, t_off, t_len = w.generate_pairs(args.seed, n, args.length, args.error,
+                                                        first_index=rank * n, n_threads=min(32, os.cpu_count() or 8))
+    d_blob = torch.from_numpy(blob).to(dev)
+    d_qoff = torch.from_numpy(q_off.view(np.int64)).to(dev)
+    d_toff = torch.from_numpy(t_off.view(np.int64)).to(dev)
+    d_qlen = torch.from_numpy(q_len.view(np.int32)).to(dev)
+    d_tlen = torch.from_numpy(t_len.view(np.int32)).to(dev)
+    max_len = int(max(q_len.max(), t_len.max()))
+    sum_len = int(q_len.astype(np.int64).sum() + t_len.astype(np.int64).sum())
+    ops_cap = sum_len // 4 + 8 * n + 1024
+    d_rec = torch.empty((n, L.REC_WORDS), dtype=torch.int32, device=dev)
+    d_ops = torch.empty(ops_cap, dtype=torch.int64, device=dev)
+
+    al = w.New(w.DefaultPenalties, w.Options(GlobalAlignment=not args.semi_global), device=local_rank)
+    if not args.no_adaptive:
+        assert al.AdaptiveReduction(w.DefaultAdaptiveOption) is None
+    prm = al._params()
+    lib = L.lib()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    timing = L.Timing()
+
+    def step():
+        needed = C.c_uint64()
+        rc = lib.wfahip_align_batch_device(al._ctx, C.byref(prm), d_blob.data_ptr(), blob.size, d_qoff.data_ptr(),
+                                           d_qlen.data_ptr(), d_toff.data_ptr(), d_tlen.data_ptr(), n, max_len,
+                                           d_rec.data_ptr(), d_ops.data_ptr(), ops_cap, C.byref(needed), stream)
+        L.check(rc, "wfahip_align_batch_device")
+        lib.wfahip_last_timing(al._ctx, C.byref(timing))
+        n_ops = int(needed.value)
+        if world > 1:  # result gather onto rank 0 over RCCL/xGMI (fixed-size records, then padded op arrays)
+            cnt = torch.tensor([n_ops], dtype=torch.int64, device=dev)
+            dist.all_reduce(cnt, op=dist.ReduceOp.MAX)
+            m = int(cnt.item())
+            recs = [torch.empty_like(d_rec) for _ in range(world)] if rank == 0 else None
+            dist.gather(d_rec, recs, dst=0)
+            opl = [torch.empty(m, dtype=torch.int64, device=dev) for _ in range(world)] if rank == 0 else None
+            dist.gather(d_ops[:m], opl, dst=0)
+        return n_ops
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    kernel_ms, main_ms = [], []
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        n_ops = step()
+        kernel_ms.append(timing.kernel_ms)
+        main_ms.append(timing.main_kernel_ms)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed = float(tt.item())
+
+    # ---- accounting for the roofline (algorithmic bytes)
+    rec = d_rec.cpu().numpy().view(np.uint32)
+    ok = rec[:, L.REC_STATUS] == 0
+    cells = int(rec[:, L.REC_CELLS_LO].astype(np.uint64).sum())
+    n_ops_total = int(rec[:, L.REC_OPS_LEN].astype(np.uint64).sum())
+    alg_bytes = 4 * cells + sum_len + 64 * n + 8 * n_ops_total
+    k_ms = float(np.mean(kernel_ms))
+    main_k_ms = float(np.mean(main_ms))
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9  # GB/s over the alignment kernels of one step
+
+    out = None
+    if rank == 0:
+        total_pairs = n * world * args.steps
+        value = total_pairs / elapsed
+        cfg = {"workload": f"{n} x {args.length} bp pairs/GPU @{args.error:.0%} error, "
+                           f"{'semi-global' if args.semi_global else 'global'} gap-affine 4/6/2, "
+                           f"wf-adaptive {'off' if args.no_adaptive else '10/50/1'}, seed {args.seed}",
+               "pairs_per_gpu": n, "length": args.length, "error_rate": args.error,
+               "parallelism": f"pair-sharded x{world}", "status_ok": int(ok.sum()),
+               "gcells_per_s": value * args.length * args.length / 1e9,
+               "kernel_ms_per_step": k_ms, "main_kernel_ms": main_k_ms, "launches_per_step": int(timing.n_launches),
+               "retried_pairs": int(timing.n_retried_pairs), "arena_gib": timing.arena_bytes / 2 ** 30,
+               "wf_cells_per_pair": cells / n, "cigar_ops_per_pair": n_ops_total / n}
+        out = {"metric": "aligned pairs/sec (and Gcells/s) on 1e6 synthetic 1 kbp pairs @5% error",
+               "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "u32", "data": "synthetic", "config": cfg,
+               "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                            "frac": achieved / 8000.0, "traffic": None,
+                            "algorithmic_bytes_per_launch": alg_bytes, "kernel": "wfa_generic_kernel<1,0>",
+                            "kernel_ms": k_ms}}
+        # ---- CPU baseline: the oracle (a literal port of the reference's algorithm) on a bounded sample of the
+        # same dataset, on this box's host cores.  Reported baseline, not the target.
+        if args.cpu_sample > 0:
+            from oracle import oracle as O
+            ns = min(args.cpu_sample, n)
+            p = O.make_params(global_alignment=not args.semi_global,
+                              adaptive=None if args.no_adaptive else (10, 50, 1))
+            t1 = time.perf_counter()
+            ref = O.align_batch(p, blob, q_off[:ns], q_len[:ns], t_off[:ns], t_len[:ns], n_threads=args.cpu_threads,
+                                want_ops=False)
+            dt = time.perf_counter() - t1
+            same = bool(np.array_equal(ref.score, rec[:ns, L.REC_SCORE]) and
+                        np.array_equal(ref.align_len, rec[:ns, L.REC_ALIGN_LEN]))
+            out["cpu_baseline"] = {"value": ns / dt, "unit": "pairs/s", "cores": args.cpu_threads, "kind": "port",
+                                   "sample": f"first {ns} pairs of the same dataset, oracle/wfa_oracle.c "
+                                             f"(C restatement of the Go reference; Go itself is not installed), "
+                                             f"{dt:.1f} s", "scores_match_gpu": same,
+                                   "published_reference": "6483 pairs/s (wfa-go, laptop, 1 thread; README.md:330)"}
+        print(json.dumps(out), flush=True)
+    w.RecycleAligner(al)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -229,9 +229,10 @@ def test_long_pair_semiglobal(built):
 
 
 def test_full_size_properties(built):
-    """BASELINE config sizes are too big for the oracle: check size-independent properties on 2e5 x 1 kbp --
-    every CIGAR consumes exactly both sequences, statistics are consistent with the ops, the score equals the
-    CIGAR's gap-affine cost, and a second run is bit-identical (determinism)."""
+    """Size-independent properties at a BASELINE-sized batch (2e5 x 1 kbp): every CIGAR's gap-affine cost equals
+    its score, it consumes exactly both sequences (except where the reference's own off-by-one overshoot,
+    SURVEY.md 3.3 `next`, yields a CIGAR one base too long -- about 1 pair in 2e5, reproduced bit-for-bit),
+    statistics are consistent with the ops, and a second run is bit-identical (determinism)."""
     import wfa_amd as w
     n = 200_000
     blob, q_off, q_len, t_off, t_len = w.generate_pairs(seed=3, n_pairs=n, length=1000, error_rate=0.05)
@@ -245,14 +246,30 @@ def test_full_size_properties(built):
     letters = (a.ops >> np.uint64(32)).astype(np.uint8)
     counts = (a.ops & np.uint64(0xFFFFFFFF)).astype(np.int64)
     pair_of_op = np.repeat(np.arange(n), a.ops_len)
-    q_used = np.bincount(pair_of_op, weights=counts * np.isin(letters, list(b"MXDH")), minlength=n)
-    t_used = np.bincount(pair_of_op, weights=counts * np.isin(letters, list(b"MXI")), minlength=n)
-    assert np.array_equal(q_used.astype(np.int64), q_len.astype(np.int64))
-    assert np.array_equal(t_used.astype(np.int64), t_len.astype(np.int64))
-    # gap-affine cost from ops == score (global: every op counts)
+    q_used = np.bincount(pair_of_op, weights=counts * np.isin(letters, list(b"MXDH")), minlength=n).astype(np.int64)
+    t_used = np.bincount(pair_of_op, weights=counts * np.isin(letters, list(b"MXI")), minlength=n).astype(np.int64)
+    dq, dt = q_used - q_len.astype(np.int64), t_used - t_len.astype(np.int64)
+    assert (np.abs(dq) <= 1).all() and (np.abs(dt) <= 1).all()
+    assert ((dq != 0) | (dt != 0)).sum() <= n // 10_000
     cost = np.bincount(pair_of_op, weights=(letters == ord("X")) * counts * 4
                        + np.isin(letters, list(b"IDH")) * (6 + 2 * counts), minlength=n)
     assert np.array_equal(cost.astype(np.int64), a.score.astype(np.int64))
     matches = np.bincount(pair_of_op, weights=(letters == ord("M")) * counts, minlength=n)
     assert (a.matches <= matches).all()
     al.close()
+
+
+def test_full_size_parity_c3(built):
+    """BASELINE configs[2] at full size (1e6 x 1 kbp @5 %, global + wf-adaptive) against the oracle run on
+    all host cores of the GPU box (seconds there), plus configs[1] (1e5 x 150 bp @2 %, adaptive off)."""
+    import os
+    import wfa_amd as w
+    from oracle import oracle as O
+    thr = max(8, (os.cpu_count() or 8) // 2)
+    for (n, length, err, seed, ad) in ((1_000_000, 1000, 0.05, 3, (10, 50, 1)), (100_000, 150, 0.02, 2, None)):
+        data = w.generate_pairs(seed=seed, n_pairs=n, length=length, error_rate=err, n_threads=32)
+        al = _aligner(True, ad)
+        got = al.align_arrays(*data)
+        want = O.align_batch(_oracle_params(True, ad), *data, n_threads=thr)
+        assert_batch_equal(got, want, f"full size L={length}")
+        al.close()
