@@ -31,13 +31,15 @@ enum { REC_STATUS = 0, REC_SCORE, REC_TBEGIN, REC_TEND, REC_QBEGIN, REC_QEND, RE
        REC_N_SCORES };
 
 // One directory entry per score index (score / g): the M, I and D rows of that score share the
-// diagonal range [lo, lo+w) and sit at arena[base], arena[base+w], arena[base+2w].  w == 0 means no
-// wavefront exists at that score in any component (Component.HasScore false, wfa_component.go:81-86).
+// diagonal range [lo, lo+w) and sit at arena[base], arena[base+stride], arena[base+2*stride].
+// w == 0 means no wavefront exists at that score in any component (Component.HasScore false,
+// wfa_component.go:81-86).  After wf-adaptive pruning the entry is narrowed to the surviving band
+// (base moves right, stride keeps the row pitch), so later scores only visit live diagonals.
 struct alignas(16) DirEnt {
     uint32_t base;
     int32_t  lo;
     int32_t  w;
-    uint32_t pad;
+    uint32_t stride;
 };
 
 struct KParams {

@@ -214,7 +214,7 @@ struct ArenaView {
         e.base = r.x;
         e.lo   = (int)r.y;
         e.w    = (int)r.z;
-        e.pad  = r.w;
+        e.stride = r.w;
         return e;
     }
     // Component.GetRaw (wfa_component.go:150-155 + wfa_wavefront.go:163-169); s may have wrapped
@@ -225,7 +225,7 @@ struct ArenaView {
         if (idx >= n_ent) return 0u;
         DirEnt e = ent(idx);
         if (e.w <= 0 || k < e.lo || k >= e.lo + e.w) return 0u;
-        return A[(uint64_t)e.base + (uint64_t)comp * (uint32_t)e.w + (uint32_t)(k - e.lo)];
+        return A[(uint64_t)e.base + (uint64_t)comp * e.stride + (uint32_t)(k - e.lo)];
     }
 };
 

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(64 * WAVES) void wfa_generic_kernel(const KParams P
         auto load_ent = [&](uint32_t idx) {
             const uint4 r = *dir_ptr(idx);
             DirEnt      d;
-            d.base = r.x, d.lo = (int)r.y, d.w = (int)r.z, d.pad = r.w;
+            d.base = r.x, d.lo = (int)r.y, d.w = (int)r.z, d.stride = r.w;
             return d;
         };
         const DirEnt none = {0u, 0, 0, 0u};
@@ -133,13 +133,13 @@ __global__ __launch_bounds__(64 * WAVES) void wfa_generic_kernel(const KParams P
             if (tid == 0) {
                 red[0] = INT32_MAX, red[1] = INT32_MIN, red[2] = 0, red[3] = INT32_MAX;
                 red[4] = INT32_MAX, red[5] = INT32_MIN, red[6] = 0, red[7] = INT32_MIN;
-                *dir_ptr(si) = make_uint4(base, (uint32_t)lo, (uint32_t)W, 0u);
+                *dir_ptr(si) = make_uint4(base, (uint32_t)lo, (uint32_t)W, (uint32_t)W);
             }
             __syncthreads();
 
             auto src = [&](const DirEnt &d, int comp, int k) -> uint32_t {
                 return (d.w > 0 && k >= d.lo && k < d.lo + d.w)
-                           ? A[(uint64_t)d.base + (uint64_t)comp * (uint32_t)d.w + (uint32_t)(k - d.lo)]
+                           ? A[(uint64_t)d.base + (uint64_t)comp * d.stride + (uint32_t)(k - d.lo)]
                            : 0u;
             };
 
@@ -179,6 +179,7 @@ __global__ __launch_bounds__(64 * WAVES) void wfa_generic_kernel(const KParams P
             }
 
             // ---- reduce (wfa.go:461-540) when M exists at s and its Lo..Hi span is wide enough
+            int nlo = mlo, nhi = mhi;  // surviving band: I and D only hold cells where M does
             if (P.adaptive && mhi >= mlo && (mhi - mlo + 1) >= (int)P.min_wf_len && mind != INT32_MAX) {
                 const int maxdiff = (int)P.max_dist_diff;
                 int       first_ok = INT32_MAX, last_ok = INT32_MIN, anyfail = 0;
@@ -210,19 +211,23 @@ __global__ __launch_bounds__(64 * WAVES) void wfa_generic_kernel(const KParams P
                     lead = wave_max(lead);
                     if (lane == 0) atomicMax(&red[7], lead);
                     __syncthreads();
-                    lead           = red[7];
-                    const int _lo  = (lead != INT32_MIN) ? lead + 1 : mlo;
-                    const int _hi  = last_ok;  // wfa.go:517-524
-                    for (int64_t i = tid; i < W; i += G) {  // wfa.go:526-535: Delete in M, I and D
+                    lead = red[7];
+                    nlo  = (lead != INT32_MIN) ? lead + 1 : mlo;
+                    nhi  = last_ok;  // wfa.go:517-524
+                    // wfa.go:526-535 deletes k outside [_lo,_hi] in M, I and D: here the rows are simply narrowed
+                    for (int64_t i = tid; i < W; i += G) {
                         const int k = lo + (int)i;
-                        if (k < _lo || k > _hi) {
-                            my_cells -= (rowM[i] != 0u) + (rowI[i] != 0u) + (rowD[i] != 0u);
-                            rowM[i] = 0u, rowI[i] = 0u, rowD[i] = 0u;
-                        }
+                        if (k < nlo || k > nhi) my_cells -= (rowM[i] != 0u) + (rowI[i] != 0u) + (rowD[i] != 0u);
                     }
                 }
-                __syncthreads();
             }
+            if (nlo != lo || nhi != hi) {  // narrow the directory entry to the live band
+                if (tid == 0)
+                    *dir_ptr(si) = (nhi >= nlo) ? make_uint4(base + (uint32_t)(nlo - lo), (uint32_t)nlo,
+                                                             (uint32_t)(nhi - nlo + 1), (uint32_t)W)
+                                                : make_uint4(0u, 0u, 0u, 0u);
+            }
+            __syncthreads();
         }
 
         // ---- count stored cells across the group

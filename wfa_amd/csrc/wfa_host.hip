@@ -619,8 +619,10 @@ extern "C" int wfahip_debug_wavefronts(wfahip_ctx *ctx, const wfahip_params *p, 
     for (uint32_t i = 0; i < n_ent; i++) {
         const uint32_t *e = &dir[(size_t)(n_ent - 1 - i) * 4];
         if ((int32_t)e[2] <= 0) continue;
-        HIP_TRY(hipMemcpy(*words + pos, static_cast<uint32_t *>(ctx->arena.p) + e[0], 12ull * e[2],
-                          hipMemcpyDeviceToHost));
+        for (int c = 0; c < 3; c++)  // M, I, D rows are e[3] (row pitch) words apart
+            HIP_TRY(hipMemcpy(*words + pos + (uint64_t)c * e[2],
+                              static_cast<uint32_t *>(ctx->arena.p) + e[0] + (uint64_t)c * e[3], 4ull * e[2],
+                              hipMemcpyDeviceToHost));
         (*rows)[ri++] = wfahip_row{i * g, (int32_t)e[1], e[2], pos};
         pos += 3ull * e[2];
     }
