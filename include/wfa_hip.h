@@ -97,7 +97,10 @@ typedef struct {
     uint64_t cells_stored;     /* sum over pairs of non-zero wavefront words stored */
     uint64_t ops_written;      /* CIGAR ops written */
     uint64_t arena_bytes;      /* arena footprint allocated */
-    double   main_kernel_ms;   /* duration of the first (dominant) alignment kernel launch */
+    double   main_kernel_ms;   /* total duration of the dominant kernel's launches (packed forward kernel when it
+                                  ran, else the first generic launch) */
+    uint32_t n_main_launches;  /* launches of that kernel (one per chunk) */
+    uint32_t n_packed_pairs;   /* pairs finished by the packed forward + backtrace kernels */
 } wfahip_timing;
 
 typedef struct wfahip_ctx wfahip_ctx;

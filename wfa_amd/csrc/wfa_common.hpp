@@ -71,6 +71,14 @@ struct KParams {
     uint32_t lds_seq_words;
     // debug: keep slot 0's arena intact and publish its final directory size
     uint32_t *debug_info;  // [0] = number of directory entries, [1] = final score
+
+    // ---- packed (sub-wave) forward kernel + deferred backtrace kernel
+    uint32_t  chunk_first, chunk_n;  // pairs [chunk_first, chunk_first + chunk_n); arena slot = index in chunk
+    uint4    *pair_meta;             // per pair of the chunk: {status, final score, directory entries, cells}
+    uint32_t  dx, doe, de;           // x/g, (o+e)/g, e/g
+    uint32_t  dm, di;                // ring depths: max(dx,doe)+1 (M), de+1 (I and D)
+    uint32_t  sub_lds_words;         // LDS words owned by one 32-lane subgroup
+    uint32_t  min_xe;                // min(x, e): bounds the number of CIGAR ops by 2*score/min_xe + 8
 };
 
 }  // namespace wfa

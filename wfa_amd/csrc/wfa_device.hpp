@@ -261,6 +261,69 @@ struct OpsWriter {
     }
 };
 
+// Same interface, for the lane-per-pair backtrace kernel: ops are written from the END of the pair's
+// region towards its start, so the finished list is already in forward order (process()'s reversal,
+// wfa_cigar.go:142-146, becomes a no-op) at buf[cap-n .. cap).  The statistics of process()
+// (wfa_cigar.go:168-211: span first-M .. last-M) are accumulated while emitting: in emission order the
+// span runs from the first emitted M to the last emitted M.
+struct OpsWriterRev {
+    uint64_t *buf;
+    uint32_t  cap;
+    uint32_t  n;
+    uint64_t  cur;
+    bool      overflow;
+    bool      seenM;
+    uint32_t  alen, matches, gaps, regions;      // committed (up to the latest M)
+    uint32_t  p_len, p_gaps, p_regions;          // pending since the latest M
+    uint64_t  last;                              // last flushed op (for the no-M case)
+    WFA_DEV void init(uint64_t *b, uint32_t c) {
+        buf = b, cap = c, n = 0, cur = 0, overflow = false, seenM = false;
+        alen = matches = gaps = regions = 0;
+        p_len = p_gaps = p_regions = 0;
+        last = 0;
+    }
+    WFA_DEV void add(uint32_t letter, uint32_t cnt) {
+        if (cur != 0 && (uint32_t)(cur >> 32) == letter) {
+            cur += cnt;
+            return;
+        }
+        flush();
+        cur = ((uint64_t)letter << 32) | cnt;
+    }
+    WFA_DEV void flush() {
+        if (cur == 0) return;
+        if (n < cap)
+            buf[cap - 1 - n] = cur;
+        else
+            overflow = true;
+        n++;
+        const uint32_t letter = (uint32_t)(cur >> 32), cnt = (uint32_t)cur;
+        if (letter == 'M') {
+            if (!seenM) {
+                seenM = true;
+                alen = cnt, matches = cnt;
+            } else {
+                alen += p_len + cnt, matches += cnt, gaps += p_gaps, regions += p_regions;
+            }
+            p_len = p_gaps = p_regions = 0;
+        } else {
+            p_len += cnt;
+            if (letter == 'I' || letter == 'D') p_gaps += cnt, p_regions++;
+        }
+        last = cur;
+        cur  = 0;
+    }
+    // process() with no M op at all: begin = end = 0 -> only the first op of the forward list counts
+    WFA_DEV void finish() {
+        if (!seenM && n > 0) {
+            const uint32_t letter = (uint32_t)(last >> 32), cnt = (uint32_t)last;
+            alen = cnt, matches = 0;
+            gaps    = (letter == 'I' || letter == 'D') ? cnt : 0u;
+            regions = (letter == 'I' || letter == 'D') ? 1u : 0u;
+        }
+    }
+};
+
 WFA_DEV uint32_t op_letter(uint32_t tag) {  // wfaOps = ".IIDDXMH" (wfa_backtrace_types.go:37)
     const uint32_t tbl0 = ('.') | ('I' << 8) | ('I' << 16) | ('D' << 24);
     const uint32_t tbl1 = ('D') | ('X' << 8) | ('M' << 16) | ('H' << 24);
@@ -332,8 +395,9 @@ WFA_DEV void backtrace_start(const ArenaView &av, int n, int m, uint32_t s, uint
 
 // backTrace (wfa.go:703-983), one lane.  Source lookups are plain Gets with NO bounds rejection,
 // exactly as the reference recomputes the pre-extension offset.
+template <class Writer>
 WFA_DEV void back_trace(const ArenaView &av, int lenQ, int lenT, uint32_t s, int Ak, bool semiGlobal,
-                        uint32_t px, uint32_t po, uint32_t pe, OpsWriter &ow, TraceOut &out) {
+                        uint32_t px, uint32_t po, uint32_t pe, Writer &ow, TraceOut &out) {
     out.score  = s;
     out.tbegin = out.tend = out.qbegin = out.qend = 0;
 

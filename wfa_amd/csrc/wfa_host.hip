@@ -5,6 +5,7 @@
 // entry points return WFAHIP_ERR_NO_DEVICE.
 #include "../../include/wfa_hip.h"
 #include "wfa_generic.hpp"
+#include "wfa_packed.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -44,13 +45,16 @@ struct wfahip_ctx {
     int           num_cus    = 256;
     size_t        total_mem  = 0;
     hipStream_t   stream     = nullptr;
-    hipEvent_t    ev0 = nullptr, ev1 = nullptr, evA = nullptr, evB = nullptr;
-    DevBuf        arena, ctrl, redo, work;
+    hipEvent_t    ev0 = nullptr, ev1 = nullptr, evA = nullptr, evB = nullptr, evC = nullptr;
+    DevBuf        arena, ctrl, redo, work, meta;
     DevBuf        in_blob, in_qoff, in_qlen, in_toff, in_tlen, out_rec, out_ops;  // host-entry staging
     // options (0 = automatic)
     int64_t       opt_arena_bytes_per_slot = 0;
     int64_t       opt_slots                = 0;
     int64_t       opt_threads_per_pair     = 0;
+    int64_t       opt_packed               = 1;  // 0: never use the packed (sub-wave) kernel
+    int64_t       opt_packed_arena_bytes   = 0;  // per pair, 0 = automatic
+    int64_t       opt_chunk_pairs          = 0;  // 0 = automatic
     int           force_mode               = -1;  // debug: start the ladder in this mode
     wfahip_timing timing{};
     char          last_error[256] = {0};
@@ -207,7 +211,8 @@ extern "C" int wfahip_create(int device_id, wfahip_ctx **out) {
     }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
-        hipEventCreate(&ctx->evA) != hipSuccess || hipEventCreate(&ctx->evB) != hipSuccess) {
+        hipEventCreate(&ctx->evA) != hipSuccess || hipEventCreate(&ctx->evB) != hipSuccess ||
+        hipEventCreate(&ctx->evC) != hipSuccess) {
         delete ctx;
         return WFAHIP_ERR_HIP;
     }
@@ -218,13 +223,14 @@ extern "C" int wfahip_create(int device_id, wfahip_ctx **out) {
 extern "C" void wfahip_destroy(wfahip_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    for (DevBuf *b : {&ctx->arena, &ctx->ctrl, &ctx->redo, &ctx->work, &ctx->in_blob, &ctx->in_qoff, &ctx->in_qlen,
+    for (DevBuf *b : {&ctx->arena, &ctx->ctrl, &ctx->redo, &ctx->work, &ctx->meta, &ctx->in_blob, &ctx->in_qoff, &ctx->in_qlen,
                       &ctx->in_toff, &ctx->in_tlen, &ctx->out_rec, &ctx->out_ops})
         release(*b);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->evA) (void)hipEventDestroy(ctx->evA);
     if (ctx->evB) (void)hipEventDestroy(ctx->evB);
+    if (ctx->evC) (void)hipEventDestroy(ctx->evC);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -238,6 +244,12 @@ extern "C" int wfahip_set_option(wfahip_ctx *ctx, const char *key, int64_t value
         ctx->opt_slots = value;
     else if (k == "threads_per_pair")
         ctx->opt_threads_per_pair = value;
+    else if (k == "packed")
+        ctx->opt_packed = value;
+    else if (k == "packed_arena_bytes")
+        ctx->opt_packed_arena_bytes = value;
+    else if (k == "chunk_pairs")
+        ctx->opt_chunk_pairs = value;
     else
         return WFAHIP_ERR_BAD_ARG;
     return WFAHIP_OK;
@@ -311,14 +323,90 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
     HIP_TRY(hipEventRecord(ctx->ev0, st));
 
     std::deque<Job> jobs;
-    {
+    std::vector<uint32_t> no_memory;
+    const int             max_level = 6;
+    bool                  first     = true;
+
+    // ---- pass 1: packed sub-wave forward kernel + lane-per-pair backtrace kernel, chunk by chunk
+    bool packed_done = false;
+    if (ctx->opt_packed && !debug_single && ctx->force_mode < 0 && P.global_alignment) {
+        const uint32_t dx = P.x / P.g, doe = P.oe / P.g, de = P.e / P.g;
+        const uint32_t dm = std::max(dx, doe) + 1, di = de + 1;
+        const uint32_t seq_words = (max_len + 15) / 16 + 1;
+        const uint64_t sub_words = packed_sub_lds_words(seq_words, dm, di);
+        const size_t   lds_bytes = (size_t)sub_words * 2 * 4;
+        if (lds_bytes <= 20 * 1024) {  // keeps >= 8 waves per CU resident
+            uint64_t words = std::max<uint64_t>(4096, 16ull * max_len);
+            if (ctx->opt_packed_arena_bytes > 0) words = std::max<uint64_t>(1024, ctx->opt_packed_arena_bytes / 4);
+            words = (words + 3) & ~3ull;
+            uint64_t budget = (uint64_t)((double)ctx->total_mem * 0.35);
+            uint64_t chunk  = std::max<uint64_t>(1, std::min<uint64_t>(n_pairs, budget / (words * 4ull)));
+            if (ctx->opt_chunk_pairs > 0) chunk = std::min<uint64_t>(chunk, (uint64_t)ctx->opt_chunk_pairs);
+            rc = ensure(ctx, ctx->arena, (size_t)(words * 4ull * chunk));
+            if (rc == WFAHIP_ERR_OOM) {
+                chunk = std::max<uint64_t>(1, chunk / 4);
+                rc    = ensure(ctx, ctx->arena, (size_t)(words * 4ull * chunk));
+            }
+            if (rc) return rc;
+            if ((rc = ensure(ctx, ctx->meta, chunk * 16))) return rc;
+            ctx->timing.arena_bytes = words * 4ull * chunk;
+            P.arena = static_cast<uint32_t *>(ctx->arena.p), P.arena_words = words;
+            P.pair_meta     = static_cast<uint4 *>(ctx->meta.p);
+            P.dx = dx, P.doe = doe, P.de = de, P.dm = dm, P.di = di;
+            P.lds_seq_words = seq_words;
+            P.sub_lds_words = (uint32_t)sub_words;
+            P.min_xe        = std::min(P.x, P.e);
+            P.work          = nullptr;
+            const uint32_t waves_per_cu = (uint32_t)std::min<size_t>(32, LDS_MAX_BYTES / lds_bytes);
+            for (uint64_t c0 = 0; c0 < n_pairs; c0 += chunk) {
+                const uint64_t cn = std::min<uint64_t>(chunk, n_pairs - c0);
+                P.chunk_first = (uint32_t)c0, P.chunk_n = (uint32_t)cn;
+                const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)ctx->num_cus * waves_per_cu, (cn + 1) / 2);
+                HIP_TRY(hipMemsetAsync(d_ctrl, 0, 4, st));  // queue_head only
+                HIP_TRY(hipEventRecord(ctx->evA, st));
+                hipLaunchKernelGGL(wfa_packed_kernel, dim3(grid), dim3(64), lds_bytes, st, P);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipEventRecord(ctx->evB, st));
+                hipLaunchKernelGGL(wfa_backtrace_kernel, dim3((uint32_t)((cn + 255) / 256)), dim3(256), 0, st, P);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipEventRecord(ctx->evC, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                float msF = 0, msB = 0;
+                HIP_TRY(hipEventElapsedTime(&msF, ctx->evA, ctx->evB));
+                HIP_TRY(hipEventElapsedTime(&msB, ctx->evB, ctx->evC));
+                ctx->timing.kernel_ms += msF + msB;
+                ctx->timing.main_kernel_ms += msF;
+                ctx->timing.n_main_launches++;
+                ctx->timing.n_launches += 2;
+            }
+            first       = false;
+            packed_done = true;
+            uint32_t hc[CTRL_WORDS];
+            HIP_TRY(hipMemcpy(hc, d_ctrl, sizeof hc, hipMemcpyDeviceToHost));
+            const uint32_t n_redo          = hc[1];
+            ctx->timing.n_packed_pairs     = (uint32_t)(n_pairs - n_redo);
+            ctx->timing.n_retried_pairs += n_redo;
+            if (n_redo) {
+                std::vector<uint32_t> ids(n_redo), stw(n_redo);
+                HIP_TRY(hipMemcpy(ids.data(), ctx->redo.p, n_redo * 4ull, hipMemcpyDeviceToHost));
+                std::sort(ids.begin(), ids.end());
+                for (uint32_t i = 0; i < n_redo; i++)
+                    HIP_TRY(hipMemcpy(&stw[i], P.rec + (uint64_t)ids[i] * REC_WORDS, 4, hipMemcpyDeviceToHost));
+                Job jb, ja;
+                jb.mode = 1, jb.level = 0, jb.all = false;
+                ja.mode = 0, ja.level = 0, ja.all = false;
+                for (uint32_t i = 0; i < n_redo; i++)
+                    (stw[i] == ST_REDO_BYTES ? jb : ja).pairs.push_back(ids[i]);
+                if (!ja.pairs.empty()) jobs.push_back(std::move(ja));
+                if (!jb.pairs.empty()) jobs.push_back(std::move(jb));
+            }
+        }
+    }
+    if (!packed_done) {
         Job j;
         j.mode = ctx->force_mode == 1 ? 1 : 0, j.level = 0, j.all = true;
         jobs.push_back(std::move(j));
     }
-    std::vector<uint32_t> no_memory;
-    const int             max_level = 6;
-    bool                  first     = true;
 
     while (!jobs.empty()) {
         Job job = std::move(jobs.front());
@@ -370,7 +458,7 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, ctx->evA, ctx->evB));
         ctx->timing.kernel_ms += ms;
-        if (first) ctx->timing.main_kernel_ms = ms, first = false;
+        if (first) ctx->timing.main_kernel_ms = ms, ctx->timing.n_main_launches = 1, first = false;
         ctx->timing.n_launches++;
 
         const uint32_t n_redo = hctrl[1];

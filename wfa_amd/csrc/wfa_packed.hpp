@@ -1,0 +1,285 @@
+// wfa_packed.hpp -- kernel B: the throughput path for short/medium global alignments, plus the
+// lane-per-pair backtrace kernel that follows it.
+//
+// Measured on 1 kbp @5 % pairs (wf-adaptive 10/50/1) the live band of a wavefront is ~18 diagonals wide
+// (p99 39, never above 51), so a whole wave64 per pair leaves most lanes idle.  Here a wave carries TWO
+// pairs, one per 32-lane half ("subgroup"); lane j of a subgroup owns diagonals lo+j and lo+32+j (the
+// second tile only runs when some subgroup's range is wider than 32), i.e. up to 64 diagonals per pair.
+// A pair whose range would exceed 64 is handed to the generic kernel (ST_REDO_BAND).
+//
+// Data placement per subgroup:
+//   LDS   2-bit packed query/target; a ring of the last max(x,o+e)/g+1 M rows and e/g+1 I/D rows
+//         indexed by (k & 63), with each row's live range [lo, lo+w) kept beside it.  The five
+//         sources of WF_NEXT (wfa.go:579,580,614,615,650) are ds_read_b32 at neighbouring indices.
+//   HBM   every finished row is stored once (only the band that survives wf-adaptive) into the
+//         pair's arena + a 16-byte directory entry; the backtrace kernel walks them afterwards.
+//
+// Both halves of a wave run the same instruction stream with their own score counter; a half that
+// finishes its pair pulls the next one from the device queue while the other keeps stepping.
+#pragma once
+#include "wfa_device.hpp"
+
+namespace wfa {
+
+constexpr int PK_G     = 32;  // lanes per pair
+constexpr int PK_TILES = 2;   // diagonals per lane
+constexpr int PK_WCAP  = PK_G * PK_TILES;
+
+// LDS words one subgroup needs
+__host__ __device__ inline uint32_t packed_sub_lds_words(uint32_t seq_words, uint32_t dm, uint32_t di) {
+    return 2u * seq_words + (dm + 2u * di) * PK_WCAP + 2u * (dm + di) + 2u;
+}
+
+WFA_DEV uint32_t half_of(unsigned long long ballot, int sub) {
+    return sub ? (uint32_t)(ballot >> 32) : (uint32_t)ballot;
+}
+WFA_DEV int sub_min(int v) {  // min over the 32 lanes of a half (xor masks < 32 stay inside it)
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v = imin2(v, __shfl_xor(v, o, 64));
+    return v;
+}
+WFA_DEV uint32_t sub_sum(uint32_t v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(64) void wfa_packed_kernel(const KParams P) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int lane = threadIdx.x, j = lane & 31, sub = lane >> 5;
+    const int lead = sub << 5;
+
+    const uint32_t SW = P.lds_seq_words, DM = P.dm, DI = P.di;
+    uint32_t *const L     = lds + sub * P.sub_lds_words;
+    uint32_t *const lq    = L;
+    uint32_t *const lt    = L + SW;
+    uint32_t *const ringM = L + 2 * SW;
+    uint32_t *const ringI = ringM + DM * PK_WCAP;
+    uint32_t *const ringD = ringI + DI * PK_WCAP;
+    int *const      metaM = reinterpret_cast<int *>(ringD + DI * PK_WCAP);  // [DM][2] = {lo, w}
+    int *const      metaE = metaM + 2 * DM;                                 // [DI][2]
+
+    const uint32_t x = P.x, oe = P.oe, e = P.e, g = P.g;
+    const uint64_t cap = P.arena_words;
+
+    // per-subgroup state (identical in the 32 lanes of a half)
+    int       st = 0;  // 0 = needs a pair, 1 = running, 2 = queue exhausted
+    uint32_t  pidx = 0, pair = 0;
+    int       n = 0, m = 0, Ak = 0;
+    uint32_t  s = 0, si = 0, cm = 0, ce = 0;
+    uint32_t  top = 0;
+    uint32_t *A = nullptr;
+    uint32_t  my_cells = 0;
+    SeqView<0> sv;
+    sv.q = lq, sv.t = lt, sv.n = 0, sv.m = 0;
+
+    for (;;) {
+        // ---------------------------------------------------------------- refill (divergent per half)
+        if (st == 0) {
+            uint32_t wi = 0;
+            if (j == 0) wi = atomicAdd(P.queue_head, 1u);
+            wi = __shfl(wi, lead, 64);
+            if (wi >= P.chunk_n) {
+                st = 2;
+            } else {
+                pidx = wi;
+                pair = P.chunk_first + wi;
+                const uint32_t nq = P.q_len[pair], mt = P.t_len[pair];
+                uint32_t status = ST_PENDING;
+                if (nq == 0 || mt == 0)
+                    status = ST_EMPTY;  // wfa.go:204-206
+                else if (nq > 0x1FFFFFFFu || mt > 0x1FFFFFFFu)
+                    status = ST_TOO_LONG;  // wfa.go:207-209
+                else if (((nq > mt ? nq : mt) + 15u) / 16u + 1u > SW)
+                    status = ST_REDO_LDS;
+                if (status == ST_PENDING) {
+                    bool bad = stage_pack<PK_G>(P.blob, P.q_off[pair], nq, lq, j);
+                    bad |= stage_pack<PK_G>(P.blob, P.t_off[pair], mt, lt, j);
+                    if (half_of(__ballot(bad), sub) != 0u) status = ST_REDO_BYTES;
+                }
+                if (status != ST_PENDING) {
+                    if (j == 0) {
+                        P.pair_meta[pidx] = make_uint4(status, 0u, 0u, 0u);
+                        if (status >= ST_REDO_BYTES) P.redo_list[atomicAdd(P.redo_count, 1u)] = pair;
+                    }
+                    // stay in state 0: the next loop iteration pulls another pair
+                } else {
+                    n = (int)nq, m = (int)mt, Ak = m - n;
+                    sv.n = n, sv.m = m;
+                    s = 0, si = 0, cm = 0, ce = 0, top = 0, my_cells = 0;
+                    A  = P.arena + (uint64_t)pidx * cap;
+                    st = 1;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (__ballot(st != 2) == 0ull) break;
+        const bool run = (st == 1);
+
+        // ---------------------------------------------------------------- one score step
+        // sources: M[s-x], M[s-o-e], I[s-e], D[s-e]  (wfa.go:557-560; missing when diff > s)
+        const bool hasX = run && s >= x, hasO = run && s >= oe, hasE = run && s >= e;
+        uint32_t   slotX = cm + DM - P.dx, slotO = cm + DM - P.doe, slotE = ce + DI - P.de;
+        slotX -= (slotX >= DM) ? DM : 0u, slotO -= (slotO >= DM) ? DM : 0u, slotE -= (slotE >= DI) ? DI : 0u;
+        int loX = 0, wX = 0, loO = 0, wO = 0, loE = 0, wE = 0;
+        if (hasX) loX = metaM[2 * slotX], wX = metaM[2 * slotX + 1];
+        if (hasO) loO = metaM[2 * slotO], wO = metaM[2 * slotO + 1];
+        if (hasE) loE = metaE[2 * slotE], wE = metaE[2 * slotE + 1];
+
+        int lo = INT32_MAX, hi = INT32_MIN;
+        if (wX > 0) lo = imin2(lo, loX - 1), hi = imax2(hi, loX + wX);
+        if (wO > 0) lo = imin2(lo, loO - 1), hi = imax2(hi, loO + wO);
+        if (wE > 0) lo = imin2(lo, loE - 1), hi = imax2(hi, loE + wE);
+        lo = imax2(lo, -(n - 1));  // wfa.go:562-563
+        hi = imin2(hi, m - 1);
+        const bool seeded = run && (s == 0u || s == x);  // global: M[0][0] or M[x][0] (wfa.go:155-160)
+        if (seeded) lo = imin2(lo, 0), hi = imax2(hi, 0);
+        if (!run) lo = 0, hi = -1;
+        const int W = (hi >= lo) ? hi - lo + 1 : 0;
+        const bool too_wide = W > PK_WCAP;
+        const bool wide     = __ballot(W > PK_G && !too_wide) != 0ull;  // wave-uniform: second tile needed
+
+        uint32_t cM[PK_TILES], cI[PK_TILES], cD[PK_TILES];
+        uint32_t mbits[PK_TILES];
+        bool     term = false;
+#pragma unroll
+        for (int t = 0; t < PK_TILES; t++) {
+            cM[t] = cI[t] = cD[t] = 0u;
+            mbits[t]              = 0u;
+            if (t == 1 && !wide) continue;
+            const int  k   = lo + PK_G * t + j;
+            const bool act = run && !too_wide && k <= hi;
+            uint32_t   mo_km1 = 0, ie_km1 = 0, mo_kp1 = 0, de_kp1 = 0, mx_k = 0;
+            if (act) {
+                if ((uint32_t)(k - 1 - loO) < (uint32_t)wO) mo_km1 = ringM[slotO * PK_WCAP + ((k - 1) & (PK_WCAP - 1))];
+                if ((uint32_t)(k + 1 - loO) < (uint32_t)wO) mo_kp1 = ringM[slotO * PK_WCAP + ((k + 1) & (PK_WCAP - 1))];
+                if ((uint32_t)(k - 1 - loE) < (uint32_t)wE) ie_km1 = ringI[slotE * PK_WCAP + ((k - 1) & (PK_WCAP - 1))];
+                if ((uint32_t)(k + 1 - loE) < (uint32_t)wE) de_kp1 = ringD[slotE * PK_WCAP + ((k + 1) & (PK_WCAP - 1))];
+                if ((uint32_t)(k - loX) < (uint32_t)wX) mx_k = ringM[slotX * PK_WCAP + (k & (PK_WCAP - 1))];
+                Cell c = next_cell(mo_km1, ie_km1, mo_kp1, de_kp1, mx_k, k, n, m);
+                if (seeded && k == 0 && c.M == 0u) c.M = seed_word<0>(sv, 0, s, x, true);
+                c.M   = extend_word<0>(sv, c.M, k);
+                cM[t] = c.M, cI[t] = c.I, cD[t] = c.D;
+                if (k == Ak && (int)(c.M >> TAG_BITS) >= m) term = true;  // wfa.go:235-239
+            }
+            mbits[t] = half_of(__ballot(cM[t] != 0u), sub);
+        }
+        term = half_of(__ballot(term), sub) != 0u;
+        const unsigned long long mmask = (unsigned long long)mbits[0] | ((unsigned long long)mbits[1] << 32);
+        int nlo = 0, nhi = -1;  // band to keep; M.Lo/Hi of the reference = tight range of M cells
+        if (mmask != 0ull) nlo = lo + __builtin_ctzll(mmask), nhi = lo + 63 - __builtin_clzll(mmask);
+
+        // ---------------------------------------------------------------- wf-adaptive (wfa.go:461-540)
+        const bool want_reduce = run && !term && P.adaptive && mmask != 0ull && (nhi - nlo + 1) >= (int)P.min_wf_len;
+        if (__ballot(want_reduce) != 0ull) {
+            int d[PK_TILES], dm = INT32_MAX;
+#pragma unroll
+            for (int t = 0; t < PK_TILES; t++) {
+                d[t] = reduce_dist(cM[t], lo + PK_G * t + j, n, m);
+                if (d[t] >= 0) dm = imin2(dm, d[t]);
+            }
+            const int mind = sub_min(dm);
+            unsigned long long vmask = 0ull, okmask = 0ull;
+#pragma unroll
+            for (int t = 0; t < PK_TILES; t++) {
+                const bool valid = d[t] >= 0;
+                const bool okc   = valid && (d[t] - mind <= (int)P.max_dist_diff);
+                vmask |= (unsigned long long)half_of(__ballot(valid), sub) << (32 * t);
+                okmask |= (unsigned long long)half_of(__ballot(okc), sub) << (32 * t);
+            }
+            if (want_reduce && mind != INT32_MAX && (vmask & ~okmask) != 0ull) {  // some distance failed
+                const int                first_ok = __builtin_ctzll(okmask);
+                const unsigned long long leadm    = vmask & ((1ull << first_ok) - 1ull);
+                if (leadm != 0ull) nlo = lo + 64 - __builtin_clzll(leadm);  // one past the last leading failure
+                nhi = lo + 63 - __builtin_clzll(okmask);                    // last valid non-failing entry
+            }
+        }
+
+        // ---------------------------------------------------------------- store the surviving band
+        const int  wn       = (nhi >= nlo) ? nhi - nlo + 1 : 0;
+        const bool no_room  = run && ((uint64_t)top + 3ull * (uint32_t)wn + 4ull * (si + 2u) > cap);
+        const bool give_up  = run && (too_wide || no_room);
+        const bool store_ok = run && !give_up;
+        if (store_ok) {
+            uint32_t *const rowM = A + top;
+#pragma unroll
+            for (int t = 0; t < PK_TILES; t++) {
+                if (t == 1 && !wide) continue;
+                const int k = lo + PK_G * t + j;
+                if (k >= nlo && k <= nhi) {
+                    const int i = k - nlo;
+                    rowM[i] = cM[t], rowM[wn + i] = cI[t], rowM[2 * wn + i] = cD[t];
+                    const uint32_t r = (uint32_t)k & (PK_WCAP - 1);
+                    ringM[cm * PK_WCAP + r] = cM[t], ringI[ce * PK_WCAP + r] = cI[t], ringD[ce * PK_WCAP + r] = cD[t];
+                    my_cells += (cM[t] != 0u) + (cI[t] != 0u) + (cD[t] != 0u);
+                }
+            }
+            if (j == 0) {
+                metaM[2 * cm] = nlo, metaM[2 * cm + 1] = wn;
+                metaE[2 * ce] = nlo, metaE[2 * ce + 1] = wn;
+                *reinterpret_cast<uint4 *>(A + cap - 4ull * (si + 1)) =
+                    wn > 0 ? make_uint4(top, (uint32_t)nlo, (uint32_t)wn, (uint32_t)wn) : make_uint4(0u, 0u, 0u, 0u);
+            }
+            top += 3u * (uint32_t)wn;
+        }
+        // ---------------------------------------------------------------- finish / advance
+        if (give_up || (run && term)) {
+            const uint32_t cells = sub_sum(my_cells);
+            if (j == 0) {
+                if (give_up) {
+                    P.pair_meta[pidx]                        = make_uint4(too_wide ? ST_REDO_BAND : ST_REDO_ARENA, 0u, 0u, 0u);
+                    P.redo_list[atomicAdd(P.redo_count, 1u)] = pair;
+                } else {
+                    P.pair_meta[pidx] = make_uint4(ST_OK, s, si + 1u, cells);
+                }
+            }
+            st = 0;
+        } else if (run) {
+            s += g, si += 1u;
+            cm = (cm + 1u == DM) ? 0u : cm + 1u;
+            ce = (ce + 1u == DI) ? 0u : ce + 1u;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+// Lane-per-pair backtrace (wfa.go:703-983) + process() statistics + result record for the pairs the packed
+// kernel finished.  Global alignment only (the packed kernel's scope).
+__global__ __launch_bounds__(256) void wfa_backtrace_kernel(const KParams P) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P.chunk_n) return;
+    const uint32_t pair = P.chunk_first + idx;
+    const uint4    meta = P.pair_meta[idx];
+    uint32_t *const rec = P.rec + (uint64_t)pair * REC_WORDS;
+    if (meta.x != ST_OK) {
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+        uint4 *r4     = reinterpret_cast<uint4 *>(rec);
+        r4[0] = make_uint4(meta.x, 0u, 0u, 0u), r4[1] = z, r4[2] = z, r4[3] = z;
+        return;
+    }
+    const int n = (int)P.q_len[pair], m = (int)P.t_len[pair];
+    ArenaView av;
+    av.A = P.arena + (uint64_t)idx * P.arena_words, av.cap = P.arena_words, av.g = P.g, av.n_ent = meta.z;
+    const uint32_t s_final = meta.y;
+
+    // ops region: bound = 2 * score / min(x, e) + 8 entries, carved from the shared ops buffer
+    const uint32_t bound = 2u * (s_final / P.min_xe) + 8u;
+    const uint64_t off   = atomicAdd(P.ops_cursor, (unsigned long long)bound);
+    OpsWriterRev   ow;
+    const bool     fits = off + bound <= P.ops_cap;
+    ow.init(P.ops + off, fits ? bound : 0u);
+    TraceOut to;
+    back_trace(av, n, m, s_final, m - n, false, P.x, P.o, P.e, ow, to);
+    ow.finish();
+    // (when the ops buffer is too small the host sees ops_cursor > ops_cap and re-runs with a bigger one)
+    const uint64_t first = off + bound - ow.n;
+    uint4 *r4            = reinterpret_cast<uint4 *>(rec);
+    r4[0] = make_uint4(ST_OK, to.score, (uint32_t)to.tbegin, (uint32_t)to.tend);
+    r4[1] = make_uint4((uint32_t)to.qbegin, (uint32_t)to.qend, ow.alen, ow.matches);
+    r4[2] = make_uint4(ow.gaps, ow.regions, ow.n, (uint32_t)first);
+    r4[3] = make_uint4((uint32_t)(first >> 32), meta.w, 0u, s_final);
+}
+
+}  // namespace wfa
