@@ -124,7 +124,7 @@ def main():
     alg_bytes = 4 * cells + sum_len + 64 * n + 8 * n_ops_total
     k_ms = float(np.mean(kernel_ms))
     main_k_ms = float(np.mean(main_ms))
-    achieved = alg_bytes / (k_ms * 1e-3) / 1e9  # GB/s over the alignment kernels of one step
+    achieved = alg_bytes / (main_k_ms * 1e-3) / 1e9  # GB/s over the dominant kernel's launches of one step
 
     out = None
     if rank == 0:
@@ -137,6 +137,7 @@ def main():
                "parallelism": f"pair-sharded x{world}", "status_ok": int(ok.sum()),
                "gcells_per_s": value * args.length * args.length / 1e9,
                "kernel_ms_per_step": k_ms, "main_kernel_ms": main_k_ms, "launches_per_step": int(timing.n_launches),
+               "packed_pairs": int(timing.n_packed_pairs),
                "retried_pairs": int(timing.n_retried_pairs), "arena_gib": timing.arena_bytes / 2 ** 30,
                "wf_cells_per_pair": cells / n, "cigar_ops_per_pair": n_ops_total / n}
         out = {"metric": "aligned pairs/sec (and Gcells/s) on 1e6 synthetic 1 kbp pairs @5% error",
@@ -145,8 +146,11 @@ def main():
                "vs_baseline": None, "dtype": "u32", "data": "synthetic", "config": cfg,
                "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                             "frac": achieved / 8000.0, "traffic": None,
-                            "algorithmic_bytes_per_launch": alg_bytes, "kernel": "wfa_generic_kernel<1,0>",
-                            "kernel_ms": k_ms}}
+                            "algorithmic_bytes_per_launch": alg_bytes,
+                            "kernel": "wfa_packed_kernel" if timing.n_packed_pairs else "wfa_generic_kernel<1,0>",
+                            "kernel_ms": main_k_ms, "all_kernels_ms": k_ms,
+                            "note": "achieved = algorithmic bytes of one step / duration of the dominant "
+                                    "(forward) kernel's launches in that step; peak = 8 TB/s HBM3E spec"}}
         # ---- CPU baseline: the oracle (a literal port of the reference's algorithm) on a bounded sample of the
         # same dataset, on this box's host cores.  Reported baseline, not the target.
         if args.cpu_sample > 0:
