@@ -1,0 +1,19 @@
+#!/bin/bash
+# Diagnostic: build a stamped copy of the library (per-phase s_memtime shares of the packed kernel) and run
+# one pass of the bench workload with it.  Never used for timing numbers.
+set -e
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $REPO
+mkdir -p /tmp/wfa_stamps/wfa_amd/lib
+cp -r wfa_amd/*.py /tmp/wfa_stamps/wfa_amd/
+hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DWFA_STAMPS -shared -o /tmp/wfa_stamps/wfa_amd/lib/libwfahip.so wfa_amd/csrc/wfa_host.hip wfa_amd/csrc/wfa_gen.cpp
+cd /tmp/wfa_stamps && python3 - "$@" <<'PY'
+import sys, numpy as np
+sys.path.insert(0, "/tmp/wfa_stamps")
+import wfa_amd as w
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
+data = w.generate_pairs(3, n, 1000, 0.05, n_threads=32)
+al = w.New(); al.AdaptiveReduction(w.DefaultAdaptiveOption)
+r = al.align_arrays(*data); r = al.align_arrays(*data)
+print(al.last_timing())
+PY

@@ -357,6 +357,12 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
             P.sub_lds_words = (uint32_t)sub_words;
             P.min_xe        = std::min(P.x, P.e);
             P.work          = nullptr;
+#ifdef WFA_STAMPS
+            static DevBuf stampbuf;
+            if ((rc = ensure(ctx, stampbuf, 64))) return rc;
+            HIP_TRY(hipMemsetAsync(stampbuf.p, 0, 64, st));
+            P.debug_info = static_cast<uint32_t *>(stampbuf.p);
+#endif
             const uint32_t waves_per_cu = (uint32_t)std::min<size_t>(32, LDS_MAX_BYTES / lds_bytes);
             for (uint64_t c0 = 0; c0 < n_pairs; c0 += chunk) {
                 const uint64_t cn = std::min<uint64_t>(chunk, n_pairs - c0);
@@ -379,6 +385,18 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
                 ctx->timing.n_main_launches++;
                 ctx->timing.n_launches += 2;
             }
+#ifdef WFA_STAMPS
+            {
+                unsigned long long acc[8];
+                HIP_TRY(hipMemcpy(acc, P.debug_info, 64, hipMemcpyDeviceToHost));
+                unsigned long long tot = 0;
+                for (int i = 0; i < 6; i++) tot += acc[i];
+                const char *nm[6] = {"refill", "meta+range", "sources+next+extend", "masks+reduce", "stores", "advance"};
+                for (int i = 0; i < 6; i++)
+                    std::fprintf(stderr, "[stamps] %-22s %6.2f %%  (%llu cyc)\n", nm[i], 100.0 * acc[i] / (double)tot, acc[i]);
+                P.debug_info = nullptr;
+            }
+#endif
             first       = false;
             packed_done = true;
             uint32_t hc[CTRL_WORDS];

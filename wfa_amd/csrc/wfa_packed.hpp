@@ -21,6 +21,24 @@
 
 namespace wfa {
 
+// Diagnostic build only (-DWFA_STAMPS): per-phase s_memtime shares, summed per wave into debug_info
+// (never part of the shipped library; see scripts/stamps.sh).
+#ifdef WFA_STAMPS
+#define WFA_STAMP(i)                                                                                  \
+    do {                                                                                              \
+        unsigned long long _t;                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");                   \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        stamp_acc[i] += _t - stamp_prev;                                                              \
+        stamp_prev = _t;                                                                              \
+    } while (0)
+#else
+#define WFA_STAMP(i) \
+    do {             \
+    } while (0)
+#endif
+
 constexpr int PK_G     = 32;  // lanes per pair
 constexpr int PK_TILES = 2;   // diagonals per lane
 constexpr int PK_WCAP  = PK_G * PK_TILES;
@@ -72,6 +90,10 @@ __global__ __launch_bounds__(64) void wfa_packed_kernel(const KParams P) {
     uint32_t  my_cells = 0;
     SeqView<0> sv;
     sv.q = lq, sv.t = lt, sv.n = 0, sv.m = 0;
+#ifdef WFA_STAMPS
+    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+#endif
 
     for (;;) {
         // ---------------------------------------------------------------- refill (divergent per half)
@@ -116,6 +138,7 @@ __global__ __launch_bounds__(64) void wfa_packed_kernel(const KParams P) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (__ballot(st != 2) == 0ull) break;
         const bool run = (st == 1);
+        WFA_STAMP(0);  // refill
 
         // ---------------------------------------------------------------- one score step
         // sources: M[s-x], M[s-o-e], I[s-e], D[s-e]  (wfa.go:557-560; missing when diff > s)
@@ -143,6 +166,7 @@ __global__ __launch_bounds__(64) void wfa_packed_kernel(const KParams P) {
         uint32_t cM[PK_TILES], cI[PK_TILES], cD[PK_TILES];
         uint32_t mbits[PK_TILES];
         bool     term = false;
+        WFA_STAMP(1);  // ring meta + range
 #pragma unroll
         for (int t = 0; t < PK_TILES; t++) {
             cM[t] = cI[t] = cD[t] = 0u;
@@ -165,6 +189,7 @@ __global__ __launch_bounds__(64) void wfa_packed_kernel(const KParams P) {
             }
             mbits[t] = half_of(__ballot(cM[t] != 0u), sub);
         }
+        WFA_STAMP(2);  // sources + next + extend
         term = half_of(__ballot(term), sub) != 0u;
         const unsigned long long mmask = (unsigned long long)mbits[0] | ((unsigned long long)mbits[1] << 32);
         int nlo = 0, nhi = -1;  // band to keep; M.Lo/Hi of the reference = tight range of M cells
@@ -196,6 +221,7 @@ __global__ __launch_bounds__(64) void wfa_packed_kernel(const KParams P) {
             }
         }
 
+        WFA_STAMP(3);  // masks + wf-adaptive
         // ---------------------------------------------------------------- store the surviving band
         const int  wn       = (nhi >= nlo) ? nhi - nlo + 1 : 0;
         const bool no_room  = run && ((uint64_t)top + 3ull * (uint32_t)wn + 4ull * (si + 2u) > cap);
@@ -223,6 +249,7 @@ __global__ __launch_bounds__(64) void wfa_packed_kernel(const KParams P) {
             }
             top += 3u * (uint32_t)wn;
         }
+        WFA_STAMP(4);  // stores
         // ---------------------------------------------------------------- finish / advance
         if (give_up || (run && term)) {
             const uint32_t cells = sub_sum(my_cells);
@@ -242,7 +269,14 @@ __global__ __launch_bounds__(64) void wfa_packed_kernel(const KParams P) {
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        WFA_STAMP(5);  // finish / advance
     }
+#ifdef WFA_STAMPS
+    if (lane == 0 && P.debug_info) {
+        unsigned long long *acc = reinterpret_cast<unsigned long long *>(P.debug_info);
+        for (int i = 0; i < 8; i++) atomicAdd(acc + i, stamp_acc[i]);
+    }
+#endif
 }
 
 // Lane-per-pair backtrace (wfa.go:703-983) + process() statistics + result record for the pairs the packed
