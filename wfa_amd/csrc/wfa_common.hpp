@@ -65,7 +65,7 @@ struct KParams {
     uint64_t           *ops;
     uint64_t            ops_cap;
     unsigned long long *ops_cursor;
-    uint32_t           *redo_list;  // pairs needing another configuration
+    uint32_t           *redo_list;  // {pair, status} of pairs needing another configuration
     uint32_t           *redo_count;
     // LDS budget of this launch: words available for EACH packed sequence (incl. 1 pad word)
     uint32_t lds_seq_words;

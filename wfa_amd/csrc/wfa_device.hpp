@@ -15,6 +15,13 @@ WFA_DEV uint32_t umax2(uint32_t a, uint32_t b) { return a > b ? a : b; }
 WFA_DEV int      imin2(int a, int b) { return a < b ? a : b; }
 WFA_DEV int      imax2(int a, int b) { return a > b ? a : b; }
 
+// A pair this launch cannot finish: queue it (with the reason) for the host's next configuration.
+WFA_DEV void push_redo(const KParams &P, uint32_t pair, uint32_t status) {
+    const uint32_t i     = atomicAdd(P.redo_count, 1u);
+    P.redo_list[2u * i]      = pair;
+    P.redo_list[2u * i + 1u] = status;
+}
+
 // ---------------------------------------------------------------------------------------------
 // wave64 reductions (DPP/ds_swizzle via __shfl_xor; 64 lanes, not 32)
 WFA_DEV int wave_min(int v) {

@@ -57,8 +57,8 @@ __global__ __launch_bounds__(64 * WAVES) void wfa_generic_kernel(const KParams P
             const uint32_t need = ((imax2(n, m) + 15) >> 4) + 1;
             if (need > P.lds_seq_words) {
                 if (tid == 0) {
-                    rec[REC_STATUS]                          = ST_REDO_LDS;
-                    P.redo_list[atomicAdd(P.redo_count, 1u)] = pair;
+                    rec[REC_STATUS] = ST_REDO_LDS;
+                    push_redo(P, pair, ST_REDO_LDS);
                 }
                 continue;
             }
@@ -70,8 +70,8 @@ __global__ __launch_bounds__(64 * WAVES) void wfa_generic_kernel(const KParams P
             __syncthreads();
             if (red[9]) {  // non-ACGT byte: the byte-compare configuration must take this pair
                 if (tid == 0) {
-                    rec[REC_STATUS]                          = ST_REDO_BYTES;
-                    P.redo_list[atomicAdd(P.redo_count, 1u)] = pair;
+                    rec[REC_STATUS] = ST_REDO_BYTES;
+                    push_redo(P, pair, ST_REDO_BYTES);
                 }
                 continue;
             }
@@ -238,8 +238,8 @@ __global__ __launch_bounds__(64 * WAVES) void wfa_generic_kernel(const KParams P
 
         if (overflow || !done) {
             if (tid == 0) {
-                rec[REC_STATUS]                          = ST_REDO_ARENA;
-                P.redo_list[atomicAdd(P.redo_count, 1u)] = pair;
+                rec[REC_STATUS] = ST_REDO_ARENA;
+                push_redo(P, pair, ST_REDO_ARENA);
             }
             continue;
         }
@@ -263,8 +263,8 @@ __global__ __launch_bounds__(64 * WAVES) void wfa_generic_kernel(const KParams P
             back_trace(av, n, m, minS, lastK, !glob, x, P.o, e, ow, to);
 
             if (ow.overflow) {
-                rec[REC_STATUS]                          = ST_REDO_ARENA;
-                P.redo_list[atomicAdd(P.redo_count, 1u)] = pair;
+                rec[REC_STATUS] = ST_REDO_ARENA;
+                push_redo(P, pair, ST_REDO_ARENA);
             } else {
                 // process() (wfa_cigar.go:136-214): the forward list is the scratch list reversed
                 const uint32_t L   = ow.n;

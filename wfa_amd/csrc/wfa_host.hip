@@ -299,7 +299,7 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
 
     rc = ensure(ctx, ctx->ctrl, CTRL_WORDS * 4);
     if (rc) return rc;
-    rc = ensure(ctx, ctx->redo, n_pairs * 4);
+    rc = ensure(ctx, ctx->redo, n_pairs * 8);
     if (rc) return rc;
     uint32_t *d_ctrl = static_cast<uint32_t *>(ctx->ctrl.p);
 
@@ -405,16 +405,14 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
             ctx->timing.n_packed_pairs     = (uint32_t)(n_pairs - n_redo);
             ctx->timing.n_retried_pairs += n_redo;
             if (n_redo) {
-                std::vector<uint32_t> ids(n_redo), stw(n_redo);
-                HIP_TRY(hipMemcpy(ids.data(), ctx->redo.p, n_redo * 4ull, hipMemcpyDeviceToHost));
-                std::sort(ids.begin(), ids.end());
-                for (uint32_t i = 0; i < n_redo; i++)
-                    HIP_TRY(hipMemcpy(&stw[i], P.rec + (uint64_t)ids[i] * REC_WORDS, 4, hipMemcpyDeviceToHost));
+                std::vector<uint64_t> ent(n_redo);  // {pair, status}
+                HIP_TRY(hipMemcpy(ent.data(), ctx->redo.p, n_redo * 8ull, hipMemcpyDeviceToHost));
+                std::sort(ent.begin(), ent.end(), [](uint64_t a, uint64_t b) { return (uint32_t)a < (uint32_t)b; });
                 Job jb, ja;
                 jb.mode = 1, jb.level = 0, jb.all = false;
                 ja.mode = 0, ja.level = 0, ja.all = false;
                 for (uint32_t i = 0; i < n_redo; i++)
-                    (stw[i] == ST_REDO_BYTES ? jb : ja).pairs.push_back(ids[i]);
+                    ((uint32_t)(ent[i] >> 32) == ST_REDO_BYTES ? jb : ja).pairs.push_back((uint32_t)ent[i]);
                 if (!ja.pairs.empty()) jobs.push_back(std::move(ja));
                 if (!jb.pairs.empty()) jobs.push_back(std::move(jb));
             }
@@ -482,20 +480,15 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
         const uint32_t n_redo = hctrl[1];
         if (n_redo) {
             ctx->timing.n_retried_pairs += n_redo;
-            std::vector<uint32_t> ids(n_redo), st_words(n_redo);
-            HIP_TRY(hipMemcpy(ids.data(), ctx->redo.p, n_redo * 4ull, hipMemcpyDeviceToHost));
-            std::sort(ids.begin(), ids.end());
-            // fetch each pair's status word (strided gather; redo sets are small)
-            for (uint32_t i = 0; i < n_redo; i++)
-                HIP_TRY(hipMemcpy(&st_words[i], P.rec + (uint64_t)ids[i] * REC_WORDS, 4, hipMemcpyDeviceToHost));
+            std::vector<uint64_t> ent(n_redo);  // {pair, status}
+            HIP_TRY(hipMemcpy(ent.data(), ctx->redo.p, n_redo * 8ull, hipMemcpyDeviceToHost));
+            std::sort(ent.begin(), ent.end(), [](uint64_t a, uint64_t b) { return (uint32_t)a < (uint32_t)b; });
             Job jb, ja;
             jb.mode = 1, jb.level = job.level, jb.all = false;
             ja.mode = job.mode, ja.level = job.level + 1, ja.all = false;
             for (uint32_t i = 0; i < n_redo; i++) {
-                if (st_words[i] == ST_REDO_BYTES || st_words[i] == ST_REDO_LDS)
-                    jb.pairs.push_back(ids[i]);
-                else
-                    ja.pairs.push_back(ids[i]);
+                const uint32_t stw = (uint32_t)(ent[i] >> 32);
+                (stw == ST_REDO_BYTES || stw == ST_REDO_LDS ? jb : ja).pairs.push_back((uint32_t)ent[i]);
             }
             if (!jb.pairs.empty()) jobs.push_back(std::move(jb));
             if (!ja.pairs.empty()) jobs.push_back(std::move(ja));

@@ -51,14 +51,22 @@ __host__ __device__ inline uint32_t packed_sub_lds_words(uint32_t seq_words, uin
 WFA_DEV uint32_t half_of(unsigned long long ballot, int sub) {
     return sub ? (uint32_t)(ballot >> 32) : (uint32_t)ballot;
 }
-WFA_DEV int sub_min(int v) {  // min over the 32 lanes of a half (xor masks < 32 stay inside it)
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) v = imin2(v, __shfl_xor(v, o, 64));
+// Reductions over the 32 lanes of a half: four DPP steps inside each 16-lane row (quad_perm x2,
+// row_half_mirror, row_mirror), then one ds_swizzle SWAP16 to combine the two rows of the half.
+WFA_DEV int sub_min(int v) {
+    v = imin2(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));
+    v = imin2(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));
+    v = imin2(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));
+    v = imin2(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));
+    v = imin2(v, __builtin_amdgcn_ds_swizzle(v, 0x401F));
     return v;
 }
 WFA_DEV uint32_t sub_sum(uint32_t v) {
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v += (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401F);
     return v;
 }
 
@@ -122,7 +130,7 @@ __global__ __launch_bounds__(64) void wfa_packed_kernel(const KParams P) {
                 if (status != ST_PENDING) {
                     if (j == 0) {
                         P.pair_meta[pidx] = make_uint4(status, 0u, 0u, 0u);
-                        if (status >= ST_REDO_BYTES) P.redo_list[atomicAdd(P.redo_count, 1u)] = pair;
+                        if (status >= ST_REDO_BYTES) push_redo(P, pair, status);
                     }
                     // stay in state 0: the next loop iteration pulls another pair
                 } else {
@@ -255,8 +263,8 @@ __global__ __launch_bounds__(64) void wfa_packed_kernel(const KParams P) {
             const uint32_t cells = sub_sum(my_cells);
             if (j == 0) {
                 if (give_up) {
-                    P.pair_meta[pidx]                        = make_uint4(too_wide ? ST_REDO_BAND : ST_REDO_ARENA, 0u, 0u, 0u);
-                    P.redo_list[atomicAdd(P.redo_count, 1u)] = pair;
+                    P.pair_meta[pidx] = make_uint4(too_wide ? ST_REDO_BAND : ST_REDO_ARENA, 0u, 0u, 0u);
+                    push_redo(P, pair, too_wide ? ST_REDO_BAND : ST_REDO_ARENA);
                 } else {
                     P.pair_meta[pidx] = make_uint4(ST_OK, s, si + 1u, cells);
                 }
