@@ -53,6 +53,7 @@ def main():
     entry.build()
     import wfa_amd as w
     from wfa_amd import _lib as L
+    from wfa_amd.shard import gather_results
 
     n = args.pairs
     # ---- synthetic input (host generation, then H2D: outside the timed region)
@@ -86,13 +87,7 @@ def main():
         lib.wfahip_last_timing(al._ctx, C.byref(timing))
         n_ops = int(needed.value)
         if world > 1:  # result gather onto rank 0 over RCCL/xGMI (fixed-size records, then padded op arrays)
-            cnt = torch.tensor([n_ops], dtype=torch.int64, device=dev)
-            dist.all_reduce(cnt, op=dist.ReduceOp.MAX)
-            m = int(cnt.item())
-            recs = [torch.empty_like(d_rec) for _ in range(world)] if rank == 0 else None
-            dist.gather(d_rec, recs, dst=0)
-            opl = [torch.empty(m, dtype=torch.int64, device=dev) for _ in range(world)] if rank == 0 else None
-            dist.gather(d_ops[:m], opl, dst=0)
+            gather_results(d_rec, d_ops, n_ops, dst=0)
         return n_ops
 
     def sync_all():

@@ -1,0 +1,199 @@
+// Package wfa is the drop-in replacement of github.com/shenwei356/wfa's alignment path: the same exported
+// API (Penalties, Options, AdaptiveReductionOption, New, RecycleAligner, (*Aligner).AdaptiveReduction,
+// Align, AlignPointers, AlignmentResult, CIGAR, ...), with the wavefront extend/next loop, wf-adaptive
+// reduction and backtrace running on an AMD MI355X through libwfahip.so (include/wfa_hip.h).
+//
+// NOTE: the build container has no Go toolchain, so this file has never been compiled; it is kept
+// deliberately thin (buffer marshalling only) and mirrors wfa_amd/aligner.py, which IS exercised by the
+// test-suite through the identical C-ABI.  See INTEGRATION.md.
+package wfa
+
+/*
+#cgo CFLAGS: -I${SRCDIR}/../../include
+#cgo LDFLAGS: -L${SRCDIR}/../../wfa_amd/lib -lwfahip
+#include <stdlib.h>
+#include "wfa_hip.h"
+*/
+import "C"
+
+import (
+	"fmt"
+	"runtime"
+	"unsafe"
+)
+
+// Penalties contains the gap-affine penalties, Match is 0.  (reference: wfa.go:32-36)
+type Penalties struct {
+	Mismatch uint32
+	GapOpen  uint32
+	GapExt   uint32
+}
+
+// DefaultPenalties is from the WFA paper.  (wfa.go:39-43)
+var DefaultPenalties = &Penalties{Mismatch: 4, GapOpen: 6, GapExt: 2}
+
+// AdaptiveReductionOption contains the parameters for adaptive reduction.  (wfa.go:46-50)
+type AdaptiveReductionOption struct {
+	MinWFLen    uint32
+	MaxDistDiff uint32
+	CutoffStep  uint32 // not used yet (by the reference either).
+}
+
+// DefaultAdaptiveOption: 10, 50, 1.  (wfa.go:56-60)
+var DefaultAdaptiveOption = &AdaptiveReductionOption{MinWFLen: 10, MaxDistDiff: 50, CutoffStep: 1}
+
+// Options: global or semi-global alignment.  (wfa.go:64-66)
+type Options struct {
+	GlobalAlignment bool
+}
+
+// DefaultOptions is the default option.  (wfa.go:69-71)
+var DefaultOptions = &Options{GlobalAlignment: true}
+
+// ErrEmptySeq / ErrSeqTooLong / MaxSeqLen: wfa.go:186-193.
+var ErrEmptySeq error = fmt.Errorf("wfa: invalid empty sequence")
+
+const MaxSeqLen int = 1<<(32-3) - 1
+
+var ErrSeqTooLong error = fmt.Errorf("wfa: sequences longer than %d are not supported", MaxSeqLen)
+
+// Aligner holds one device context.  Like the reference's (wfa.go:73-78) it must not be used from several
+// goroutines at once; create one per goroutine (different Aligners may run concurrently).
+type Aligner struct {
+	p   *Penalties
+	ad  *AdaptiveReductionOption
+	opt *Options
+	ctx *C.wfahip_ctx
+}
+
+// New returns a new Aligner bound to the current HIP device.  (wfa.go:120)
+func New(p *Penalties, opt *Options) *Aligner {
+	algn := &Aligner{p: p, opt: opt}
+	if rc := C.wfahip_create(C.int(-1), &algn.ctx); rc != 0 {
+		panic(fmt.Sprintf("wfa: %s", C.GoString(C.wfahip_strerror(rc))))
+	}
+	return algn
+}
+
+// RecycleAligner releases the device context.  (wfa.go:102)
+func RecycleAligner(algn *Aligner) {
+	if algn != nil && algn.ctx != nil {
+		C.wfahip_destroy(algn.ctx)
+		algn.ctx = nil
+	}
+}
+
+// AdaptiveReduction sets the adaptive reduction parameters.  (wfa.go:134-140, same error text)
+func (algn *Aligner) AdaptiveReduction(ad *AdaptiveReductionOption) error {
+	if ad.MinWFLen == 0 {
+		return fmt.Errorf("cutoff step should not be 0")
+	}
+	algn.ad = ad
+	return nil
+}
+
+func (algn *Aligner) params() C.wfahip_params {
+	var p C.wfahip_params
+	p.mismatch, p.gap_open, p.gap_ext = C.uint32_t(algn.p.Mismatch), C.uint32_t(algn.p.GapOpen), C.uint32_t(algn.p.GapExt)
+	if algn.opt.GlobalAlignment {
+		p.global_alignment = 1
+	}
+	if algn.ad != nil {
+		p.adaptive = 1
+		p.min_wf_len, p.max_dist_diff, p.cutoff_step = C.uint32_t(algn.ad.MinWFLen), C.uint32_t(algn.ad.MaxDistDiff), C.uint32_t(algn.ad.CutoffStep)
+	}
+	return p
+}
+
+// Align performs alignment with two sequences.  (wfa.go:196)
+func (algn *Aligner) Align(q, t []byte) (*AlignmentResult, error) {
+	return algn.AlignPointers(&q, &t)
+}
+
+// AlignPointers performs alignment with two sequences. The arguments are pointers.  (wfa.go:201)
+func (algn *Aligner) AlignPointers(q, t *[]byte) (*AlignmentResult, error) {
+	if len(*q) == 0 || len(*t) == 0 {
+		return nil, ErrEmptySeq
+	}
+	if len(*q) > MaxSeqLen || len(*t) > MaxSeqLen {
+		return nil, ErrSeqTooLong
+	}
+	rs, errs := algn.AlignBatch([][]byte{*q}, [][]byte{*t})
+	return rs[0], errs[0]
+}
+
+// AlignBatch aligns qs[i] against ts[i] for every i in one device call (new: a GPU needs batches).
+// Sequences are copied into one flat blob: C never sees Go pointers inside Go memory (cgo pointer rules) and
+// keeps nothing after the call returns.
+func (algn *Aligner) AlignBatch(qs, ts [][]byte) ([]*AlignmentResult, []error) {
+	n := len(qs)
+	results := make([]*AlignmentResult, n)
+	errs := make([]error, n)
+	if n == 0 {
+		return results, errs
+	}
+	qOff, tOff := make([]C.uint64_t, n), make([]C.uint64_t, n)
+	qLen, tLen := make([]C.uint32_t, n), make([]C.uint32_t, n)
+	total := 0
+	for i := 0; i < n; i++ { // 16-byte aligned starts (lets the kernel stage with aligned dword loads)
+		qOff[i] = C.uint64_t(total)
+		qLen[i] = C.uint32_t(len(qs[i]))
+		total += (len(qs[i]) + 15) &^ 15
+		tOff[i] = C.uint64_t(total)
+		tLen[i] = C.uint32_t(len(ts[i]))
+		total += (len(ts[i]) + 15) &^ 15
+	}
+	blob := make([]byte, total+16)
+	for i := 0; i < n; i++ {
+		copy(blob[qOff[i]:], qs[i])
+		copy(blob[tOff[i]:], ts[i])
+	}
+	p := algn.params()
+	var out C.wfahip_results
+	rc := C.wfahip_align_batch(algn.ctx, &p, (*C.uint8_t)(unsafe.Pointer(&blob[0])), C.uint64_t(len(blob)),
+		&qOff[0], &qLen[0], &tOff[0], &tLen[0], C.uint64_t(n), &out)
+	runtime.KeepAlive(blob)
+	if rc != 0 {
+		err := fmt.Errorf("wfa: %s", C.GoString(C.wfahip_strerror(rc)))
+		for i := range errs {
+			errs[i] = err
+		}
+		return results, errs
+	}
+	defer C.wfahip_results_free(&out)
+	status := unsafe.Slice((*int32)(unsafe.Pointer(out.status)), n)
+	score := unsafe.Slice((*uint32)(unsafe.Pointer(out.score)), n)
+	tb := unsafe.Slice((*int32)(unsafe.Pointer(out.tbegin)), n)
+	te := unsafe.Slice((*int32)(unsafe.Pointer(out.tend)), n)
+	qb := unsafe.Slice((*int32)(unsafe.Pointer(out.qbegin)), n)
+	qe := unsafe.Slice((*int32)(unsafe.Pointer(out.qend)), n)
+	al := unsafe.Slice((*uint32)(unsafe.Pointer(out.align_len)), n)
+	ma := unsafe.Slice((*uint32)(unsafe.Pointer(out.matches)), n)
+	ga := unsafe.Slice((*uint32)(unsafe.Pointer(out.gaps)), n)
+	gr := unsafe.Slice((*uint32)(unsafe.Pointer(out.gap_regions)), n)
+	oo := unsafe.Slice((*uint64)(unsafe.Pointer(out.ops_off)), n)
+	ol := unsafe.Slice((*uint32)(unsafe.Pointer(out.ops_len)), n)
+	var ops []uint64
+	if out.n_ops > 0 {
+		ops = unsafe.Slice((*uint64)(unsafe.Pointer(out.ops)), int(out.n_ops))
+	}
+	for i := 0; i < n; i++ {
+		switch status[i] {
+		case 0:
+			r := NewAlignmentResult(algn.opt.GlobalAlignment)
+			r.Ops = append(r.Ops[:0], ops[oo[i]:oo[i]+uint64(ol[i])]...) // copied into pool-owned memory
+			r.Score = score[i]
+			r.TBegin, r.TEnd, r.QBegin, r.QEnd = int(tb[i]), int(te[i]), int(qb[i]), int(qe[i])
+			r.AlignLen, r.Matches, r.Gaps, r.GapRegions = al[i], ma[i], ga[i], gr[i]
+			r.proccessed = true // ops arrive reversed + merged (process(), wfa_cigar.go:136-214, ran on the device)
+			results[i] = r
+		case 1:
+			errs[i] = ErrEmptySeq
+		case 2:
+			errs[i] = ErrSeqTooLong
+		default:
+			errs[i] = fmt.Errorf("wfa: out of device memory for this pair")
+		}
+	}
+	return results, errs
+}

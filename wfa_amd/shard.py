@@ -1,0 +1,54 @@
+"""Pair sharding and result gather for multi-GPU runs (one process per GPU, torch.distributed).
+
+Alignments share no state (the reference's own model is one Aligner per goroutine, wfa.go:73-78), so a batch
+is cut into contiguous shards of pairs, one per rank, with NO collective on the data path.  The only exchange
+is the gather of results onto rank 0: fixed-size 64-byte records, then the CIGAR op arrays padded to the
+largest shard (counts are agreed with one tiny all-reduce).  Backend "nccl" is RCCL over xGMI on the GPU box;
+the same code runs over "gloo" on CPU tensors in the tests.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_total: int, rank: int, world: int) -> Tuple[int, int]:
+    """[begin, end) of the pairs rank `rank` owns: contiguous, sizes differ by at most one."""
+    base, rem = divmod(n_total, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+def gather_results(rec: torch.Tensor, ops: torch.Tensor, n_ops: int, dst: int = 0
+                   ) -> Optional[Tuple[List[torch.Tensor], List[torch.Tensor]]]:
+    """Gather every rank's result records [n_i, 16] (int32) and the used prefix of its op buffer (int64).
+
+    Shards may differ in size, so both arrays are padded to the largest shard before `dist.gather`.  Returns
+    (records per rank, ops per rank) on `dst` (trimmed back to each rank's true sizes), None elsewhere.
+    The OPS_OFF fields of a record index into that rank's own op array.
+    """
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = rec.device
+    sizes = torch.tensor([rec.shape[0], n_ops], dtype=torch.int64, device=dev)
+    all_sizes = [torch.empty_like(sizes) for _ in range(world)]
+    dist.all_gather(all_sizes, sizes)
+    max_rec = max(int(s[0]) for s in all_sizes)
+    max_ops = max(int(s[1]) for s in all_sizes)
+
+    def padded(t: torch.Tensor, rows: int) -> torch.Tensor:
+        if t.shape[0] == rows:
+            return t.contiguous()
+        out = torch.zeros((rows,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
+        out[:t.shape[0]] = t
+        return out
+
+    rec_p, ops_p = padded(rec, max_rec), padded(ops[:n_ops], max_ops)
+    recs = [torch.empty_like(rec_p) for _ in range(world)] if rank == dst else None
+    opss = [torch.empty_like(ops_p) for _ in range(world)] if rank == dst else None
+    dist.gather(rec_p, recs, dst=dst)
+    dist.gather(ops_p, opss, dst=dst)
+    if rank != dst:
+        return None
+    return ([r[:int(s[0])] for r, s in zip(recs, all_sizes)], [o[:int(s[1])] for o, s in zip(opss, all_sizes)])
