@@ -45,6 +45,8 @@ struct wfahip_ctx {
     int           num_cus    = 256;
     size_t        total_mem  = 0;
     hipStream_t   stream     = nullptr;
+    hipStream_t   stream2    = nullptr;  // backtrace kernels of chunk c overlap the forward kernel of chunk c+1
+    std::vector<hipEvent_t> evpool;
     hipEvent_t    ev0 = nullptr, ev1 = nullptr, evA = nullptr, evB = nullptr, evC = nullptr;
     DevBuf        arena, ctrl, redo, work, meta;
     DevBuf        in_blob, in_qoff, in_qlen, in_toff, in_tlen, out_rec, out_ops;  // host-entry staging
@@ -55,6 +57,8 @@ struct wfahip_ctx {
     int64_t       opt_packed               = 1;  // 0: never use the packed (sub-wave) kernel
     int64_t       opt_packed_arena_bytes   = 0;  // per pair, 0 = automatic
     int64_t       opt_chunk_pairs          = 0;  // 0 = automatic
+    int64_t       opt_packed_waves_per_cu  = 0;  // 0 = automatic
+    int64_t       opt_overlap              = 1;  // 0: backtrace on the same stream as the forward kernel
     int           force_mode               = -1;  // debug: start the ladder in this mode
     wfahip_timing timing{};
     char          last_error[256] = {0};
@@ -210,6 +214,7 @@ extern "C" int wfahip_create(int device_id, wfahip_ctx **out) {
         ctx->total_mem = prop.totalGlobalMem;
     }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
         hipEventCreate(&ctx->evA) != hipSuccess || hipEventCreate(&ctx->evB) != hipSuccess ||
         hipEventCreate(&ctx->evC) != hipSuccess) {
@@ -231,7 +236,9 @@ extern "C" void wfahip_destroy(wfahip_ctx *ctx) {
     if (ctx->evA) (void)hipEventDestroy(ctx->evA);
     if (ctx->evB) (void)hipEventDestroy(ctx->evB);
     if (ctx->evC) (void)hipEventDestroy(ctx->evC);
+    for (hipEvent_t e : ctx->evpool) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     delete ctx;
 }
 
@@ -250,6 +257,10 @@ extern "C" int wfahip_set_option(wfahip_ctx *ctx, const char *key, int64_t value
         ctx->opt_packed_arena_bytes = value;
     else if (k == "chunk_pairs")
         ctx->opt_chunk_pairs = value;
+    else if (k == "packed_waves_per_cu")
+        ctx->opt_packed_waves_per_cu = value;
+    else if (k == "overlap")
+        ctx->opt_overlap = value;
     else
         return WFAHIP_ERR_BAD_ARG;
     return WFAHIP_OK;
@@ -339,19 +350,25 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
             uint64_t words = std::max<uint64_t>(4096, 16ull * max_len);
             if (ctx->opt_packed_arena_bytes > 0) words = std::max<uint64_t>(1024, ctx->opt_packed_arena_bytes / 4);
             words = (words + 3) & ~3ull;
-            uint64_t budget = (uint64_t)((double)ctx->total_mem * 0.35);
+            // Chunking: every pair of a chunk owns an arena until its backtrace has run.  Two chunk buffers
+            // alternate so the (latency-bound) backtrace kernel of chunk c runs on a second stream beside the
+            // (issue-bound) forward kernel of chunk c+1.
+            const uint32_t waves_lds    = (uint32_t)std::min<size_t>(32, LDS_MAX_BYTES / lds_bytes);
+            const bool     overlap      = ctx->opt_overlap != 0;
+            uint32_t       waves_per_cu = overlap ? std::min<uint32_t>(waves_lds, 24) : waves_lds;
+            if (ctx->opt_packed_waves_per_cu > 0) waves_per_cu = std::min<uint32_t>(waves_lds, (uint32_t)ctx->opt_packed_waves_per_cu);
+            const uint64_t resident = 2ull * ctx->num_cus * waves_per_cu;  // pairs in flight
+            uint64_t budget = (uint64_t)((double)ctx->total_mem * 0.35) / (overlap ? 2 : 1);
             uint64_t chunk  = std::max<uint64_t>(1, std::min<uint64_t>(n_pairs, budget / (words * 4ull)));
+            if (overlap && n_pairs >= 8 * resident) chunk = std::min<uint64_t>(chunk, (n_pairs + 3) / 4);
             if (ctx->opt_chunk_pairs > 0) chunk = std::min<uint64_t>(chunk, (uint64_t)ctx->opt_chunk_pairs);
-            rc = ensure(ctx, ctx->arena, (size_t)(words * 4ull * chunk));
-            if (rc == WFAHIP_ERR_OOM) {
-                chunk = std::max<uint64_t>(1, chunk / 4);
-                rc    = ensure(ctx, ctx->arena, (size_t)(words * 4ull * chunk));
-            }
+            const uint64_t n_chunks = (n_pairs + chunk - 1) / chunk;
+            const uint32_t n_buf    = (overlap && n_chunks > 1) ? 2 : 1;
+            rc = ensure(ctx, ctx->arena, (size_t)(words * 4ull * chunk * n_buf));
             if (rc) return rc;
-            if ((rc = ensure(ctx, ctx->meta, chunk * 16))) return rc;
-            ctx->timing.arena_bytes = words * 4ull * chunk;
-            P.arena = static_cast<uint32_t *>(ctx->arena.p), P.arena_words = words;
-            P.pair_meta     = static_cast<uint4 *>(ctx->meta.p);
+            if ((rc = ensure(ctx, ctx->meta, chunk * 16 * n_buf))) return rc;
+            ctx->timing.arena_bytes = words * 4ull * chunk * n_buf;
+            P.arena_words   = words;
             P.dx = dx, P.doe = doe, P.de = de, P.dm = dm, P.di = di;
             P.lds_seq_words = seq_words;
             P.sub_lds_words = (uint32_t)sub_words;
@@ -363,23 +380,41 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
             HIP_TRY(hipMemsetAsync(stampbuf.p, 0, 64, st));
             P.debug_info = static_cast<uint32_t *>(stampbuf.p);
 #endif
-            const uint32_t waves_per_cu = (uint32_t)std::min<size_t>(32, LDS_MAX_BYTES / lds_bytes);
-            for (uint64_t c0 = 0; c0 < n_pairs; c0 += chunk) {
-                const uint64_t cn = std::min<uint64_t>(chunk, n_pairs - c0);
+            while (ctx->evpool.size() < 4 * n_chunks) {
+                hipEvent_t e;
+                HIP_TRY(hipEventCreate(&e));
+                ctx->evpool.push_back(e);
+            }
+            hipStream_t st_bt = (n_buf == 2) ? ctx->stream2 : st;
+            for (uint64_t c = 0; c < n_chunks; c++) {
+                const uint64_t c0 = c * chunk, cn = std::min<uint64_t>(chunk, n_pairs - c0);
+                hipEvent_t evFa = ctx->evpool[4 * c], evFb = ctx->evpool[4 * c + 1];
+                hipEvent_t evBa = ctx->evpool[4 * c + 2], evBb = ctx->evpool[4 * c + 3];
+                const uint32_t buf = (uint32_t)(c % n_buf);
+                P.arena       = static_cast<uint32_t *>(ctx->arena.p) + (uint64_t)buf * chunk * words;
+                P.pair_meta   = static_cast<uint4 *>(ctx->meta.p) + (uint64_t)buf * chunk;
                 P.chunk_first = (uint32_t)c0, P.chunk_n = (uint32_t)cn;
                 const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)ctx->num_cus * waves_per_cu, (cn + 1) / 2);
+                if (n_buf == 2 && c >= 2) HIP_TRY(hipStreamWaitEvent(st, ctx->evpool[4 * (c - 2) + 3], 0));  // buffer free
                 HIP_TRY(hipMemsetAsync(d_ctrl, 0, 4, st));  // queue_head only
-                HIP_TRY(hipEventRecord(ctx->evA, st));
+                HIP_TRY(hipEventRecord(evFa, st));
                 hipLaunchKernelGGL(wfa_packed_kernel, dim3(grid), dim3(64), lds_bytes, st, P);
                 HIP_TRY(hipGetLastError());
-                HIP_TRY(hipEventRecord(ctx->evB, st));
-                hipLaunchKernelGGL(wfa_backtrace_kernel, dim3((uint32_t)((cn + 255) / 256)), dim3(256), 0, st, P);
+                HIP_TRY(hipEventRecord(evFb, st));
+                if (st_bt != st) HIP_TRY(hipStreamWaitEvent(st_bt, evFb, 0));
+                HIP_TRY(hipEventRecord(evBa, st_bt));
+                hipLaunchKernelGGL(wfa_backtrace_kernel, dim3((uint32_t)((cn + 255) / 256)), dim3(256), 0, st_bt, P);
                 HIP_TRY(hipGetLastError());
-                HIP_TRY(hipEventRecord(ctx->evC, st));
-                HIP_TRY(hipStreamSynchronize(st));
+                HIP_TRY(hipEventRecord(evBb, st_bt));
+            }
+            if (st_bt != st)
+                for (uint64_t c = (n_chunks >= 2 ? n_chunks - 2 : 0); c < n_chunks; c++)
+                    HIP_TRY(hipStreamWaitEvent(st, ctx->evpool[4 * c + 3], 0));
+            HIP_TRY(hipStreamSynchronize(st));
+            for (uint64_t c = 0; c < n_chunks; c++) {
                 float msF = 0, msB = 0;
-                HIP_TRY(hipEventElapsedTime(&msF, ctx->evA, ctx->evB));
-                HIP_TRY(hipEventElapsedTime(&msB, ctx->evB, ctx->evC));
+                HIP_TRY(hipEventElapsedTime(&msF, ctx->evpool[4 * c], ctx->evpool[4 * c + 1]));
+                HIP_TRY(hipEventElapsedTime(&msB, ctx->evpool[4 * c + 2], ctx->evpool[4 * c + 3]));
                 ctx->timing.kernel_ms += msF + msB;
                 ctx->timing.main_kernel_ms += msF;
                 ctx->timing.n_main_launches++;
