@@ -6,6 +6,7 @@
 #include "../../include/wfa_hip.h"
 #include "wfa_generic.hpp"
 #include "wfa_packed.hpp"
+#include "wfa_reg.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -54,7 +55,8 @@ struct wfahip_ctx {
     int64_t       opt_arena_bytes_per_slot = 0;
     int64_t       opt_slots                = 0;
     int64_t       opt_threads_per_pair     = 0;
-    int64_t       opt_packed               = 1;  // 0: never use the packed (sub-wave) kernel
+    int64_t       opt_packed               = 1;  // 0: never use the packed (sub-wave) kernels
+    int64_t       opt_reg                  = 1;  // 0: never use the register-window kernel
     int64_t       opt_packed_arena_bytes   = 0;  // per pair, 0 = automatic
     int64_t       opt_chunk_pairs          = 0;  // 0 = automatic
     int64_t       opt_packed_waves_per_cu  = 0;  // 0 = automatic
@@ -253,6 +255,8 @@ extern "C" int wfahip_set_option(wfahip_ctx *ctx, const char *key, int64_t value
         ctx->opt_threads_per_pair = value;
     else if (k == "packed")
         ctx->opt_packed = value;
+    else if (k == "reg")
+        ctx->opt_reg = value;
     else if (k == "packed_arena_bytes")
         ctx->opt_packed_arena_bytes = value;
     else if (k == "chunk_pairs")
@@ -338,67 +342,86 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
     const int             max_level = 6;
     bool                  first     = true;
 
-    // ---- pass 1: packed sub-wave forward kernel + lane-per-pair backtrace kernel, chunk by chunk
+    // ---- pass 1: sub-wave forward kernels + lane-per-pair backtrace kernel, chunk by chunk.
+    //      kind 2 = register-window kernel (4 pairs per wave), kind 1 = LDS-ring packed kernel (2 pairs per wave).
     bool packed_done = false;
     if (ctx->opt_packed && !debug_single && ctx->force_mode < 0 && P.global_alignment) {
         const uint32_t dx = P.x / P.g, doe = P.oe / P.g, de = P.e / P.g;
         const uint32_t dm = std::max(dx, doe) + 1, di = de + 1;
         const uint32_t seq_words = (max_len + 15) / 16 + 1;
         const uint64_t sub_words = packed_sub_lds_words(seq_words, dm, di);
-        const size_t   lds_bytes = (size_t)sub_words * 2 * 4;
-        if (lds_bytes <= 20 * 1024) {  // keeps >= 8 waves per CU resident
-            uint64_t words = std::max<uint64_t>(4096, 16ull * max_len);
-            if (ctx->opt_packed_arena_bytes > 0) words = std::max<uint64_t>(1024, ctx->opt_packed_arena_bytes / 4);
-            words = (words + 3) & ~3ull;
+        const size_t   lds_b     = (size_t)sub_words * 2 * 4;       // packed kernel: two halves
+        const size_t   lds_c     = (size_t)seq_words * 2 * 4 * 4;   // register kernel: four rows, sequences only
+        const bool     can_b     = lds_b <= 20 * 1024;
+        const bool     can_c     = ctx->opt_reg && dx == 2 && doe == 4 && de == 1 && lds_c <= 20 * 1024;
+        uint64_t       words     = std::max<uint64_t>(4096, 16ull * max_len);
+        if (ctx->opt_packed_arena_bytes > 0) words = std::max<uint64_t>(1024, ctx->opt_packed_arena_bytes / 4);
+        words = (words + 3) & ~3ull;
+        P.arena_words   = words;
+        P.dx = dx, P.doe = doe, P.de = de, P.dm = dm, P.di = di;
+        P.lds_seq_words = seq_words;
+        P.sub_lds_words = (uint32_t)sub_words;
+        P.min_xe        = std::min(P.x, P.e);
+#ifdef WFA_STAMPS
+        static DevBuf stampbuf;
+        if ((rc = ensure(ctx, stampbuf, 64))) return rc;
+        HIP_TRY(hipMemsetAsync(stampbuf.p, 0, 64, st));
+        P.debug_info = static_cast<uint32_t *>(stampbuf.p);
+#endif
+        // one pass over `count` pairs (identity range when list == nullptr); returns the {pair,status} redo entries
+        auto forward_pass = [&](int kind, const std::vector<uint32_t> *list, uint64_t count,
+                                std::vector<uint64_t> &redo_out) -> int {
+            const size_t   lds_bytes    = kind == 2 ? lds_c : lds_b;
+            const uint32_t pairs_wave   = kind == 2 ? 4 : 2;
+            const uint32_t waves_lds    = (uint32_t)std::min<size_t>(32, LDS_MAX_BYTES / lds_bytes);
+            const bool     overlap      = ctx->opt_overlap != 0;
+            uint32_t       waves_per_cu = kind == 2 ? std::min<uint32_t>(waves_lds, 20)
+                                                    : (overlap ? std::min<uint32_t>(waves_lds, 24) : waves_lds);
+            if (ctx->opt_packed_waves_per_cu > 0)
+                waves_per_cu = std::min<uint32_t>(waves_lds, (uint32_t)ctx->opt_packed_waves_per_cu);
             // Chunking: every pair of a chunk owns an arena until its backtrace has run.  Two chunk buffers
             // alternate so the (latency-bound) backtrace kernel of chunk c runs on a second stream beside the
             // (issue-bound) forward kernel of chunk c+1.
-            const uint32_t waves_lds    = (uint32_t)std::min<size_t>(32, LDS_MAX_BYTES / lds_bytes);
-            const bool     overlap      = ctx->opt_overlap != 0;
-            uint32_t       waves_per_cu = overlap ? std::min<uint32_t>(waves_lds, 24) : waves_lds;
-            if (ctx->opt_packed_waves_per_cu > 0) waves_per_cu = std::min<uint32_t>(waves_lds, (uint32_t)ctx->opt_packed_waves_per_cu);
-            const uint64_t resident = 2ull * ctx->num_cus * waves_per_cu;  // pairs in flight
+            const uint64_t resident = (uint64_t)pairs_wave * ctx->num_cus * waves_per_cu;  // pairs in flight
             uint64_t budget = (uint64_t)((double)ctx->total_mem * 0.35) / (overlap ? 2 : 1);
-            uint64_t chunk  = std::max<uint64_t>(1, std::min<uint64_t>(n_pairs, budget / (words * 4ull)));
-            if (overlap && n_pairs >= 8 * resident) chunk = std::min<uint64_t>(chunk, (n_pairs + 3) / 4);
+            uint64_t chunk  = std::max<uint64_t>(1, std::min<uint64_t>(count, budget / (words * 4ull)));
+            if (overlap && count >= 8 * resident) chunk = std::min<uint64_t>(chunk, (count + 7) / 8);
             if (ctx->opt_chunk_pairs > 0) chunk = std::min<uint64_t>(chunk, (uint64_t)ctx->opt_chunk_pairs);
-            const uint64_t n_chunks = (n_pairs + chunk - 1) / chunk;
+            const uint64_t n_chunks = (count + chunk - 1) / chunk;
             const uint32_t n_buf    = (overlap && n_chunks > 1) ? 2 : 1;
-            rc = ensure(ctx, ctx->arena, (size_t)(words * 4ull * chunk * n_buf));
-            if (rc) return rc;
-            if ((rc = ensure(ctx, ctx->meta, chunk * 16 * n_buf))) return rc;
-            ctx->timing.arena_bytes = words * 4ull * chunk * n_buf;
-            P.arena_words   = words;
-            P.dx = dx, P.doe = doe, P.de = de, P.dm = dm, P.di = di;
-            P.lds_seq_words = seq_words;
-            P.sub_lds_words = (uint32_t)sub_words;
-            P.min_xe        = std::min(P.x, P.e);
-            P.work          = nullptr;
-#ifdef WFA_STAMPS
-            static DevBuf stampbuf;
-            if ((rc = ensure(ctx, stampbuf, 64))) return rc;
-            HIP_TRY(hipMemsetAsync(stampbuf.p, 0, 64, st));
-            P.debug_info = static_cast<uint32_t *>(stampbuf.p);
-#endif
+            int rc2 = ensure(ctx, ctx->arena, (size_t)(words * 4ull * chunk * n_buf));
+            if (rc2) return rc2;
+            if ((rc2 = ensure(ctx, ctx->meta, chunk * 16 * n_buf))) return rc2;
+            ctx->timing.arena_bytes = std::max<uint64_t>(ctx->timing.arena_bytes, words * 4ull * chunk * n_buf);
+            if (list) {
+                if ((rc2 = ensure(ctx, ctx->work, count * 4))) return rc2;
+                HIP_TRY(hipMemcpyAsync(ctx->work.p, list->data(), count * 4, hipMemcpyHostToDevice, st));
+            }
             while (ctx->evpool.size() < 4 * n_chunks) {
                 hipEvent_t e;
                 HIP_TRY(hipEventCreate(&e));
                 ctx->evpool.push_back(e);
             }
+            HIP_TRY(hipMemsetAsync(d_ctrl, 0, 8, st));  // queue_head, redo_count
             hipStream_t st_bt = (n_buf == 2) ? ctx->stream2 : st;
             for (uint64_t c = 0; c < n_chunks; c++) {
-                const uint64_t c0 = c * chunk, cn = std::min<uint64_t>(chunk, n_pairs - c0);
+                const uint64_t c0 = c * chunk, cn = std::min<uint64_t>(chunk, count - c0);
                 hipEvent_t evFa = ctx->evpool[4 * c], evFb = ctx->evpool[4 * c + 1];
                 hipEvent_t evBa = ctx->evpool[4 * c + 2], evBb = ctx->evpool[4 * c + 3];
                 const uint32_t buf = (uint32_t)(c % n_buf);
                 P.arena       = static_cast<uint32_t *>(ctx->arena.p) + (uint64_t)buf * chunk * words;
                 P.pair_meta   = static_cast<uint4 *>(ctx->meta.p) + (uint64_t)buf * chunk;
                 P.chunk_first = (uint32_t)c0, P.chunk_n = (uint32_t)cn;
-                const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)ctx->num_cus * waves_per_cu, (cn + 1) / 2);
+                P.work        = list ? static_cast<const uint32_t *>(ctx->work.p) + c0 : nullptr;
+                const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)ctx->num_cus * waves_per_cu,
+                                                                  (cn + pairs_wave - 1) / pairs_wave);
                 if (n_buf == 2 && c >= 2) HIP_TRY(hipStreamWaitEvent(st, ctx->evpool[4 * (c - 2) + 3], 0));  // buffer free
                 HIP_TRY(hipMemsetAsync(d_ctrl, 0, 4, st));  // queue_head only
                 HIP_TRY(hipEventRecord(evFa, st));
-                hipLaunchKernelGGL(wfa_packed_kernel, dim3(grid), dim3(64), lds_bytes, st, P);
+                if (kind == 2)
+                    hipLaunchKernelGGL((wfa_reg_kernel<2, 4, 1>), dim3(grid), dim3(64), lds_bytes, st, P);
+                else
+                    hipLaunchKernelGGL(wfa_packed_kernel, dim3(grid), dim3(64), lds_bytes, st, P);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipEventRecord(evFb, st));
                 if (st_bt != st) HIP_TRY(hipStreamWaitEvent(st_bt, evFb, 0));
@@ -410,16 +433,54 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
             if (st_bt != st)
                 for (uint64_t c = (n_chunks >= 2 ? n_chunks - 2 : 0); c < n_chunks; c++)
                     HIP_TRY(hipStreamWaitEvent(st, ctx->evpool[4 * c + 3], 0));
+            uint32_t hc[CTRL_WORDS];
+            HIP_TRY(hipMemcpyAsync(hc, d_ctrl, sizeof hc, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             for (uint64_t c = 0; c < n_chunks; c++) {
                 float msF = 0, msB = 0;
                 HIP_TRY(hipEventElapsedTime(&msF, ctx->evpool[4 * c], ctx->evpool[4 * c + 1]));
                 HIP_TRY(hipEventElapsedTime(&msB, ctx->evpool[4 * c + 2], ctx->evpool[4 * c + 3]));
                 ctx->timing.kernel_ms += msF + msB;
-                ctx->timing.main_kernel_ms += msF;
-                ctx->timing.n_main_launches++;
+                if (!list) ctx->timing.main_kernel_ms += msF, ctx->timing.n_main_launches++;
                 ctx->timing.n_launches += 2;
             }
+            P.work = nullptr;
+            redo_out.assign(hc[1], 0);
+            if (hc[1]) {
+                HIP_TRY(hipMemcpy(redo_out.data(), ctx->redo.p, hc[1] * 8ull, hipMemcpyDeviceToHost));
+                std::sort(redo_out.begin(), redo_out.end(), [](uint64_t a, uint64_t b) { return (uint32_t)a < (uint32_t)b; });
+            }
+            return WFAHIP_OK;
+        };
+
+        if (can_b || can_c) {
+            std::vector<uint64_t> redo1, redo2;
+            if ((rc = forward_pass(can_c ? 2 : 1, nullptr, n_pairs, redo1))) return rc;
+            ctx->timing.n_packed_pairs = (uint32_t)(n_pairs - redo1.size());
+            ctx->timing.n_retried_pairs += (uint32_t)redo1.size();
+            Job jb, ja;
+            jb.mode = 1, jb.level = 0, jb.all = false;
+            ja.mode = 0, ja.level = 0, ja.all = false;
+            if (can_c && can_b && !redo1.empty()) {
+                // second chance on the LDS-ring kernel (64-diagonal bands at any alignment) for band/arena misses
+                std::vector<uint32_t> lst;
+                for (uint64_t e : redo1) {
+                    const uint32_t stw = (uint32_t)(e >> 32);
+                    if (stw == ST_REDO_BYTES) jb.pairs.push_back((uint32_t)e);
+                    else if (stw == ST_REDO_BAND) lst.push_back((uint32_t)e);
+                    else ja.pairs.push_back((uint32_t)e);
+                }
+                if (!lst.empty()) {
+                    if ((rc = forward_pass(1, &lst, lst.size(), redo2))) return rc;
+                    ctx->timing.n_packed_pairs += (uint32_t)(lst.size() - redo2.size());
+                    for (uint64_t e : redo2) ((uint32_t)(e >> 32) == ST_REDO_BYTES ? jb : ja).pairs.push_back((uint32_t)e);
+                }
+            } else {
+                for (uint64_t e : redo1) ((uint32_t)(e >> 32) == ST_REDO_BYTES ? jb : ja).pairs.push_back((uint32_t)e);
+            }
+            std::sort(ja.pairs.begin(), ja.pairs.end());
+            if (!ja.pairs.empty()) jobs.push_back(std::move(ja));
+            if (!jb.pairs.empty()) jobs.push_back(std::move(jb));
 #ifdef WFA_STAMPS
             {
                 unsigned long long acc[8];
@@ -434,23 +495,6 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
 #endif
             first       = false;
             packed_done = true;
-            uint32_t hc[CTRL_WORDS];
-            HIP_TRY(hipMemcpy(hc, d_ctrl, sizeof hc, hipMemcpyDeviceToHost));
-            const uint32_t n_redo          = hc[1];
-            ctx->timing.n_packed_pairs     = (uint32_t)(n_pairs - n_redo);
-            ctx->timing.n_retried_pairs += n_redo;
-            if (n_redo) {
-                std::vector<uint64_t> ent(n_redo);  // {pair, status}
-                HIP_TRY(hipMemcpy(ent.data(), ctx->redo.p, n_redo * 8ull, hipMemcpyDeviceToHost));
-                std::sort(ent.begin(), ent.end(), [](uint64_t a, uint64_t b) { return (uint32_t)a < (uint32_t)b; });
-                Job jb, ja;
-                jb.mode = 1, jb.level = 0, jb.all = false;
-                ja.mode = 0, ja.level = 0, ja.all = false;
-                for (uint32_t i = 0; i < n_redo; i++)
-                    ((uint32_t)(ent[i] >> 32) == ST_REDO_BYTES ? jb : ja).pairs.push_back((uint32_t)ent[i]);
-                if (!ja.pairs.empty()) jobs.push_back(std::move(ja));
-                if (!jb.pairs.empty()) jobs.push_back(std::move(jb));
-            }
         }
     }
     if (!packed_done) {

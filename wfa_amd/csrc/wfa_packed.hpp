@@ -113,7 +113,7 @@ __global__ __launch_bounds__(64, 8) void wfa_packed_kernel(const KParams P) {
                 st = 2;
             } else {
                 pidx = wi;
-                pair = P.chunk_first + wi;
+                pair = P.work ? P.work[wi] : P.chunk_first + wi;
                 const uint32_t nq = P.q_len[pair], mt = P.t_len[pair];
                 uint32_t status = ST_PENDING;
                 if (nq == 0 || mt == 0)
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(64, 8) void wfa_packed_kernel(const KParams P) {
 __global__ __launch_bounds__(256) void wfa_backtrace_kernel(const KParams P) {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= P.chunk_n) return;
-    const uint32_t pair = P.chunk_first + idx;
+    const uint32_t pair = P.work ? P.work[idx] : P.chunk_first + idx;
     const uint4    meta = P.pair_meta[idx];
     uint32_t *const rec = P.rec + (uint64_t)pair * REC_WORDS;
     if (meta.x != ST_OK) {

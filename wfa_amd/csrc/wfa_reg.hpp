@@ -1,0 +1,309 @@
+// wfa_reg.hpp -- kernel C: register-window forward kernel, FOUR pairs per wave64.
+//
+// Each 16-lane DPP row of a wave owns one pair; lane j of a row holds the four diagonals
+// kb + 16*t + j (t = 0..3) of a 64-diagonal window whose base kb follows the band in steps of 16.
+// The wavefront rows WF_NEXT needs -- M[s-x], M[s-o-e], I[s-e], D[s-e] (wfa.go:557-560) -- never leave
+// the register file: the last max(x,o+e)/g M rows and e/g I/D rows are kept per lane, the k-1 / k+1
+// neighbours (wfa.go:579,580,614,615) are fetched with DPP row shifts (row_shr:1 / row_shl:1, with
+// row_ror carrying the lane across the 16-lane tile boundary), and the ring advances by register
+// moves.  Cells outside a row's surviving band are kept at 0, so "exists" is simply word != 0.
+// LDS holds only the 2-bit packed sequences.  Every finished row is stored once to the pair's HBM
+// arena for the backtrace kernel (wfa_packed.hpp), exactly like the packed kernel does.
+//
+// The ring depths are compile-time (template on x/g, (o+e)/g, e/g); the default penalties 4/6/2 and
+// every set with the same ratios use <2,4,1>.  Other penalty shapes take the LDS-ring packed kernel.
+// A pair whose band does not fit the 64-diagonal window is handed on (ST_REDO_BAND).
+#pragma once
+#include "wfa_device.hpp"
+#include "wfa_packed.hpp"
+
+namespace wfa {
+
+constexpr int RG_G = 16;  // lanes per pair = one DPP row
+constexpr int RG_T = 4;   // diagonals per lane
+constexpr int RG_W = RG_G * RG_T;
+
+// R[k-1] for the lanes of tile `cur`: lanes 1..15 take their left neighbour, lane 0 takes lane 15 of the
+// tile below (row_ror:1 rotates it into lane 0; row_shr:1 leaves lane 0 untouched: bound_ctrl off).
+WFA_DEV uint32_t row_prev(uint32_t cur, uint32_t prev_tile) {
+    const int carry = __builtin_amdgcn_update_dpp(0, (int)prev_tile, 0x121, 0xf, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_update_dpp(carry, (int)cur, 0x111, 0xf, 0xf, false);
+}
+// R[k+1]: lanes 0..14 take their right neighbour, lane 15 takes lane 0 of the tile above (row_ror:15).
+WFA_DEV uint32_t row_next(uint32_t cur, uint32_t next_tile) {
+    const int carry = __builtin_amdgcn_update_dpp(0, (int)next_tile, 0x12F, 0xf, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_update_dpp(carry, (int)cur, 0x101, 0xf, 0xf, false);
+}
+WFA_DEV int grp_min(int v) {  // min over the 16 lanes of a DPP row
+    v = imin2(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));
+    v = imin2(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));
+    v = imin2(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));
+    v = imin2(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));
+    return v;
+}
+WFA_DEV uint32_t grp_sum(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xf, 0xf, false);
+    return v;
+}
+WFA_DEV uint32_t grp_bits(unsigned long long ballot, int grp) { return (uint32_t)(ballot >> (16 * grp)) & 0xFFFFu; }
+WFA_DEV int ctz_pair(uint32_t lo32, uint32_t hi32) { return lo32 ? __builtin_ctz(lo32) : 32 + __builtin_ctz(hi32); }
+WFA_DEV int msb_pair(uint32_t lo32, uint32_t hi32) { return hi32 ? 63 - __builtin_clz(hi32) : 31 - __builtin_clz(lo32); }
+
+constexpr int RG_EMPTY_LO = 0x3FFFFFFF, RG_EMPTY_HI = -0x3FFFFFFF;
+
+template <int DX, int DOE, int DE>
+__global__ __launch_bounds__(64) void wfa_reg_kernel(const KParams P) {
+    constexpr int RM = DX > DOE ? DX : DOE;  // M rows kept: scores s-g .. s-RM*g
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int lane = threadIdx.x, j = lane & 15, grp = lane >> 4;
+    const int lead = grp << 4;
+
+    const uint32_t  SW = P.lds_seq_words;
+    uint32_t *const lq = lds + grp * 2 * SW;
+    uint32_t *const lt = lq + SW;
+
+    const uint32_t x = P.x, g = P.g;
+    const uint64_t cap = P.arena_words;
+
+    // per-pair state (identical in the 16 lanes of a row)
+    int        st = 0;  // 0 = needs a pair, 1 = running, 2 = queue exhausted
+    uint32_t   pidx = 0, pair = 0;
+    int        n = 0, m = 0, Ak = 0, kb = 0;
+    uint32_t   s = 0, si = 0, top = 0, my_cells = 0;
+    uint32_t  *A = nullptr;
+    SeqView<0> sv;
+    sv.q = lq, sv.t = lt, sv.n = 0, sv.m = 0;
+
+    uint32_t Mh[RM][RG_T], Ih[DE][RG_T], Dh[DE][RG_T];  // [0] = previous score, [d] = d+1 scores back
+    int      rlo[RM], rhi[RM], elo[DE], ehi[DE];         // live range of each kept row (absolute k)
+#pragma unroll
+    for (int d = 0; d < RM; d++) {
+        rlo[d] = RG_EMPTY_LO, rhi[d] = RG_EMPTY_HI;
+#pragma unroll
+        for (int t = 0; t < RG_T; t++) Mh[d][t] = 0u;
+    }
+#pragma unroll
+    for (int d = 0; d < DE; d++) {
+        elo[d] = RG_EMPTY_LO, ehi[d] = RG_EMPTY_HI;
+#pragma unroll
+        for (int t = 0; t < RG_T; t++) Ih[d][t] = 0u, Dh[d][t] = 0u;
+    }
+
+    for (;;) {
+        // ---------------------------------------------------------------- refill (divergent per row)
+        if (st == 0) {
+            uint32_t wi = 0;
+            if (j == 0) wi = atomicAdd(P.queue_head, 1u);
+            wi = __shfl(wi, lead, 64);
+            if (wi >= P.chunk_n) {
+                st = 2;
+            } else {
+                pidx = wi;
+                pair = P.work ? P.work[wi] : P.chunk_first + wi;
+                const uint32_t nq = P.q_len[pair], mt = P.t_len[pair];
+                uint32_t status = ST_PENDING;
+                if (nq == 0 || mt == 0)
+                    status = ST_EMPTY;  // wfa.go:204-206
+                else if (nq > 0x1FFFFFFFu || mt > 0x1FFFFFFFu)
+                    status = ST_TOO_LONG;  // wfa.go:207-209
+                else if (((nq > mt ? nq : mt) + 15u) / 16u + 1u > SW)
+                    status = ST_REDO_LDS;
+                if (status == ST_PENDING) {
+                    bool bad = stage_pack<RG_G>(P.blob, P.q_off[pair], nq, lq, j);
+                    bad |= stage_pack<RG_G>(P.blob, P.t_off[pair], mt, lt, j);
+                    if (grp_bits(__ballot(bad), grp) != 0u) status = ST_REDO_BYTES;
+                }
+                if (status != ST_PENDING) {
+                    if (j == 0) {
+                        P.pair_meta[pidx] = make_uint4(status, 0u, 0u, 0u);
+                        if (status >= ST_REDO_BYTES) push_redo(P, pair, status);
+                    }
+                } else {
+                    n = (int)nq, m = (int)mt, Ak = m - n;
+                    sv.n = n, sv.m = m;
+                    s = 0, si = 0, top = 0, my_cells = 0;
+                    kb = (Ak / 2) - RG_W / 2;  // window [kb, kb+64) around the main diagonals
+                    if (kb > -RG_G / 2) kb = -RG_G / 2;  // k = 0 (the seed) must be inside, in tile 0 if possible
+                    if (kb + RG_W <= 0) kb = -RG_W + RG_G / 2;
+                    A = P.arena + (uint64_t)pidx * cap;
+#pragma unroll
+                    for (int d = 0; d < RM; d++) {
+                        rlo[d] = RG_EMPTY_LO, rhi[d] = RG_EMPTY_HI;
+#pragma unroll
+                        for (int t = 0; t < RG_T; t++) Mh[d][t] = 0u;
+                    }
+#pragma unroll
+                    for (int d = 0; d < DE; d++) {
+                        elo[d] = RG_EMPTY_LO, ehi[d] = RG_EMPTY_HI;
+#pragma unroll
+                        for (int t = 0; t < RG_T; t++) Ih[d][t] = 0u, Dh[d][t] = 0u;
+                    }
+                    st = 1;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (__ballot(st != 2) == 0ull) break;
+        const bool run = (st == 1);
+
+        // ---------------------------------------------------------------- range of this score (wfa.go:557-563)
+        int lo = INT32_MAX, hi = INT32_MIN;
+        if (rhi[DX - 1] >= rlo[DX - 1]) lo = imin2(lo, rlo[DX - 1] - 1), hi = imax2(hi, rhi[DX - 1] + 1);
+        if (rhi[DOE - 1] >= rlo[DOE - 1]) lo = imin2(lo, rlo[DOE - 1] - 1), hi = imax2(hi, rhi[DOE - 1] + 1);
+        if (ehi[DE - 1] >= elo[DE - 1]) lo = imin2(lo, elo[DE - 1] - 1), hi = imax2(hi, ehi[DE - 1] + 1);
+        lo = imax2(lo, -(n - 1));
+        hi = imin2(hi, m - 1);
+        const bool seeded = run && (s == 0u || s == x);  // global: M[0][0] or M[x][0] (wfa.go:155-160)
+        if (seeded) lo = imin2(lo, 0), hi = imax2(hi, 0);
+        if (!run) lo = 0, hi = -1;
+        const bool nonempty = hi >= lo;
+
+        // ---------------------------------------------------------------- keep the band inside the window
+        int all_lo = RG_EMPTY_LO, all_hi = RG_EMPTY_HI;  // every row still in the ring must stay inside too
+#pragma unroll
+        for (int d = 0; d < RM; d++) all_lo = imin2(all_lo, rlo[d]), all_hi = imax2(all_hi, rhi[d]);
+#pragma unroll
+        for (int d = 0; d < DE; d++) all_lo = imin2(all_lo, elo[d]), all_hi = imax2(all_hi, ehi[d]);
+        if (nonempty) all_lo = imin2(all_lo, lo), all_hi = imax2(all_hi, hi);
+        const bool need_dn = run && nonempty && all_lo < kb;                // window moves down 16 diagonals
+        const bool need_up = run && nonempty && !need_dn && all_lo - 1 >= kb + RG_G;  // keep the band start in tile 0
+        if (__ballot(need_dn || need_up) != 0ull) {
+            const int sh = need_dn ? -1 : (need_up ? 1 : 0);
+            auto shift4 = [&](uint32_t(&R)[RG_T]) {
+                uint32_t o0 = R[0], o1 = R[1], o2 = R[2], o3 = R[3];
+                R[0] = sh < 0 ? 0u : (sh > 0 ? o1 : o0);
+                R[1] = sh < 0 ? o0 : (sh > 0 ? o2 : o1);
+                R[2] = sh < 0 ? o1 : (sh > 0 ? o3 : o2);
+                R[3] = sh < 0 ? o2 : (sh > 0 ? 0u : o3);
+            };
+#pragma unroll
+            for (int d = 0; d < RM; d++) shift4(Mh[d]);
+#pragma unroll
+            for (int d = 0; d < DE; d++) shift4(Ih[d]), shift4(Dh[d]);
+            kb += sh * RG_G;
+        }
+        const bool too_wide = run && nonempty && (all_lo < kb || all_hi > kb + RG_W - 1);
+
+        // ---------------------------------------------------------------- next + seeds + extend, tile by tile
+        uint32_t cM[RG_T], cI[RG_T], cD[RG_T], mb[RG_T];
+        uint32_t termbits = 0u;
+#pragma unroll
+        for (int t = 0; t < RG_T; t++) {
+            cM[t] = cI[t] = cD[t] = 0u, mb[t] = 0u;
+            const int  k   = kb + RG_G * t + j;
+            const bool inr = run && !too_wide && k >= lo && k <= hi;
+            if (__ballot(inr) == 0ull) continue;  // wave-uniform: no pair of this wave touches tile t
+            const uint32_t mo_km1 = row_prev(Mh[DOE - 1][t], t > 0 ? Mh[DOE - 1][t - 1] : 0u);
+            const uint32_t ie_km1 = row_prev(Ih[DE - 1][t], t > 0 ? Ih[DE - 1][t - 1] : 0u);
+            const uint32_t mo_kp1 = row_next(Mh[DOE - 1][t], t < RG_T - 1 ? Mh[DOE - 1][t + 1] : 0u);
+            const uint32_t de_kp1 = row_next(Dh[DE - 1][t], t < RG_T - 1 ? Dh[DE - 1][t + 1] : 0u);
+            const uint32_t mx_k   = Mh[DX - 1][t];
+            Cell c = next_cell(mo_km1, ie_km1, mo_kp1, de_kp1, mx_k, k, n, m);
+            if (!inr) c.M = c.I = c.D = 0u;
+            if (seeded && k == 0 && c.M == 0u && inr) c.M = seed_word<0>(sv, 0, s, x, true);
+            c.M   = extend_word<0>(sv, c.M, k);
+            cM[t] = c.M, cI[t] = c.I, cD[t] = c.D;
+            mb[t] = grp_bits(__ballot(c.M != 0u), grp);
+            termbits |= grp_bits(__ballot(k == Ak && (int)(c.M >> TAG_BITS) >= m && c.M != 0u), grp);  // wfa.go:235-239
+        }
+        const bool     term = termbits != 0u;
+        const uint32_t mlo32 = mb[0] | (mb[1] << 16), mhi32 = mb[2] | (mb[3] << 16);
+        const bool     anyM = (mlo32 | mhi32) != 0u;
+        int nlo = 0, nhi = -1;  // band to keep = M.Lo..M.Hi of the reference (tight range of M cells)
+        if (anyM) nlo = kb + ctz_pair(mlo32, mhi32), nhi = kb + msb_pair(mlo32, mhi32);
+
+        // ---------------------------------------------------------------- wf-adaptive (wfa.go:461-540)
+        const bool want_reduce = run && !term && P.adaptive && anyM && (nhi - nlo + 1) >= (int)P.min_wf_len;
+        if (__ballot(want_reduce) != 0ull) {
+            int d[RG_T], dmin = INT32_MAX;
+#pragma unroll
+            for (int t = 0; t < RG_T; t++) {
+                d[t] = reduce_dist(cM[t], kb + RG_G * t + j, n, m);
+                if (d[t] >= 0) dmin = imin2(dmin, d[t]);
+            }
+            const int mind = grp_min(dmin);
+            uint32_t  vb[RG_T], ob[RG_T];
+#pragma unroll
+            for (int t = 0; t < RG_T; t++) {
+                const bool valid = d[t] >= 0;
+                const bool okc   = valid && (d[t] - mind <= (int)P.max_dist_diff);
+                vb[t] = grp_bits(__ballot(valid), grp);
+                ob[t] = grp_bits(__ballot(okc), grp);
+            }
+            const uint32_t vlo = vb[0] | (vb[1] << 16), vhi = vb[2] | (vb[3] << 16);
+            const uint32_t olo = ob[0] | (ob[1] << 16), ohi = ob[2] | (ob[3] << 16);
+            if (want_reduce && mind != INT32_MAX && ((vlo & ~olo) | (vhi & ~ohi)) != 0u) {  // some distance failed
+                const int first_ok = ctz_pair(olo, ohi);
+                // valid entries before the first non-failing one: all of them failed (wfa.go:503-516)
+                const uint32_t below_lo = first_ok >= 32 ? 0xFFFFFFFFu : ((1u << first_ok) - 1u);
+                const uint32_t below_hi = first_ok >= 32 ? ((first_ok == 64) ? 0xFFFFFFFFu : ((1u << (first_ok - 32)) - 1u)) : 0u;
+                const uint32_t llo = vlo & below_lo, lhi = vhi & below_hi;
+                if ((llo | lhi) != 0u) nlo = kb + msb_pair(llo, lhi) + 1;  // one past the last leading failure
+                nhi = kb + msb_pair(olo, ohi);                              // last valid non-failing entry
+            }
+        }
+
+        // ---------------------------------------------------------------- store the surviving band
+        const int  wn       = (nhi >= nlo) ? nhi - nlo + 1 : 0;
+        const bool no_room  = run && ((uint64_t)top + 3ull * (uint32_t)wn + 4ull * (si + 2u) > cap);
+        const bool give_up  = run && (too_wide || no_room);
+        const bool store_ok = run && !give_up;
+        uint32_t *const rowM = A + top;
+#pragma unroll
+        for (int t = 0; t < RG_T; t++) {
+            const int  k    = kb + RG_G * t + j;
+            const bool keep = store_ok && k >= nlo && k <= nhi;
+            if (!keep) cM[t] = cI[t] = cD[t] = 0u;  // Delete of wfa.go:526-535: the words never exist
+            if (__ballot(keep) == 0ull) continue;
+            if (keep) {
+                const int i = k - nlo;
+                rowM[i] = cM[t], rowM[wn + i] = cI[t], rowM[2 * wn + i] = cD[t];
+                my_cells += (cM[t] != 0u) + (cI[t] != 0u) + (cD[t] != 0u);
+            }
+        }
+        if (store_ok && j == 0)
+            *reinterpret_cast<uint4 *>(A + cap - 4ull * (si + 1)) =
+                wn > 0 ? make_uint4(top, (uint32_t)nlo, (uint32_t)wn, (uint32_t)wn) : make_uint4(0u, 0u, 0u, 0u);
+        if (store_ok) top += 3u * (uint32_t)wn;
+
+        // ---------------------------------------------------------------- advance the register ring
+#pragma unroll
+        for (int d = RM - 1; d > 0; d--) {
+            rlo[d] = rlo[d - 1], rhi[d] = rhi[d - 1];
+#pragma unroll
+            for (int t = 0; t < RG_T; t++) Mh[d][t] = Mh[d - 1][t];
+        }
+#pragma unroll
+        for (int d = DE - 1; d > 0; d--) {
+            elo[d] = elo[d - 1], ehi[d] = ehi[d - 1];
+#pragma unroll
+            for (int t = 0; t < RG_T; t++) Ih[d][t] = Ih[d - 1][t], Dh[d][t] = Dh[d - 1][t];
+        }
+        rlo[0] = elo[0] = wn > 0 ? nlo : RG_EMPTY_LO;
+        rhi[0] = ehi[0] = wn > 0 ? nhi : RG_EMPTY_HI;
+#pragma unroll
+        for (int t = 0; t < RG_T; t++) Mh[0][t] = cM[t], Ih[0][t] = cI[t], Dh[0][t] = cD[t];
+
+        // ---------------------------------------------------------------- finish / next score
+        if (give_up || (run && term)) {
+            const uint32_t cells = grp_sum(my_cells);
+            if (j == 0) {
+                if (give_up) {
+                    P.pair_meta[pidx] = make_uint4(too_wide ? ST_REDO_BAND : ST_REDO_ARENA, 0u, 0u, 0u);
+                    push_redo(P, pair, too_wide ? ST_REDO_BAND : ST_REDO_ARENA);
+                } else {
+                    P.pair_meta[pidx] = make_uint4(ST_OK, s, si + 1u, cells);
+                }
+            }
+            st = 0;
+        } else if (run) {
+            s += g, si += 1u;
+        }
+    }
+}
+
+}  // namespace wfa
