@@ -92,6 +92,10 @@ __global__ __launch_bounds__(64) void wfa_reg_kernel(const KParams P) {
         for (int t = 0; t < RG_T; t++) Ih[d][t] = 0u, Dh[d][t] = 0u;
     }
 
+#ifdef WFA_STAMPS
+    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+#endif
     for (;;) {
         // ---------------------------------------------------------------- refill (divergent per row)
         if (st == 0) {
@@ -149,6 +153,7 @@ __global__ __launch_bounds__(64) void wfa_reg_kernel(const KParams P) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (__ballot(st != 2) == 0ull) break;
         const bool run = (st == 1);
+        WFA_STAMP(0);  // refill
 
         // ---------------------------------------------------------------- range of this score (wfa.go:557-563)
         int lo = INT32_MAX, hi = INT32_MIN;
@@ -188,6 +193,7 @@ __global__ __launch_bounds__(64) void wfa_reg_kernel(const KParams P) {
         }
         const bool too_wide = run && nonempty && (all_lo < kb || all_hi > kb + RG_W - 1);
 
+        WFA_STAMP(1);  // range + window
         // ---------------------------------------------------------------- next + seeds + extend, tile by tile
         uint32_t cM[RG_T], cI[RG_T], cD[RG_T], mb[RG_T];
         uint32_t termbits = 0u;
@@ -210,6 +216,7 @@ __global__ __launch_bounds__(64) void wfa_reg_kernel(const KParams P) {
             mb[t] = grp_bits(__ballot(c.M != 0u), grp);
             termbits |= grp_bits(__ballot(k == Ak && (int)(c.M >> TAG_BITS) >= m && c.M != 0u), grp);  // wfa.go:235-239
         }
+        WFA_STAMP(2);  // sources + next + extend
         const bool     term = termbits != 0u;
         const uint32_t mlo32 = mb[0] | (mb[1] << 16), mhi32 = mb[2] | (mb[3] << 16);
         const bool     anyM = (mlo32 | mhi32) != 0u;
@@ -247,6 +254,7 @@ __global__ __launch_bounds__(64) void wfa_reg_kernel(const KParams P) {
             }
         }
 
+        WFA_STAMP(3);  // masks + wf-adaptive
         // ---------------------------------------------------------------- store the surviving band
         const int  wn       = (nhi >= nlo) ? nhi - nlo + 1 : 0;
         const bool no_room  = run && ((uint64_t)top + 3ull * (uint32_t)wn + 4ull * (si + 2u) > cap);
@@ -270,6 +278,7 @@ __global__ __launch_bounds__(64) void wfa_reg_kernel(const KParams P) {
                 wn > 0 ? make_uint4(top, (uint32_t)nlo, (uint32_t)wn, (uint32_t)wn) : make_uint4(0u, 0u, 0u, 0u);
         if (store_ok) top += 3u * (uint32_t)wn;
 
+        WFA_STAMP(4);  // stores
         // ---------------------------------------------------------------- advance the register ring
 #pragma unroll
         for (int d = RM - 1; d > 0; d--) {
@@ -303,7 +312,14 @@ __global__ __launch_bounds__(64) void wfa_reg_kernel(const KParams P) {
         } else if (run) {
             s += g, si += 1u;
         }
+        WFA_STAMP(5);  // ring advance + finish
     }
+#ifdef WFA_STAMPS
+    if (lane == 0 && P.debug_info) {
+        unsigned long long *acc = reinterpret_cast<unsigned long long *>(P.debug_info);
+        for (int i = 0; i < 8; i++) atomicAdd(acc + i, stamp_acc[i]);
+    }
+#endif
 }
 
 }  // namespace wfa
