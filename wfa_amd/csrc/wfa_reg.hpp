@@ -59,7 +59,6 @@ __global__ __launch_bounds__(64) void wfa_reg_kernel(const KParams P) {
     constexpr int RM = DX > DOE ? DX : DOE;  // M rows kept: scores s-g .. s-RM*g
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int lane = threadIdx.x, j = lane & 15, grp = lane >> 4;
-    const int lead = grp << 4;
 
     const uint32_t  SW = P.lds_seq_words;
     uint32_t *const lq = lds + grp * 2 * SW;
@@ -97,56 +96,64 @@ __global__ __launch_bounds__(64) void wfa_reg_kernel(const KParams P) {
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
 #endif
     for (;;) {
-        // ---------------------------------------------------------------- refill (divergent per row)
-        if (st == 0) {
+        // ---------------------------------------------------------------- refill: rows that need a pair are
+        // served one after the other, and ALL 64 lanes stage + 2-bit pack that row's sequences (coalesced
+        // dword loads), so a refill costs one pass of the wave instead of four passes of 16 lanes.
+        for (unsigned long long need = __ballot(st == 0); need != 0ull;) {
+            const int r = __builtin_ctzll(need) >> 4;  // wave-uniform row index
+            need &= ~(0xFFFFull << (16 * r));
             uint32_t wi = 0;
-            if (j == 0) wi = atomicAdd(P.queue_head, 1u);
-            wi = __shfl(wi, lead, 64);
+            if (lane == 16 * r) wi = atomicAdd(P.queue_head, 1u);
+            wi = __shfl(wi, 16 * r, 64);
+            const bool mine = (grp == r);
             if (wi >= P.chunk_n) {
-                st = 2;
-            } else {
-                pidx = wi;
-                pair = P.work ? P.work[wi] : P.chunk_first + wi;
-                const uint32_t nq = P.q_len[pair], mt = P.t_len[pair];
-                uint32_t status = ST_PENDING;
-                if (nq == 0 || mt == 0)
-                    status = ST_EMPTY;  // wfa.go:204-206
-                else if (nq > 0x1FFFFFFFu || mt > 0x1FFFFFFFu)
-                    status = ST_TOO_LONG;  // wfa.go:207-209
-                else if (((nq > mt ? nq : mt) + 15u) / 16u + 1u > SW)
-                    status = ST_REDO_LDS;
-                if (status == ST_PENDING) {
-                    bool bad = stage_pack<RG_G>(P.blob, P.q_off[pair], nq, lq, j);
-                    bad |= stage_pack<RG_G>(P.blob, P.t_off[pair], mt, lt, j);
-                    if (grp_bits(__ballot(bad), grp) != 0u) status = ST_REDO_BYTES;
+                if (mine) st = 2;
+                continue;
+            }
+            const uint32_t pr = P.work ? P.work[wi] : P.chunk_first + wi;
+            const uint32_t nq = P.q_len[pr], mt = P.t_len[pr];
+            uint32_t status = ST_PENDING;
+            if (nq == 0 || mt == 0)
+                status = ST_EMPTY;  // wfa.go:204-206
+            else if (nq > 0x1FFFFFFFu || mt > 0x1FFFFFFFu)
+                status = ST_TOO_LONG;  // wfa.go:207-209
+            else if (((nq > mt ? nq : mt) + 15u) / 16u + 1u > SW)
+                status = ST_REDO_LDS;
+            if (status == ST_PENDING) {
+                uint32_t *const rq = lds + r * 2 * SW;
+                bool bad = stage_pack<64>(P.blob, P.q_off[pr], nq, rq, lane);
+                bad |= stage_pack<64>(P.blob, P.t_off[pr], mt, rq + SW, lane);
+                if (__ballot(bad) != 0ull) status = ST_REDO_BYTES;
+            }
+            if (status != ST_PENDING) {
+                if (lane == 16 * r) {
+                    P.pair_meta[wi] = make_uint4(status, 0u, 0u, 0u);
+                    if (status >= ST_REDO_BYTES) push_redo(P, pr, status);
                 }
-                if (status != ST_PENDING) {
-                    if (j == 0) {
-                        P.pair_meta[pidx] = make_uint4(status, 0u, 0u, 0u);
-                        if (status >= ST_REDO_BYTES) push_redo(P, pair, status);
-                    }
-                } else {
-                    n = (int)nq, m = (int)mt, Ak = m - n;
-                    sv.n = n, sv.m = m;
-                    s = 0, si = 0, top = 0, my_cells = 0;
-                    kb = (Ak / 2) - RG_W / 2;  // window [kb, kb+64) around the main diagonals
-                    if (kb > -RG_G / 2) kb = -RG_G / 2;  // k = 0 (the seed) must be inside, in tile 0 if possible
-                    if (kb + RG_W <= 0) kb = -RG_W + RG_G / 2;
-                    A = P.arena + (uint64_t)pidx * cap;
+                continue;  // the row stays in state 0 and pulls another pair in the next round
+            }
+            if (mine) {
+                pidx = wi, pair = pr;
+                n = (int)nq, m = (int)mt, Ak = m - n;
+                sv.n = n, sv.m = m;
+                s = 0, si = 0, top = 0, my_cells = 0;
+                kb = (Ak / 2) - RG_W / 2;            // window [kb, kb+64) around the main diagonals
+                if (kb > -RG_G / 2) kb = -RG_G / 2;  // k = 0 (the seed) must be inside, in tile 0 if possible
+                if (kb + RG_W <= 0) kb = -RG_W + RG_G / 2;
+                A = P.arena + (uint64_t)pidx * cap;
 #pragma unroll
-                    for (int d = 0; d < RM; d++) {
-                        rlo[d] = RG_EMPTY_LO, rhi[d] = RG_EMPTY_HI;
+                for (int d = 0; d < RM; d++) {
+                    rlo[d] = RG_EMPTY_LO, rhi[d] = RG_EMPTY_HI;
 #pragma unroll
-                        for (int t = 0; t < RG_T; t++) Mh[d][t] = 0u;
-                    }
-#pragma unroll
-                    for (int d = 0; d < DE; d++) {
-                        elo[d] = RG_EMPTY_LO, ehi[d] = RG_EMPTY_HI;
-#pragma unroll
-                        for (int t = 0; t < RG_T; t++) Ih[d][t] = 0u, Dh[d][t] = 0u;
-                    }
-                    st = 1;
+                    for (int t = 0; t < RG_T; t++) Mh[d][t] = 0u;
                 }
+#pragma unroll
+                for (int d = 0; d < DE; d++) {
+                    elo[d] = RG_EMPTY_LO, ehi[d] = RG_EMPTY_HI;
+#pragma unroll
+                    for (int t = 0; t < RG_T; t++) Ih[d][t] = 0u, Dh[d][t] = 0u;
+                }
+                st = 1;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -196,13 +203,16 @@ __global__ __launch_bounds__(64) void wfa_reg_kernel(const KParams P) {
         WFA_STAMP(1);  // range + window
         // ---------------------------------------------------------------- next + seeds + extend, tile by tile
         uint32_t cM[RG_T], cI[RG_T], cD[RG_T], mb[RG_T];
+        int      ev[RG_T], eh[RG_T];  // position of the next window of a cell that is still matching (ev < 0: done)
+        bool     act[RG_T];           // wave-uniform: some pair of this wave touches tile t
         uint32_t termbits = 0u;
 #pragma unroll
         for (int t = 0; t < RG_T; t++) {
-            cM[t] = cI[t] = cD[t] = 0u, mb[t] = 0u;
+            cM[t] = cI[t] = cD[t] = 0u, mb[t] = 0u, ev[t] = -1, eh[t] = 0;
             const int  k   = kb + RG_G * t + j;
             const bool inr = run && !too_wide && k >= lo && k <= hi;
-            if (__ballot(inr) == 0ull) continue;  // wave-uniform: no pair of this wave touches tile t
+            act[t]         = __ballot(inr) != 0ull;
+            if (!act[t]) continue;
             const uint32_t mo_km1 = row_prev(Mh[DOE - 1][t], t > 0 ? Mh[DOE - 1][t - 1] : 0u);
             const uint32_t ie_km1 = row_prev(Ih[DE - 1][t], t > 0 ? Ih[DE - 1][t - 1] : 0u);
             const uint32_t mo_kp1 = row_next(Mh[DOE - 1][t], t < RG_T - 1 ? Mh[DOE - 1][t + 1] : 0u);
@@ -211,10 +221,44 @@ __global__ __launch_bounds__(64) void wfa_reg_kernel(const KParams P) {
             Cell c = next_cell(mo_km1, ie_km1, mo_kp1, de_kp1, mx_k, k, n, m);
             if (!inr) c.M = c.I = c.D = 0u;
             if (seeded && k == 0 && c.M == 0u && inr) c.M = seed_word<0>(sv, 0, s, x, true);
-            c.M   = extend_word<0>(sv, c.M, k);
+            // WF_EXTEND, first 16-base window (wfa.go:394-455): almost every off-path diagonal stops here
+            const int h = (int)(c.M >> TAG_BITS), v = h - k;
+            if (c.M != 0u && v > 0 && v < n && h < m) {
+                const int      rem = imin2(n - v, m - h);
+                const uint32_t xr  = SeqView<0>::win16(lq, v) ^ SeqView<0>::win16(lt, h);
+                const int      cnt = imin2(xr ? (__builtin_ctz(xr) >> 1) : 16, rem);
+                c.M += (uint32_t)cnt << TAG_BITS;
+                if (xr == 0u && rem > 16) ev[t] = v + 16, eh[t] = h + 16;
+            }
             cM[t] = c.M, cI[t] = c.I, cD[t] = c.D;
-            mb[t] = grp_bits(__ballot(c.M != 0u), grp);
-            termbits |= grp_bits(__ballot(k == Ak && (int)(c.M >> TAG_BITS) >= m && c.M != 0u), grp);  // wfa.go:235-239
+        }
+        // the few cells (normally the one on the alignment path) whose first window matched completely
+        for (;;) {
+            bool more = false;
+#pragma unroll
+            for (int t = 0; t < RG_T; t++) more |= (ev[t] >= 0);
+            if (__ballot(more) == 0ull) break;
+#pragma unroll
+            for (int t = 0; t < RG_T; t++) {
+                if (!act[t]) continue;
+                if (ev[t] >= 0) {
+                    const int      rem = imin2(n - ev[t], m - eh[t]);
+                    const uint32_t xr  = SeqView<0>::win16(lq, ev[t]) ^ SeqView<0>::win16(lt, eh[t]);
+                    const int      cnt = imin2(xr ? (__builtin_ctz(xr) >> 1) : 16, rem);
+                    cM[t] += (uint32_t)cnt << TAG_BITS;
+                    if (xr == 0u && rem > 16)
+                        ev[t] += 16, eh[t] += 16;
+                    else
+                        ev[t] = -1;
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < RG_T; t++) {
+            if (!act[t]) continue;
+            const int k = kb + RG_G * t + j;
+            mb[t]       = grp_bits(__ballot(cM[t] != 0u), grp);
+            termbits |= grp_bits(__ballot(k == Ak && (int)(cM[t] >> TAG_BITS) >= m && cM[t] != 0u), grp);  // wfa.go:235-239
         }
         WFA_STAMP(2);  // sources + next + extend
         const bool     term = termbits != 0u;
@@ -229,13 +273,15 @@ __global__ __launch_bounds__(64) void wfa_reg_kernel(const KParams P) {
             int d[RG_T], dmin = INT32_MAX;
 #pragma unroll
             for (int t = 0; t < RG_T; t++) {
-                d[t] = reduce_dist(cM[t], kb + RG_G * t + j, n, m);
+                d[t] = act[t] ? reduce_dist(cM[t], kb + RG_G * t + j, n, m) : -1;
                 if (d[t] >= 0) dmin = imin2(dmin, d[t]);
             }
             const int mind = grp_min(dmin);
             uint32_t  vb[RG_T], ob[RG_T];
 #pragma unroll
             for (int t = 0; t < RG_T; t++) {
+                vb[t] = ob[t] = 0u;
+                if (!act[t]) continue;
                 const bool valid = d[t] >= 0;
                 const bool okc   = valid && (d[t] - mind <= (int)P.max_dist_diff);
                 vb[t] = grp_bits(__ballot(valid), grp);
@@ -263,6 +309,7 @@ __global__ __launch_bounds__(64) void wfa_reg_kernel(const KParams P) {
         uint32_t *const rowM = A + top;
 #pragma unroll
         for (int t = 0; t < RG_T; t++) {
+            if (!act[t]) continue;  // nothing was computed in this tile: its registers are already 0
             const int  k    = kb + RG_G * t + j;
             const bool keep = store_ok && k >= nlo && k <= nhi;
             if (!keep) cM[t] = cI[t] = cD[t] = 0u;  // Delete of wfa.go:526-535: the words never exist
