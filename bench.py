@@ -142,7 +142,8 @@ def main():
                "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                             "frac": achieved / 8000.0, "traffic": None,
                             "algorithmic_bytes_per_launch": alg_bytes,
-                            "kernel": "wfa_packed_kernel" if timing.n_packed_pairs else "wfa_generic_kernel<1,0>",
+                            "kernel": ["wfa_generic_kernel<1,0>", "wfa_packed_kernel",
+                                       "wfa_reg_kernel<2,4,1>"][int(timing.main_kernel_kind)],
                             "kernel_ms": main_k_ms, "all_kernels_ms": k_ms,
                             "note": "achieved = algorithmic bytes of one step / duration of the dominant "
                                     "(forward) kernel's launches in that step; peak = 8 TB/s HBM3E spec"}}

@@ -100,7 +100,9 @@ typedef struct {
     double   main_kernel_ms;   /* total duration of the dominant kernel's launches (packed forward kernel when it
                                   ran, else the first generic launch) */
     uint32_t n_main_launches;  /* launches of that kernel (one per chunk) */
-    uint32_t n_packed_pairs;   /* pairs finished by the packed forward + backtrace kernels */
+    uint32_t n_packed_pairs;   /* pairs finished by the sub-wave forward + backtrace kernels */
+    uint32_t main_kernel_kind; /* 0 = wfa_generic_kernel, 1 = wfa_packed_kernel, 2 = wfa_reg_kernel */
+    uint32_t reserved;
 } wfahip_timing;
 
 typedef struct wfahip_ctx wfahip_ctx;

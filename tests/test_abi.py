@@ -26,7 +26,7 @@ def test_struct_layouts(built):
     from wfa_amd import _lib
     assert C.sizeof(_lib.Params) == 28
     assert C.sizeof(_lib.Results) == 15 * 8
-    assert C.sizeof(_lib.Timing) == 64
+    assert C.sizeof(_lib.Timing) == 72
     assert C.sizeof(_lib.Row) == 24
 
 

@@ -456,6 +456,7 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
         if (can_b || can_c) {
             std::vector<uint64_t> redo1, redo2;
             if ((rc = forward_pass(can_c ? 2 : 1, nullptr, n_pairs, redo1))) return rc;
+            ctx->timing.main_kernel_kind = can_c ? 2 : 1;
             ctx->timing.n_packed_pairs = (uint32_t)(n_pairs - redo1.size());
             ctx->timing.n_retried_pairs += (uint32_t)redo1.size();
             Job jb, ja;
