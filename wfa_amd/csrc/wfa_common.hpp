@@ -31,16 +31,18 @@ enum { REC_STATUS = 0, REC_SCORE, REC_TBEGIN, REC_TEND, REC_QBEGIN, REC_QEND, RE
        REC_N_SCORES };
 
 // One directory entry per score index (score / g): the M, I and D rows of that score share the
-// diagonal range [lo, lo+w) and sit at arena[base], arena[base+stride], arena[base+2*stride].
+// diagonal range [lo, lo+w) and sit at arena[base], arena[base+stride], arena[base+2*stride] (32-byte entry).
 // w == 0 means no wavefront exists at that score in any component (Component.HasScore false,
 // wfa_component.go:81-86).  After wf-adaptive pruning the entry is narrowed to the surviving band
 // (base moves right, stride keeps the row pitch), so later scores only visit live diagonals.
 struct alignas(16) DirEnt {
-    uint32_t base;
+    uint64_t base;  // word index inside the slot (64-bit: 100 kbp semi-global pairs need > 16 Gi words)
     int32_t  lo;
     int32_t  w;
     uint32_t stride;
+    uint32_t pad[3];
 };
+constexpr int DIR_WORDS = 8;  // 32-byte entries
 
 struct KParams {
     // input (device pointers)

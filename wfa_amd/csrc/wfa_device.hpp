@@ -208,22 +208,29 @@ WFA_DEV int reduce_dist(uint32_t raw, int k, int n, int m) {
 
 // ---------------------------------------------------------------------------------------------
 // Arena access used by the end-cell search and the backtrace.  The directory grows downward from the
-// end of the slot: entry i sits at arena + cap - 4*(i+1) words.
+// end of the slot: entry i sits at arena + cap - DIR_WORDS*(i+1) words.
+WFA_DEV DirEnt load_dir(const uint32_t *p) {
+    const uint4 r = *reinterpret_cast<const uint4 *>(p);
+    const uint  st = p[4];
+    DirEnt      e;
+    e.base   = (uint64_t)r.x | ((uint64_t)r.y << 32);
+    e.lo     = (int)r.z;
+    e.w      = (int)r.w;
+    e.stride = st;
+    return e;
+}
+WFA_DEV void store_dir(uint32_t *p, uint64_t base, int lo, int w, uint32_t stride) {
+    *reinterpret_cast<uint4 *>(p) = make_uint4((uint32_t)base, (uint32_t)(base >> 32), (uint32_t)lo, (uint32_t)w);
+    p[4]                          = stride;
+}
+
 struct ArenaView {
     const uint32_t *A;
     uint64_t        cap;    // words
     uint32_t        g;      // score granularity gcd(x, o+e, e): only multiples of g can exist
     uint32_t        n_ent;  // directory entries written (scores 0, g, .., (n_ent-1)*g)
 
-    WFA_DEV DirEnt ent(uint32_t idx) const {
-        const uint4 r = *reinterpret_cast<const uint4 *>(A + cap - 4ull * (idx + 1));
-        DirEnt      e;
-        e.base = r.x;
-        e.lo   = (int)r.y;
-        e.w    = (int)r.z;
-        e.stride = r.w;
-        return e;
-    }
+    WFA_DEV DirEnt ent(uint32_t idx) const { return load_dir(A + cap - (uint64_t)DIR_WORDS * (idx + 1)); }
     // Component.GetRaw (wfa_component.go:150-155 + wfa_wavefront.go:163-169); s may have wrapped
     // below zero (uint32), which lands beyond the directory like the reference's len check.
     WFA_DEV uint32_t get_raw(int comp, uint32_t s, int k) const {
@@ -232,7 +239,7 @@ struct ArenaView {
         if (idx >= n_ent) return 0u;
         DirEnt e = ent(idx);
         if (e.w <= 0 || k < e.lo || k >= e.lo + e.w) return 0u;
-        return A[(uint64_t)e.base + (uint64_t)comp * e.stride + (uint32_t)(k - e.lo)];
+        return A[e.base + (uint64_t)comp * e.stride + (uint32_t)(k - e.lo)];
     }
 };
 

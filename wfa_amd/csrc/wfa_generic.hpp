@@ -89,14 +89,9 @@ __global__ __launch_bounds__(64 * WAVES) void wfa_generic_kernel(const KParams P
         bool           overflow = false, done = false;
         uint32_t       s_final = 0;
         uint64_t       my_cells = 0;
-        auto dir_ptr = [&](uint32_t idx) { return reinterpret_cast<uint4 *>(A + cap - 4ull * (idx + 1)); };
-        auto load_ent = [&](uint32_t idx) {
-            const uint4 r = *dir_ptr(idx);
-            DirEnt      d;
-            d.base = r.x, d.lo = (int)r.y, d.w = (int)r.z, d.stride = r.w;
-            return d;
-        };
-        const DirEnt none = {0u, 0, 0, 0u};
+        auto dir_ptr  = [&](uint32_t idx) { return A + cap - (uint64_t)DIR_WORDS * (idx + 1); };
+        auto load_ent = [&](uint32_t idx) { return load_dir(dir_ptr(idx)); };
+        const DirEnt none = {0ull, 0, 0, 0u, {0u, 0u, 0u}};
 
         for (uint32_t s = 0;; s += g) {
             const uint32_t si = s / g;
@@ -117,29 +112,29 @@ __global__ __launch_bounds__(64 * WAVES) void wfa_generic_kernel(const KParams P
 
             // room for 3 rows + this directory entry (+ ops scratch is checked later)
             const int64_t W = (hi >= lo) ? ((int64_t)hi - lo + 1) : 0;
-            if (top + 3ull * (uint64_t)W + 4ull * (si + 2) > cap || top + 3ull * (uint64_t)W > 0xFFFFFFFFull) {
+            if (top + 3ull * (uint64_t)W + (uint64_t)DIR_WORDS * (si + 2) > cap) {
                 overflow = true;
                 break;
             }
             if (W == 0) {
-                if (tid == 0) *dir_ptr(si) = make_uint4(0u, 0u, 0u, 0u);
+                if (tid == 0) store_dir(dir_ptr(si), 0ull, 0, 0, 0u);
                 n_ent = si + 1;
                 __syncthreads();  // the entry may be a source of the very next score
                 continue;
             }
-            const uint32_t base = (uint32_t)top;
+            const uint64_t base = top;
             uint32_t *const rowM = A + base, *const rowI = rowM + W, *const rowD = rowI + W;
 
             if (tid == 0) {
                 red[0] = INT32_MAX, red[1] = INT32_MIN, red[2] = 0, red[3] = INT32_MAX;
                 red[4] = INT32_MAX, red[5] = INT32_MIN, red[6] = 0, red[7] = INT32_MIN;
-                *dir_ptr(si) = make_uint4(base, (uint32_t)lo, (uint32_t)W, (uint32_t)W);
+                store_dir(dir_ptr(si), base, lo, (int)W, (uint32_t)W);
             }
             __syncthreads();
 
             auto src = [&](const DirEnt &d, int comp, int k) -> uint32_t {
                 return (d.w > 0 && k >= d.lo && k < d.lo + d.w)
-                           ? A[(uint64_t)d.base + (uint64_t)comp * d.stride + (uint32_t)(k - d.lo)]
+                           ? A[d.base + (uint64_t)comp * d.stride + (uint32_t)(k - d.lo)]
                            : 0u;
             };
 
@@ -222,10 +217,12 @@ __global__ __launch_bounds__(64 * WAVES) void wfa_generic_kernel(const KParams P
                 }
             }
             if (nlo != lo || nhi != hi) {  // narrow the directory entry to the live band
-                if (tid == 0)
-                    *dir_ptr(si) = (nhi >= nlo) ? make_uint4(base + (uint32_t)(nlo - lo), (uint32_t)nlo,
-                                                             (uint32_t)(nhi - nlo + 1), (uint32_t)W)
-                                                : make_uint4(0u, 0u, 0u, 0u);
+                if (tid == 0) {
+                    if (nhi >= nlo)
+                        store_dir(dir_ptr(si), base + (uint64_t)(nlo - lo), nlo, nhi - nlo + 1, (uint32_t)W);
+                    else
+                        store_dir(dir_ptr(si), 0ull, 0, 0, 0u);
+                }
             }
             __syncthreads();
         }
@@ -255,7 +252,7 @@ __global__ __launch_bounds__(64 * WAVES) void wfa_generic_kernel(const KParams P
 
             // ops scratch: free arena words between the rows and the directory
             uint64_t  scratch0 = (top + 1ull) & ~1ull;
-            uint64_t  dir_lo   = cap - 4ull * (uint64_t)n_ent;
+            uint64_t  dir_lo   = cap - (uint64_t)DIR_WORDS * (uint64_t)n_ent;
             uint64_t  room     = dir_lo > scratch0 ? (dir_lo - scratch0) / 2ull : 0ull;
             OpsWriter ow;
             ow.init(reinterpret_cast<uint64_t *>(A + scratch0), (uint32_t)(room > 0xFFFFFFFFull ? 0xFFFFFFFFull : room));

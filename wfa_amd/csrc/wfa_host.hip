@@ -153,7 +153,7 @@ int make_cfg(wfahip_ctx *ctx, uint32_t max_len, int mode, int level, uint64_t n_
     if (ctx->opt_arena_bytes_per_slot > 0) base_words = std::max<uint64_t>(4096, ctx->opt_arena_bytes_per_slot / 4);
     uint64_t words = base_words;
     for (int i = 0; i < level; i++) words *= 8;
-    words         = (words + 3) & ~3ull;  // directory entries are 16-byte aligned from the slot end
+    words         = (words + 7) & ~7ull;  // directory entries are 32-byte aligned from the slot end
     c.arena_words = words;
 
     // resident workgroups per CU: 32 wave slots, LDS, and keep <= 8 blocks of >=256 threads
@@ -356,7 +356,7 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
         const bool     can_c     = ctx->opt_reg && dx == 2 && doe == 4 && de == 1 && lds_c <= 20 * 1024;
         uint64_t       words     = std::max<uint64_t>(4096, 16ull * max_len);
         if (ctx->opt_packed_arena_bytes > 0) words = std::max<uint64_t>(1024, ctx->opt_packed_arena_bytes / 4);
-        words = (words + 3) & ~3ull;
+        words = (words + 7) & ~7ull;
         P.arena_words   = words;
         P.dx = dx, P.doe = doe, P.de = de, P.dm = dm, P.di = di;
         P.lds_seq_words = seq_words;
@@ -780,30 +780,32 @@ extern "C" int wfahip_debug_wavefronts(wfahip_ctx *ctx, const wfahip_params *p, 
     }
     if (recw[REC_STATUS] != ST_OK) return WFAHIP_ERR_INTERNAL;
 
-    const uint64_t cap   = (uint64_t)(((bytes / 4) + 3) & ~3ll);
+    const uint64_t cap   = (uint64_t)(((bytes / 4) + 7) & ~7ll);
     const uint32_t n_ent = hctrl[4];
-    std::vector<uint32_t> dir((size_t)n_ent * 4);
-    HIP_TRY(hipMemcpy(dir.data(), static_cast<uint32_t *>(ctx->arena.p) + cap - 4ull * n_ent, dir.size() * 4,
-                      hipMemcpyDeviceToHost));
+    std::vector<uint32_t> dir((size_t)n_ent * DIR_WORDS);
+    HIP_TRY(hipMemcpy(dir.data(), static_cast<uint32_t *>(ctx->arena.p) + cap - (uint64_t)DIR_WORDS * n_ent,
+                      dir.size() * 4, hipMemcpyDeviceToHost));
+    // entry i (score i*g) sits DIR_WORDS*(i+1) words below the slot end: {base_lo, base_hi, lo, w, stride, ...}
+    auto entry = [&](uint32_t i) { return &dir[(size_t)(n_ent - 1 - i) * DIR_WORDS]; };
     uint64_t total = 0, nr = 0;
-    for (uint32_t i = 0; i < n_ent; i++) {
-        const uint32_t *e = &dir[(size_t)(n_ent - 1 - i) * 4];
-        if ((int32_t)e[2] > 0) total += 3ull * e[2], nr++;
-    }
+    for (uint32_t i = 0; i < n_ent; i++)
+        if ((int32_t)entry(i)[3] > 0) total += 3ull * entry(i)[3], nr++;
     *rows  = static_cast<wfahip_row *>(std::malloc(std::max<uint64_t>(nr, 1) * sizeof(wfahip_row)));
     *words = static_cast<uint32_t *>(std::malloc(std::max<uint64_t>(total, 1) * 4));
     if (!*rows || !*words) return WFAHIP_ERR_OOM;
     const uint32_t g = gcd_u32(gcd_u32(p->mismatch, p->gap_open + p->gap_ext), p->gap_ext);
     uint64_t       pos = 0, ri = 0;
     for (uint32_t i = 0; i < n_ent; i++) {
-        const uint32_t *e = &dir[(size_t)(n_ent - 1 - i) * 4];
-        if ((int32_t)e[2] <= 0) continue;
-        for (int c = 0; c < 3; c++)  // M, I, D rows are e[3] (row pitch) words apart
-            HIP_TRY(hipMemcpy(*words + pos + (uint64_t)c * e[2],
-                              static_cast<uint32_t *>(ctx->arena.p) + e[0] + (uint64_t)c * e[3], 4ull * e[2],
+        const uint32_t *e = entry(i);
+        const uint32_t  w = e[3], stride = e[4];
+        if ((int32_t)w <= 0) continue;
+        const uint64_t base = (uint64_t)e[0] | ((uint64_t)e[1] << 32);
+        for (int c = 0; c < 3; c++)  // M, I, D rows are `stride` words apart
+            HIP_TRY(hipMemcpy(*words + pos + (uint64_t)c * w,
+                              static_cast<uint32_t *>(ctx->arena.p) + base + (uint64_t)c * stride, 4ull * w,
                               hipMemcpyDeviceToHost));
-        (*rows)[ri++] = wfahip_row{i * g, (int32_t)e[1], e[2], pos};
-        pos += 3ull * e[2];
+        (*rows)[ri++] = wfahip_row{i * g, (int32_t)e[2], w, pos};
+        pos += 3ull * w;
     }
     *n_rows = nr, *n_words = total;
     if (res) {

@@ -232,7 +232,7 @@ __global__ __launch_bounds__(64, 8) void wfa_packed_kernel(const KParams P) {
         WFA_STAMP(3);  // masks + wf-adaptive
         // ---------------------------------------------------------------- store the surviving band
         const int  wn       = (nhi >= nlo) ? nhi - nlo + 1 : 0;
-        const bool no_room  = run && ((uint64_t)top + 3ull * (uint32_t)wn + 4ull * (si + 2u) > cap);
+        const bool no_room  = run && ((uint64_t)top + 3ull * (uint32_t)wn + (uint64_t)DIR_WORDS * (si + 2u) > cap);
         const bool give_up  = run && (too_wide || no_room);
         const bool store_ok = run && !give_up;
         if (store_ok) {
@@ -252,8 +252,7 @@ __global__ __launch_bounds__(64, 8) void wfa_packed_kernel(const KParams P) {
             if (j == 0) {
                 metaM[2 * cm] = nlo, metaM[2 * cm + 1] = wn;
                 metaE[2 * ce] = nlo, metaE[2 * ce + 1] = wn;
-                *reinterpret_cast<uint4 *>(A + cap - 4ull * (si + 1)) =
-                    wn > 0 ? make_uint4(top, (uint32_t)nlo, (uint32_t)wn, (uint32_t)wn) : make_uint4(0u, 0u, 0u, 0u);
+                store_dir(A + cap - (uint64_t)DIR_WORDS * (si + 1), wn > 0 ? (uint64_t)top : 0ull, wn > 0 ? nlo : 0, wn, (uint32_t)wn);
             }
             top += 3u * (uint32_t)wn;
         }

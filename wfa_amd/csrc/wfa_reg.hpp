@@ -303,7 +303,7 @@ __global__ __launch_bounds__(64) void wfa_reg_kernel(const KParams P) {
         WFA_STAMP(3);  // masks + wf-adaptive
         // ---------------------------------------------------------------- store the surviving band
         const int  wn       = (nhi >= nlo) ? nhi - nlo + 1 : 0;
-        const bool no_room  = run && ((uint64_t)top + 3ull * (uint32_t)wn + 4ull * (si + 2u) > cap);
+        const bool no_room  = run && ((uint64_t)top + 3ull * (uint32_t)wn + (uint64_t)DIR_WORDS * (si + 2u) > cap);
         const bool give_up  = run && (too_wide || no_room);
         const bool store_ok = run && !give_up;
         uint32_t *const rowM = A + top;
@@ -321,8 +321,7 @@ __global__ __launch_bounds__(64) void wfa_reg_kernel(const KParams P) {
             }
         }
         if (store_ok && j == 0)
-            *reinterpret_cast<uint4 *>(A + cap - 4ull * (si + 1)) =
-                wn > 0 ? make_uint4(top, (uint32_t)nlo, (uint32_t)wn, (uint32_t)wn) : make_uint4(0u, 0u, 0u, 0u);
+            store_dir(A + cap - (uint64_t)DIR_WORDS * (si + 1), wn > 0 ? (uint64_t)top : 0ull, wn > 0 ? nlo : 0, wn, (uint32_t)wn);
         if (store_ok) top += 3u * (uint32_t)wn;
 
         WFA_STAMP(4);  // stores
