@@ -241,14 +241,53 @@ __global__ __launch_bounds__(64 * WAVES) void wfa_generic_kernel(const KParams P
             continue;
         }
 
-        // ---- end-cell search (semi-global) + backtrace + result record: lane 0 of wave 0
+        // ---- semi-global end cell (backtraceStartPosistion, wfa.go:270-375), all threads: per score the
+        // reference scans down from Ak and up from Ak+1, skipping absent cells, until the first cell that either
+        // leaves the matrix (break) or lies on the last row/column (hit).  That is the NEAREST break-or-hit cell
+        // on each side, found here with one min-reduction per side; a hit at a score <= the best so far wins,
+        // the upward scan overriding the downward one at equal score.
         __syncthreads();
+        uint32_t minS  = s_final;
+        int      lastK = Ak;
+        if (!glob) {
+            ArenaView av0;
+            av0.A = A, av0.cap = cap, av0.g = g, av0.n_ent = n_ent;
+            unsigned int *const ured = reinterpret_cast<unsigned int *>(red);
+            for (uint32_t idx = s_final / g + 1; idx-- > 0;) {
+                const DirEnt e = av0.ent(idx);
+                if (e.w <= 0) continue;  // !M.HasScore(_s)
+                if (tid == 0) ured[4] = 0xFFFFFFFFu, ured[5] = 0xFFFFFFFFu;
+                __syncthreads();
+                const uint32_t *row = A + e.base;
+                unsigned int keyD = 0xFFFFFFFFu, keyU = 0xFFFFFFFFu;
+                for (int64_t i = tid; i < e.w; i += G) {
+                    const uint32_t raw = row[i];
+                    if (raw == 0u) continue;
+                    const int  k = e.lo + (int)i, h = (int)(raw >> TAG_BITS), v = h - k;
+                    const bool stop = (v <= 0 || v > n || h > m);
+                    const bool hit  = !stop && ((v == n && h >= n) || (h == m && v >= m));
+                    if (!(stop || hit)) continue;
+                    if (k <= Ak)
+                        keyD = min(keyD, ((unsigned int)(Ak - k) << 1) | (hit ? 0u : 1u));
+                    else
+                        keyU = min(keyU, ((unsigned int)(k - Ak - 1) << 1) | (hit ? 0u : 1u));
+                }
+                keyD = (unsigned int)wave_min((int)(keyD ^ 0x80000000u)) ^ 0x80000000u;  // unsigned min via signed min
+                keyU = (unsigned int)wave_min((int)(keyU ^ 0x80000000u)) ^ 0x80000000u;
+                if (lane == 0) atomicMin(&ured[4], keyD), atomicMin(&ured[5], keyU);
+                __syncthreads();
+                keyD = ured[4], keyU = ured[5];
+                const uint32_t _s = idx * g;
+                if (keyD != 0xFFFFFFFFu && (keyD & 1u) == 0u && _s <= minS) lastK = Ak - (int)(keyD >> 1), minS = _s;
+                if (keyU != 0xFFFFFFFFu && (keyU & 1u) == 0u && _s <= minS) lastK = Ak + 1 + (int)(keyU >> 1), minS = _s;
+                __syncthreads();
+            }
+        }
+
+        // ---- backtrace + result record: lane 0 of wave 0
         if (tid == 0) {
             ArenaView av;
             av.A = A, av.cap = cap, av.g = g, av.n_ent = n_ent;
-            uint32_t minS  = s_final;
-            int      lastK = Ak;
-            if (!glob) backtrace_start(av, n, m, s_final, minS, lastK);  // wfa.go:258-261
 
             // ops scratch: free arena words between the rows and the directory
             uint64_t  scratch0 = (top + 1ull) & ~1ull;
