@@ -228,6 +228,20 @@ def test_long_pair_semiglobal(built):
         al.close()
 
 
+def test_config5_sample(built):
+    """BASELINE configs[4] in miniature: 40 kbp pairs @10 %, semi-global + wf-adaptive.  The seeded wavefronts
+    are ~8e4 diagonals wide for thousands of scores (the reference's own rules), so this exercises the
+    1024-thread configuration, the arena retry ladder into multi-GB slots and the parallel end-cell search."""
+    import wfa_amd as w
+    from oracle import oracle as O
+    data = w.generate_pairs(seed=5, n_pairs=2, length=40000, error_rate=0.10)
+    al = _aligner(False, (10, 50, 1))
+    got = al.align_arrays(*data)
+    assert_batch_equal(got, O.align_batch(_oracle_params(False), *data, n_threads=2), "C5 sample")
+    assert al.last_timing().n_launches >= 2
+    al.close()
+
+
 def test_full_size_properties(built):
     """Size-independent properties at a BASELINE-sized batch (2e5 x 1 kbp): every CIGAR's gap-affine cost equals
     its score, it consumes exactly both sequences (except where the reference's own off-by-one overshoot,
