@@ -268,35 +268,46 @@ __global__ __launch_bounds__(64) void wfa_reg_kernel(const KParams P) {
         if (anyM) nlo = kb + ctz_pair(mlo32, mhi32), nhi = kb + msb_pair(mlo32, mhi32);
 
         // ---------------------------------------------------------------- wf-adaptive (wfa.go:461-540)
+        // The remaining distance of wfa.go:488 is max(m-h, n-v) = max(m, n+k) - h, and an entry is usable iff
+        // k <= h < min(m, n+k) (wfa.go:483).  The first/last non-failing positions and the last failing one
+        // before them are min/max reductions over the 16 lanes of the row (DPP), no masks needed.
         const bool want_reduce = run && !term && P.adaptive && anyM && (nhi - nlo + 1) >= (int)P.min_wf_len;
         if (__ballot(want_reduce) != 0ull) {
-            int d[RG_T], dmin = INT32_MAX;
+            int  dd[RG_T], dmin = INT32_MAX;
+            bool vd[RG_T];
 #pragma unroll
             for (int t = 0; t < RG_T; t++) {
-                d[t] = act[t] ? reduce_dist(cM[t], kb + RG_G * t + j, n, m) : -1;
-                if (d[t] >= 0) dmin = imin2(dmin, d[t]);
+                dd[t] = 0, vd[t] = false;
+                if (!act[t]) continue;
+                const int k = kb + RG_G * t + j, h = (int)(cM[t] >> TAG_BITS), nk = n + k;
+                vd[t] = cM[t] != 0u && h >= k && h < imin2(m, nk);
+                dd[t] = imax2(m, nk) - h;
+                if (vd[t]) dmin = imin2(dmin, dd[t]);
             }
             const int mind = grp_min(dmin);
-            uint32_t  vb[RG_T], ob[RG_T];
+            const int thr  = mind == INT32_MAX ? INT32_MAX : mind + (int)P.max_dist_diff;
+            int       okmin = RG_W, okmax = -1;
+            bool      failed = false;
 #pragma unroll
             for (int t = 0; t < RG_T; t++) {
-                vb[t] = ob[t] = 0u;
                 if (!act[t]) continue;
-                const bool valid = d[t] >= 0;
-                const bool okc   = valid && (d[t] - mind <= (int)P.max_dist_diff);
-                vb[t] = grp_bits(__ballot(valid), grp);
-                ob[t] = grp_bits(__ballot(okc), grp);
+                const bool okc = vd[t] && dd[t] <= thr;
+                if (okc) okmin = imin2(okmin, RG_G * t + j), okmax = RG_G * t + j;
+                failed |= vd[t] && !okc;
             }
-            const uint32_t vlo = vb[0] | (vb[1] << 16), vhi = vb[2] | (vb[3] << 16);
-            const uint32_t olo = ob[0] | (ob[1] << 16), ohi = ob[2] | (ob[3] << 16);
-            if (want_reduce && mind != INT32_MAX && ((vlo & ~olo) | (vhi & ~ohi)) != 0u) {  // some distance failed
-                const int first_ok = ctz_pair(olo, ohi);
-                // valid entries before the first non-failing one: all of them failed (wfa.go:503-516)
-                const uint32_t below_lo = first_ok >= 32 ? 0xFFFFFFFFu : ((1u << first_ok) - 1u);
-                const uint32_t below_hi = first_ok >= 32 ? ((first_ok == 64) ? 0xFFFFFFFFu : ((1u << (first_ok - 32)) - 1u)) : 0u;
-                const uint32_t llo = vlo & below_lo, lhi = vhi & below_hi;
-                if ((llo | lhi) != 0u) nlo = kb + msb_pair(llo, lhi) + 1;  // one past the last leading failure
-                nhi = kb + msb_pair(olo, ohi);                              // last valid non-failing entry
+            const bool anyfail = grp_bits(__ballot(failed && mind != INT32_MAX), grp) != 0u;
+            if (__ballot(want_reduce && anyfail) != 0ull) {
+                const int first_ok = grp_min(okmin);
+                const int last_ok  = -grp_min(-okmax);
+                int       vmax     = -1;  // last usable entry before the first non-failing one (all of them failed)
+#pragma unroll
+                for (int t = 0; t < RG_T; t++)
+                    if (act[t] && vd[t] && RG_G * t + j < first_ok) vmax = RG_G * t + j;
+                const int leadp = -grp_min(-vmax);
+                if (want_reduce && anyfail) {
+                    if (leadp >= 0) nlo = kb + leadp + 1;  // wfa.go:509-511
+                    nhi = kb + last_ok;                      // wfa.go:517-524
+                }
             }
         }
 
