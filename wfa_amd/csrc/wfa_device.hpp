@@ -128,6 +128,8 @@ WFA_DEV bool stage_pack(const uint8_t *blob, uint64_t off, uint32_t len, uint32_
 //   mx_k   = M[s-x][k].   n = len(q), m = len(t).
 struct Cell {
     uint32_t M, I, D;  // raw words; 0 = nothing stored
+    uint32_t off0;     // what backTrace recomputes for this M cell (wfa.go:766-817): the pre-extension offset
+                       // from the sources WITHOUT the bounds rejections of next(); 0 = no source at all
 };
 
 WFA_DEV Cell next_cell(uint32_t mo_km1, uint32_t ie_km1, uint32_t mo_kp1, uint32_t de_kp1, uint32_t mx_k,
@@ -170,7 +172,26 @@ WFA_DEV Cell next_cell(uint32_t mo_km1, uint32_t ie_km1, uint32_t mo_kp1, uint32
     else
         tM = tD;
     c.M = (uI | uD | fM) ? ((Msk << TAG_BITS) | tM) : 0u;
+    // backTrace's view of the same cell: plain Gets, no rejection; InsExt / DelExt look only at their own pair of
+    // sources (wfa.go:767-788), every other tag takes the 3-way maximum (wfa.go:790-811)
+    const uint32_t Iu = (mo_km1 | ie_km1) ? umax2(mo_km1 >> TAG_BITS, ie_km1 >> TAG_BITS) + 1u : 0u;
+    const uint32_t Du = (mo_kp1 | de_kp1) ? umax2(mo_kp1 >> TAG_BITS, de_kp1 >> TAG_BITS) : 0u;
+    const uint32_t Xu = mx_k ? (mx_k >> TAG_BITS) + 1u : 0u;
+    // (a cell with no accepted source can only become a seed afterwards: Match/Mismatch tag = 3-way branch)
+    c.off0 = (c.M != 0u && tM == TAG_INS_EXT) ? Iu : ((c.M != 0u && tM == TAG_DEL_EXT) ? Du : umax2(umax2(Iu, Du), Xu));
     return c;
+}
+
+// Compact backtrace word (sub-wave pipeline only): everything backTrace needs from a diagonal of one score.
+//   bits 0-2  tag of the M cell (0 = no M cell)      bits 3-4  I cell: 0 none, 1 InsOpen, 2 InsExt
+//   bits 5-6  D cell: 0 none, 1 DelOpen, 2 DelExt     bits 7-31 off0 of the M cell (25 bits)
+// The walk never re-reads a cell's extended offset: it tracks h itself (wfa.go:851-853,886-909) and only
+// fetches the next cell's tag (wfa.go:915-920), so the offsets themselves need not be stored.
+WFA_DEV uint32_t compact_word(const Cell &c) {
+    if (c.M == 0u) return 0u;
+    const uint32_t ti = c.I ? ((c.I & TAG_MASK) == TAG_INS_OPEN ? 1u : 2u) : 0u;
+    const uint32_t td = c.D ? ((c.D & TAG_MASK) == TAG_DEL_OPEN ? 1u : 2u) : 0u;
+    return (c.M & TAG_MASK) | (ti << 3) | (td << 5) | (c.off0 << 7);
 }
 
 // Seeds of initComponents (wfa.go:143-184) that belong to score s, as a raw word for diagonal k
@@ -335,6 +356,35 @@ struct OpsWriterRev {
             gaps    = (letter == 'I' || letter == 'D') ? cnt : 0u;
             regions = (letter == 'I' || letter == 'D') ? 1u : 0u;
         }
+    }
+};
+
+// Compact arena of the sub-wave pipeline: one word per diagonal per score, 16-byte directory entries
+// {base, lo, w, -} growing down from the slot end.
+struct CompactView {
+    const uint32_t *A;
+    uint64_t        cap;
+    uint32_t        g, n_ent;
+    WFA_DEV uint32_t word(uint32_t s, int k) const {
+        if (s % g != 0u) return 0u;
+        const uint32_t idx = s / g;
+        if (idx >= n_ent) return 0u;
+        const uint4 e = *reinterpret_cast<const uint4 *>(A + cap - 4ull * (idx + 1));
+        const int   lo = (int)e.y, w = (int)e.z;
+        if (w <= 0 || k < lo || k >= lo + w) return 0u;
+        return A[e.x + (uint32_t)(k - lo)];
+    }
+    // tag of the cell of component comp (0 = M, 1 = I, 2 = D) at (s, k); 0 = absent
+    WFA_DEV uint32_t tag(int comp, uint32_t s, int k, uint32_t &off0) const {
+        const uint32_t wd = word(s, k);
+        off0              = wd >> 7;
+        if (comp == 0) return wd & TAG_MASK;
+        if (comp == 1) {
+            const uint32_t t = (wd >> 3) & 3u;
+            return t == 1u ? TAG_INS_OPEN : (t == 2u ? TAG_INS_EXT : 0u);
+        }
+        const uint32_t t = (wd >> 5) & 3u;
+        return t == 1u ? TAG_DEL_OPEN : (t == 2u ? TAG_DEL_EXT : 0u);
     }
 };
 
@@ -564,6 +614,92 @@ WFA_DEV void back_trace(const ArenaView &av, int lenQ, int lenT, uint32_t s, int
     ow.flush();
     out.tbegin = tBegin;  // wfa.go:979
     out.qbegin = qBegin;
+}
+
+// backTrace (wfa.go:703-983) over the compact arena, global alignment.  h_start = extended offset of the end
+// cell M[s][Ak].  Same control flow as back_trace(); the source recomputation is replaced by the stored off0
+// (M cells) -- for a cell reached inside the I or D component the reference only tests its offset0 against 0,
+// and it cannot be 0 there: an InsExt/InsOpen (DelExt/DelOpen) tag is only given when that source existed.
+template <class Writer>
+WFA_DEV void back_trace_compact(const CompactView &cv, int lenQ, int lenT, uint32_t s, int Ak, uint32_t h_start,
+                                uint32_t px, uint32_t po, uint32_t pe, Writer &ow, TraceOut &out) {
+    out.score  = s;
+    out.tbegin = out.tend = out.qbegin = out.qend = 0;
+    int      k = Ak, h = (int)h_start, v = h - k, h0;
+    int      qBegin = 0, tBegin = 0, nMatches;
+    bool     previousFromM = true, firstMatch = true;
+    int      comp = 0;  // component the current cell lives in
+    uint32_t off0 = 0;
+    uint32_t wfaType = cv.tag(0, s, k, off0);  // wfa.go:738-742
+
+    if (h < lenT)  // wfa.go:746-750
+        ow.add('I', (uint32_t)lenT - (uint32_t)h);
+    else if (v < lenQ)
+        ow.add('H', (uint32_t)lenQ - (uint32_t)v);
+
+    while (v > 0 && h > 0) {
+        int      M0;
+        uint32_t offset0;
+        if (wfaType == TAG_INS_EXT)
+            M0 = 1, offset0 = comp == 0 ? off0 : 1u;
+        else if (wfaType == TAG_DEL_EXT)
+            M0 = 2, offset0 = comp == 0 ? off0 : 1u;
+        else
+            M0 = 0, offset0 = comp == 0 ? off0 : 1u;
+        if (offset0 == 0u) break;  // fromItself / offset0 == 0 (wfa.go:818-825)
+        h0 = (int)offset0;
+        if (previousFromM) {  // only ever true for cells of the M component (wfa.go:833-869)
+            nMatches = h - h0;
+            if (nMatches > 0) {
+                if (firstMatch) firstMatch = false, out.tend = h, out.qend = v;
+                ow.add('M', (uint32_t)nMatches);
+            }
+            h = h0;
+            v = h - k;
+            if (wfaType == TAG_MATCH)
+                tBegin = h, qBegin = v;
+            else if (nMatches > 0)
+                tBegin = h + 1, qBegin = v + 1;
+            if (h <= 0 || v <= 0) break;
+        }
+        ow.add(op_letter(wfaType), 1);  // wfa.go:872-873
+        previousFromM = true;           // wfa.go:885-909
+        bool stop     = false;
+        switch (wfaType) {
+        case TAG_MISMATCH: s -= px; h--; break;
+        case TAG_INS_OPEN: s -= po + pe; k--; h--; break;
+        case TAG_INS_EXT: s -= pe; k--; h--; previousFromM = false; break;
+        case TAG_DEL_OPEN: s -= po + pe; k++; break;
+        case TAG_DEL_EXT: s -= pe; k++; previousFromM = false; break;
+        default: stop = true; break;
+        }
+        if (stop) break;
+        v = h - k;
+        uint32_t       noff0;
+        const uint32_t nt = cv.tag(M0, s, k, noff0);  // wfa.go:915-920: a missing cell ends the walk, the old
+        if (nt == 0u) break;                           // tag stays in wfaType for the tail below
+        wfaType = nt, off0 = noff0, comp = M0;
+    }
+    if (h > 0 && v > 0) {  // wfa.go:930-968
+        nMatches = imin2(h, v) - 1;
+        if (nMatches > 0) {
+            if (firstMatch) firstMatch = false, out.tend = h, out.qend = v;
+            ow.add('M', (uint32_t)nMatches);
+            h -= nMatches, v -= nMatches;
+            if (wfaType == TAG_MATCH)
+                tBegin = h, qBegin = v;
+            else
+                tBegin = h + 1, qBegin = v + 1;
+        } else if (wfaType == TAG_MATCH) {
+            tBegin = h, qBegin = v;
+            if (firstMatch) firstMatch = false, out.tend = h, out.qend = v;
+        }
+        ow.add(op_letter(wfaType), 1);
+    }
+    if (v > 1) ow.add('H', (uint32_t)(v - 1));  // wfa.go:970-972
+    if (h > 1) ow.add('I', (uint32_t)(h - 1));  // wfa.go:974-976
+    ow.flush();
+    out.tbegin = tBegin, out.qbegin = qBegin;
 }
 
 }  // namespace wfa

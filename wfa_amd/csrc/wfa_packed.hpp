@@ -171,14 +171,14 @@ __global__ __launch_bounds__(64, 8) void wfa_packed_kernel(const KParams P) {
         const bool too_wide = W > PK_WCAP;
         const bool wide     = __ballot(W > PK_G && !too_wide) != 0ull;  // wave-uniform: second tile needed
 
-        uint32_t cM[PK_TILES], cI[PK_TILES], cD[PK_TILES];
+        uint32_t cM[PK_TILES], cI[PK_TILES], cD[PK_TILES], cO[PK_TILES];
         uint32_t mbits[PK_TILES];
         bool     term = false;
         WFA_STAMP(1);  // ring meta + range
 #pragma unroll
         for (int t = 0; t < PK_TILES; t++) {
-            cM[t] = cI[t] = cD[t] = 0u;
-            mbits[t]              = 0u;
+            cM[t] = cI[t] = cD[t] = cO[t] = 0u;
+            mbits[t]                      = 0u;
             if (t == 1 && !wide) continue;
             const int  k   = lo + PK_G * t + j;
             const bool act = run && !too_wide && k <= hi;
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(64, 8) void wfa_packed_kernel(const KParams P) {
                 Cell c = next_cell(mo_km1, ie_km1, mo_kp1, de_kp1, mx_k, k, n, m);
                 if (seeded && k == 0 && c.M == 0u) c.M = seed_word<0>(sv, 0, s, x, true);
                 c.M   = extend_word<0>(sv, c.M, k);
-                cM[t] = c.M, cI[t] = c.I, cD[t] = c.D;
+                cM[t] = c.M, cI[t] = c.I, cD[t] = c.D, cO[t] = c.off0;
                 if (k == Ak && (int)(c.M >> TAG_BITS) >= m) term = true;  // wfa.go:235-239
             }
             mbits[t] = half_of(__ballot(cM[t] != 0u), sub);
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(64, 8) void wfa_packed_kernel(const KParams P) {
         WFA_STAMP(3);  // masks + wf-adaptive
         // ---------------------------------------------------------------- store the surviving band
         const int  wn       = (nhi >= nlo) ? nhi - nlo + 1 : 0;
-        const bool no_room  = run && ((uint64_t)top + 3ull * (uint32_t)wn + (uint64_t)DIR_WORDS * (si + 2u) > cap);
+        const bool no_room  = run && ((uint64_t)top + (uint32_t)wn + 4ull * (si + 2u) > cap);
         const bool give_up  = run && (too_wide || no_room);
         const bool store_ok = run && !give_up;
         if (store_ok) {
@@ -242,8 +242,9 @@ __global__ __launch_bounds__(64, 8) void wfa_packed_kernel(const KParams P) {
                 if (t == 1 && !wide) continue;
                 const int k = lo + PK_G * t + j;
                 if (k >= nlo && k <= nhi) {
-                    const int i = k - nlo;
-                    rowM[i] = cM[t], rowM[wn + i] = cI[t], rowM[2 * wn + i] = cD[t];
+                    Cell c;
+                    c.M = cM[t], c.I = cI[t], c.D = cD[t], c.off0 = cO[t];
+                    rowM[k - nlo] = compact_word(c);  // one compact backtrace word per surviving diagonal
                     const uint32_t r = (uint32_t)k & (PK_WCAP - 1);
                     ringM[cm * PK_WCAP + r] = cM[t], ringI[ce * PK_WCAP + r] = cI[t], ringD[ce * PK_WCAP + r] = cD[t];
                     my_cells += (cM[t] != 0u) + (cI[t] != 0u) + (cD[t] != 0u);
@@ -252,20 +253,26 @@ __global__ __launch_bounds__(64, 8) void wfa_packed_kernel(const KParams P) {
             if (j == 0) {
                 metaM[2 * cm] = nlo, metaM[2 * cm + 1] = wn;
                 metaE[2 * ce] = nlo, metaE[2 * ce + 1] = wn;
-                store_dir(A + cap - (uint64_t)DIR_WORDS * (si + 1), wn > 0 ? (uint64_t)top : 0ull, wn > 0 ? nlo : 0, wn, (uint32_t)wn);
+                *reinterpret_cast<uint4 *>(A + cap - 4ull * (si + 1)) =
+                    wn > 0 ? make_uint4(top, (uint32_t)nlo, (uint32_t)wn, 0u) : make_uint4(0u, 0u, 0u, 0u);
             }
-            top += 3u * (uint32_t)wn;
+            top += (uint32_t)wn;
         }
         WFA_STAMP(4);  // stores
         // ---------------------------------------------------------------- finish / advance
         if (give_up || (run && term)) {
             const uint32_t cells = sub_sum(my_cells);
+            int            hf    = 0;  // extended offset of the end cell M[s][Ak]: where the backtrace starts
+#pragma unroll
+            for (int t = 0; t < PK_TILES; t++)
+                if (lo + PK_G * t + j == Ak) hf = (int)(cM[t] >> TAG_BITS);
+            hf = -sub_min(-hf);
             if (j == 0) {
                 if (give_up) {
                     P.pair_meta[pidx] = make_uint4(too_wide ? ST_REDO_BAND : ST_REDO_ARENA, 0u, 0u, 0u);
                     push_redo(P, pair, too_wide ? ST_REDO_BAND : ST_REDO_ARENA);
                 } else {
-                    P.pair_meta[pidx] = make_uint4(ST_OK, s, si + 1u, cells);
+                    P.pair_meta[pidx] = make_uint4(ST_OK, s, (uint32_t)hf, cells);
                 }
             }
             st = 0;
@@ -301,9 +308,9 @@ __global__ __launch_bounds__(256) void wfa_backtrace_kernel(const KParams P) {
         return;
     }
     const int n = (int)P.q_len[pair], m = (int)P.t_len[pair];
-    ArenaView av;
-    av.A = P.arena + (uint64_t)idx * P.arena_words, av.cap = P.arena_words, av.g = P.g, av.n_ent = meta.z;
     const uint32_t s_final = meta.y;
+    CompactView cv;
+    cv.A = P.arena + (uint64_t)idx * P.arena_words, cv.cap = P.arena_words, cv.g = P.g, cv.n_ent = s_final / P.g + 1u;
 
     // ops region: bound = 2 * score / min(x, e) + 8 entries, carved from the shared ops buffer
     const uint32_t bound = 2u * (s_final / P.min_xe) + 8u;
@@ -312,7 +319,7 @@ __global__ __launch_bounds__(256) void wfa_backtrace_kernel(const KParams P) {
     const bool     fits = off + bound <= P.ops_cap;
     ow.init(P.ops + off, fits ? bound : 0u);
     TraceOut to;
-    back_trace(av, n, m, s_final, m - n, false, P.x, P.o, P.e, ow, to);
+    back_trace_compact(cv, n, m, s_final, m - n, meta.z, P.x, P.o, P.e, ow, to);
     ow.finish();
     // (when the ops buffer is too small the host sees ops_cursor > ops_cap and re-runs with a bigger one)
     const uint64_t first = off + bound - ow.n;

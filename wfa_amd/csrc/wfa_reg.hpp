@@ -202,13 +202,13 @@ __global__ __launch_bounds__(64) void wfa_reg_kernel(const KParams P) {
 
         WFA_STAMP(1);  // range + window
         // ---------------------------------------------------------------- next + seeds + extend, tile by tile
-        uint32_t cM[RG_T], cI[RG_T], cD[RG_T], mb[RG_T];
+        uint32_t cM[RG_T], cI[RG_T], cD[RG_T], cO[RG_T], mb[RG_T];  // cO = backtrace off0 of the M cell
         int      ev[RG_T], eh[RG_T];  // position of the next window of a cell that is still matching (ev < 0: done)
         bool     act[RG_T];           // wave-uniform: some pair of this wave touches tile t
         uint32_t termbits = 0u;
 #pragma unroll
         for (int t = 0; t < RG_T; t++) {
-            cM[t] = cI[t] = cD[t] = 0u, mb[t] = 0u, ev[t] = -1, eh[t] = 0;
+            cM[t] = cI[t] = cD[t] = cO[t] = 0u, mb[t] = 0u, ev[t] = -1, eh[t] = 0;
             const int  k   = kb + RG_G * t + j;
             const bool inr = run && !too_wide && k >= lo && k <= hi;
             act[t]         = __ballot(inr) != 0ull;
@@ -221,6 +221,7 @@ __global__ __launch_bounds__(64) void wfa_reg_kernel(const KParams P) {
             Cell c = next_cell(mo_km1, ie_km1, mo_kp1, de_kp1, mx_k, k, n, m);
             if (!inr) c.M = c.I = c.D = 0u;
             if (seeded && k == 0 && c.M == 0u && inr) c.M = seed_word<0>(sv, 0, s, x, true);
+            cO[t] = c.off0;
             // WF_EXTEND, first 16-base window (wfa.go:394-455): almost every off-path diagonal stops here
             const int h = (int)(c.M >> TAG_BITS), v = h - k;
             if (c.M != 0u && v > 0 && v < n && h < m) {
@@ -314,10 +315,10 @@ __global__ __launch_bounds__(64) void wfa_reg_kernel(const KParams P) {
         WFA_STAMP(3);  // masks + wf-adaptive
         // ---------------------------------------------------------------- store the surviving band
         const int  wn       = (nhi >= nlo) ? nhi - nlo + 1 : 0;
-        const bool no_room  = run && ((uint64_t)top + 3ull * (uint32_t)wn + (uint64_t)DIR_WORDS * (si + 2u) > cap);
+        const bool no_room  = run && ((uint64_t)top + (uint32_t)wn + 4ull * (si + 2u) > cap);
         const bool give_up  = run && (too_wide || no_room);
         const bool store_ok = run && !give_up;
-        uint32_t *const rowM = A + top;
+        uint32_t *const row = A + top;  // one compact backtrace word per surviving diagonal
 #pragma unroll
         for (int t = 0; t < RG_T; t++) {
             if (!act[t]) continue;  // nothing was computed in this tile: its registers are already 0
@@ -326,14 +327,16 @@ __global__ __launch_bounds__(64) void wfa_reg_kernel(const KParams P) {
             if (!keep) cM[t] = cI[t] = cD[t] = 0u;  // Delete of wfa.go:526-535: the words never exist
             if (__ballot(keep) == 0ull) continue;
             if (keep) {
-                const int i = k - nlo;
-                rowM[i] = cM[t], rowM[wn + i] = cI[t], rowM[2 * wn + i] = cD[t];
+                Cell c;
+                c.M = cM[t], c.I = cI[t], c.D = cD[t], c.off0 = cO[t];
+                row[k - nlo] = compact_word(c);
                 my_cells += (cM[t] != 0u) + (cI[t] != 0u) + (cD[t] != 0u);
             }
         }
         if (store_ok && j == 0)
-            store_dir(A + cap - (uint64_t)DIR_WORDS * (si + 1), wn > 0 ? (uint64_t)top : 0ull, wn > 0 ? nlo : 0, wn, (uint32_t)wn);
-        if (store_ok) top += 3u * (uint32_t)wn;
+            *reinterpret_cast<uint4 *>(A + cap - 4ull * (si + 1)) =
+                wn > 0 ? make_uint4(top, (uint32_t)nlo, (uint32_t)wn, 0u) : make_uint4(0u, 0u, 0u, 0u);
+        if (store_ok) top += (uint32_t)wn;
 
         WFA_STAMP(4);  // stores
         // ---------------------------------------------------------------- advance the register ring
@@ -357,12 +360,17 @@ __global__ __launch_bounds__(64) void wfa_reg_kernel(const KParams P) {
         // ---------------------------------------------------------------- finish / next score
         if (give_up || (run && term)) {
             const uint32_t cells = grp_sum(my_cells);
+            int            hf    = 0;  // extended offset of the end cell M[s][Ak]: where the backtrace starts
+#pragma unroll
+            for (int t = 0; t < RG_T; t++)
+                if (kb + RG_G * t + j == Ak) hf = (int)(Mh[0][t] >> TAG_BITS);
+            hf = -grp_min(-hf);
             if (j == 0) {
                 if (give_up) {
                     P.pair_meta[pidx] = make_uint4(too_wide ? ST_REDO_BAND : ST_REDO_ARENA, 0u, 0u, 0u);
                     push_redo(P, pair, too_wide ? ST_REDO_BAND : ST_REDO_ARENA);
                 } else {
-                    P.pair_meta[pidx] = make_uint4(ST_OK, s, si + 1u, cells);
+                    P.pair_meta[pidx] = make_uint4(ST_OK, s, (uint32_t)hf, cells);
                 }
             }
             st = 0;
