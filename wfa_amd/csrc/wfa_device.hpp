@@ -130,6 +130,7 @@ struct Cell {
     uint32_t M, I, D;  // raw words; 0 = nothing stored
     uint32_t off0;     // what backTrace recomputes for this M cell (wfa.go:766-817): the pre-extension offset
                        // from the sources WITHOUT the bounds rejections of next(); 0 = no source at all
+    bool     rej;      // a source was rejected by next(): off0 must come from off0_unrejected()
 };
 
 WFA_DEV Cell next_cell(uint32_t mo_km1, uint32_t ie_km1, uint32_t mo_kp1, uint32_t de_kp1, uint32_t mx_k,
@@ -172,14 +173,22 @@ WFA_DEV Cell next_cell(uint32_t mo_km1, uint32_t ie_km1, uint32_t mo_kp1, uint32
     else
         tM = tD;
     c.M = (uI | uD | fM) ? ((Msk << TAG_BITS) | tM) : 0u;
-    // backTrace's view of the same cell: plain Gets, no rejection; InsExt / DelExt look only at their own pair of
-    // sources (wfa.go:767-788), every other tag takes the 3-way maximum (wfa.go:790-811)
+    // backTrace's view of the same cell (wfa.go:766-817) uses plain Gets with no rejection.  Unless one of the
+    // five sources was rejected above, that is simply Isk (InsExt tag), Dsk (DelExt tag) or Msk (any other tag);
+    // c.rej flags the rare cells near a sequence end where the caller must use off0_unrejected() instead.
+    c.off0 = c.M == 0u ? 0u : (tM == TAG_INS_EXT ? Isk : (tM == TAG_DEL_EXT ? Dsk : Msk));
+    c.rej  = (mo_km1 != 0u && (int)(mo_km1 >> TAG_BITS) > m) | (ie_km1 != 0u && !fI) |
+            (mo_kp1 != 0u && (int)(mo_kp1 >> TAG_BITS) - k > n) | (de_kp1 != 0u && !fD) | (mx_k != 0u && !fM);
+    return c;
+}
+
+// The reference's recomputation without bounds rejection; tag = the tag the M cell finally carries.
+WFA_DEV uint32_t off0_unrejected(uint32_t mo_km1, uint32_t ie_km1, uint32_t mo_kp1, uint32_t de_kp1, uint32_t mx_k,
+                                 uint32_t tag) {
     const uint32_t Iu = (mo_km1 | ie_km1) ? umax2(mo_km1 >> TAG_BITS, ie_km1 >> TAG_BITS) + 1u : 0u;
     const uint32_t Du = (mo_kp1 | de_kp1) ? umax2(mo_kp1 >> TAG_BITS, de_kp1 >> TAG_BITS) : 0u;
     const uint32_t Xu = mx_k ? (mx_k >> TAG_BITS) + 1u : 0u;
-    // (a cell with no accepted source can only become a seed afterwards: Match/Mismatch tag = 3-way branch)
-    c.off0 = (c.M != 0u && tM == TAG_INS_EXT) ? Iu : ((c.M != 0u && tM == TAG_DEL_EXT) ? Du : umax2(umax2(Iu, Du), Xu));
-    return c;
+    return tag == TAG_INS_EXT ? Iu : (tag == TAG_DEL_EXT ? Du : umax2(umax2(Iu, Du), Xu));
 }
 
 // Compact backtrace word (sub-wave pipeline only): everything backTrace needs from a diagonal of one score.
@@ -187,11 +196,11 @@ WFA_DEV Cell next_cell(uint32_t mo_km1, uint32_t ie_km1, uint32_t mo_kp1, uint32
 //   bits 5-6  D cell: 0 none, 1 DelOpen, 2 DelExt     bits 7-31 off0 of the M cell (25 bits)
 // The walk never re-reads a cell's extended offset: it tracks h itself (wfa.go:851-853,886-909) and only
 // fetches the next cell's tag (wfa.go:915-920), so the offsets themselves need not be stored.
-WFA_DEV uint32_t compact_word(const Cell &c) {
-    if (c.M == 0u) return 0u;
-    const uint32_t ti = c.I ? ((c.I & TAG_MASK) == TAG_INS_OPEN ? 1u : 2u) : 0u;
-    const uint32_t td = c.D ? ((c.D & TAG_MASK) == TAG_DEL_OPEN ? 1u : 2u) : 0u;
-    return (c.M & TAG_MASK) | (ti << 3) | (td << 5) | (c.off0 << 7);
+WFA_DEV uint32_t compact_word(uint32_t M, uint32_t I, uint32_t D, uint32_t off0) {
+    // InsOpen/InsExt are tags 1/2 and DelOpen/DelExt 3/4 (wfa_backtrace_types.go:27-31): I -> tag, D -> tag - 2
+    const uint32_t td = D ? (D & TAG_MASK) - 2u : 0u;
+    const uint32_t wd = (M & TAG_MASK) | ((I & 3u) << 3) | (td << 5) | (off0 << 7);
+    return M ? wd : 0u;
 }
 
 // Seeds of initComponents (wfa.go:143-184) that belong to score s, as a raw word for diagonal k

@@ -192,7 +192,8 @@ __global__ __launch_bounds__(64, 8) void wfa_packed_kernel(const KParams P) {
                 Cell c = next_cell(mo_km1, ie_km1, mo_kp1, de_kp1, mx_k, k, n, m);
                 if (seeded && k == 0 && c.M == 0u) c.M = seed_word<0>(sv, 0, s, x, true);
                 c.M   = extend_word<0>(sv, c.M, k);
-                cM[t] = c.M, cI[t] = c.I, cD[t] = c.D, cO[t] = c.off0;
+                cM[t] = c.M, cI[t] = c.I, cD[t] = c.D;
+                cO[t] = c.rej ? off0_unrejected(mo_km1, ie_km1, mo_kp1, de_kp1, mx_k, c.M & TAG_MASK) : c.off0;
                 if (k == Ak && (int)(c.M >> TAG_BITS) >= m) term = true;  // wfa.go:235-239
             }
             mbits[t] = half_of(__ballot(cM[t] != 0u), sub);
@@ -242,9 +243,7 @@ __global__ __launch_bounds__(64, 8) void wfa_packed_kernel(const KParams P) {
                 if (t == 1 && !wide) continue;
                 const int k = lo + PK_G * t + j;
                 if (k >= nlo && k <= nhi) {
-                    Cell c;
-                    c.M = cM[t], c.I = cI[t], c.D = cD[t], c.off0 = cO[t];
-                    rowM[k - nlo] = compact_word(c);  // one compact backtrace word per surviving diagonal
+                    rowM[k - nlo] = compact_word(cM[t], cI[t], cD[t], cO[t]);  // one compact backtrace word per diagonal
                     const uint32_t r = (uint32_t)k & (PK_WCAP - 1);
                     ringM[cm * PK_WCAP + r] = cM[t], ringI[ce * PK_WCAP + r] = cI[t], ringD[ce * PK_WCAP + r] = cD[t];
                     my_cells += (cM[t] != 0u) + (cI[t] != 0u) + (cD[t] != 0u);

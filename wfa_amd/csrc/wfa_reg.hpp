@@ -222,6 +222,8 @@ __global__ __launch_bounds__(64) void wfa_reg_kernel(const KParams P) {
             if (!inr) c.M = c.I = c.D = 0u;
             if (seeded && k == 0 && c.M == 0u && inr) c.M = seed_word<0>(sv, 0, s, x, true);
             cO[t] = c.off0;
+            if (__ballot(c.rej && inr) != 0ull)  // rare: a source was rejected near a sequence end
+                cO[t] = c.rej ? off0_unrejected(mo_km1, ie_km1, mo_kp1, de_kp1, mx_k, c.M & TAG_MASK) : cO[t];
             // WF_EXTEND, first 16-base window (wfa.go:394-455): almost every off-path diagonal stops here
             const int h = (int)(c.M >> TAG_BITS), v = h - k;
             if (c.M != 0u && v > 0 && v < n && h < m) {
@@ -327,9 +329,7 @@ __global__ __launch_bounds__(64) void wfa_reg_kernel(const KParams P) {
             if (!keep) cM[t] = cI[t] = cD[t] = 0u;  // Delete of wfa.go:526-535: the words never exist
             if (__ballot(keep) == 0ull) continue;
             if (keep) {
-                Cell c;
-                c.M = cM[t], c.I = cI[t], c.D = cD[t], c.off0 = cO[t];
-                row[k - nlo] = compact_word(c);
+                row[k - nlo] = compact_word(cM[t], cI[t], cD[t], cO[t]);
                 my_cells += (cM[t] != 0u) + (cI[t] != 0u) + (cD[t] != 0u);
             }
         }
