@@ -70,7 +70,7 @@ WFA_DEV uint32_t sub_sum(uint32_t v) {
     return v;
 }
 
-__global__ __launch_bounds__(64, 8) void wfa_packed_kernel(const KParams P) {
+__global__ __launch_bounds__(64, 7) void wfa_packed_kernel(const KParams P) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int lane = threadIdx.x, j = lane & 31, sub = lane >> 5;
     const int lead = sub << 5;

@@ -55,7 +55,7 @@ WFA_DEV int msb_pair(uint32_t lo32, uint32_t hi32) { return hi32 ? 63 - __builti
 constexpr int RG_EMPTY_LO = 0x3FFFFFFF, RG_EMPTY_HI = -0x3FFFFFFF;
 
 template <int DX, int DOE, int DE>
-__global__ __launch_bounds__(64) void wfa_reg_kernel(const KParams P) {
+__global__ __launch_bounds__(64, 5) void wfa_reg_kernel(const KParams P) {
     constexpr int RM = DX > DOE ? DX : DOE;  // M rows kept: scores s-g .. s-RM*g
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int lane = threadIdx.x, j = lane & 15, grp = lane >> 4;
