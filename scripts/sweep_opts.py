@@ -21,7 +21,7 @@ def run():
     L.check(lib.wfahip_align_batch_device(al._ctx, C.byref(prm), d[0].data_ptr(), blob.size, d[1].data_ptr(), d[2].data_ptr(),
             d[3].data_ptr(), d[4].data_ptr(), n, int(max(q_len.max(), t_len.max())), rec.data_ptr(), ops.data_ptr(), ops_cap, C.byref(need), None))
     lib.wfahip_last_timing(al._ctx, C.byref(tm))
-defaults = dict(overlap=1, packed_waves_per_cu=0, chunk_pairs=0, packed=1, reg=1)
+defaults = dict(overlap=0, packed_waves_per_cu=0, chunk_pairs=0, packed=1, reg=1)
 res = {i: [] for i in range(len(variants))}
 ref = None
 for rnd in range(4):

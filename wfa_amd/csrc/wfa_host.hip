@@ -60,7 +60,7 @@ struct wfahip_ctx {
     int64_t       opt_packed_arena_bytes   = 0;  // per pair, 0 = automatic
     int64_t       opt_chunk_pairs          = 0;  // 0 = automatic
     int64_t       opt_packed_waves_per_cu  = 0;  // 0 = automatic
-    int64_t       opt_overlap              = 1;  // 0: backtrace on the same stream as the forward kernel
+    int64_t       opt_overlap              = 0;  // 1: backtrace of chunk c on a second stream beside the forward kernel of chunk c+1 (measured: no gain)
     int           force_mode               = -1;  // debug: start the ladder in this mode
     wfahip_timing timing{};
     char          last_error[256] = {0};
