@@ -24,3 +24,13 @@ for f, r in rows("pmc_*/**/*counter_collection.csv"):
         acc[key] += float(r["Counter_Value"]); cnt[key] += 1
 for k in sorted(acc):
     print(k, "sum", acc[k], "dispatches", cnt[k])
+
+import json
+pm = {}
+for k in sorted(acc):
+    name, counter, grid = k
+    if counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        pm.setdefault(name.strip(), {}).setdefault(grid, {})[counter + "_KB"] = acc[k] / cnt[k]
+with open(os.path.join(out, "pmc_hbm.json"), "w") as f:
+    json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KB per dispatch, keyed by kernel and grid size",
+               "kernels": pm}, f, indent=1)

@@ -354,7 +354,7 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
         const size_t   lds_c     = (size_t)seq_words * 2 * 4 * 4;   // register kernel: four rows, sequences only
         const bool     can_b     = lds_b <= 20 * 1024;
         const bool     can_c     = ctx->opt_reg && dx == 2 && doe == 4 && de == 1 && lds_c <= 20 * 1024;
-        uint64_t       words     = std::max<uint64_t>(4096, 16ull * max_len);
+        uint64_t       words     = std::max<uint64_t>(1024, 8ull * max_len);  // compact rows: 1 word per diagonal
         if (ctx->opt_packed_arena_bytes > 0) words = std::max<uint64_t>(1024, ctx->opt_packed_arena_bytes / 4);
         words = (words + 7) & ~7ull;
         P.arena_words   = words;
