@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--no-adaptive", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=60_000, help="pairs timed on one host core (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=1)
+    ap.add_argument("--opt", action="append", default=[], help="library option key=value (experiments)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -73,6 +74,9 @@ def main():
     al = w.New(w.DefaultPenalties, w.Options(GlobalAlignment=not args.semi_global), device=local_rank)
     if not args.no_adaptive:
         assert al.AdaptiveReduction(w.DefaultAdaptiveOption) is None
+    for kv in args.opt:
+        key, val = kv.split("=")
+        L.check(L.lib().wfahip_set_option(al._ctx, key.encode(), int(val)), "wfahip_set_option")
     prm = al._params()
     lib = L.lib()
     stream = torch.cuda.current_stream(dev).cuda_stream
@@ -126,7 +130,9 @@ def main():
     # gfx950: FETCH_SIZE counts half the bytes of the coalesced input reads (checked against the known 2.0 GB of
     # sequence bytes the forward kernel must read: it reports 1.12 GB), so it is doubled; WRITE_SIZE is taken as is.
     traffic, traffic_src = None, None
-    kname = ["wfa_generic_kernel<1, 0>", "wfa_packed_kernel", "wfa_reg_kernel<2, 4, 1>"][int(timing.main_kernel_kind)]
+    KNAMES = ["wfa_generic_kernel<1, 0>", "wfa_packed_kernel", "wfa_reg_kernel<2, 4, 1>", "wfa_blk_kernel<16>",
+              "wfa_blk_kernel<8>"]
+    kname = KNAMES[int(timing.main_kernel_kind)]
     default_workload = (n == 1_000_000 and args.length == 1000 and abs(args.error - 0.05) < 1e-9 and args.seed == 3
                         and not args.semi_global and not args.no_adaptive)
     if default_workload:
@@ -166,8 +172,7 @@ def main():
                "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                             "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
                             "algorithmic_bytes_per_launch": alg_bytes,
-                            "kernel": ["wfa_generic_kernel<1,0>", "wfa_packed_kernel",
-                                       "wfa_reg_kernel<2,4,1>"][int(timing.main_kernel_kind)],
+                            "kernel": kname,
                             "kernel_ms": main_k_ms, "all_kernels_ms": k_ms,
                             "note": "achieved = algorithmic bytes of one step / duration of the dominant "
                                     "(forward) kernel's launches in that step; peak = 8 TB/s HBM3E spec"}}

@@ -101,7 +101,7 @@ typedef struct {
                                   ran, else the first generic launch) */
     uint32_t n_main_launches;  /* launches of that kernel (one per chunk) */
     uint32_t n_packed_pairs;   /* pairs finished by the sub-wave forward + backtrace kernels */
-    uint32_t main_kernel_kind; /* 0 = wfa_generic_kernel, 1 = wfa_packed_kernel, 2 = wfa_reg_kernel */
+    uint32_t main_kernel_kind; /* 0 = wfa_generic_kernel, 1 = wfa_packed_kernel, 2 = wfa_reg_kernel, 3 = wfa_blk_kernel<16>, 4 = wfa_blk_kernel<8> */
     uint32_t reserved;
 } wfahip_timing;
 

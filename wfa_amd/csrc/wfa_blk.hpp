@@ -1,0 +1,488 @@
+// wfa_blk.hpp -- kernel D: blocked register-window forward kernel (64/G pairs per wave64).
+//
+// A group of G lanes (G = 16: one DPP row, or G = 8: half a row) owns one pair; lane j of the group holds the
+// PP = 64/G CONSECUTIVE diagonals kb + PP*j + p (p = 0..PP-1) of a 64-diagonal window that follows the band in
+// steps of 16.  Consequences of the blocked layout:
+//   * the k-1 / k+1 sources of WF_NEXT (wfa.go:579,580,614,615) are the lane's own neighbouring registers for
+//     all but one position, so a score step needs four DPP lane shifts in total (Mo/I below, Mo/D above);
+//   * a lane's PP finished cells are adjacent in the arena: one 16-byte store per lane and row;
+//   * every per-pair reduction (band range, wf-adaptive) is a 3- or 4-stage DPP butterfly inside the group.
+// The register rings hold bare offsets (0 = absent), not offset<<3|tag words: WF_NEXT only reads offsets
+// (wfa.go:579-655 strip the tag), and the tags go straight into the compact backtrace word that is stored.
+// The ring of the last four M rows is indexed by (step & 3) with the step loop unrolled four times, so the ring
+// advances by renaming, not by register moves: with penalties shaped 2:4:1 (x : o+e : e in units of g) the row
+// written at step i replaces M[s-o-e], the row it was computed from, and M[s-x] is slot (i+2)&3.
+//
+// Fast path / exact path.  The bounds rejections of next() (offset > m, offset-k > n; wfa.go:581-588,616-623,
+// 651-654), the k-range clamp (wfa.go:562-563) and the termination test (wfa.go:235-239) can only matter once
+// some cell of the pair has reached a sequence end (h >= m or v >= n).  Until then -- almost the whole
+// alignment -- the wave runs a rejection-free WF_NEXT in which backTrace's unbounded recomputation of the
+// pre-extension offset (wfa.go:766-817) equals the offset just computed.  A sticky per-pair flag, set by the
+// first cell that hits an end, switches the wave to the exact code (bit-for-bit the rules of next_cell()).
+//
+// Output protocol = kernel C's: one compact backtrace word per diagonal (compact_word()), 16-byte directory
+// entries growing down from the end of the pair's arena slot, pair_meta for wfa_backtrace_kernel.  Rows are
+// stored lane-aligned (the band padded to a multiple of PP with absent = 0 words).
+#pragma once
+#include "wfa_device.hpp"
+#include "wfa_packed.hpp"
+#include <type_traits>
+
+namespace wfa {
+
+template <int G>
+struct BlkOps;
+
+template <>
+struct BlkOps<16> {
+    // value held by lane j-1 / j+1 of the group; 0 beyond the group edge (bound_ctrl)
+    static WFA_DEV uint32_t dn1(uint32_t x, int) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true); }
+    static WFA_DEV uint32_t up1(uint32_t x, int) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x101, 0xf, 0xf, true); }
+    // window moves by 16 diagonals = 4 lanes: registers move towards higher (shr) / lower (shl) lanes
+    static WFA_DEV uint32_t shr(uint32_t x, int) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true); }
+    static WFA_DEV uint32_t shl(uint32_t x, int) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x104, 0xf, 0xf, true); }
+    template <class F>
+    static WFA_DEV int reduce(int v, F f) {
+        v = f(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));
+        v = f(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));
+        v = f(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));
+        v = f(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));
+        return v;
+    }
+};
+
+template <>
+struct BlkOps<8> {
+    static WFA_DEV uint32_t dn1(uint32_t x, int j) {
+        const uint32_t r = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);
+        return j == 0 ? 0u : r;
+    }
+    static WFA_DEV uint32_t up1(uint32_t x, int j) {
+        const uint32_t r = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x101, 0xf, 0xf, true);
+        return j == 7 ? 0u : r;
+    }
+    static WFA_DEV uint32_t shr(uint32_t x, int j) {  // 16 diagonals = 2 lanes
+        const uint32_t r = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);
+        return j < 2 ? 0u : r;
+    }
+    static WFA_DEV uint32_t shl(uint32_t x, int j) {
+        const uint32_t r = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x102, 0xf, 0xf, true);
+        return j >= 6 ? 0u : r;
+    }
+    template <class F>
+    static WFA_DEV int reduce(int v, F f) {
+        v = f(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));
+        v = f(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));
+        v = f(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));
+        return v;
+    }
+};
+
+WFA_DEV uint32_t umin2(uint32_t a, uint32_t b) { return a < b ? a : b; }
+WFA_DEV uint32_t umax3(uint32_t a, uint32_t b, uint32_t c) { return umax2(umax2(a, b), c); }
+
+constexpr int BK_BIG = 0x3FFFFFFF;
+
+template <int G>
+__global__ __launch_bounds__(64, (G == 16 ? 4 : 2)) void wfa_blk_kernel(const KParams P) {
+    constexpr int PP  = 64 / G;   // diagonals per lane
+    constexpr int NG  = 64 / G;   // pairs per wave
+    constexpr int W   = 64;       // window width in diagonals
+    using Ops         = BlkOps<G>;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int lane = threadIdx.x, j = lane & (G - 1), grp = lane / G;
+
+    const uint32_t        SW = P.lds_seq_words;
+    const uint32_t *const lq = lds + grp * 2 * SW;
+    const uint32_t *const lt = lq + SW;
+    const uint64_t        cap      = P.arena_words;
+    const int             mdd      = (int)P.max_dist_diff;
+    const int             minwf    = (int)P.min_wf_len;
+    const bool            adaptive = P.adaptive != 0;
+    const uint32_t        seed_si  = P.dx;  // the mismatch seed M[x][0] belongs to step x/g
+
+    const auto fmin = [](int a, int b) { return a < b ? a : b; };
+    const auto fmax = [](int a, int b) { return a > b ? a : b; };
+    const auto fadd = [](int a, int b) { return a + b; };
+    const auto f_or = [](int a, int b) { return a | b; };
+
+    // per-pair state (identical in the G lanes of a group)
+    int        st = 0;  // 0 = needs a pair, 1 = running, 2 = queue exhausted
+    uint32_t   pidx = 0, pair = 0, si = 0, top = 0, cells = 0;
+    int        n = 0, m = 0, Ak = 0, kb = 0, k0 = 0, room = 0;
+    bool       slow = false, first_eq = false;
+    uint32_t  *A = nullptr;
+
+    uint32_t M[4][PP], I[PP], D[PP];  // offsets, 0 = absent; M[i & 3] = row of step i
+    int      rlo[4], rhi[4];          // band of each kept M row (absolute k); empty = (BIG, -BIG)
+    int      lim[PP], lmx[PP];        // min(n + k, m) and max(n + k, m) of the lane's diagonals
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        rlo[d] = BK_BIG, rhi[d] = -BK_BIG;
+#pragma unroll
+        for (int p = 0; p < PP; p++) M[d][p] = 0u;
+    }
+#pragma unroll
+    for (int p = 0; p < PP; p++) I[p] = D[p] = 0u, lim[p] = 0, lmx[p] = 0;
+
+    const auto set_window = [&]() {
+        k0 = kb + PP * j;
+#pragma unroll
+        for (int p = 0; p < PP; p++) lim[p] = imin2(n + k0 + p, m), lmx[p] = imax2(n + k0 + p, m);
+    };
+    const auto clear_rings = [&]() {
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            rlo[d] = BK_BIG, rhi[d] = -BK_BIG;
+#pragma unroll
+            for (int p = 0; p < PP; p++) M[d][p] = 0u;
+        }
+#pragma unroll
+        for (int p = 0; p < PP; p++) I[p] = D[p] = 0u;
+    };
+
+#ifdef WFA_STAMPS
+    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+#endif
+    // one score step of every running pair; PH = step & 3 selects the ring slots at compile time.
+    // Returns true when the queue is exhausted and no pair is left.
+    const auto step = [&](auto ph_c) __attribute__((always_inline)) -> bool {
+        constexpr int ph = decltype(ph_c)::value;
+        {
+            // ------------------------------------------------------------ refill: groups that need a pair are served
+            // one after the other and ALL 64 lanes stage + 2-bit pack that group's sequences (coalesced dword loads).
+            for (unsigned long long need = __ballot(st == 0); need != 0ull;) {
+                const int r = __builtin_ctzll(need) / G;  // wave-uniform group index
+                need &= ~((G == 16 ? 0xFFFFull : 0xFFull) << (G * r));
+                uint32_t wi = 0;
+                if (lane == G * r) wi = atomicAdd(P.queue_head, 1u);
+                wi = __shfl(wi, G * r, 64);
+                const bool mine = (grp == r);
+                if (wi >= P.chunk_n) {
+                    if (mine) st = 2;
+                    continue;
+                }
+                const uint32_t pr = P.work ? P.work[wi] : P.chunk_first + wi;
+                const uint32_t nq = P.q_len[pr], mt = P.t_len[pr];
+                uint32_t       status = ST_PENDING;
+                if (nq == 0 || mt == 0)
+                    status = ST_EMPTY;  // wfa.go:204-206
+                else if (nq > 0x1FFFFFFFu || mt > 0x1FFFFFFFu)
+                    status = ST_TOO_LONG;  // wfa.go:207-209
+                else if (((nq > mt ? nq : mt) + 15u) / 16u + 1u > SW)
+                    status = ST_REDO_LDS;
+                if (status == ST_PENDING) {
+                    uint32_t *const rq = lds + r * 2 * SW;
+                    bool bad = stage_pack<64>(P.blob, P.q_off[pr], nq, rq, lane);
+                    bad |= stage_pack<64>(P.blob, P.t_off[pr], mt, rq + SW, lane);
+                    if (__ballot(bad) != 0ull) status = ST_REDO_BYTES;
+                }
+                if (status != ST_PENDING) {
+                    if (lane == G * r) {
+                        P.pair_meta[wi] = make_uint4(status, 0u, 0u, 0u);
+                        if (status >= ST_REDO_BYTES) push_redo(P, pr, status);
+                    }
+                    continue;  // the group stays in state 0 and pulls another pair in the next round
+                }
+                if (mine) {
+                    pidx = wi, pair = pr;
+                    n = (int)nq, m = (int)mt, Ak = m - n;
+                    si = 0, top = 0, cells = 0, slow = false;
+                    kb   = -32 + imax2(-24, imin2(24, Ak / 2));  // k = 0 (the seed) inside, biased towards Ak
+                    A    = P.arena + (uint64_t)pidx * cap;
+                    room = (int)imin2((int)(cap > 0x3FFFFFF0ull ? 0x3FFFFFF0ull : cap), 0x3FFFFFF0) - 8;
+                    first_eq = ((lq[0] ^ lt[0]) & 3u) == 0u;  // q[0] == t[0] (wfa.go:155)
+                    set_window();
+                    clear_rings();
+                    st = 1;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (__ballot(st != 2) == 0ull) return true;
+            const bool run = (st == 1);
+            WFA_STAMP(0);  // refill
+
+            uint32_t(&Mo)[PP] = M[ph];            // M[s-o-e]: read as a source, then replaced by the new row
+            uint32_t(&Mx)[PP] = M[(ph + 2) & 3];  // M[s-x]
+
+            // ------------------------------------------------------------ WF_NEXT (wfa.go:549-700)
+            uint32_t nM[PP], nI[PP], nD[PP], wd[PP], cc[PP];
+            const uint32_t a_edge = Ops::dn1(Mo[PP - 1], j), b_edge = Ops::dn1(I[PP - 1], j);
+            const uint32_t c_edge = Ops::up1(Mo[0], j), d_edge = Ops::up1(D[0], j);
+            const bool     slow_any = __ballot(run && slow) != 0ull;
+            if (!slow_any) {
+#pragma unroll
+                for (int p = 0; p < PP; p++) {
+                    const uint32_t a = p ? Mo[p - 1] : a_edge, b = p ? I[p - 1] : b_edge;
+                    const uint32_t c = p < PP - 1 ? Mo[p + 1] : c_edge, d = p < PP - 1 ? D[p + 1] : d_edge;
+                    const uint32_t x = Mx[p];
+                    const uint32_t mi = umax2(a, b), tI = umin2(mi, 1u), Isk = mi + tI;  // wfa.go:579-609
+                    const uint32_t Dsk = umax2(c, d), tD = umin2(Dsk, 1u);               // wfa.go:614-645
+                    const uint32_t x1  = x + umin2(x, 1u);
+                    const uint32_t Msk = umax3(Isk, Dsk, x1);                            // wfa.go:655
+                    const uint32_t ic = tI + (a < b ? 1u : 0u);  // 0 none, 1 InsOpen, 2 InsExt
+                    const uint32_t dc = tD + (c < d ? 1u : 0u);  // 0 none, 1 DelOpen, 2 DelExt
+                    const uint32_t tg = Msk == x1 ? (uint32_t)TAG_MISMATCH : (Msk == Isk ? ic : dc + 2u);  // wfa.go:657-693
+                    const uint32_t w  = (Msk << 7) | (dc << 5) | (ic << 3) | tg;
+                    nM[p] = Msk, nI[p] = Isk, nD[p] = Dsk;
+                    wd[p] = Msk ? w : 0u;
+                    cc[p] = tI + tD + umin2(Msk, 1u);
+                }
+            } else {
+#pragma unroll
+                for (int p = 0; p < PP; p++) {
+                    const int      k  = k0 + p;
+                    const uint32_t a0 = p ? Mo[p - 1] : a_edge, b0 = p ? I[p - 1] : b_edge;
+                    const uint32_t c0 = p < PP - 1 ? Mo[p + 1] : c_edge, d0 = p < PP - 1 ? D[p + 1] : d_edge;
+                    const uint32_t x0 = Mx[p];
+                    // rejections: > m (not >=) for I and X sources, offset - k > n for D and X sources
+                    const uint32_t a = (int)a0 > m ? 0u : a0, b = (int)b0 > m ? 0u : b0;
+                    const uint32_t c = (int)c0 - k > n ? 0u : c0, d = (int)d0 - k > n ? 0u : d0;
+                    const uint32_t x = ((int)x0 > m || (int)x0 - k > n) ? 0u : x0;
+                    const uint32_t mi = umax2(a, b), tI = umin2(mi, 1u), Isk = mi + tI;
+                    const uint32_t Dsk = umax2(c, d), tD = umin2(Dsk, 1u);
+                    const uint32_t x1  = x + umin2(x, 1u);
+                    const uint32_t Msk = umax3(Isk, Dsk, x1);
+                    const uint32_t ic = tI + (a < b ? 1u : 0u);
+                    const uint32_t dc = tD + (c < d ? 1u : 0u);
+                    const uint32_t tg = Msk == x1 ? (uint32_t)TAG_MISMATCH : (Msk == Isk ? ic : dc + 2u);
+                    // backTrace recomputes the pre-extension offset from the un-rejected sources (wfa.go:766-817)
+                    const uint32_t mu = umax2(a0, b0), Iu = mu + umin2(mu, 1u), Du = umax2(c0, d0);
+                    const uint32_t Xu = x0 + umin2(x0, 1u);
+                    const uint32_t o0 = tg == TAG_INS_EXT ? Iu : (tg == TAG_DEL_EXT ? Du : umax3(Iu, Du, Xu));
+                    const bool     kin = k >= -(n - 1) && k <= m - 1;  // wfa.go:562-563
+                    const uint32_t w   = (o0 << 7) | (dc << 5) | (ic << 3) | tg;
+                    nM[p] = kin ? Msk : 0u, nI[p] = kin ? Isk : 0u, nD[p] = kin ? Dsk : 0u;
+                    wd[p] = (kin && Msk) ? w : 0u;
+                    cc[p] = kin ? tI + tD + umin2(Msk, 1u) : 0u;
+                }
+            }
+            // seeds of initComponents (wfa.go:155-160): M[0][0] = 1/Match or M[x][0] = 1/Mismatch
+            if (__ballot(run && (si == 0u || si == seed_si)) != 0ull) {
+                const bool want = run && ((si == 0u && first_eq) || (si == seed_si && !first_eq));
+#pragma unroll
+                for (int p = 0; p < PP; p++)
+                    if (want && k0 + p == 0 && nM[p] == 0u)
+                        nM[p] = 1u, wd[p] = first_eq ? (uint32_t)TAG_MATCH : (uint32_t)TAG_MISMATCH, cc[p] = 1u;
+            }
+            WFA_STAMP(1);  // next
+
+            // ------------------------------------------------------------ WF_EXTEND (wfa.go:381-458), first 16 bases
+            uint32_t cmask = 0u;  // positions whose first window matched completely and may go on
+#pragma unroll
+            for (int p = 0; p < PP; p++) {
+                const int      h   = (int)nM[p];
+                int            rem = lim[p] - h;  // bases left on this diagonal; <= 0: at / past an end (wfa.go:404)
+                rem                = h ? rem : 0;
+                rem                = imax2(rem, 0);
+                const int      v   = imax2(h - (k0 + p), 0);
+                const uint32_t xr  = SeqView<0>::win16(lq, v) ^ SeqView<0>::win16(lt, h);
+                const uint32_t cnt = umin2(umin2(((uint32_t)__ffs((int)xr) - 1u) >> 1, (uint32_t)rem), 16u);
+                nM[p] += cnt;
+                if (xr == 0u && rem > 16) cmask |= 1u << p;
+            }
+            // the few cells (normally the one on the alignment path) that matched a whole window
+            while (__ballot(cmask != 0u) != 0ull) {
+                const int psel = __ffs((int)cmask) - 1;
+                int       h = 0, lm = 0;
+#pragma unroll
+                for (int p = 0; p < PP; p++)
+                    if (psel == p) h = (int)nM[p], lm = lim[p];
+                const int      rem = imax2(lm - h, 0);
+                const int      v   = imax2(h - (k0 + psel), 0);
+                const uint32_t xr  = SeqView<0>::win16(lq, v) ^ SeqView<0>::win16(lt, h);
+                const uint32_t cnt = umin2(umin2(((uint32_t)__ffs((int)xr) - 1u) >> 1, (uint32_t)rem), 16u);
+                if (cmask != 0u) {
+#pragma unroll
+                    for (int p = 0; p < PP; p++)
+                        if (psel == p) nM[p] = (uint32_t)h + cnt;
+                    if (!(xr == 0u && rem > 16)) cmask &= cmask - 1u;
+                }
+            }
+            WFA_STAMP(2);  // extend
+
+            // ------------------------------------------------------------ ends reached? termination (wfa.go:235-239)
+            bool hitl = false;
+#pragma unroll
+            for (int p = 0; p < PP; p++) hitl |= (nM[p] != 0u && (int)nM[p] >= lim[p]);
+            bool term = false;
+            if (__ballot(hitl) != 0ull) {
+                bool tl = false;
+#pragma unroll
+                for (int p = 0; p < PP; p++) tl |= (k0 + p == Ak && nM[p] != 0u && (int)nM[p] >= m);
+                const int r = Ops::reduce((hitl ? 1 : 0) | (tl ? 2 : 0), f_or);
+                slow |= (r & 1) != 0;
+                term = run && (r & 2) != 0;
+            }
+
+            // ------------------------------------------------------------ tight range of the M cells = M.Lo/M.Hi
+            int lkey = BK_BIG, hkey = -BK_BIG;
+#pragma unroll
+            for (int p = PP - 1; p >= 0; p--) lkey = nM[p] ? p : lkey;
+#pragma unroll
+            for (int p = 0; p < PP; p++) hkey = nM[p] ? p : hkey;
+            const int  glo  = Ops::reduce(lkey + PP * j, fmin);  // window-relative index of the first / last M cell
+            const int  ghi  = Ops::reduce(hkey + PP * j, fmax);
+            const bool anyM = ghi >= 0;
+            int        ilo = glo, ihi = ghi;  // band to keep (window-relative)
+
+            // ------------------------------------------------------------ wf-adaptive (wfa.go:461-540)
+            // remaining distance (wfa.go:488) = max(m-h, n-v) = max(m, n+k) - h; an entry is usable iff h < min(m, n+k)
+            const bool want_reduce = run && !term && adaptive && anyM && (ghi - glo + 1) >= minwf;
+            if (__ballot(want_reduce) != 0ull) {
+                int  dd[PP], dmin = BK_BIG, dmax = -BK_BIG;
+                bool vd[PP];
+#pragma unroll
+                for (int p = 0; p < PP; p++) {
+                    vd[p] = nM[p] != 0u && (int)nM[p] < lim[p];
+                    dd[p] = lmx[p] - (int)nM[p];
+                    dmin  = vd[p] ? imin2(dmin, dd[p]) : dmin;
+                    dmax  = vd[p] ? imax2(dmax, dd[p]) : dmax;
+                }
+                const int  mind  = Ops::reduce(dmin, fmin);
+                const int  maxd  = Ops::reduce(dmax, fmax);
+                const int  thr   = mind + mdd;
+                const bool found = want_reduce && mind != BK_BIG && maxd > thr;  // some distance fails (wfa.go:507)
+                if (__ballot(found) != 0ull) {
+                    int okmin = BK_BIG, okmax = -BK_BIG;
+#pragma unroll
+                    for (int p = 0; p < PP; p++) {
+                        const bool okc = vd[p] && dd[p] <= thr;
+                        okmin          = okc ? imin2(okmin, PP * j + p) : okmin;
+                        okmax          = okc ? PP * j + p : okmax;
+                    }
+                    const int first_ok = Ops::reduce(okmin, fmin);
+                    const int last_ok  = Ops::reduce(okmax, fmax);
+                    int       vmax     = -1;  // last usable entry before the first non-failing one: all of them failed
+#pragma unroll
+                    for (int p = 0; p < PP; p++) vmax = (vd[p] && PP * j + p < first_ok) ? PP * j + p : vmax;
+                    const int leadp = Ops::reduce(vmax, fmax);
+                    if (found) {
+                        if (leadp >= 0) ilo = leadp + 1;  // wfa.go:509-511
+                        ihi = last_ok;                     // wfa.go:517-524
+                    }
+                }
+            }
+            WFA_STAMP(3);  // ranges + wf-adaptive
+
+            // ------------------------------------------------------------ store the surviving band (lane-aligned)
+            const bool has  = run && anyM && ihi >= ilo;
+            const int  jl   = ilo / PP, jh = ihi / PP;               // first / last lane that holds a surviving cell
+            const int  wn   = has ? (jh - jl + 1) * PP : 0;
+            const bool no_room = run && wn + 4 > room;
+            const bool keepl   = has && !no_room;
+            uint32_t   csum    = 0u;
+#pragma unroll
+            for (int p = 0; p < PP; p++) {
+                const int  ix   = PP * j + p;
+                const bool keep = keepl && ix >= ilo && ix <= ihi;  // Delete of wfa.go:526-535: the words never exist
+                nM[p] = keep ? nM[p] : 0u, nI[p] = keep ? nI[p] : 0u, nD[p] = keep ? nD[p] : 0u;
+                wd[p] = keep ? wd[p] : 0u;
+                csum += keep ? cc[p] : 0u;
+            }
+            cells += csum;
+            if (keepl && j >= jl && j <= jh) {
+                uint32_t *const row = A + top + (uint32_t)(PP * (j - jl));
+                if constexpr (PP == 4) {
+                    *reinterpret_cast<uint4 *>(row) = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+                } else {
+                    *reinterpret_cast<uint4 *>(row)     = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+                    *reinterpret_cast<uint4 *>(row + 4) = make_uint4(wd[4], wd[5], wd[6], wd[7]);
+                }
+            }
+            if (run && !no_room && j == 0)
+                *reinterpret_cast<uint4 *>(A + cap - 4ull * (si + 1)) =
+                    wn > 0 ? make_uint4(top, (uint32_t)(kb + PP * jl), (uint32_t)wn, 0u) : make_uint4(0u, 0u, 0u, 0u);
+            top += (uint32_t)(keepl ? wn : 0);
+            room -= (keepl ? wn : 0) + 4;
+            WFA_STAMP(4);  // stores
+
+            // ------------------------------------------------------------ the new row enters the rings
+#pragma unroll
+            for (int p = 0; p < PP; p++) Mo[p] = nM[p], I[p] = nI[p], D[p] = nD[p];
+            rlo[ph] = keepl ? kb + ilo : BK_BIG;
+            rhi[ph] = keepl ? kb + ihi : -BK_BIG;
+
+            // ------------------------------------------------------------ finish / next score
+            bool fin = run && (term || no_room);
+            if (__ballot(fin) != 0ull) {
+                const uint32_t ctot = (uint32_t)Ops::reduce((int)cells, fadd);
+                int            hf   = 0;  // extended offset of the end cell M[s][Ak]: where the backtrace starts
+#pragma unroll
+                for (int p = 0; p < PP; p++)
+                    if (k0 + p == Ak) hf = (int)Mo[p];
+                hf = Ops::reduce(hf, fmax);
+                if (fin && j == 0) {
+                    if (no_room) {
+                        P.pair_meta[pidx] = make_uint4(ST_REDO_ARENA, 0u, 0u, 0u);
+                        push_redo(P, pair, ST_REDO_ARENA);
+                    } else {
+                        P.pair_meta[pidx] = make_uint4(ST_OK, si * P.g, (uint32_t)hf, ctot);
+                    }
+                }
+                if (fin) {
+                    st = 0;
+                    clear_rings();
+                }
+            }
+            if (run && !fin) si += 1u;
+
+            // ------------------------------------------------------------ keep every kept row inside [kb+1, kb+62]
+            {
+                const int  ulo = imin2(imin2(rlo[0], rlo[1]), imin2(rlo[2], rlo[3]));
+                const int  uhi = imax2(imax2(rhi[0], rhi[1]), imax2(rhi[2], rhi[3]));
+                const bool live    = run && !fin && uhi >= ulo;
+                const bool need_dn = live && ulo <= kb;
+                const bool need_up = live && uhi >= kb + W - 1;
+                if (__ballot(need_dn || need_up) != 0ull) {
+                    const bool wide = (need_dn && (need_up || uhi >= kb - 16 + W - 1)) || (need_up && ulo <= kb + 16);
+                    const bool dn = need_dn && !wide, up = need_up && !wide;
+#pragma unroll
+                    for (int d = 0; d < 4; d++)
+#pragma unroll
+                        for (int p = 0; p < PP; p++) {
+                            const uint32_t a = Ops::shr(M[d][p], j), b = Ops::shl(M[d][p], j);
+                            M[d][p]          = dn ? a : (up ? b : M[d][p]);
+                        }
+#pragma unroll
+                    for (int p = 0; p < PP; p++) {
+                        const uint32_t a = Ops::shr(I[p], j), b = Ops::shl(I[p], j);
+                        const uint32_t c = Ops::shr(D[p], j), d = Ops::shl(D[p], j);
+                        I[p]             = dn ? a : (up ? b : I[p]);
+                        D[p]             = dn ? c : (up ? d : D[p]);
+                    }
+                    kb += dn ? -16 : (up ? 16 : 0);
+                    set_window();
+                    if (__ballot(wide) != 0ull) {  // the band does not fit the window: hand the pair on
+                        if (wide && j == 0) {
+                            P.pair_meta[pidx] = make_uint4(ST_REDO_BAND, 0u, 0u, 0u);
+                            push_redo(P, pair, ST_REDO_BAND);
+                        }
+                        if (wide) {
+                            st = 0;
+                            clear_rings();
+                        }
+                    }
+                }
+            }
+            WFA_STAMP(5);  // ring + finish + window
+        }
+        return false;
+    };
+    for (;;) {
+        if (step(std::integral_constant<int, 0>{})) break;
+        if (step(std::integral_constant<int, 1>{})) break;
+        if (step(std::integral_constant<int, 2>{})) break;
+        if (step(std::integral_constant<int, 3>{})) break;
+    }
+#ifdef WFA_STAMPS
+    if (lane == 0 && P.debug_info) {
+        unsigned long long *acc = reinterpret_cast<unsigned long long *>(P.debug_info);
+        for (int i = 0; i < 8; i++) atomicAdd(acc + i, stamp_acc[i]);
+    }
+#endif
+}
+
+}  // namespace wfa

@@ -7,6 +7,7 @@
 #include "wfa_generic.hpp"
 #include "wfa_packed.hpp"
 #include "wfa_reg.hpp"
+#include "wfa_blk.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -57,6 +58,7 @@ struct wfahip_ctx {
     int64_t       opt_threads_per_pair     = 0;
     int64_t       opt_packed               = 1;  // 0: never use the packed (sub-wave) kernels
     int64_t       opt_reg                  = 1;  // 0: never use the register-window kernel
+    int64_t       opt_blk                  = 16; // blocked register-window kernel: lanes per pair (16 or 8), 0 = off
     int64_t       opt_packed_arena_bytes   = 0;  // per pair, 0 = automatic
     int64_t       opt_chunk_pairs          = 0;  // 0 = automatic
     int64_t       opt_packed_waves_per_cu  = 0;  // 0 = automatic
@@ -257,6 +259,8 @@ extern "C" int wfahip_set_option(wfahip_ctx *ctx, const char *key, int64_t value
         ctx->opt_packed = value;
     else if (k == "reg")
         ctx->opt_reg = value;
+    else if (k == "blk")
+        ctx->opt_blk = (value == 8 || value == 16) ? value : 0;
     else if (k == "packed_arena_bytes")
         ctx->opt_packed_arena_bytes = value;
     else if (k == "chunk_pairs")
@@ -352,8 +356,11 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
         const uint64_t sub_words = packed_sub_lds_words(seq_words, dm, di);
         const size_t   lds_b     = (size_t)sub_words * 2 * 4;       // packed kernel: two halves
         const size_t   lds_c     = (size_t)seq_words * 2 * 4 * 4;   // register kernel: four rows, sequences only
+        const size_t   lds_d     = (size_t)seq_words * 2 * 4 * (ctx->opt_blk == 8 ? 8 : 4) + 16;  // blocked kernel
         const bool     can_b     = lds_b <= 20 * 1024;
         const bool     can_c     = ctx->opt_reg && dx == 2 && doe == 4 && de == 1 && lds_c <= 20 * 1024;
+        const bool     can_d     = ctx->opt_blk && dx == 2 && doe == 4 && de == 1 && max_len < 32768 &&
+                               lds_d <= (ctx->opt_blk == 8 ? 40 : 20) * 1024;
         uint64_t       words     = std::max<uint64_t>(1024, 8ull * max_len);  // compact rows: 1 word per diagonal
         if (ctx->opt_packed_arena_bytes > 0) words = std::max<uint64_t>(1024, ctx->opt_packed_arena_bytes / 4);
         words = (words + 7) & ~7ull;
@@ -371,12 +378,13 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
         // one pass over `count` pairs (identity range when list == nullptr); returns the {pair,status} redo entries
         auto forward_pass = [&](int kind, const std::vector<uint32_t> *list, uint64_t count,
                                 std::vector<uint64_t> &redo_out) -> int {
-            const size_t   lds_bytes    = kind == 2 ? lds_c : lds_b;
-            const uint32_t pairs_wave   = kind == 2 ? 4 : 2;
+            const size_t   lds_bytes    = kind >= 3 ? lds_d : (kind == 2 ? lds_c : lds_b);
+            const uint32_t pairs_wave   = kind == 4 ? 8 : (kind >= 2 ? 4 : 2);
             const uint32_t waves_lds    = (uint32_t)std::min<size_t>(32, LDS_MAX_BYTES / lds_bytes);
             const bool     overlap      = ctx->opt_overlap != 0;
-            uint32_t       waves_per_cu = kind == 2 ? std::min<uint32_t>(waves_lds, 20)
-                                                    : (overlap ? std::min<uint32_t>(waves_lds, 24) : waves_lds);
+            uint32_t       waves_per_cu = kind == 4 ? std::min<uint32_t>(waves_lds, 12)
+                                          : kind >= 2 ? std::min<uint32_t>(waves_lds, 20)
+                                                      : (overlap ? std::min<uint32_t>(waves_lds, 24) : waves_lds);
             if (ctx->opt_packed_waves_per_cu > 0)
                 waves_per_cu = std::min<uint32_t>(waves_lds, (uint32_t)ctx->opt_packed_waves_per_cu);
             // Chunking: every pair of a chunk owns an arena until its backtrace has run.  Two chunk buffers
@@ -418,7 +426,11 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
                 if (n_buf == 2 && c >= 2) HIP_TRY(hipStreamWaitEvent(st, ctx->evpool[4 * (c - 2) + 3], 0));  // buffer free
                 HIP_TRY(hipMemsetAsync(d_ctrl, 0, 4, st));  // queue_head only
                 HIP_TRY(hipEventRecord(evFa, st));
-                if (kind == 2)
+                if (kind == 4)
+                    hipLaunchKernelGGL((wfa_blk_kernel<8>), dim3(grid), dim3(64), lds_bytes, st, P);
+                else if (kind == 3)
+                    hipLaunchKernelGGL((wfa_blk_kernel<16>), dim3(grid), dim3(64), lds_bytes, st, P);
+                else if (kind == 2)
                     hipLaunchKernelGGL((wfa_reg_kernel<2, 4, 1>), dim3(grid), dim3(64), lds_bytes, st, P);
                 else
                     hipLaunchKernelGGL(wfa_packed_kernel, dim3(grid), dim3(64), lds_bytes, st, P);
@@ -453,16 +465,17 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
             return WFAHIP_OK;
         };
 
-        if (can_b || can_c) {
+        if (can_b || can_c || can_d) {
             std::vector<uint64_t> redo1, redo2;
-            if ((rc = forward_pass(can_c ? 2 : 1, nullptr, n_pairs, redo1))) return rc;
-            ctx->timing.main_kernel_kind = can_c ? 2 : 1;
+            const int kind1 = can_d ? (ctx->opt_blk == 8 ? 4 : 3) : (can_c ? 2 : 1);
+            if ((rc = forward_pass(kind1, nullptr, n_pairs, redo1))) return rc;
+            ctx->timing.main_kernel_kind = (uint32_t)kind1;
             ctx->timing.n_packed_pairs = (uint32_t)(n_pairs - redo1.size());
             ctx->timing.n_retried_pairs += (uint32_t)redo1.size();
             Job jb, ja;
             jb.mode = 1, jb.level = 0, jb.all = false;
             ja.mode = 0, ja.level = 0, ja.all = false;
-            if (can_c && can_b && !redo1.empty()) {
+            if (kind1 >= 2 && can_b && !redo1.empty()) {
                 // second chance on the LDS-ring kernel (64-diagonal bands at any alignment) for band/arena misses
                 std::vector<uint32_t> lst;
                 for (uint64_t e : redo1) {
@@ -488,7 +501,7 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
                 HIP_TRY(hipMemcpy(acc, P.debug_info, 64, hipMemcpyDeviceToHost));
                 unsigned long long tot = 0;
                 for (int i = 0; i < 6; i++) tot += acc[i];
-                const char *nm[6] = {"refill", "meta+range", "sources+next+extend", "masks+reduce", "stores", "advance"};
+                const char *nm[6] = {"refill", "next", "extend", "ranges+reduce", "stores", "ring+finish+window"};
                 for (int i = 0; i < 6; i++)
                     std::fprintf(stderr, "[stamps] %-22s %6.2f %%  (%llu cyc)\n", nm[i], 100.0 * acc[i] / (double)tot, acc[i]);
                 P.debug_info = nullptr;
