@@ -16,8 +16,8 @@ oracle:
 	$(MAKE) -C oracle -s
 
 asm: $(SRC) $(HDR)
-	@mkdir -p build
-	$(HIPCC) $(HIPFLAGS) -save-temps=obj -c -o build/wfa_host.o wfa_amd/csrc/wfa_host.hip -Rpass-analysis=kernel-resource-usage 2> build/resource_usage.txt || true
+	@mkdir -p build/asm
+	$(HIPCC) $(HIPFLAGS) -save-temps=obj -c -o build/asm/wfa_host.o wfa_amd/csrc/wfa_host.hip -Rpass-analysis=kernel-resource-usage 2> build/asm/resource_usage.txt || true
 
 clean:
 	rm -rf $(LIB) build

@@ -1,0 +1,7 @@
+#!/bin/bash
+# Build a named library variant for scripts/ab.sh.  Usage: scripts/mkvariant.sh <name> [extra hipcc flags...]
+set -e
+N=$1; shift
+mkdir -p build/variants
+hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function "$@" -shared -o build/variants/$N.so wfa_amd/csrc/wfa_host.hip wfa_amd/csrc/wfa_gen.cpp 2>/dev/null
+echo built build/variants/$N.so

@@ -41,14 +41,6 @@ struct BlkOps<16> {
     // window moves by 16 diagonals = 4 lanes: registers move towards higher (shr) / lower (shl) lanes
     static WFA_DEV uint32_t shr(uint32_t x, int) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true); }
     static WFA_DEV uint32_t shl(uint32_t x, int) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x104, 0xf, 0xf, true); }
-    template <class F>
-    static WFA_DEV int reduce(int v, F f) {
-        v = f(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));
-        v = f(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));
-        v = f(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));
-        v = f(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));
-        return v;
-    }
 };
 
 template <>
@@ -69,26 +61,80 @@ struct BlkOps<8> {
         const uint32_t r = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x102, 0xf, 0xf, true);
         return j >= 6 ? 0u : r;
     }
-    template <class F>
-    static WFA_DEV int reduce(int v, F f) {
-        v = f(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));
-        v = f(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));
-        v = f(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));
-        return v;
-    }
 };
+
+// Butterfly reductions inside a group, written as DPP-fused VOP2 instructions (one instruction per stage and
+// value).  hipcc lowers the same butterfly from __builtin_amdgcn_update_dpp to mov + mov_dpp + op per stage.
+// A DPP operand may be read two wait states after the VALU instruction that wrote it: the partner value's
+// instruction plus one s_nop fill them.
+#define WFA_DPP_CTL_XOR1 "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+#define WFA_DPP_CTL_XOR2 "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+#define WFA_DPP_CTL_HMIR "row_half_mirror row_mask:0xf bank_mask:0xf"
+#define WFA_DPP_CTL_MIR "row_mirror row_mask:0xf bank_mask:0xf"
+#define WFA_DPP_ST2(opa, opb, ctl) opa " %0, %0, %0 " ctl "\n\t" opb " %1, %1, %1 " ctl "\n\t"
+#define WFA_DPP_ST1(opa, ctl) opa " %0, %0, %0 " ctl "\n\t"
+
+template <int G>
+struct BlkRed {
+    // a <- reduce(opa) over the group, b <- reduce(opb) over the group
+#define WFA_RED2(name, opa, opb)                                                                          \
+    static WFA_DEV void name(int &a, int &b) {                                                            \
+        if constexpr (G == 16)                                                                            \
+            asm("s_nop 1\n\t" WFA_DPP_ST2(opa, opb, WFA_DPP_CTL_XOR1) "s_nop 0\n\t" WFA_DPP_ST2(          \
+                    opa, opb, WFA_DPP_CTL_XOR2) "s_nop 0\n\t" WFA_DPP_ST2(opa, opb, WFA_DPP_CTL_HMIR)     \
+                    "s_nop 0\n\t" WFA_DPP_ST2(opa, opb, WFA_DPP_CTL_MIR)                                  \
+                : "+v"(a), "+v"(b));                                                                      \
+        else                                                                                              \
+            asm("s_nop 1\n\t" WFA_DPP_ST2(opa, opb, WFA_DPP_CTL_XOR1) "s_nop 0\n\t" WFA_DPP_ST2(          \
+                    opa, opb, WFA_DPP_CTL_XOR2) "s_nop 0\n\t" WFA_DPP_ST2(opa, opb, WFA_DPP_CTL_HMIR)     \
+                : "+v"(a), "+v"(b));                                                                      \
+    }
+#define WFA_RED1(name, opa)                                                                               \
+    static WFA_DEV int name(int a) {                                                                      \
+        if constexpr (G == 16)                                                                            \
+            asm("s_nop 1\n\t" WFA_DPP_ST1(opa, WFA_DPP_CTL_XOR1) "s_nop 1\n\t" WFA_DPP_ST1(               \
+                    opa, WFA_DPP_CTL_XOR2) "s_nop 1\n\t" WFA_DPP_ST1(opa, WFA_DPP_CTL_HMIR)               \
+                    "s_nop 1\n\t" WFA_DPP_ST1(opa, WFA_DPP_CTL_MIR)                                       \
+                : "+v"(a));                                                                               \
+        else                                                                                              \
+            asm("s_nop 1\n\t" WFA_DPP_ST1(opa, WFA_DPP_CTL_XOR1) "s_nop 1\n\t" WFA_DPP_ST1(               \
+                    opa, WFA_DPP_CTL_XOR2) "s_nop 1\n\t" WFA_DPP_ST1(opa, WFA_DPP_CTL_HMIR)               \
+                : "+v"(a));                                                                               \
+        return a;                                                                                         \
+    }
+    WFA_RED2(min_max, "v_min_i32_dpp", "v_max_i32_dpp")
+    WFA_RED2(max_add, "v_max_i32_dpp", "v_add_u32_dpp")
+    WFA_RED1(max1, "v_max_i32_dpp")
+    WFA_RED1(or1, "v_or_b32_dpp")
+#undef WFA_RED2
+#undef WFA_RED1
+};
+
+WFA_DEV uint32_t ffbl_raw(uint32_t x) {  // index of the lowest set bit; 0xFFFFFFFF for x == 0
+    uint32_t r;
+    asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
 
 WFA_DEV uint32_t umin2(uint32_t a, uint32_t b) { return a < b ? a : b; }
 WFA_DEV uint32_t umax3(uint32_t a, uint32_t b, uint32_t c) { return umax2(umax2(a, b), c); }
 
 constexpr int BK_BIG = 0x3FFFFFFF;
+#ifndef WFA_BLK8_WAVES
+#define WFA_BLK8_WAVES 2
+#endif
 
 template <int G>
-__global__ __launch_bounds__(64, (G == 16 ? 4 : 2)) void wfa_blk_kernel(const KParams P) {
+__global__ __launch_bounds__(64, (G == 16 ? 4 : WFA_BLK8_WAVES)) void wfa_blk_kernel(const KParams P) {
     constexpr int PP  = 64 / G;   // diagonals per lane
     constexpr int NG  = 64 / G;   // pairs per wave
     constexpr int W   = 64;       // window width in diagonals
     using Ops         = BlkOps<G>;
+#ifdef WFA_MARKS
+#define WFA_MARK(i) asm volatile("; ##MARK " #i)
+#else
+#define WFA_MARK(i) do {} while (0)
+#endif
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int lane = threadIdx.x, j = lane & (G - 1), grp = lane / G;
 
@@ -101,21 +147,18 @@ __global__ __launch_bounds__(64, (G == 16 ? 4 : 2)) void wfa_blk_kernel(const KP
     const bool            adaptive = P.adaptive != 0;
     const uint32_t        seed_si  = P.dx;  // the mismatch seed M[x][0] belongs to step x/g
 
-    const auto fmin = [](int a, int b) { return a < b ? a : b; };
-    const auto fmax = [](int a, int b) { return a > b ? a : b; };
-    const auto fadd = [](int a, int b) { return a + b; };
-    const auto f_or = [](int a, int b) { return a | b; };
+    using Red = BlkRed<G>;
 
     // per-pair state (identical in the G lanes of a group)
     int        st = 0;  // 0 = needs a pair, 1 = running, 2 = queue exhausted
     uint32_t   pidx = 0, pair = 0, si = 0, top = 0, cells = 0;
     int        n = 0, m = 0, Ak = 0, kb = 0, k0 = 0, room = 0;
     bool       slow = false, first_eq = false;
-    uint32_t  *A = nullptr;
+    uint32_t  *rowp = nullptr, *dirp = nullptr;  // next row / next directory entry of the pair's arena slot
 
     uint32_t M[4][PP], I[PP], D[PP];  // offsets, 0 = absent; M[i & 3] = row of step i
     int      rlo[4], rhi[4];          // band of each kept M row (absolute k); empty = (BIG, -BIG)
-    int      lim[PP], lmx[PP];        // min(n + k, m) and max(n + k, m) of the lane's diagonals
+    int      lim[PP], lmx[PP];        // max(1, min(n + k, m)) and max(n + k, m) of the lane's diagonals
 #pragma unroll
     for (int d = 0; d < 4; d++) {
         rlo[d] = BK_BIG, rhi[d] = -BK_BIG;
@@ -128,7 +171,7 @@ __global__ __launch_bounds__(64, (G == 16 ? 4 : 2)) void wfa_blk_kernel(const KP
     const auto set_window = [&]() {
         k0 = kb + PP * j;
 #pragma unroll
-        for (int p = 0; p < PP; p++) lim[p] = imin2(n + k0 + p, m), lmx[p] = imax2(n + k0 + p, m);
+        for (int p = 0; p < PP; p++) lim[p] = imax2(1, imin2(n + k0 + p, m)), lmx[p] = imax2(n + k0 + p, m);
     };
     const auto clear_rings = [&]() {
 #pragma unroll
@@ -190,7 +233,8 @@ __global__ __launch_bounds__(64, (G == 16 ? 4 : 2)) void wfa_blk_kernel(const KP
                     n = (int)nq, m = (int)mt, Ak = m - n;
                     si = 0, top = 0, cells = 0, slow = false;
                     kb   = -32 + imax2(-24, imin2(24, Ak / 2));  // k = 0 (the seed) inside, biased towards Ak
-                    A    = P.arena + (uint64_t)pidx * cap;
+                    rowp = P.arena + (uint64_t)pidx * cap;
+                    dirp = rowp + cap - 4;
                     room = (int)imin2((int)(cap > 0x3FFFFFF0ull ? 0x3FFFFFF0ull : cap), 0x3FFFFFF0) - 8;
                     first_eq = ((lq[0] ^ lt[0]) & 3u) == 0u;  // q[0] == t[0] (wfa.go:155)
                     set_window();
@@ -202,7 +246,7 @@ __global__ __launch_bounds__(64, (G == 16 ? 4 : 2)) void wfa_blk_kernel(const KP
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (__ballot(st != 2) == 0ull) return true;
             const bool run = (st == 1);
-            WFA_STAMP(0);  // refill
+            WFA_STAMP(0); WFA_MARK(0);  // refill
 
             uint32_t(&Mo)[PP] = M[ph];            // M[s-o-e]: read as a source, then replaced by the new row
             uint32_t(&Mx)[PP] = M[(ph + 2) & 3];  // M[s-x]
@@ -267,124 +311,125 @@ __global__ __launch_bounds__(64, (G == 16 ? 4 : 2)) void wfa_blk_kernel(const KP
                     if (want && k0 + p == 0 && nM[p] == 0u)
                         nM[p] = 1u, wd[p] = first_eq ? (uint32_t)TAG_MATCH : (uint32_t)TAG_MISMATCH, cc[p] = 1u;
             }
-            WFA_STAMP(1);  // next
+            WFA_STAMP(1); WFA_MARK(1);  // next
 
             // ------------------------------------------------------------ WF_EXTEND (wfa.go:381-458), first 16 bases
             uint32_t cmask = 0u;  // positions whose first window matched completely and may go on
 #pragma unroll
             for (int p = 0; p < PP; p++) {
-                const int      h   = (int)nM[p];
-                int            rem = lim[p] - h;  // bases left on this diagonal; <= 0: at / past an end (wfa.go:404)
-                rem                = h ? rem : 0;
-                rem                = imax2(rem, 0);
-                const int      v   = imax2(h - (k0 + p), 0);
-                const uint32_t xr  = SeqView<0>::win16(lq, v) ^ SeqView<0>::win16(lt, h);
-                const uint32_t cnt = umin2(umin2(((uint32_t)__ffs((int)xr) - 1u) >> 1, (uint32_t)rem), 16u);
-                nM[p] += cnt;
-                if (xr == 0u && rem > 16) cmask |= 1u << p;
+                const int      h    = (int)nM[p];
+                const int      rem  = lim[p] - h;  // bases left on this diagonal; <= 0: at / past an end (wfa.go:404)
+                const int      remc = h ? imin2(imax2(rem, 0), 16) : 0;
+                const int      v    = h - (k0 + p);  // absent cells read a harmless word (LDS reads cannot fault)
+                const uint32_t xr   = SeqView<0>::win16(lq, v) ^ SeqView<0>::win16(lt, h);
+                nM[p] += umin2(ffbl_raw(xr) >> 1, (uint32_t)remc);
+                if (xr == 0u && rem > 16 && h) cmask |= 1u << p;
             }
-            // the few cells (normally the one on the alignment path) that matched a whole window
+            // the few cells (normally the one on the alignment path) that matched a whole window: each lane takes its
+            // candidates one at a time and keeps comparing 16-base windows until a mismatch or a sequence end
             while (__ballot(cmask != 0u) != 0ull) {
-                const int psel = __ffs((int)cmask) - 1;
+                const int psel = (int)ffbl_raw(cmask);  // -1 in lanes without a candidate
                 int       h = 0, lm = 0;
 #pragma unroll
                 for (int p = 0; p < PP; p++)
                     if (psel == p) h = (int)nM[p], lm = lim[p];
-                const int      rem = imax2(lm - h, 0);
-                const int      v   = imax2(h - (k0 + psel), 0);
-                const uint32_t xr  = SeqView<0>::win16(lq, v) ^ SeqView<0>::win16(lt, h);
-                const uint32_t cnt = umin2(umin2(((uint32_t)__ffs((int)xr) - 1u) >> 1, (uint32_t)rem), 16u);
-                if (cmask != 0u) {
+                const int kd = k0 + psel;
+                bool      go = cmask != 0u;
+                do {
+                    const int      rem = lm - h;
+                    const uint32_t xr  = SeqView<0>::win16(lq, h - kd) ^ SeqView<0>::win16(lt, h);
+                    const uint32_t cnt = umin2(ffbl_raw(xr) >> 1, (uint32_t)imin2(imax2(rem, 0), 16));
+                    h += go ? (int)cnt : 0;
+                    go = go && xr == 0u && rem > 16;
+                } while (__ballot(go) != 0ull);
 #pragma unroll
-                    for (int p = 0; p < PP; p++)
-                        if (psel == p) nM[p] = (uint32_t)h + cnt;
-                    if (!(xr == 0u && rem > 16)) cmask &= cmask - 1u;
-                }
+                for (int p = 0; p < PP; p++)
+                    if (psel == p) nM[p] = (uint32_t)h;
+                cmask &= cmask - 1u;
             }
-            WFA_STAMP(2);  // extend
+            WFA_STAMP(2); WFA_MARK(2);  // extend
 
             // ------------------------------------------------------------ ends reached? termination (wfa.go:235-239)
-            bool hitl = false;
+            bool nz[PP], hit[PP], hitl = false;
 #pragma unroll
-            for (int p = 0; p < PP; p++) hitl |= (nM[p] != 0u && (int)nM[p] >= lim[p]);
+            for (int p = 0; p < PP; p++) nz[p] = nM[p] != 0u, hit[p] = nM[p] >= (uint32_t)lim[p], hitl |= hit[p];
             bool term = false;
             if (__ballot(hitl) != 0ull) {
                 bool tl = false;
 #pragma unroll
-                for (int p = 0; p < PP; p++) tl |= (k0 + p == Ak && nM[p] != 0u && (int)nM[p] >= m);
-                const int r = Ops::reduce((hitl ? 1 : 0) | (tl ? 2 : 0), f_or);
+                for (int p = 0; p < PP; p++) tl |= (k0 + p == Ak && nz[p] && (int)nM[p] >= m);
+                const int r = Red::or1((hitl ? 1 : 0) | (tl ? 2 : 0));
                 slow |= (r & 1) != 0;
                 term = run && (r & 2) != 0;
             }
 
             // ------------------------------------------------------------ tight range of the M cells = M.Lo/M.Hi
-            int lkey = BK_BIG, hkey = -BK_BIG;
+            int glo = BK_BIG, ghi = -BK_BIG;  // window-relative index of the lane's first / last M cell
 #pragma unroll
-            for (int p = PP - 1; p >= 0; p--) lkey = nM[p] ? p : lkey;
+            for (int p = PP - 1; p >= 0; p--) glo = nz[p] ? PP * j + p : glo;
 #pragma unroll
-            for (int p = 0; p < PP; p++) hkey = nM[p] ? p : hkey;
-            const int  glo  = Ops::reduce(lkey + PP * j, fmin);  // window-relative index of the first / last M cell
-            const int  ghi  = Ops::reduce(hkey + PP * j, fmax);
+            for (int p = 0; p < PP; p++) ghi = nz[p] ? PP * j + p : ghi;
+            Red::min_max(glo, ghi);
             const bool anyM = ghi >= 0;
             int        ilo = glo, ihi = ghi;  // band to keep (window-relative)
+            uint32_t   csum = 0u;
+#pragma unroll
+            for (int p = 0; p < PP; p++) csum += cc[p];
 
             // ------------------------------------------------------------ wf-adaptive (wfa.go:461-540)
             // remaining distance (wfa.go:488) = max(m-h, n-v) = max(m, n+k) - h; an entry is usable iff h < min(m, n+k)
             const bool want_reduce = run && !term && adaptive && anyM && (ghi - glo + 1) >= minwf;
             if (__ballot(want_reduce) != 0ull) {
-                int  dd[PP], dmin = BK_BIG, dmax = -BK_BIG;
+                int  dd[PP], mind = BK_BIG, maxd = -BK_BIG;
                 bool vd[PP];
 #pragma unroll
                 for (int p = 0; p < PP; p++) {
-                    vd[p] = nM[p] != 0u && (int)nM[p] < lim[p];
+                    vd[p] = nz[p] && !hit[p];
                     dd[p] = lmx[p] - (int)nM[p];
-                    dmin  = vd[p] ? imin2(dmin, dd[p]) : dmin;
-                    dmax  = vd[p] ? imax2(dmax, dd[p]) : dmax;
+                    mind  = vd[p] ? imin2(mind, dd[p]) : mind;
+                    maxd  = vd[p] ? imax2(maxd, dd[p]) : maxd;
                 }
-                const int  mind  = Ops::reduce(dmin, fmin);
-                const int  maxd  = Ops::reduce(dmax, fmax);
+                Red::min_max(mind, maxd);
                 const int  thr   = mind + mdd;
                 const bool found = want_reduce && mind != BK_BIG && maxd > thr;  // some distance fails (wfa.go:507)
                 if (__ballot(found) != 0ull) {
-                    int okmin = BK_BIG, okmax = -BK_BIG;
+                    int first_ok = BK_BIG, last_ok = -BK_BIG;
 #pragma unroll
-                    for (int p = 0; p < PP; p++) {
-                        const bool okc = vd[p] && dd[p] <= thr;
-                        okmin          = okc ? imin2(okmin, PP * j + p) : okmin;
-                        okmax          = okc ? PP * j + p : okmax;
-                    }
-                    const int first_ok = Ops::reduce(okmin, fmin);
-                    const int last_ok  = Ops::reduce(okmax, fmax);
-                    int       vmax     = -1;  // last usable entry before the first non-failing one: all of them failed
+                    for (int p = PP - 1; p >= 0; p--) first_ok = (vd[p] && dd[p] <= thr) ? PP * j + p : first_ok;
 #pragma unroll
-                    for (int p = 0; p < PP; p++) vmax = (vd[p] && PP * j + p < first_ok) ? PP * j + p : vmax;
-                    const int leadp = Ops::reduce(vmax, fmax);
+                    for (int p = 0; p < PP; p++) last_ok = (vd[p] && dd[p] <= thr) ? PP * j + p : last_ok;
+                    Red::min_max(first_ok, last_ok);
+                    int leadp = -1;  // last usable entry before the first non-failing one: all of them failed
+#pragma unroll
+                    for (int p = 0; p < PP; p++) leadp = (vd[p] && PP * j + p < first_ok) ? PP * j + p : leadp;
+                    leadp = Red::max1(leadp);
                     if (found) {
                         if (leadp >= 0) ilo = leadp + 1;  // wfa.go:509-511
                         ihi = last_ok;                     // wfa.go:517-524
                     }
+                    csum = 0u;
+#pragma unroll
+                    for (int p = 0; p < PP; p++) {  // Delete of wfa.go:526-535: the words never exist
+                        const int  ix   = PP * j + p;
+                        const bool keep = ix >= ilo && ix <= ihi;
+                        nM[p] = keep ? nM[p] : 0u, nI[p] = keep ? nI[p] : 0u, nD[p] = keep ? nD[p] : 0u;
+                        wd[p] = keep ? wd[p] : 0u;
+                        csum += keep ? cc[p] : 0u;
+                    }
                 }
             }
-            WFA_STAMP(3);  // ranges + wf-adaptive
+            WFA_STAMP(3); WFA_MARK(3);  // ranges + wf-adaptive
 
             // ------------------------------------------------------------ store the surviving band (lane-aligned)
-            const bool has  = run && anyM && ihi >= ilo;
-            const int  jl   = ilo / PP, jh = ihi / PP;               // first / last lane that holds a surviving cell
-            const int  wn   = has ? (jh - jl + 1) * PP : 0;
+            // (groups that are not running hold all-zero rings: every cell above is absent, anyM is false)
+            const bool has     = anyM && ihi >= ilo;
+            const int  jl = (int)((uint32_t)ilo / PP), jh = (int)((uint32_t)ihi / PP);  // first / last lane with a surviving cell
+            const int  wn      = has ? (jh - jl + 1) * PP : 0;
             const bool no_room = run && wn + 4 > room;
             const bool keepl   = has && !no_room;
-            uint32_t   csum    = 0u;
-#pragma unroll
-            for (int p = 0; p < PP; p++) {
-                const int  ix   = PP * j + p;
-                const bool keep = keepl && ix >= ilo && ix <= ihi;  // Delete of wfa.go:526-535: the words never exist
-                nM[p] = keep ? nM[p] : 0u, nI[p] = keep ? nI[p] : 0u, nD[p] = keep ? nD[p] : 0u;
-                wd[p] = keep ? wd[p] : 0u;
-                csum += keep ? cc[p] : 0u;
-            }
-            cells += csum;
+            cells += keepl ? csum : 0u;
             if (keepl && j >= jl && j <= jh) {
-                uint32_t *const row = A + top + (uint32_t)(PP * (j - jl));
+                uint32_t *const row = rowp + PP * (j - jl);
                 if constexpr (PP == 4) {
                     *reinterpret_cast<uint4 *>(row) = make_uint4(wd[0], wd[1], wd[2], wd[3]);
                 } else {
@@ -393,11 +438,13 @@ __global__ __launch_bounds__(64, (G == 16 ? 4 : 2)) void wfa_blk_kernel(const KP
                 }
             }
             if (run && !no_room && j == 0)
-                *reinterpret_cast<uint4 *>(A + cap - 4ull * (si + 1)) =
+                *reinterpret_cast<uint4 *>(dirp) =
                     wn > 0 ? make_uint4(top, (uint32_t)(kb + PP * jl), (uint32_t)wn, 0u) : make_uint4(0u, 0u, 0u, 0u);
             top += (uint32_t)(keepl ? wn : 0);
+            rowp += keepl ? wn : 0;
+            dirp -= 4;
             room -= (keepl ? wn : 0) + 4;
-            WFA_STAMP(4);  // stores
+            WFA_STAMP(4); WFA_MARK(4);  // stores
 
             // ------------------------------------------------------------ the new row enters the rings
 #pragma unroll
@@ -408,18 +455,18 @@ __global__ __launch_bounds__(64, (G == 16 ? 4 : 2)) void wfa_blk_kernel(const KP
             // ------------------------------------------------------------ finish / next score
             bool fin = run && (term || no_room);
             if (__ballot(fin) != 0ull) {
-                const uint32_t ctot = (uint32_t)Ops::reduce((int)cells, fadd);
-                int            hf   = 0;  // extended offset of the end cell M[s][Ak]: where the backtrace starts
+                int ctot = (int)cells;
+                int hf   = 0;  // extended offset of the end cell M[s][Ak]: where the backtrace starts
 #pragma unroll
                 for (int p = 0; p < PP; p++)
                     if (k0 + p == Ak) hf = (int)Mo[p];
-                hf = Ops::reduce(hf, fmax);
+                Red::max_add(hf, ctot);
                 if (fin && j == 0) {
                     if (no_room) {
                         P.pair_meta[pidx] = make_uint4(ST_REDO_ARENA, 0u, 0u, 0u);
                         push_redo(P, pair, ST_REDO_ARENA);
                     } else {
-                        P.pair_meta[pidx] = make_uint4(ST_OK, si * P.g, (uint32_t)hf, ctot);
+                        P.pair_meta[pidx] = make_uint4(ST_OK, si * P.g, (uint32_t)hf, (uint32_t)ctot);
                     }
                 }
                 if (fin) {
@@ -467,7 +514,7 @@ __global__ __launch_bounds__(64, (G == 16 ? 4 : 2)) void wfa_blk_kernel(const KP
                     }
                 }
             }
-            WFA_STAMP(5);  // ring + finish + window
+            WFA_STAMP(5); WFA_MARK(5);  // ring + finish + window
         }
         return false;
     };
