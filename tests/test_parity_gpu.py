@@ -188,6 +188,55 @@ def test_unaligned_blob_offsets(built):
     al.close()
 
 
+@pytest.mark.parametrize("opts,kind", [({"blk": 16}, 3), ({"blk": 8}, 4), ({"blk": 0}, 2), ({"blk": 0, "reg": 0}, 1),
+                                       ({"packed": 0}, 0)])
+def test_forward_kernel_variants(built, opts, kind):
+    """Every forward kernel (blocked register-window with 16 / 8 lanes per pair, strided register-window, LDS-ring
+    packed, generic) on one mixed batch: unequal lengths (the 64-diagonal window has to follow the band up and
+    down), 15 % error (bands that outgrow the window are handed down the ladder), short reads, wf-adaptive on
+    and off, and a per-pair arena too small for some pairs."""
+    import wfa_amd as w
+    from oracle import oracle as O
+    rng = np.random.default_rng(77)
+    qs, ts = [], []
+    for i in range(1500):
+        L = int(rng.integers(20, 900))
+        q = rng.integers(0, 4, L)
+        t = list(q)
+        ne = int(L * (0.15 if i % 5 == 0 else 0.04))
+        for _ in range(ne):
+            kind_e, pos = int(rng.integers(0, 3)), int(rng.integers(0, max(1, len(t))))
+            if kind_e == 0 and t:
+                t[pos] = int(rng.integers(0, 4))
+            elif kind_e == 1:
+                t.insert(pos, int(rng.integers(0, 4)))
+            elif t:
+                del t[pos]
+        if i % 7 == 0:  # long overhang: |m - n| up to 200
+            extra = list(rng.integers(0, 4, int(rng.integers(1, 200))))
+            t = (extra + t) if i % 2 else (t + extra)
+        if i % 11 == 0:
+            q = q[int(rng.integers(0, min(150, L - 1))):]
+        qs.append(bytes(b"ACGT"[c] for c in q) or b"A")
+        ts.append(bytes(b"ACGT"[c] for c in t) or b"C")
+    data = w.make_blob(qs, ts)
+    for ad in ((10, 50, 1), None, (4, 10, 1)):
+        want = O.align_batch(_oracle_params(True, ad), *data, n_threads=8)
+        for small_arena in (False, True):
+            al = _aligner(True, ad)
+            for k, v in opts.items():
+                al.set_option(k, v)
+            if small_arena:
+                al.set_option("packed_arena_bytes", 6 * 1024)
+            got = al.align_arrays(*data)
+            t = al.last_timing()
+            assert t.main_kernel_kind == kind, (opts, t.main_kernel_kind)
+            if small_arena and kind != 0:
+                assert t.n_retried_pairs > 0
+            assert_batch_equal(got, want, f"opts={opts} ad={ad} small_arena={small_arena}")
+            al.close()
+
+
 def test_small_arena_forces_retry_ladder(built):
     """A deliberately tiny wavefront arena: pairs overflow, are re-run with 8x slots, results unchanged."""
     import wfa_amd as w

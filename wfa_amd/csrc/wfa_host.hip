@@ -51,6 +51,9 @@ struct wfahip_ctx {
     std::vector<hipEvent_t> evpool;
     hipEvent_t    ev0 = nullptr, ev1 = nullptr, evA = nullptr, evB = nullptr, evC = nullptr;
     DevBuf        arena, ctrl, redo, work, meta;
+    DevBuf        arena2, meta2;             // retry passes run beside the first pass's backtrace kernel
+    hipEvent_t    evBtA = nullptr, evBtB = nullptr;
+    bool          bt_pending = false;        // the first pass's backtrace kernel is still running on stream2
     DevBuf        in_blob, in_qoff, in_qlen, in_toff, in_tlen, out_rec, out_ops;  // host-entry staging
     // options (0 = automatic)
     int64_t       opt_arena_bytes_per_slot = 0;
@@ -62,6 +65,7 @@ struct wfahip_ctx {
     int64_t       opt_packed_arena_bytes   = 0;  // per pair, 0 = automatic
     int64_t       opt_chunk_pairs          = 0;  // 0 = automatic
     int64_t       opt_packed_waves_per_cu  = 0;  // 0 = automatic
+    int64_t       opt_tail_overlap         = 1;  // 1: retry passes overlap the backtrace kernel of the first pass
     int64_t       opt_overlap              = 0;  // 1: backtrace of chunk c on a second stream beside the forward kernel of chunk c+1 (measured: no gain)
     int           force_mode               = -1;  // debug: start the ladder in this mode
     wfahip_timing timing{};
@@ -221,7 +225,8 @@ extern "C" int wfahip_create(int device_id, wfahip_ctx **out) {
         hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
         hipEventCreate(&ctx->evA) != hipSuccess || hipEventCreate(&ctx->evB) != hipSuccess ||
-        hipEventCreate(&ctx->evC) != hipSuccess) {
+        hipEventCreate(&ctx->evC) != hipSuccess || hipEventCreate(&ctx->evBtA) != hipSuccess ||
+        hipEventCreate(&ctx->evBtB) != hipSuccess) {
         delete ctx;
         return WFAHIP_ERR_HIP;
     }
@@ -232,7 +237,7 @@ extern "C" int wfahip_create(int device_id, wfahip_ctx **out) {
 extern "C" void wfahip_destroy(wfahip_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    for (DevBuf *b : {&ctx->arena, &ctx->ctrl, &ctx->redo, &ctx->work, &ctx->meta, &ctx->in_blob, &ctx->in_qoff, &ctx->in_qlen,
+    for (DevBuf *b : {&ctx->arena, &ctx->arena2, &ctx->meta2, &ctx->ctrl, &ctx->redo, &ctx->work, &ctx->meta, &ctx->in_blob, &ctx->in_qoff, &ctx->in_qlen,
                       &ctx->in_toff, &ctx->in_tlen, &ctx->out_rec, &ctx->out_ops})
         release(*b);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -240,6 +245,8 @@ extern "C" void wfahip_destroy(wfahip_ctx *ctx) {
     if (ctx->evA) (void)hipEventDestroy(ctx->evA);
     if (ctx->evB) (void)hipEventDestroy(ctx->evB);
     if (ctx->evC) (void)hipEventDestroy(ctx->evC);
+    if (ctx->evBtA) (void)hipEventDestroy(ctx->evBtA);
+    if (ctx->evBtB) (void)hipEventDestroy(ctx->evBtB);
     for (hipEvent_t e : ctx->evpool) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
@@ -269,6 +276,8 @@ extern "C" int wfahip_set_option(wfahip_ctx *ctx, const char *key, int64_t value
         ctx->opt_packed_waves_per_cu = value;
     else if (k == "overlap")
         ctx->opt_overlap = value;
+    else if (k == "tail_overlap")
+        ctx->opt_tail_overlap = value;
     else
         return WFAHIP_ERR_BAD_ARG;
     return WFAHIP_OK;
@@ -298,6 +307,10 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
     if (rc != WFAHIP_OK) return rc;
     if (n_pairs > 0xFFFFFFF0ull) return WFAHIP_ERR_BAD_ARG;
     ctx->timing = wfahip_timing{};
+    if (ctx->bt_pending) {  // a previous call failed half-way: let its backtrace kernel drain before buffers are reused
+        (void)hipStreamSynchronize(ctx->stream2);
+        ctx->bt_pending = false;
+    }
     if (ops_needed) *ops_needed = 0;
     if (n_pairs == 0) return WFAHIP_OK;
     if (!d_q_off || !d_q_len || !d_t_off || !d_t_len || !d_rec || (!d_ops && ops_cap)) return WFAHIP_ERR_BAD_ARG;
@@ -376,8 +389,12 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
         P.debug_info = static_cast<uint32_t *>(stampbuf.p);
 #endif
         // one pass over `count` pairs (identity range when list == nullptr); returns the {pair,status} redo entries
+        // detach_bt: (first pass, one chunk) the backtrace kernel goes to stream2 and is only waited for at the very
+        // end of the call, so the retry passes -- which use the second arena -- run beside it.
         auto forward_pass = [&](int kind, const std::vector<uint32_t> *list, uint64_t count,
-                                std::vector<uint64_t> &redo_out) -> int {
+                                std::vector<uint64_t> &redo_out, bool detach_bt) -> int {
+            DevBuf &arena_buf = ctx->bt_pending ? ctx->arena2 : ctx->arena;
+            DevBuf &meta_buf  = ctx->bt_pending ? ctx->meta2 : ctx->meta;
             const size_t   lds_bytes    = kind >= 3 ? lds_d : (kind == 2 ? lds_c : lds_b);
             const uint32_t pairs_wave   = kind == 4 ? 8 : (kind >= 2 ? 4 : 2);
             const uint32_t waves_lds    = (uint32_t)std::min<size_t>(32, LDS_MAX_BYTES / lds_bytes);
@@ -397,9 +414,10 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
             if (ctx->opt_chunk_pairs > 0) chunk = std::min<uint64_t>(chunk, (uint64_t)ctx->opt_chunk_pairs);
             const uint64_t n_chunks = (count + chunk - 1) / chunk;
             const uint32_t n_buf    = (overlap && n_chunks > 1) ? 2 : 1;
-            int rc2 = ensure(ctx, ctx->arena, (size_t)(words * 4ull * chunk * n_buf));
+            int rc2 = ensure(ctx, arena_buf, (size_t)(words * 4ull * chunk * n_buf));
             if (rc2) return rc2;
-            if ((rc2 = ensure(ctx, ctx->meta, chunk * 16 * n_buf))) return rc2;
+            if ((rc2 = ensure(ctx, meta_buf, chunk * 16 * n_buf))) return rc2;
+            detach_bt = detach_bt && n_chunks == 1 && ctx->opt_tail_overlap != 0;
             ctx->timing.arena_bytes = std::max<uint64_t>(ctx->timing.arena_bytes, words * 4ull * chunk * n_buf);
             if (list) {
                 if ((rc2 = ensure(ctx, ctx->work, count * 4))) return rc2;
@@ -411,14 +429,15 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
                 ctx->evpool.push_back(e);
             }
             HIP_TRY(hipMemsetAsync(d_ctrl, 0, 8, st));  // queue_head, redo_count
-            hipStream_t st_bt = (n_buf == 2) ? ctx->stream2 : st;
+            hipStream_t st_bt = (n_buf == 2 || detach_bt) ? ctx->stream2 : st;
             for (uint64_t c = 0; c < n_chunks; c++) {
                 const uint64_t c0 = c * chunk, cn = std::min<uint64_t>(chunk, count - c0);
                 hipEvent_t evFa = ctx->evpool[4 * c], evFb = ctx->evpool[4 * c + 1];
-                hipEvent_t evBa = ctx->evpool[4 * c + 2], evBb = ctx->evpool[4 * c + 3];
+                hipEvent_t evBa = detach_bt ? ctx->evBtA : ctx->evpool[4 * c + 2];
+                hipEvent_t evBb = detach_bt ? ctx->evBtB : ctx->evpool[4 * c + 3];
                 const uint32_t buf = (uint32_t)(c % n_buf);
-                P.arena       = static_cast<uint32_t *>(ctx->arena.p) + (uint64_t)buf * chunk * words;
-                P.pair_meta   = static_cast<uint4 *>(ctx->meta.p) + (uint64_t)buf * chunk;
+                P.arena       = static_cast<uint32_t *>(arena_buf.p) + (uint64_t)buf * chunk * words;
+                P.pair_meta   = static_cast<uint4 *>(meta_buf.p) + (uint64_t)buf * chunk;
                 P.chunk_first = (uint32_t)c0, P.chunk_n = (uint32_t)cn;
                 P.work        = list ? static_cast<const uint32_t *>(ctx->work.p) + c0 : nullptr;
                 const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)ctx->num_cus * waves_per_cu,
@@ -442,16 +461,17 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipEventRecord(evBb, st_bt));
             }
-            if (st_bt != st)
+            if (st_bt != st && !detach_bt)
                 for (uint64_t c = (n_chunks >= 2 ? n_chunks - 2 : 0); c < n_chunks; c++)
                     HIP_TRY(hipStreamWaitEvent(st, ctx->evpool[4 * c + 3], 0));
             uint32_t hc[CTRL_WORDS];
             HIP_TRY(hipMemcpyAsync(hc, d_ctrl, sizeof hc, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
+            HIP_TRY(hipStreamSynchronize(st));  // (detach_bt: the forward kernel is done, the backtrace may still run)
+            if (detach_bt) ctx->bt_pending = true;
             for (uint64_t c = 0; c < n_chunks; c++) {
                 float msF = 0, msB = 0;
                 HIP_TRY(hipEventElapsedTime(&msF, ctx->evpool[4 * c], ctx->evpool[4 * c + 1]));
-                HIP_TRY(hipEventElapsedTime(&msB, ctx->evpool[4 * c + 2], ctx->evpool[4 * c + 3]));
+                if (!detach_bt) HIP_TRY(hipEventElapsedTime(&msB, ctx->evpool[4 * c + 2], ctx->evpool[4 * c + 3]));
                 ctx->timing.kernel_ms += msF + msB;
                 if (!list) ctx->timing.main_kernel_ms += msF, ctx->timing.n_main_launches++;
                 ctx->timing.n_launches += 2;
@@ -468,7 +488,7 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
         if (can_b || can_c || can_d) {
             std::vector<uint64_t> redo1, redo2;
             const int kind1 = can_d ? (ctx->opt_blk == 8 ? 4 : 3) : (can_c ? 2 : 1);
-            if ((rc = forward_pass(kind1, nullptr, n_pairs, redo1))) return rc;
+            if ((rc = forward_pass(kind1, nullptr, n_pairs, redo1, true))) return rc;
             ctx->timing.main_kernel_kind = (uint32_t)kind1;
             ctx->timing.n_packed_pairs = (uint32_t)(n_pairs - redo1.size());
             ctx->timing.n_retried_pairs += (uint32_t)redo1.size();
@@ -485,7 +505,7 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
                     else ja.pairs.push_back((uint32_t)e);
                 }
                 if (!lst.empty()) {
-                    if ((rc = forward_pass(1, &lst, lst.size(), redo2))) return rc;
+                    if ((rc = forward_pass(1, &lst, lst.size(), redo2, false))) return rc;
                     ctx->timing.n_packed_pairs += (uint32_t)(lst.size() - redo2.size());
                     for (uint64_t e : redo2) ((uint32_t)(e >> 32) == ST_REDO_BYTES ? jb : ja).pairs.push_back((uint32_t)e);
                 }
@@ -538,15 +558,16 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
             }
             continue;
         }
-        rc = ensure(ctx, ctx->arena, (size_t)cfg.arena_words * 4ull * cfg.slots);
+        DevBuf &jarena = ctx->bt_pending ? ctx->arena2 : ctx->arena;
+        rc = ensure(ctx, jarena, (size_t)cfg.arena_words * 4ull * cfg.slots);
         if (rc == WFAHIP_ERR_OOM && cfg.slots > 1) {  // shrink once
             cfg.slots = std::max<uint32_t>(1, cfg.slots / 4);
-            rc        = ensure(ctx, ctx->arena, (size_t)cfg.arena_words * 4ull * cfg.slots);
+            rc        = ensure(ctx, jarena, (size_t)cfg.arena_words * 4ull * cfg.slots);
         }
         if (rc) return rc;
         ctx->timing.arena_bytes = std::max<uint64_t>(ctx->timing.arena_bytes, (uint64_t)cfg.arena_words * 4ull * cfg.slots);
 
-        P.arena = static_cast<uint32_t *>(ctx->arena.p), P.arena_words = cfg.arena_words;
+        P.arena = static_cast<uint32_t *>(jarena.p), P.arena_words = cfg.arena_words;
         P.lds_seq_words = cfg.lds_seq_words;
         P.n_work        = (uint32_t)n_work;
         if (job.all) {
@@ -588,6 +609,7 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
         }
         if (debug_single) break;
     }
+    if (ctx->bt_pending) HIP_TRY(hipStreamWaitEvent(st, ctx->evBtB, 0));
     HIP_TRY(hipEventRecord(ctx->ev1, st));
 
     for (uint32_t pid : no_memory) {
@@ -599,6 +621,11 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
     HIP_TRY(hipMemcpyAsync(hctrl, d_ctrl, sizeof hctrl, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     float ms = 0;
+    if (ctx->bt_pending) {
+        HIP_TRY(hipEventElapsedTime(&ms, ctx->evBtA, ctx->evBtB));
+        ctx->timing.kernel_ms += ms;
+        ctx->bt_pending = false;
+    }
     HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     ctx->timing.total_ms    = ms;
     const uint64_t cursor   = (uint64_t)hctrl[2] | ((uint64_t)hctrl[3] << 32);
