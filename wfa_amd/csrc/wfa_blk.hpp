@@ -20,9 +20,9 @@
 // pre-extension offset (wfa.go:766-817) equals the offset just computed.  A sticky per-pair flag, set by the
 // first cell that hits an end, switches the wave to the exact code (bit-for-bit the rules of next_cell()).
 //
-// Output protocol = kernel C's: one compact backtrace word per diagonal (compact_word()), 16-byte directory
-// entries growing down from the end of the pair's arena slot, pair_meta for wfa_backtrace_kernel.  Rows are
-// stored lane-aligned (the band padded to a multiple of PP with absent = 0 words).
+// Output: one compact backtrace word per diagonal (compact_word()) in the fixed-pitch arena layout (CompactView
+// fmt 1: 64 words per score, diagonal k at slot k & 63; the window base stays a multiple of PP so a lane's PP
+// words are one aligned 16/32-byte store), and pair_meta for wfa_backtrace_kernel.
 #pragma once
 #include "wfa_device.hpp"
 #include "wfa_packed.hpp"
@@ -151,10 +151,10 @@ __global__ __launch_bounds__(64, (G == 16 ? 4 : WFA_BLK8_WAVES)) void wfa_blk_ke
 
     // per-pair state (identical in the G lanes of a group)
     int        st = 0;  // 0 = needs a pair, 1 = running, 2 = queue exhausted
-    uint32_t   pidx = 0, pair = 0, si = 0, top = 0, cells = 0;
-    int        n = 0, m = 0, Ak = 0, kb = 0, k0 = 0, room = 0;
+    uint32_t   pidx = 0, pair = 0, si = 0, cells = 0;
+    int        n = 0, m = 0, Ak = 0, kb = 0, k0 = 0, rows_left = 0;
     bool       slow = false, first_eq = false;
-    uint32_t  *rowp = nullptr, *dirp = nullptr;  // next row / next directory entry of the pair's arena slot
+    uint32_t  *rowp = nullptr;  // row of the current score in the pair's arena slot (64 words per score)
 
     uint32_t M[4][PP], I[PP], D[PP];  // offsets, 0 = absent; M[i & 3] = row of step i
     int      rlo[4], rhi[4];          // band of each kept M row (absolute k); empty = (BIG, -BIG)
@@ -231,11 +231,10 @@ __global__ __launch_bounds__(64, (G == 16 ? 4 : WFA_BLK8_WAVES)) void wfa_blk_ke
                 if (mine) {
                     pidx = wi, pair = pr;
                     n = (int)nq, m = (int)mt, Ak = m - n;
-                    si = 0, top = 0, cells = 0, slow = false;
-                    kb   = -32 + imax2(-24, imin2(24, Ak / 2));  // k = 0 (the seed) inside, biased towards Ak
+                    si = 0, cells = 0, slow = false;
+                    kb   = -32 + PP * imax2(-24 / PP, imin2(24 / PP, Ak / (2 * PP)));  // k = 0 (the seed) inside, biased towards Ak
                     rowp = P.arena + (uint64_t)pidx * cap;
-                    dirp = rowp + cap - 4;
-                    room = (int)imin2((int)(cap > 0x3FFFFFF0ull ? 0x3FFFFFF0ull : cap), 0x3FFFFFF0) - 8;
+                    rows_left = (int)(cap / 64);
                     first_eq = ((lq[0] ^ lt[0]) & 3u) == 0u;  // q[0] == t[0] (wfa.go:155)
                     set_window();
                     clear_rings();
@@ -420,16 +419,16 @@ __global__ __launch_bounds__(64, (G == 16 ? 4 : WFA_BLK8_WAVES)) void wfa_blk_ke
             }
             WFA_STAMP(3); WFA_MARK(3);  // ranges + wf-adaptive
 
-            // ------------------------------------------------------------ store the surviving band (lane-aligned)
-            // (groups that are not running hold all-zero rings: every cell above is absent, anyM is false)
-            const bool has     = anyM && ihi >= ilo;
-            const int  jl = (int)((uint32_t)ilo / PP), jh = (int)((uint32_t)ihi / PP);  // first / last lane with a surviving cell
-            const int  wn      = has ? (jh - jl + 1) * PP : 0;
-            const bool no_room = run && wn + 4 > room;
-            const bool keepl   = has && !no_room;
+            // ------------------------------------------------------------ store the surviving band
+            // (groups that are not running hold all-zero rings: every cell above is absent)
+            const bool no_room = run && rows_left <= 0;
+            const bool keepl   = anyM && ihi >= ilo && !no_room;
             cells += keepl ? csum : 0u;
-            if (keepl && j >= jl && j <= jh) {
-                uint32_t *const row = rowp + PP * (j - jl);
+            uint32_t anyw = 0u;
+#pragma unroll
+            for (int p = 0; p < PP; p++) anyw |= wd[p];
+            if (keepl && anyw != 0u) {
+                uint32_t *const row = rowp + ((uint32_t)k0 & 63u);
                 if constexpr (PP == 4) {
                     *reinterpret_cast<uint4 *>(row) = make_uint4(wd[0], wd[1], wd[2], wd[3]);
                 } else {
@@ -437,13 +436,8 @@ __global__ __launch_bounds__(64, (G == 16 ? 4 : WFA_BLK8_WAVES)) void wfa_blk_ke
                     *reinterpret_cast<uint4 *>(row + 4) = make_uint4(wd[4], wd[5], wd[6], wd[7]);
                 }
             }
-            if (run && !no_room && j == 0)
-                *reinterpret_cast<uint4 *>(dirp) =
-                    wn > 0 ? make_uint4(top, (uint32_t)(kb + PP * jl), (uint32_t)wn, 0u) : make_uint4(0u, 0u, 0u, 0u);
-            top += (uint32_t)(keepl ? wn : 0);
-            rowp += keepl ? wn : 0;
-            dirp -= 4;
-            room -= (keepl ? wn : 0) + 4;
+            rowp += 64;
+            rows_left -= 1;
             WFA_STAMP(4); WFA_MARK(4);  // stores
 
             // ------------------------------------------------------------ the new row enters the rings

@@ -370,14 +370,21 @@ struct OpsWriterRev {
 
 // Compact arena of the sub-wave pipeline: one word per diagonal per score, 16-byte directory entries
 // {base, lo, w, -} growing down from the slot end.
+//
+// Fixed-pitch variant (fmt 1, written by the blocked register-window kernel): the row of score index i starts at
+// word 64*i and diagonal k sits at slot k & 63 -- a row never spans more than 64 diagonals -- so a backtrace step
+// is ONE load with no directory lookup in front of it.  Slots outside a row's surviving band are never written;
+// the walk never looks at them: every tag names a source cell that existed (after its own row's wf-adaptive)
+// when the cell was computed.
 struct CompactView {
     const uint32_t *A;
     uint64_t        cap;
-    uint32_t        g, n_ent;
+    uint32_t        g, n_ent, fmt;
     WFA_DEV uint32_t word(uint32_t s, int k) const {
         if (s % g != 0u) return 0u;
         const uint32_t idx = s / g;
         if (idx >= n_ent) return 0u;
+        if (fmt == 1u) return A[64u * idx + ((uint32_t)k & 63u)];
         const uint4 e = *reinterpret_cast<const uint4 *>(A + cap - 4ull * (idx + 1));
         const int   lo = (int)e.y, w = (int)e.z;
         if (w <= 0 || k < lo || k >= lo + w) return 0u;

@@ -374,10 +374,10 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
         const bool     can_c     = ctx->opt_reg && dx == 2 && doe == 4 && de == 1 && lds_c <= 20 * 1024;
         const bool     can_d     = ctx->opt_blk && dx == 2 && doe == 4 && de == 1 && max_len < 32768 &&
                                lds_d <= (ctx->opt_blk == 8 ? 40 : 20) * 1024;
-        uint64_t       words     = std::max<uint64_t>(1024, 8ull * max_len);  // compact rows: 1 word per diagonal
-        if (ctx->opt_packed_arena_bytes > 0) words = std::max<uint64_t>(1024, ctx->opt_packed_arena_bytes / 4);
-        words = (words + 7) & ~7ull;
-        P.arena_words   = words;
+        uint64_t       words_dir = std::max<uint64_t>(1024, 8ull * max_len);  // compact rows: 1 word per diagonal
+        if (ctx->opt_packed_arena_bytes > 0) words_dir = std::max<uint64_t>(1024, ctx->opt_packed_arena_bytes / 4);
+        words_dir = (words_dir + 7) & ~7ull;
+        P.arena_words   = words_dir;
         P.dx = dx, P.doe = doe, P.de = de, P.dm = dm, P.di = di;
         P.lds_seq_words = seq_words;
         P.sub_lds_words = (uint32_t)sub_words;
@@ -397,6 +397,9 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
             DevBuf &meta_buf  = ctx->bt_pending ? ctx->meta2 : ctx->meta;
             const size_t   lds_bytes    = kind >= 3 ? lds_d : (kind == 2 ? lds_c : lds_b);
             const uint32_t pairs_wave   = kind == 4 ? 8 : (kind >= 2 ? 4 : 2);
+            // blocked kernel: fixed-pitch arena (64 words per score, no directory), 16 words per base
+            const uint64_t words        = kind >= 3 ? std::max<uint64_t>((words_dir * 2 + 63) & ~63ull, 2048) : words_dir;
+            P.arena_words = words, P.compact_fmt = kind >= 3 ? 1u : 0u;
             const uint32_t waves_lds    = (uint32_t)std::min<size_t>(32, LDS_MAX_BYTES / lds_bytes);
             const bool     overlap      = ctx->opt_overlap != 0;
             uint32_t       waves_per_cu = kind == 4 ? std::min<uint32_t>(waves_lds, 12)

@@ -310,6 +310,7 @@ __global__ __launch_bounds__(256) void wfa_backtrace_kernel(const KParams P) {
     const uint32_t s_final = meta.y;
     CompactView cv;
     cv.A = P.arena + (uint64_t)idx * P.arena_words, cv.cap = P.arena_words, cv.g = P.g, cv.n_ent = s_final / P.g + 1u;
+    cv.fmt = P.compact_fmt;
 
     // ops region: bound = 2 * score / min(x, e) + 8 entries, carved from the shared ops buffer
     const uint32_t bound = 2u * (s_final / P.min_xe) + 8u;
