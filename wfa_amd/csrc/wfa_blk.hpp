@@ -352,8 +352,9 @@ __global__ __launch_bounds__(64, (G == 16 ? 4 : WFA_BLK8_WAVES)) void wfa_blk_ke
             bool nz[PP], hit[PP], hitl = false;
 #pragma unroll
             for (int p = 0; p < PP; p++) nz[p] = nM[p] != 0u, hit[p] = nM[p] >= (uint32_t)lim[p], hitl |= hit[p];
-            bool term = false;
-            if (__ballot(hitl) != 0ull) {
+            bool       term    = false;
+            const bool hit_any = __ballot(hitl) != 0ull;
+            if (hit_any) {
                 bool tl = false;
 #pragma unroll
                 for (int p = 0; p < PP; p++) tl |= (k0 + p == Ak && nz[p] && (int)nM[p] >= m);
@@ -398,14 +399,19 @@ __global__ __launch_bounds__(64, (G == 16 ? 4 : WFA_BLK8_WAVES)) void wfa_blk_ke
 #pragma unroll
                     for (int p = 0; p < PP; p++) last_ok = (vd[p] && dd[p] <= thr) ? PP * j + p : last_ok;
                     Red::min_max(first_ok, last_ok);
-                    int leadp = -1;  // last usable entry before the first non-failing one: all of them failed
+                    // wfa.go:509-511: _lo = one past the last failing entry before the first non-failing one.  The
+                    // entries between that one and first_ok are unusable ones: holes (absent cells) or cells at a
+                    // sequence end.  While no cell of the wave has reached an end they are all holes, and deleting
+                    // or keeping a hole is the same thing: _lo = first_ok gives the identical row.
+                    int newlo = first_ok;
+                    if (hit_any) {
+                        int leadp = -1;
 #pragma unroll
-                    for (int p = 0; p < PP; p++) leadp = (vd[p] && PP * j + p < first_ok) ? PP * j + p : leadp;
-                    leadp = Red::max1(leadp);
-                    if (found) {
-                        if (leadp >= 0) ilo = leadp + 1;  // wfa.go:509-511
-                        ihi = last_ok;                     // wfa.go:517-524
+                        for (int p = 0; p < PP; p++) leadp = (vd[p] && PP * j + p < first_ok) ? PP * j + p : leadp;
+                        leadp = Red::max1(leadp);
+                        newlo = leadp >= 0 ? leadp + 1 : glo;
                     }
+                    if (found) ilo = newlo, ihi = last_ok;  // wfa.go:517-524
                     csum = 0u;
 #pragma unroll
                     for (int p = 0; p < PP; p++) {  // Delete of wfa.go:526-535: the words never exist
