@@ -128,7 +128,11 @@ template <int G>
 __global__ __launch_bounds__(64, (G == 16 ? 4 : WFA_BLK8_WAVES)) void wfa_blk_kernel(const KParams P) {
     constexpr int PP  = 64 / G;   // diagonals per lane
     constexpr int NG  = 64 / G;   // pairs per wave
+#ifdef WFA_BLK_W
+    constexpr int W = WFA_BLK_W;  // experiment: pretend the window is narrower
+#else
     constexpr int W   = 64;       // window width in diagonals
+#endif
     using Ops         = BlkOps<G>;
 #ifdef WFA_MARKS
 #define WFA_MARK(i) asm volatile("; ##MARK " #i)
@@ -193,42 +197,62 @@ __global__ __launch_bounds__(64, (G == 16 ? 4 : WFA_BLK8_WAVES)) void wfa_blk_ke
     const auto step = [&](auto ph_c) __attribute__((always_inline)) -> bool {
         constexpr int ph = decltype(ph_c)::value;
         {
-            // ------------------------------------------------------------ refill: groups that need a pair are served
-            // one after the other and ALL 64 lanes stage + 2-bit pack that group's sequences (coalesced dword loads).
-            for (unsigned long long need = __ballot(st == 0); need != 0ull;) {
-                const int r = __builtin_ctzll(need) / G;  // wave-uniform group index
-                need &= ~((G == 16 ? 0xFFFFull : 0xFFull) << (G * r));
-                uint32_t wi = 0;
-                if (lane == G * r) wi = atomicAdd(P.queue_head, 1u);
-                wi = __shfl(wi, G * r, 64);
-                const bool mine = (grp == r);
-                if (wi >= P.chunk_n) {
-                    if (mine) st = 2;
-                    continue;
+            // ------------------------------------------------------------ refill: all groups that need a pair take
+            // consecutive queue entries with ONE atomic, load their pair's lengths/offsets together, and stage +
+            // 2-bit pack the sequences: short pairs (one pass of the group's own lanes) all groups at once, long
+            // pairs one group after the other with all 64 lanes (coalesced dword loads).
+            const unsigned long long need = __ballot(st == 0);
+            if (need != 0ull) {
+                uint32_t gbits = 0u;  // bit r: group r needs a pair (wave-uniform)
+#pragma unroll
+                for (int r = 0; r < NG; r++) gbits |= (uint32_t)((need >> (G * r)) & 1ull) << r;
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(P.queue_head, (uint32_t)__builtin_popcount(gbits));
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                const bool     want = st == 0;
+                const uint32_t wi   = base + (uint32_t)__builtin_popcount(gbits & ((1u << grp) - 1u));
+                const bool     got  = want && wi < P.chunk_n;
+                if (want && !got) st = 2;
+                uint32_t pr = 0, nq = 0, mt = 0;
+                uint64_t qo = 0, to = 0;
+                if (got) {
+                    pr = P.work ? P.work[wi] : P.chunk_first + wi;
+                    nq = P.q_len[pr], mt = P.t_len[pr], qo = P.q_off[pr], to = P.t_off[pr];
                 }
-                const uint32_t pr = P.work ? P.work[wi] : P.chunk_first + wi;
-                const uint32_t nq = P.q_len[pr], mt = P.t_len[pr];
-                uint32_t       status = ST_PENDING;
+                uint32_t status = ST_PENDING;
                 if (nq == 0 || mt == 0)
                     status = ST_EMPTY;  // wfa.go:204-206
                 else if (nq > 0x1FFFFFFFu || mt > 0x1FFFFFFFu)
                     status = ST_TOO_LONG;  // wfa.go:207-209
                 else if (((nq > mt ? nq : mt) + 15u) / 16u + 1u > SW)
                     status = ST_REDO_LDS;
-                if (status == ST_PENDING) {
-                    uint32_t *const rq = lds + r * 2 * SW;
-                    bool bad = stage_pack<64>(P.blob, P.q_off[pr], nq, rq, lane);
-                    bad |= stage_pack<64>(P.blob, P.t_off[pr], mt, rq + SW, lane);
-                    if (__ballot(bad) != 0ull) status = ST_REDO_BYTES;
-                }
-                if (status != ST_PENDING) {
-                    if (lane == G * r) {
-                        P.pair_meta[wi] = make_uint4(status, 0u, 0u, 0u);
-                        if (status >= ST_REDO_BYTES) push_redo(P, pr, status);
+                const bool stage = got && status == ST_PENDING;
+                bool       bad   = false;
+                if (__ballot(stage && ((nq > mt ? nq : mt) + 15u) / 16u + 1u > (uint32_t)G) == 0ull) {
+                    if (stage) {
+                        bad = stage_pack<G>(P.blob, qo, nq, const_cast<uint32_t *>(lq), j);
+                        bad |= stage_pack<G>(P.blob, to, mt, const_cast<uint32_t *>(lt), j);
                     }
-                    continue;  // the group stays in state 0 and pulls another pair in the next round
+                    bad = Red::or1(bad ? 1 : 0) != 0;
+                } else {
+                    for (unsigned long long todo = __ballot(stage); todo != 0ull;) {
+                        const int r = __builtin_ctzll(todo) / G;  // wave-uniform group index
+                        todo &= ~((G == 16 ? 0xFFFFull : 0xFFull) << (G * r));
+                        const uint64_t qo_r = ((uint64_t)__shfl((uint32_t)(qo >> 32), G * r, 64) << 32) | __shfl((uint32_t)qo, G * r, 64);
+                        const uint64_t to_r = ((uint64_t)__shfl((uint32_t)(to >> 32), G * r, 64) << 32) | __shfl((uint32_t)to, G * r, 64);
+                        const uint32_t nq_r = __shfl(nq, G * r, 64), mt_r = __shfl(mt, G * r, 64);
+                        uint32_t *const rq  = lds + r * 2 * SW;
+                        bool b = stage_pack<64>(P.blob, qo_r, nq_r, rq, lane);
+                        b |= stage_pack<64>(P.blob, to_r, mt_r, rq + SW, lane);
+                        if (__ballot(b) != 0ull && grp == r) bad = true;
+                    }
                 }
-                if (mine) {
+                if (stage && bad) status = ST_REDO_BYTES;
+                if (got && status != ST_PENDING && j == 0) {
+                    P.pair_meta[wi] = make_uint4(status, 0u, 0u, 0u);
+                    if (status >= ST_REDO_BYTES) push_redo(P, pr, status);
+                }  // (the group stays in state 0 and pulls another pair in the next round)
+                if (stage && !bad) {
                     pidx = wi, pair = pr;
                     n = (int)nq, m = (int)mt, Ak = m - n;
                     si = 0, cells = 0, slow = false;
