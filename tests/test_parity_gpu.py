@@ -222,6 +222,11 @@ def test_forward_kernel_variants(built, opts, kind):
     data = w.make_blob(qs, ts)
     for ad in ((10, 50, 1), None, (4, 10, 1)):
         want = O.align_batch(_oracle_params(True, ad), *data, n_threads=8)
+        ref = _aligner(True, ad)  # the census of stored wavefront cells must not depend on the kernel either
+        ref.set_option("packed", 0)
+        ref.align_arrays(*data)
+        want_cells = ref.last_timing().cells_stored
+        ref.close()
         for small_arena in (False, True):
             al = _aligner(True, ad)
             for k, v in opts.items():
@@ -234,6 +239,7 @@ def test_forward_kernel_variants(built, opts, kind):
             if small_arena and kind != 0:
                 assert t.n_retried_pairs > 0
             assert_batch_equal(got, want, f"opts={opts} ad={ad} small_arena={small_arena}")
+            assert t.cells_stored == want_cells, (opts, ad, small_arena)
             al.close()
 
 

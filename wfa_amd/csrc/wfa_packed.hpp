@@ -301,9 +301,14 @@ __global__ __launch_bounds__(256) void wfa_backtrace_kernel(const KParams P) {
     const uint4    meta = P.pair_meta[idx];
     uint32_t *const rec = P.rec + (uint64_t)pair * REC_WORDS;
     if (meta.x != ST_OK) {
-        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-        uint4 *r4     = reinterpret_cast<uint4 *>(rec);
-        r4[0] = make_uint4(meta.x, 0u, 0u, 0u), r4[1] = z, r4[2] = z, r4[3] = z;
+        // Final statuses (empty / too long) are recorded here.  A pair that was handed on (ST_REDO_*) gets its
+        // record from the pass that finishes it -- which may already be running beside this kernel, so this
+        // kernel must not touch that record.
+        if (meta.x < ST_REDO_BYTES) {
+            const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+            uint4 *r4     = reinterpret_cast<uint4 *>(rec);
+            r4[0] = make_uint4(meta.x, 0u, 0u, 0u), r4[1] = z, r4[2] = z, r4[3] = z;
+        }
         return;
     }
     const int n = (int)P.q_len[pair], m = (int)P.t_len[pair];
