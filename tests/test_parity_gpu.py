@@ -339,6 +339,13 @@ def test_full_size_parity_c3(built):
         data = w.generate_pairs(seed=seed, n_pairs=n, length=length, error_rate=err, n_threads=32)
         al = _aligner(True, ad)
         got = al.align_arrays(*data)
+        cells = al.last_timing().cells_stored
         want = O.align_batch(_oracle_params(True, ad), *data, n_threads=thr)
         assert_batch_equal(got, want, f"full size L={length}")
+        # the retry passes run beside the first pass's backtrace kernel: same records and same cell census as the
+        # serial schedule
+        al.set_option("tail_overlap", 0)
+        again = al.align_arrays(*data)
+        assert_batch_equal(again, want, f"full size L={length}, serial schedule")
+        assert al.last_timing().cells_stored == cells
         al.close()
