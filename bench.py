@@ -54,7 +54,7 @@ def main():
     entry.build()
     import wfa_amd as w
     from wfa_amd import _lib as L
-    from wfa_amd.shard import gather_results
+    from wfa_amd.shard import gather_results_async
 
     n = args.pairs
     # ---- synthetic input (host generation, then H2D: outside the timed region)
@@ -81,6 +81,7 @@ def main():
     lib = L.lib()
     stream = torch.cuda.current_stream(dev).cuda_stream
     timing = L.Timing()
+    pending = [None]  # the result gather in flight (multi-GPU)
 
     def step():
         needed = C.c_uint64()
@@ -90,9 +91,19 @@ def main():
         L.check(rc, "wfahip_align_batch_device")
         lib.wfahip_last_timing(al._ctx, C.byref(timing))
         n_ops = int(needed.value)
-        if world > 1:  # result gather onto rank 0 over RCCL/xGMI (fixed-size records, then padded op arrays)
-            gather_results(d_rec, d_ops, n_ops, dst=0)
+        if world > 1:
+            # Result gather onto rank 0 over RCCL/xGMI (fixed-size records, then padded op arrays).  It is started
+            # here and completed before the next one starts (or at the end of the timed region), so the exchange
+            # of batch i runs beside the alignment of batch i+1; the send buffers are private copies.
+            if pending[0] is not None:
+                pending[0].wait()
+            pending[0] = gather_results_async(d_rec, d_ops, n_ops, dst=0)
         return n_ops
+
+    def drain():
+        if pending[0] is not None:
+            pending[0].wait()
+            pending[0] = None
 
     def sync_all():
         if world > 1:
@@ -101,6 +112,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    drain()
     kernel_ms, main_ms = [], []
     sync_all()
     t0 = time.perf_counter()
@@ -108,6 +120,7 @@ def main():
         n_ops = step()
         kernel_ms.append(timing.kernel_ms)
         main_ms.append(timing.main_kernel_ms)
+    drain()  # the last gather completes inside the timed region
     sync_all()
     elapsed = time.perf_counter() - t0
     tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)

@@ -26,7 +26,7 @@ def _worker(rank, world, port, n_total, out_path):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import wfa_amd as w
-    from wfa_amd.shard import gather_results, shard_range
+    from wfa_amd.shard import gather_results, gather_results_async, shard_range
     from oracle import oracle as O
 
     b, e = shard_range(n_total, rank, world)
@@ -39,7 +39,14 @@ def _worker(rank, world, port, n_total, out_path):
     rec[:, 11] = (r.ops_off & 0xFFFFFFFF).astype(np.int64).astype(np.int32)
     ops = np.zeros(len(r.ops) + 17, dtype=np.int64)  # buffer larger than the used prefix, like the device one
     ops[:len(r.ops)] = r.ops.view(np.int64)
-    got = gather_results(torch.from_numpy(rec), torch.from_numpy(ops), len(r.ops), dst=0)
+    t_rec, t_ops = torch.from_numpy(rec.copy()), torch.from_numpy(ops.copy())
+    pend = gather_results_async(t_rec, t_ops, len(r.ops), dst=0)  # bench.py's form: buffers are reused at once
+    t_rec.zero_(), t_ops.zero_()
+    got = pend.wait()
+    again = gather_results(torch.from_numpy(rec), torch.from_numpy(ops), len(r.ops), dst=0)
+    if rank == 0:
+        assert all(torch.equal(a, b) for a, b in zip(got[0], again[0]))
+        assert all(torch.equal(a, b) for a, b in zip(got[1], again[1]))
     if rank == 0:
         recs, opss = got
         scores, cigars = [], []

@@ -21,13 +21,32 @@ def shard_range(n_total: int, rank: int, world: int) -> Tuple[int, int]:
     return begin, begin + base + (1 if rank < rem else 0)
 
 
-def gather_results(rec: torch.Tensor, ops: torch.Tensor, n_ops: int, dst: int = 0
-                   ) -> Optional[Tuple[List[torch.Tensor], List[torch.Tensor]]]:
-    """Gather every rank's result records [n_i, 16] (int32) and the used prefix of its op buffer (int64).
+class PendingGather:
+    """A result gather in flight (see gather_results_async).  `wait()` completes it: on a CUDA/HIP device the
+    current stream is made to wait for the collective, not the host."""
 
-    Shards may differ in size, so both arrays are padded to the largest shard before `dist.gather`.  Returns
-    (records per rank, ops per rank) on `dst` (trimmed back to each rank's true sizes), None elsewhere.
-    The OPS_OFF fields of a record index into that rank's own op array.
+    def __init__(self, works, keep, recs, opss, all_sizes, is_dst):
+        self._works, self._keep = works, keep  # `keep` pins the send buffers until the collective is done
+        self._recs, self._opss, self._sizes, self._is_dst = recs, opss, all_sizes, is_dst
+
+    def wait(self) -> Optional[Tuple[List[torch.Tensor], List[torch.Tensor]]]:
+        for wk in self._works:
+            wk.wait()
+        self._works, self._keep = [], None
+        if not self._is_dst:
+            return None
+        return ([r[:int(s[0])] for r, s in zip(self._recs, self._sizes)],
+                [o[:int(s[1])] for o, s in zip(self._opss, self._sizes)])
+
+
+def gather_results_async(rec: torch.Tensor, ops: torch.Tensor, n_ops: int, dst: int = 0) -> PendingGather:
+    """Start the gather of every rank's result records [n_i, 16] (int32) and the used prefix of its op buffer
+    (int64) onto `dst` and return at once.  The send buffers are private copies, so the caller may overwrite
+    `rec` / `ops` (the next batch) while the exchange runs on the collective's own stream.
+
+    Shards may differ in size, so both arrays are padded to the largest shard (sizes are agreed with one tiny
+    all-gather).  `wait()` returns (records per rank, ops per rank) on `dst`, trimmed back to each rank's true
+    sizes, None elsewhere.  The OPS_OFF fields of a record index into that rank's own op array.
     """
     world, rank = dist.get_world_size(), dist.get_rank()
     dev = rec.device
@@ -37,18 +56,22 @@ def gather_results(rec: torch.Tensor, ops: torch.Tensor, n_ops: int, dst: int = 
     max_rec = max(int(s[0]) for s in all_sizes)
     max_ops = max(int(s[1]) for s in all_sizes)
 
-    def padded(t: torch.Tensor, rows: int) -> torch.Tensor:
-        if t.shape[0] == rows:
-            return t.contiguous()
-        out = torch.zeros((rows,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
+    def padded_copy(t: torch.Tensor, rows: int) -> torch.Tensor:
+        out = torch.empty((rows,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
         out[:t.shape[0]] = t
+        if rows > t.shape[0]:
+            out[t.shape[0]:] = 0
         return out
 
-    rec_p, ops_p = padded(rec, max_rec), padded(ops[:n_ops], max_ops)
+    rec_p, ops_p = padded_copy(rec, max_rec), padded_copy(ops[:n_ops], max_ops)
     recs = [torch.empty_like(rec_p) for _ in range(world)] if rank == dst else None
     opss = [torch.empty_like(ops_p) for _ in range(world)] if rank == dst else None
-    dist.gather(rec_p, recs, dst=dst)
-    dist.gather(ops_p, opss, dst=dst)
-    if rank != dst:
-        return None
-    return ([r[:int(s[0])] for r, s in zip(recs, all_sizes)], [o[:int(s[1])] for o, s in zip(opss, all_sizes)])
+    w1 = dist.gather(rec_p, recs, dst=dst, async_op=True)
+    w2 = dist.gather(ops_p, opss, dst=dst, async_op=True)
+    return PendingGather([w1, w2], (rec_p, ops_p), recs, opss, all_sizes, rank == dst)
+
+
+def gather_results(rec: torch.Tensor, ops: torch.Tensor, n_ops: int, dst: int = 0
+                   ) -> Optional[Tuple[List[torch.Tensor], List[torch.Tensor]]]:
+    """Blocking form of gather_results_async."""
+    return gather_results_async(rec, ops, n_ops, dst).wait()
