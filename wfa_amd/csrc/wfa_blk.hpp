@@ -345,8 +345,9 @@ __global__ __launch_bounds__(64, (G == 16 ? 4 : WFA_BLK8_WAVES)) void wfa_blk_ke
                 const int      remc = h ? imin2(imax2(rem, 0), 16) : 0;
                 const int      v    = h - (k0 + p);  // absent cells read a harmless word (LDS reads cannot fault)
                 const uint32_t xr   = SeqView<0>::win16(lq, v) ^ SeqView<0>::win16(lt, h);
-                nM[p] += umin2(ffbl_raw(xr) >> 1, (uint32_t)remc);
-                if (xr == 0u && rem > 16 && h) cmask |= 1u << p;
+                const uint32_t cnt  = umin2(ffbl_raw(xr) >> 1, (uint32_t)remc);
+                nM[p] += cnt;
+                if (cnt == 16u && rem > 16) cmask |= 1u << p;  // the whole window matched and bases remain
             }
             // the few cells (normally the one on the alignment path) that matched a whole window: each lane takes its
             // candidates one at a time and keeps comparing 16-base windows until a mismatch or a sequence end
