@@ -192,10 +192,8 @@ __global__ __launch_bounds__(64, (G == 16 ? 4 : WFA_BLK8_WAVES)) void wfa_blk_ke
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
 #endif
-    // one score step of every running pair; PH = step & 3 selects the ring slots at compile time.
-    // Returns true when the queue is exhausted and no pair is left.
-    const auto step = [&](auto ph_c) __attribute__((always_inline)) -> bool {
-        constexpr int ph = decltype(ph_c)::value;
+    // refill of idle groups; returns true when the queue is exhausted and no pair is left
+    const auto refill = [&]() __attribute__((always_inline)) -> bool {
         {
             // ------------------------------------------------------------ refill: all groups that need a pair take
             // consecutive queue entries with ONE atomic, load their pair's lengths/offsets together, and stage +
@@ -267,7 +265,13 @@ __global__ __launch_bounds__(64, (G == 16 ? 4 : WFA_BLK8_WAVES)) void wfa_blk_ke
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (__ballot(st != 2) == 0ull) return true;
+            return __ballot(st != 2) == 0ull;
+        }
+    };
+    // one score step of every running pair; PH = step & 3 selects the ring slots at compile time
+    const auto step = [&](auto ph_c) __attribute__((always_inline)) {
+        constexpr int ph = decltype(ph_c)::value;
+        {
             const bool run = (st == 1);
             WFA_STAMP(0); WFA_MARK(0);  // refill
 
@@ -541,14 +545,31 @@ __global__ __launch_bounds__(64, (G == 16 ? 4 : WFA_BLK8_WAVES)) void wfa_blk_ke
             }
             WFA_STAMP(5); WFA_MARK(5);  // ring + finish + window
         }
-        return false;
     };
-    for (;;) {
-        if (step(std::integral_constant<int, 0>{})) break;
-        if (step(std::integral_constant<int, 1>{})) break;
-        if (step(std::integral_constant<int, 2>{})) break;
-        if (step(std::integral_constant<int, 3>{})) break;
+#ifndef WFA_BLK_SHARED_REFILL
+    for (;;) {  // four copies of refill + step: 68 KB of code, but measured 6 % faster than the switch below
+        if (refill()) break;
+        step(std::integral_constant<int, 0>{});
+        if (refill()) break;
+        step(std::integral_constant<int, 1>{});
+        if (refill()) break;
+        step(std::integral_constant<int, 2>{});
+        if (refill()) break;
+        step(std::integral_constant<int, 3>{});
     }
+#else
+    // experiment: one copy of the refill code, the four ring phases of the step selected by a wave-uniform switch
+    // (40 KB of code; slower: the merge after the switch costs register moves)
+    for (int ph = 0;; ph = (ph + 1) & 3) {
+        if (refill()) break;
+        switch (ph) {
+        case 0: step(std::integral_constant<int, 0>{}); break;
+        case 1: step(std::integral_constant<int, 1>{}); break;
+        case 2: step(std::integral_constant<int, 2>{}); break;
+        default: step(std::integral_constant<int, 3>{}); break;
+        }
+    }
+#endif
 #ifdef WFA_STAMPS
     if (lane == 0 && P.debug_info) {
         unsigned long long *acc = reinterpret_cast<unsigned long long *>(P.debug_info);
