@@ -498,7 +498,11 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
             Job jb, ja;
             jb.mode = 1, jb.level = 0, jb.all = false;
             ja.mode = 0, ja.level = 0, ja.all = false;
-            if (kind1 >= 2 && can_b && !redo1.empty()) {
+            // A few thousand leftovers finish sooner as one generic launch (one wave per pair, all of them resident at
+            // once, backtrace included) than through another forward + backtrace pass; beyond that the LDS-ring
+            // kernel's throughput wins.
+            const uint64_t resident_generic = (uint64_t)ctx->num_cus * 32;
+            if (kind1 >= 2 && can_b && redo1.size() > resident_generic) {
                 // second chance on the LDS-ring kernel (64-diagonal bands at any alignment) for band/arena misses
                 std::vector<uint32_t> lst;
                 for (uint64_t e : redo1) {
