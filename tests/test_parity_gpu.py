@@ -271,6 +271,30 @@ def test_multiwave_configuration(built):
             al.close()
 
 
+@pytest.mark.parametrize("team_wgs,solo_max", [(2, 0), (5, 16), (3, 4096)])
+def test_team_kernel_small(built, team_wgs, solo_max):
+    """wfa_team_kernel (several workgroups per pair, for wide wavefronts) forced onto short pairs: team mode for
+    every row (solo_max 0), switches between team and solo mode (16), solo mode after the first barrier (4096);
+    global and semi-global, wf-adaptive on and off (the arena retry ladder runs through it too)."""
+    import wfa_amd as w
+    from oracle import oracle as O
+    data = w.generate_pairs(seed=11, n_pairs=40, length=700, error_rate=0.1)
+    for glob in (True, False):
+        for ad in ((10, 50, 1), None):
+            al = _aligner(glob, ad)
+            for k, v in (("packed", 0), ("team_min_len", 1), ("team_wgs", team_wgs), ("team_solo_max", solo_max)):
+                al.set_option(k, v)
+            got = al.align_arrays(*data)
+            want = O.align_batch(_oracle_params(glob, ad), *data, n_threads=8)
+            assert_batch_equal(got, want, f"team T={team_wgs} solo_max={solo_max} glob={glob} ad={ad}")
+            ref = _aligner(glob, ad)
+            ref.set_option("packed", 0), ref.set_option("team_min_len", 0)
+            ref.align_arrays(*data)
+            assert al.last_timing().cells_stored == ref.last_timing().cells_stored
+            ref.close()
+            al.close()
+
+
 def test_long_pair_semiglobal(built):
     """One 20 kbp pair, semi-global + adaptive (wide seeded wavefronts, 256 threads per pair)."""
     import wfa_amd as w
@@ -285,15 +309,21 @@ def test_long_pair_semiglobal(built):
 
 def test_config5_sample(built):
     """BASELINE configs[4] in miniature: 40 kbp pairs @10 %, semi-global + wf-adaptive.  The seeded wavefronts
-    are ~8e4 diagonals wide for thousands of scores (the reference's own rules), so this exercises the
-    1024-thread configuration, the arena retry ladder into multi-GB slots and the parallel end-cell search."""
+    are ~8e4 diagonals wide for thousands of scores (the reference's own rules), so this exercises the team
+    kernel (several workgroups per pair: team and solo mode, team-wide end-cell search) and the arena retry
+    ladder into multi-GB slots; the one-workgroup-per-pair kernel must give the same records."""
     import wfa_amd as w
     from oracle import oracle as O
     data = w.generate_pairs(seed=5, n_pairs=2, length=40000, error_rate=0.10)
     al = _aligner(False, (10, 50, 1))
     got = al.align_arrays(*data)
-    assert_batch_equal(got, O.align_batch(_oracle_params(False), *data, n_threads=2), "C5 sample")
+    want = O.align_batch(_oracle_params(False), *data, n_threads=2)
+    assert_batch_equal(got, want, "C5 sample")
     assert al.last_timing().n_launches >= 2
+    cells = al.last_timing().cells_stored
+    al.set_option("team_min_len", 0)  # wfa_generic_kernel<16,0>
+    assert_batch_equal(al.align_arrays(*data), want, "C5 sample, one workgroup per pair")
+    assert al.last_timing().cells_stored == cells
     al.close()
 
 

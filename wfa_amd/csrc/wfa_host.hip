@@ -8,6 +8,7 @@
 #include "wfa_packed.hpp"
 #include "wfa_reg.hpp"
 #include "wfa_blk.hpp"
+#include "wfa_team.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -51,6 +52,7 @@ struct wfahip_ctx {
     std::vector<hipEvent_t> evpool;
     hipEvent_t    ev0 = nullptr, ev1 = nullptr, evA = nullptr, evB = nullptr, evC = nullptr;
     DevBuf        arena, ctrl, redo, work, meta;
+    DevBuf        team_ctl;                  // barrier counters / reduction sets of the team kernel
     DevBuf        arena2, meta2;             // retry passes run beside the first pass's backtrace kernel
     hipEvent_t    evBtA = nullptr, evBtB = nullptr;
     bool          bt_pending = false;        // the first pass's backtrace kernel is still running on stream2
@@ -65,6 +67,10 @@ struct wfahip_ctx {
     int64_t       opt_packed_arena_bytes   = 0;  // per pair, 0 = automatic
     int64_t       opt_chunk_pairs          = 0;  // 0 = automatic
     int64_t       opt_packed_waves_per_cu  = 0;  // 0 = automatic
+    int64_t       opt_team_min_len         = 8192;  // pairs at least this long use the team kernel (several workgroups
+                                                    // per pair) in the generic ladder; 0 = never
+    int64_t       opt_team_wgs             = 0;     // workgroups per team, 0 = automatic
+    int64_t       opt_team_solo_max        = TEAM_SOLO_MAX;  // rows up to this width are done by one workgroup
     int64_t       opt_tail_overlap         = 1;  // 1: retry passes overlap the backtrace kernel of the first pass
     int64_t       opt_overlap              = 0;  // 1: backtrace of chunk c on a second stream beside the forward kernel of chunk c+1 (measured: no gain)
     int           force_mode               = -1;  // debug: start the ladder in this mode
@@ -237,7 +243,7 @@ extern "C" int wfahip_create(int device_id, wfahip_ctx **out) {
 extern "C" void wfahip_destroy(wfahip_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    for (DevBuf *b : {&ctx->arena, &ctx->arena2, &ctx->meta2, &ctx->ctrl, &ctx->redo, &ctx->work, &ctx->meta, &ctx->in_blob, &ctx->in_qoff, &ctx->in_qlen,
+    for (DevBuf *b : {&ctx->arena, &ctx->team_ctl, &ctx->arena2, &ctx->meta2, &ctx->ctrl, &ctx->redo, &ctx->work, &ctx->meta, &ctx->in_blob, &ctx->in_qoff, &ctx->in_qlen,
                       &ctx->in_toff, &ctx->in_tlen, &ctx->out_rec, &ctx->out_ops})
         release(*b);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -278,6 +284,12 @@ extern "C" int wfahip_set_option(wfahip_ctx *ctx, const char *key, int64_t value
         ctx->opt_overlap = value;
     else if (k == "tail_overlap")
         ctx->opt_tail_overlap = value;
+    else if (k == "team_min_len")
+        ctx->opt_team_min_len = value;
+    else if (k == "team_wgs")
+        ctx->opt_team_wgs = value;
+    else if (k == "team_solo_max")
+        ctx->opt_team_solo_max = value;
     else
         return WFAHIP_ERR_BAD_ARG;
     return WFAHIP_OK;
@@ -556,6 +568,25 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
             cr       = make_cfg(ctx, max_len, 1, job.level, n_work, cfg);
         }
         if (debug_single) cfg.slots = 1;
+        // Wide wavefronts: a team of workgroups per pair (wfa_team_kernel) instead of one workgroup per pair.
+        uint32_t team_T = 0, team_n = 0;
+        if (cr == 0 && !debug_single && ctx->opt_team_min_len > 0 && max_len >= (uint64_t)ctx->opt_team_min_len &&
+            std::max(P.x, std::max(P.oe, P.e)) / P.g < (uint32_t)TEAM_RING) {
+            const uint32_t cus = (uint32_t)std::max(1, ctx->num_cus);
+            uint32_t t0 = (uint32_t)std::min<uint64_t>(cus, std::max<uint64_t>(2, (2ull * max_len + 4095) / 4096));
+            if (ctx->opt_team_wgs > 0) t0 = (uint32_t)std::min<int64_t>(cus, ctx->opt_team_wgs);
+            team_n = (uint32_t)std::min<uint64_t>(n_work, std::max<uint32_t>(1, cus / t0));
+            team_T = ctx->opt_team_wgs > 0 ? t0 : cus / team_n;
+            // one arena per team
+            const uint64_t budget = (uint64_t)((double)ctx->total_mem * 0.6);
+            while (team_n > 1 && (uint64_t)team_n * cfg.arena_words * 4ull > budget) team_n--;
+            if ((uint64_t)team_n * cfg.arena_words * 4ull > budget) cr = 2;
+            if (ctx->opt_team_wgs == 0) team_T = std::min<uint32_t>(cus / team_n, 2 * t0);  // ~2 cells per thread and stripe
+            cfg.slots         = team_n;
+            cfg.lds_seq_words = (cfg.lds_seq_words + 1u) & ~1u;
+            cfg.lds_bytes     = (2ull * cfg.lds_seq_words + 16 + TEAM_RING * (sizeof(DirEnt) / 4)) * 4ull;
+            if (cfg.lds_bytes > LDS_MAX_BYTES) team_T = 0;  // (cannot happen: make_cfg already bounded the sequences)
+        }
         if (cr == 2 || job.level > max_level) {
             if (job.all) {
                 no_memory.resize(n_pairs);
@@ -587,11 +618,39 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
         }
         HIP_TRY(hipMemsetAsync(d_ctrl, 0, 8, st));  // queue_head, redo_count
         HIP_TRY(hipEventRecord(ctx->evA, st));
-        HIP_TRY(launch_generic(P, cfg, st));
+        if (team_T > 0) {
+            if ((rc = ensure(ctx, ctx->team_ctl, (size_t)team_n * TEAM_CTL_WORDS * 4))) return rc;
+            HIP_TRY(hipMemsetAsync(ctx->team_ctl.p, 0, (size_t)team_n * TEAM_CTL_WORDS * 4, st));
+            auto kfn = job.mode == 0 ? wfa_team_kernel<0> : wfa_team_kernel<1>;
+            if (cfg.lds_bytes > 48 * 1024)
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)cfg.lds_bytes));
+            hipLaunchKernelGGL(kfn, dim3(team_n * team_T), dim3(TEAM_THREADS), cfg.lds_bytes, st, P,
+                               static_cast<uint32_t *>(ctx->team_ctl.p), team_T, (uint32_t)std::max<int64_t>(0, ctx->opt_team_solo_max));
+            HIP_TRY(hipGetLastError());
+        } else {
+            HIP_TRY(launch_generic(P, cfg, st));
+        }
         HIP_TRY(hipEventRecord(ctx->evB, st));
         uint32_t hctrl[CTRL_WORDS];
         HIP_TRY(hipMemcpyAsync(hctrl, d_ctrl, sizeof hctrl, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        if (team_T > 0) {  // a team barrier that ran into its spin bound
+            std::vector<uint32_t> tc((size_t)team_n * TEAM_CTL_WORDS);
+            HIP_TRY(hipMemcpy(tc.data(), ctx->team_ctl.p, tc.size() * 4, hipMemcpyDeviceToHost));
+#ifdef WFA_TEAM_STAMPS
+            for (uint32_t t = 0; t < team_n; t++) {
+                const unsigned long long *a = reinterpret_cast<const unsigned long long *>(&tc[(size_t)t * TEAM_CTL_WORDS + 64]);
+                std::fprintf(stderr, "[team %u] us: P1 %.0f  barriers %.0f  P2 %.0f  P3 %.0f  tail(team) %.0f  solo steps %.0f\n", t,
+                             a[0] / 100.0, a[1] / 100.0, a[2] / 100.0, a[3] / 100.0, a[4] / 100.0, a[5] / 100.0);
+            }
+#endif
+            for (uint32_t t = 0; t < team_n; t++)
+                if (tc[(size_t)t * TEAM_CTL_WORDS + 1] != 0u) {
+                    std::snprintf(ctx->last_error, sizeof ctx->last_error, "team kernel: barrier timeout in team %u", t);
+                    return WFAHIP_ERR_INTERNAL;
+                }
+        }
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, ctx->evA, ctx->evB));
         ctx->timing.kernel_ms += ms;

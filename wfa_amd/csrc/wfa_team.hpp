@@ -1,0 +1,605 @@
+// wfa_team.hpp -- kernel E: the general alignment kernel for WIDE wavefronts, several workgroups per pair.
+//
+// Semi-global alignment seeds a cell on every diagonal (wfa.go:163-183), and wf-adaptive only removes diagonals
+// that fall 50 bases behind the best one (wfa.go:507), so a 100 kbp pair keeps 2e5-diagonal wavefronts alive for
+// thousands of scores: 1e9 and more stored cells per pair.  One workgroup per pair (wfa_generic_kernel) then runs
+// at one CU's memory bandwidth while 255 CUs idle.  Here a TEAM of T workgroups (one per CU, all resident) works
+// on one pair at a time: every score step cuts the diagonal range into T*1024-wide stripes, workgroup b takes the
+// b-th 1024 diagonals of every stripe (coalesced rows), and the reductions of the step (tight range of M, the
+// termination test, the wf-adaptive minimum distance, first/last surviving diagonal) go through block reductions
+// in LDS, one global atomic per workgroup and a team barrier.  Same per-cell code as the generic kernel
+// (next_cell / seed_word / extend_word / reduce_dist), same arena layout (rows + 32-byte directory), same
+// backtrace.
+//
+// Inter-workgroup visibility (per-XCD L2s are not coherent, a CU's L1 is never refreshed by other CUs' stores):
+// while the team works together every arena access is an agent-scope relaxed atomic load / store (sc1: served by
+// the memory side, not by the XCD's L2), so the per-step barriers need no cache write-back or invalidate: they are
+// __syncthreads (drains every wave's stores) -> one lane: atomic arrive, bounded spin on the counter with
+// agent-scope loads -> __syncthreads.  Rows written before a barrier are read by other workgroups only after it.
+//
+// Narrow rows do not pay for barriers: when a row is at most TEAM_SOLO_MAX diagonals wide the team switches to
+// SOLO mode -- workgroup 0 runs the steps alone with plain (L2-cached) accesses and __syncthreads only, the others
+// park in a barrier -- and back to team mode when the row grows again (workgroup 0 publishes score, arena top and
+// directory; the others reload the last directory entries).  The mode switches and the end of a pair use a FENCED
+// barrier (agent-scope release before the arrive, acquire after the spin).  After wf-adaptive has collapsed the
+// band of a semi-global pair the rest of the alignment runs solo at the generic kernel's speed.
+//
+// A barrier that does not complete within the spin bound raises the team's abort flag and every workgroup leaves
+// (the host reports an internal error instead of hanging the device).
+#pragma once
+#include "wfa_device.hpp"
+
+namespace wfa {
+
+constexpr int TEAM_THREADS   = 1024;
+constexpr int TEAM_RING      = 64;   // directory entries every workgroup keeps in LDS (sources reach back < 64 scores)
+constexpr int TEAM_CTL_WORDS = 128;  // per team, in global memory: [0] barrier count [1] abort [2] work index
+                                     // [3] cells [4] command [5] score [6..7] arena top [8 + 8*set ..] three reduction sets
+                                     // [48..49] end-cell key (u64) [64..] diagnostic stamps
+constexpr uint32_t TEAM_SPIN_LIMIT = 1u << 24;
+#ifndef WFA_TEAM_U
+#define WFA_TEAM_U 2
+#endif
+constexpr int      TEAM_U          = WFA_TEAM_U;     // cells of a thread in flight together / kept in registers per row
+constexpr uint32_t TEAM_SOLO_MAX   = 4096;  // default: rows up to this width are done by workgroup 0 alone
+enum : uint32_t { TEAM_CMD_NONE = 0, TEAM_CMD_RESUME = 1, TEAM_CMD_DONE = 2 };  // ctl[4]; ctl[5] = score, ctl[6..7] = top
+
+struct TeamRed {  // one reduction set (global memory)
+    int mlo, mhi, term, mind, first_ok, last_ok, anyfail, lead;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P, uint32_t *team_ctl, uint32_t T,
+                                                                uint32_t solo_max) {
+    constexpr int G = TEAM_THREADS;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t *const lq   = lds;
+    uint32_t *const lt   = lds + P.lds_seq_words;
+    int *const      red  = reinterpret_cast<int *>(lds + 2 * (MODE == 0 ? P.lds_seq_words : 0));  // 16 ints
+    DirEnt *const   ring = reinterpret_cast<DirEnt *>(red + 16);                                   // TEAM_RING entries
+
+    const int      tid = threadIdx.x, lane = tid & 63;
+    const uint32_t team = blockIdx.x / T, b = blockIdx.x % T;
+    uint32_t *const ctl = team_ctl + (uint64_t)team * TEAM_CTL_WORDS;
+    uint32_t *const A   = P.arena + (uint64_t)team * P.arena_words;
+    const uint64_t cap  = P.arena_words;
+    const uint32_t x = P.x, oe = P.oe, e = P.e, g = P.g;
+    const int64_t  stripe = (int64_t)T * G;
+
+#ifdef WFA_TEAM_STAMPS
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memrealtime();
+#define TEAM_STAMP(i)                                                  \
+    do {                                                               \
+        const unsigned long long _t = __builtin_amdgcn_s_memrealtime(); \
+        tacc[i] += _t - tprev;                                         \
+        tprev = _t;                                                    \
+    } while (0)
+#else
+#define TEAM_STAMP(i) \
+    do {              \
+    } while (0)
+#endif
+    uint32_t bar_target = 0;  // barriers are counted: the n-th one completes at n*T arrivals
+    bool     aborted    = false;
+    auto team_barrier = [&](bool fenced) {
+        __syncthreads();
+        if (tid == 0) {
+            bar_target += T;
+            if (fenced) __threadfence();
+            bool bad = false;
+            // the last workgroup to arrive sees the full count in the value its own atomic returns
+            if (atomicAdd(&ctl[0], 1u) + 1u < bar_target) {
+                uint32_t spins = 0;
+                while (__hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < bar_target) {
+                    if ((++spins & 1023u) == 0u &&
+                        (spins > TEAM_SPIN_LIMIT || __hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                        atomicExch(&ctl[1], 1u);
+                        bad = true;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(4);
+                }
+            }
+            if (fenced) __threadfence();
+            red[15] = bad ? 1 : 0;
+        }
+        __syncthreads();
+        aborted = red[15] != 0;
+    };
+    const auto ald = [](const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    const auto ast = [](uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto tred = [&](uint32_t set) { return reinterpret_cast<TeamRed *>(ctl + 8 + 8 * set); };
+    auto reset_set = [&](TeamRed *r) {  // memory-side stores: the other workgroups' atomics must see them
+        uint32_t *const w = reinterpret_cast<uint32_t *>(r);
+        const int       v[8] = {INT32_MAX, INT32_MIN, 0, INT32_MAX, INT32_MAX, INT32_MIN, 0, INT32_MIN};
+#pragma unroll
+        for (int i = 0; i < 8; i++) __hip_atomic_store(w + i, (uint32_t)v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+
+    for (;;) {
+        // ---- the team's next pair: workgroup 0 pulls it, the barrier publishes it
+        if (b == 0 && tid == 0) {
+            const uint32_t w0 = atomicAdd(P.queue_head, 1u);
+            __hip_atomic_store(&ctl[2], w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ctl[3], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ctl[4], (uint32_t)TEAM_CMD_NONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ctl[48], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ctl[49], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            reset_set(tred(0)), reset_set(tred(1)), reset_set(tred(2));
+        }
+        team_barrier(true);
+        if (aborted) return;
+        const uint32_t wi = __hip_atomic_load(&ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (wi >= P.n_work) return;
+        const uint32_t pair = P.work ? P.work[wi] : wi;
+        uint32_t *const rec = P.rec + (uint64_t)pair * REC_WORDS;
+        const bool      lead_wg = (b == 0);
+
+        const uint32_t nq = P.q_len[pair], mt = P.t_len[pair];
+        if (nq == 0 || mt == 0 || nq > 0x1FFFFFFFu || mt > 0x1FFFFFFFu) {  // wfa.go:204-209
+            if (lead_wg && tid < REC_WORDS) rec[tid] = (tid == REC_STATUS) ? ((nq == 0 || mt == 0) ? ST_EMPTY : ST_TOO_LONG) : 0u;
+            continue;
+        }
+        const int n = (int)nq, m = (int)mt, Ak = m - n;
+
+        SeqView<MODE> sv;
+        sv.n = n, sv.m = m;
+        if constexpr (MODE == 0) {
+            const uint32_t need = ((imax2(n, m) + 15) >> 4) + 1;
+            if (need > P.lds_seq_words) {
+                if (lead_wg && tid == 0) {
+                    rec[REC_STATUS] = ST_REDO_LDS;
+                    push_redo(P, pair, ST_REDO_LDS);
+                }
+                continue;
+            }
+            if (tid == 0) red[9] = 0;
+            __syncthreads();
+            bool bad = stage_pack<G>(P.blob, P.q_off[pair], nq, lq, tid);
+            bad |= stage_pack<G>(P.blob, P.t_off[pair], mt, lt, tid);
+            if (__ballot(bad) != 0ull && lane == 0) red[9] = 1;
+            __syncthreads();
+            if (red[9]) {  // every workgroup staged the same bytes and takes the same decision
+                if (lead_wg && tid == 0) {
+                    rec[REC_STATUS] = ST_REDO_BYTES;
+                    push_redo(P, pair, ST_REDO_BYTES);
+                }
+                continue;
+            }
+            sv.q = lq, sv.t = lt;
+        } else {
+            sv.q = P.blob + P.q_off[pair];
+            sv.t = P.blob + P.t_off[pair];
+        }
+
+        // ---- score loop
+        const bool glob    = P.global_alignment != 0;
+        const int  seed_lo = glob ? 0 : -(n - 1), seed_hi = glob ? 0 : m - 1;
+        uint64_t   top     = 0;  // next free arena word (identical in every active workgroup)
+        uint32_t   n_ent   = 0;
+        bool       overflow = false, done = false;
+        uint32_t   s_final  = 0;
+        uint64_t   my_cells = 0;
+        bool       teamed   = true;  // team mode (all workgroups step together) / solo mode (workgroup 0 alone)
+        auto dir_ptr = [&](uint32_t idx) { return A + cap - (uint64_t)DIR_WORDS * (idx + 1); };
+        const DirEnt none = {0ull, 0, 0, 0u, {0u, 0u, 0u}};
+        auto put_ent = [&](uint32_t idx, uint64_t base, int lo_, int w_, uint32_t stride) {
+            if (tid == 0) {
+                DirEnt d;
+                d.base = base, d.lo = lo_, d.w = w_, d.stride = stride, d.pad[0] = d.pad[1] = d.pad[2] = 0u;
+                ring[idx % TEAM_RING] = d;
+                if (lead_wg) store_dir(dir_ptr(idx), base, lo_, w_, stride);
+            }
+        };
+        // arena words: coherent (memory-side) in team mode, plain (L2-cached) in solo mode
+        auto ldw = [&](const uint32_t *p_) { return teamed ? ald(p_) : *p_; };
+        auto stw = [&](uint32_t *p_, uint32_t v_) {
+            if (teamed)
+                ast(p_, v_);
+            else
+                *p_ = v_;
+        };
+        // one reduction of the step: block result in LDS slot `slot`, team result through the set's global word
+        auto team_min = [&](int *gword, int slot) {
+            if (teamed && tid == 0) atomicMin(gword, red[slot]);
+        };
+        auto team_max = [&](int *gword, int slot) {
+            if (teamed && tid == 0) atomicMax(gword, red[slot]);
+        };
+        auto team_or = [&](int *gword, int slot) {
+            if (teamed && tid == 0 && red[slot]) atomicOr(gword, 1);
+        };
+        auto team_get = [&](int *gword, int slot) {
+            if (teamed && tid == 0) red[slot] = __hip_atomic_load(gword, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+
+        uint32_t s = 0;
+        for (;; s += g) {
+            const uint32_t si = s / g;
+            TeamRed *const tr = tred(si % 3u);
+            // the set of the next score was last used three scores ago; every workgroup is past that score
+            if (lead_wg && tid == 0) reset_set(tred((si + 1u) % 3u));
+            // sources: M[s-x], M[s-o-e], I[s-e] / D[s-e]  (wfa.go:557-560; missing when diff > s)
+            const DirEnt eX = (s >= x) ? ring[(si - x / g) % TEAM_RING] : none;
+            const DirEnt eO = (s >= oe) ? ring[(si - oe / g) % TEAM_RING] : none;
+            const DirEnt eE = (s >= e) ? ring[(si - e / g) % TEAM_RING] : none;
+            const bool   seeded = (s == 0u) || (s == x);
+
+            int lo = INT32_MAX, hi = INT32_MIN;
+            if (eX.w > 0) lo = imin2(lo, eX.lo - 1), hi = imax2(hi, eX.lo + eX.w);
+            if (eO.w > 0) lo = imin2(lo, eO.lo - 1), hi = imax2(hi, eO.lo + eO.w);
+            if (eE.w > 0) lo = imin2(lo, eE.lo - 1), hi = imax2(hi, eE.lo + eE.w);
+            lo = imax2(lo, -(n - 1));  // wfa.go:562-563
+            hi = imin2(hi, m - 1);
+            if (s == 0u) lo = INT32_MAX, hi = INT32_MIN;  // the reference never calls next(0)
+            if (seeded) lo = imin2(lo, seed_lo), hi = imax2(hi, seed_hi);
+
+            const int64_t W = (hi >= lo) ? ((int64_t)hi - lo + 1) : 0;
+            if (top + 3ull * (uint64_t)W + (uint64_t)DIR_WORDS * (si + 2) > cap) {
+                overflow = true;
+                break;
+            }
+            __syncthreads();  // everybody has read the ring entries before the slot of this score is rewritten
+
+            // ---- mode switches (every active workgroup computes the same W)
+            if (teamed && W <= (int64_t)solo_max && T > 1) {
+                // team -> solo: the rows so far become visible to workgroup 0's plain loads; the others park
+                team_barrier(true);
+                if (aborted) return;
+                teamed = false;
+                if (!lead_wg) {
+                    bool resumed = false;
+                    for (;;) {  // parked: workgroup 0 arrives here when the row is wide again or the pair is over
+                        team_barrier(true);
+                        if (aborted) return;
+                        const uint32_t cmd = ald(&ctl[4]);
+                        if (cmd == TEAM_CMD_DONE) {  // how the pair ended: everybody takes part in the end-cell search
+                            s_final = ald(&ctl[5]);
+                            const uint32_t fl = ald(&ctl[50]);
+                            done = (fl & 1u) != 0u, overflow = (fl & 2u) != 0u;
+                            break;
+                        }
+                        if (cmd == TEAM_CMD_RESUME) {
+                            s   = ald(&ctl[5]);
+                            top = (uint64_t)ald(&ctl[6]) | ((uint64_t)ald(&ctl[7]) << 32);
+                            const uint32_t si2 = s / g;
+                            if (tid < TEAM_RING && (uint32_t)tid < si2) {  // the directory entries the next scores can source
+                                const uint32_t idx = si2 - 1u - (uint32_t)tid;
+                                ring[idx % TEAM_RING] = load_dir(dir_ptr(idx));
+                            }
+                            n_ent  = si2;
+                            teamed = true;
+                            resumed = true;
+                            __syncthreads();
+                            break;
+                        }
+                    }
+                    if (!resumed) break;  // pair over
+                    s -= g;               // redo the loop head for score s in team mode
+                    continue;
+                }
+            } else if (!teamed && W > (int64_t)solo_max) {
+                // solo -> team (only workgroup 0 is here): publish where we are and wake the others
+                if (tid == 0) {
+                    ast(&ctl[5], s), ast(&ctl[6], (uint32_t)top), ast(&ctl[7], (uint32_t)(top >> 32));
+                    ast(&ctl[4], (uint32_t)TEAM_CMD_RESUME);
+                }
+                team_barrier(true);
+                if (aborted) return;
+                teamed = true;
+            }
+
+            if (W == 0) {
+                put_ent(si, 0ull, 0, 0, 0u);
+                n_ent = si + 1;
+                __syncthreads();
+                continue;
+            }
+            const uint64_t base = top;
+            uint32_t *const rowM = A + base, *const rowI = rowM + W, *const rowD = rowI + W;
+            if (tid == 0) {
+                red[0] = INT32_MAX, red[1] = INT32_MIN, red[2] = 0, red[3] = INT32_MAX;
+                red[4] = INT32_MAX, red[5] = INT32_MIN, red[6] = 0, red[7] = INT32_MIN;
+            }
+            __syncthreads();
+            const int64_t i0 = teamed ? (int64_t)b * G + tid : tid, istep = teamed ? stripe : G;
+
+            auto src = [&](const DirEnt &d, int comp, int k) -> uint32_t {
+                return (d.w > 0 && k >= d.lo && k < d.lo + d.w)
+                           ? ldw(A + d.base + (uint64_t)comp * d.stride + (uint32_t)(k - d.lo))
+                           : 0u;
+            };
+
+            // ---- P1: next + seeds + extend, store rows, partial reductions
+            int mlo = INT32_MAX, mhi = INT32_MIN, term = 0, mind = INT32_MAX;
+            // TEAM_U cells of a thread are in flight together (their source loads overlap: in team mode every load
+            // is a memory-side round trip), and the thread's first TEAM_U cells of the row stay in registers for
+            // the wf-adaptive passes below (kM = M word, kF = number of non-zero I / D words).
+            uint32_t kM[TEAM_U], kF[TEAM_U];
+#pragma unroll
+            for (int u = 0; u < TEAM_U; u++) kM[u] = 0u, kF[u] = 0u;
+            for (int64_t i = i0; i < W; i += TEAM_U * istep) {
+                uint32_t sa[TEAM_U], sb[TEAM_U], sc_[TEAM_U], sd[TEAM_U], sx[TEAM_U];
+#pragma unroll
+                for (int u = 0; u < TEAM_U; u++) {
+                    const int64_t iu = i + u * istep;
+                    const int     k  = lo + (int)iu;
+                    const bool    on = iu < W && s != 0u;
+                    sa[u]  = on ? src(eO, 0, k - 1) : 0u;
+                    sb[u]  = on ? src(eE, 1, k - 1) : 0u;
+                    sc_[u] = on ? src(eO, 0, k + 1) : 0u;
+                    sd[u]  = on ? src(eE, 2, k + 1) : 0u;
+                    sx[u]  = on ? src(eX, 0, k) : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < TEAM_U; u++) {
+                    const int64_t iu = i + u * istep;
+                    if (iu >= W) continue;
+                    const int k = lo + (int)iu;
+                    Cell      c = {0u, 0u, 0u};
+                    if (s != 0u) c = next_cell(sa[u], sb[u], sc_[u], sd[u], sx[u], k, n, m);
+                    if (seeded && c.M == 0u) c.M = seed_word<MODE>(sv, k, s, x, glob);  // Set = last write wins (R2)
+                    c.M = extend_word<MODE>(sv, c.M, k);
+                    stw(rowM + iu, c.M), stw(rowI + iu, c.I), stw(rowD + iu, c.D);
+                    my_cells += (c.M != 0u) + (c.I != 0u) + (c.D != 0u);
+                    if (i == i0) kM[u] = c.M, kF[u] = (c.I != 0u) + (c.D != 0u);
+                    if (c.M != 0u) {
+                        mlo = imin2(mlo, k), mhi = imax2(mhi, k);
+                        if (k == Ak && (int)(c.M >> TAG_BITS) >= m) term = 1;  // wfa.go:235-239
+                        const int d = reduce_dist(c.M, k, n, m);
+                        if (d >= 0) mind = imin2(mind, d);
+                    }
+                }
+            }
+            // the thread's j-th cell of this row: from registers for j < TEAM_U, else from the arena
+            const int64_t i_rest = i0 + TEAM_U * istep;
+            mlo = wave_min(mlo), mhi = wave_max(mhi), mind = wave_min(mind);
+            term = __ballot(term) != 0ull;
+            if (lane == 0) {
+                atomicMin(&red[0], mlo), atomicMax(&red[1], mhi), atomicMin(&red[3], mind);
+                if (term) red[2] = 1;
+            }
+            __syncthreads();
+            if (teamed) {
+                team_min(&tr->mlo, 0), team_max(&tr->mhi, 1), team_or(&tr->term, 2), team_min(&tr->mind, 3);
+                TEAM_STAMP(0);
+                team_barrier(false);  // B1: the rows of this score are visible to the whole team
+                TEAM_STAMP(1);
+                if (aborted) return;
+                team_get(&tr->mlo, 0), team_get(&tr->mhi, 1), team_get(&tr->term, 2), team_get(&tr->mind, 3);
+                __syncthreads();
+            }
+            mlo = red[0], mhi = red[1], term = red[2], mind = red[3];
+            top += 3ull * (uint64_t)W;
+            n_ent = si + 1;
+            if (term) {
+                put_ent(si, base, lo, (int)W, (uint32_t)W);
+                done    = true;
+                s_final = s;
+                break;
+            }
+
+            // ---- reduce (wfa.go:461-540) when M exists at s and its Lo..Hi span is wide enough
+            int nlo = mlo, nhi = mhi;  // surviving band: I and D only hold cells where M does
+            if (P.adaptive && mhi >= mlo && (mhi - mlo + 1) >= (int)P.min_wf_len && mind != INT32_MAX) {
+                const int maxdiff = (int)P.max_dist_diff;
+                int       first_ok = INT32_MAX, last_ok = INT32_MIN, anyfail = 0;
+                auto p2cell = [&](uint32_t mw, int k) {
+                    const int d = reduce_dist(mw, k, n, m);
+                    if (d >= 0) {
+                        if (d - mind > maxdiff)
+                            anyfail = 1;
+                        else
+                            first_ok = imin2(first_ok, k), last_ok = imax2(last_ok, k);
+                    }
+                };
+#pragma unroll
+                for (int u = 0; u < TEAM_U; u++)
+                    if (i0 + u * istep < W) p2cell(kM[u], lo + (int)(i0 + u * istep));
+                for (int64_t i = i_rest; i < W; i += istep) p2cell(ldw(rowM + i), lo + (int)i);
+                first_ok = wave_min(first_ok), last_ok = wave_max(last_ok);
+                anyfail  = __ballot(anyfail) != 0ull;
+                if (lane == 0) {
+                    atomicMin(&red[4], first_ok), atomicMax(&red[5], last_ok);
+                    if (anyfail) red[6] = 1;
+                }
+                __syncthreads();
+                if (teamed) {
+                    team_min(&tr->first_ok, 4), team_max(&tr->last_ok, 5), team_or(&tr->anyfail, 6);
+                    TEAM_STAMP(2);
+                    team_barrier(false);  // B2
+                    TEAM_STAMP(1);
+                    if (aborted) return;
+                    team_get(&tr->first_ok, 4), team_get(&tr->last_ok, 5), team_get(&tr->anyfail, 6);
+                    __syncthreads();
+                }
+                first_ok = red[4], last_ok = red[5], anyfail = red[6];
+                if (anyfail) {
+                    // _lo: one past the last valid entry before the first non-failing one (wfa.go:503-516)
+                    int lead = INT32_MIN;
+#pragma unroll
+                    for (int u = 0; u < TEAM_U; u++) {
+                        const int k = lo + (int)(i0 + u * istep);
+                        if (i0 + u * istep < W && k < first_ok && reduce_dist(kM[u], k, n, m) >= 0) lead = imax2(lead, k);
+                    }
+                    for (int64_t i = i_rest; i < W; i += istep) {
+                        const int k = lo + (int)i;
+                        if (k < first_ok && reduce_dist(ldw(rowM + i), k, n, m) >= 0) lead = imax2(lead, k);
+                    }
+                    lead = wave_max(lead);
+                    if (lane == 0) atomicMax(&red[7], lead);
+                    __syncthreads();
+                    if (teamed) {
+                        team_max(&tr->lead, 7);
+                        TEAM_STAMP(3);
+                        team_barrier(false);  // B3
+                        TEAM_STAMP(1);
+                        if (aborted) return;
+                        team_get(&tr->lead, 7);
+                        __syncthreads();
+                    }
+                    lead = red[7];
+                    nlo  = (lead != INT32_MIN) ? lead + 1 : mlo;
+                    nhi  = last_ok;  // wfa.go:517-524
+                    // wfa.go:526-535 deletes k outside [_lo,_hi] in M, I and D: here the rows are simply narrowed
+#pragma unroll
+                    for (int u = 0; u < TEAM_U; u++) {
+                        const int k = lo + (int)(i0 + u * istep);
+                        if (i0 + u * istep < W && (k < nlo || k > nhi)) my_cells -= (kM[u] != 0u) + kF[u];
+                    }
+                    for (int64_t i = i_rest; i < W; i += istep) {
+                        const int k = lo + (int)i;
+                        if (k < nlo || k > nhi)
+                            my_cells -= (ldw(rowM + i) != 0u) + (ldw(rowI + i) != 0u) + (ldw(rowD + i) != 0u);
+                    }
+                }
+            }
+            if (nhi >= nlo)
+                put_ent(si, base + (uint64_t)(nlo - lo), nlo, nhi - nlo + 1, (uint32_t)W);
+            else
+                put_ent(si, 0ull, 0, 0, 0u);
+            __syncthreads();
+            TEAM_STAMP(teamed ? 4 : 5);
+        }
+#ifdef WFA_TEAM_STAMPS
+        if (lead_wg && tid == 0)
+            for (int i = 0; i < 6; i++) atomicAdd(reinterpret_cast<unsigned long long *>(ctl + 64) + i, tacc[i]), tacc[i] = 0;
+#endif
+
+        // ---- a pair that ends in solo mode: wake the parked workgroups
+        if (!teamed && lead_wg) {
+            if (tid == 0) {
+                ast(&ctl[5], s_final), ast(&ctl[50], (done ? 1u : 0u) | (overflow ? 2u : 0u));
+                ast(&ctl[4], (uint32_t)TEAM_CMD_DONE);
+            }
+            team_barrier(true);
+            if (aborted) return;
+        }
+        // ---- count stored cells across the team
+        if (tid == 0) red[10] = 0;
+        __syncthreads();
+        atomicAdd(reinterpret_cast<unsigned int *>(&red[10]), (unsigned int)(my_cells & 0xFFFFFFFFull));
+        __syncthreads();
+        if (tid == 0) atomicAdd(&ctl[3], (uint32_t)red[10]);
+        team_barrier(true);  // every row, the directory and the cell count are visible to workgroup 0
+        if (aborted) return;
+
+        if (overflow || !done) {
+            if (lead_wg && tid == 0) {
+                rec[REC_STATUS] = ST_REDO_ARENA;
+                push_redo(P, pair, ST_REDO_ARENA);
+            }
+            continue;
+        }
+        // ---- semi-global end cell (backtraceStartPosistion, wfa.go:270-375), whole team.  Per score the reference
+        // scans down from Ak and up from Ak+1, skipping absent cells, until the first cell that either leaves the
+        // matrix (break) or lies on the last row/column (hit): the NEAREST break-or-hit cell on each side.  Scanning
+        // the scores downwards, every hit replaces the previous one (its score is never above the best so far) and
+        // the upward scan overrides the downward one at equal score, so the answer is the hit at the LOWEST score
+        // that has one.  Workgroup b takes the scores s_final/g - b, - b - T, ...; one 64-bit atomic min combines.
+        uint32_t minS  = s_final;
+        int      lastK = Ak;
+        if (!glob) {
+            unsigned int *const ured = reinterpret_cast<unsigned int *>(red);
+            unsigned long long  best = ((unsigned long long)s_final << 32) | 0xFFFFFFFFull;  // low word all ones: no hit
+            for (int64_t idx = (int64_t)(s_final / g) - (int64_t)b; idx >= 0; idx -= (int64_t)T) {
+                const DirEnt en = load_dir(dir_ptr((uint32_t)idx));
+                if (en.w <= 0) continue;  // !M.HasScore(_s)
+                if (tid == 0) ured[4] = 0xFFFFFFFFu, ured[5] = 0xFFFFFFFFu;
+                __syncthreads();
+                const uint32_t *row = A + en.base;
+                unsigned int keyD = 0xFFFFFFFFu, keyU = 0xFFFFFFFFu;
+                for (int64_t i = tid; i < en.w; i += G) {
+                    const uint32_t raw = row[i];
+                    if (raw == 0u) continue;
+                    const int  k = en.lo + (int)i, h = (int)(raw >> TAG_BITS), v = h - k;
+                    const bool stop = (v <= 0 || v > n || h > m);
+                    const bool hit  = !stop && ((v == n && h >= n) || (h == m && v >= m));
+                    if (!(stop || hit)) continue;
+                    if (k <= Ak)
+                        keyD = min(keyD, ((unsigned int)(Ak - k) << 1) | (hit ? 0u : 1u));
+                    else
+                        keyU = min(keyU, ((unsigned int)(k - Ak - 1) << 1) | (hit ? 0u : 1u));
+                }
+                keyD = (unsigned int)wave_min((int)(keyD ^ 0x80000000u)) ^ 0x80000000u;  // unsigned min via signed min
+                keyU = (unsigned int)wave_min((int)(keyU ^ 0x80000000u)) ^ 0x80000000u;
+                if (lane == 0) atomicMin(&ured[4], keyD), atomicMin(&ured[5], keyU);
+                __syncthreads();
+                keyD = ured[4], keyU = ured[5];
+                const unsigned long long sc = (unsigned long long)((uint32_t)idx * g) << 32;
+                if (keyU != 0xFFFFFFFFu && (keyU & 1u) == 0u)
+                    best = min(best, sc | (uint32_t)(Ak + 1 + (int)(keyU >> 1) + 0x40000000));
+                else if (keyD != 0xFFFFFFFFu && (keyD & 1u) == 0u)
+                    best = min(best, sc | (uint32_t)(Ak - (int)(keyD >> 1) + 0x40000000));
+                __syncthreads();
+            }
+            if (tid == 0) atomicMin(reinterpret_cast<unsigned long long *>(ctl + 48), best);
+            team_barrier(false);
+            if (aborted) return;
+            if (lead_wg) {
+                const uint32_t blo = ald(&ctl[48]), bhi = ald(&ctl[49]);
+                if (blo != 0xFFFFFFFFu) minS = bhi, lastK = (int)blo - 0x40000000;
+            }
+        }
+        if (!lead_wg) continue;  // backtrace: workgroup 0 (the others wait at the next pair's barrier)
+
+        // ---- backtrace + result record: one lane
+        if (tid == 0) {
+            ArenaView av;
+            av.A = A, av.cap = cap, av.g = g, av.n_ent = n_ent;
+            uint64_t  scratch0 = (top + 1ull) & ~1ull;
+            uint64_t  dir_lo   = cap - (uint64_t)DIR_WORDS * (uint64_t)n_ent;
+            uint64_t  room     = dir_lo > scratch0 ? (dir_lo - scratch0) / 2ull : 0ull;
+            OpsWriter ow;
+            ow.init(reinterpret_cast<uint64_t *>(A + scratch0), (uint32_t)(room > 0xFFFFFFFFull ? 0xFFFFFFFFull : room));
+            TraceOut to;
+            back_trace(av, n, m, minS, lastK, !glob, x, P.o, e, ow, to);
+            if (ow.overflow) {
+                rec[REC_STATUS] = ST_REDO_ARENA;
+                push_redo(P, pair, ST_REDO_ARENA);
+            } else {
+                // process() (wfa_cigar.go:136-214): the forward list is the scratch list reversed
+                const uint32_t L   = ow.n;
+                const uint64_t off = atomicAdd(P.ops_cursor, (unsigned long long)L);
+                uint32_t begin = 0, end = 0;
+                bool     seenM = false;
+                for (uint32_t i = 0; i < L; i++) {
+                    const uint64_t op = ow.buf[L - 1 - i];
+                    if ((uint32_t)(op >> 32) == 'M') {
+                        if (!seenM) begin = i, seenM = true;
+                        end = i;
+                    }
+                    if (off + i < P.ops_cap) P.ops[off + i] = op;
+                }
+                uint32_t alen = 0, matches = 0, gaps = 0, regions = 0;
+                for (uint32_t i = begin; i <= end && i < L; i++) {
+                    const uint64_t op  = ow.buf[L - 1 - i];
+                    const uint32_t cnt = (uint32_t)op, o = (uint32_t)(op >> 32);
+                    alen += cnt;
+                    if (o == 'M')
+                        matches += cnt;
+                    else if (o == 'I' || o == 'D')
+                        gaps += cnt, regions++;
+                }
+                rec[REC_STATUS]      = ST_OK;
+                rec[REC_SCORE]       = to.score;
+                rec[REC_TBEGIN]      = (uint32_t)to.tbegin;
+                rec[REC_TEND]        = (uint32_t)to.tend;
+                rec[REC_QBEGIN]      = (uint32_t)to.qbegin;
+                rec[REC_QEND]        = (uint32_t)to.qend;
+                rec[REC_ALIGN_LEN]   = alen;
+                rec[REC_MATCHES]     = matches;
+                rec[REC_GAPS]        = gaps;
+                rec[REC_GAP_REGIONS] = regions;
+                rec[REC_OPS_LEN]     = L;
+                rec[REC_OPS_OFF_LO]  = (uint32_t)off;
+                rec[REC_OPS_OFF_HI]  = (uint32_t)(off >> 32);
+                rec[REC_CELLS_LO]    = __hip_atomic_load(&ctl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                rec[REC_CELLS_HI]    = 0u;
+                rec[REC_N_SCORES]    = s_final;
+            }
+        }
+    }
+}
+
+}  // namespace wfa
