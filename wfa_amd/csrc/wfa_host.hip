@@ -597,6 +597,10 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
             continue;
         }
         DevBuf &jarena = ctx->bt_pending ? ctx->arena2 : ctx->arena;
+        // Long pairs climbing the ladder: take the whole arena budget once instead of freeing and re-allocating a
+        // bigger buffer at every level (hipMalloc / hipFree of tens of GB cost more than the alignments).
+        if (team_T > 0 && job.level >= 2 && jarena.bytes < (size_t)((double)ctx->total_mem * 0.6))
+            (void)ensure(ctx, jarena, (size_t)((double)ctx->total_mem * 0.6));
         rc = ensure(ctx, jarena, (size_t)cfg.arena_words * 4ull * cfg.slots);
         if (rc == WFAHIP_ERR_OOM && cfg.slots > 1) {  // shrink once
             cfg.slots = std::max<uint32_t>(1, cfg.slots / 4);
