@@ -140,7 +140,15 @@ int  wfahip_align_batch_device(wfahip_ctx *ctx, const wfahip_params *p, const vo
 
 int  wfahip_last_timing(const wfahip_ctx *ctx, wfahip_timing *out);
 
-/* Tuning knobs (optional): key = "arena_bytes_per_slot", "slots", "threads_per_pair". */
+/* Tuning knobs (optional; results never depend on them).  Keys:
+ *   "blk"  16 | 8 | 0      blocked register-window forward kernel, lanes per pair (0 = off)       default 16
+ *   "reg", "packed"  0|1   allow the strided register-window / LDS-ring forward kernels           default 1
+ *   "packed_arena_bytes"   per-pair arena of the sub-wave pipeline (0 = automatic)
+ *   "chunk_pairs", "packed_waves_per_cu", "overlap"   chunking of the sub-wave pipeline
+ *   "tail_overlap"  0|1    retry passes run beside the first pass's backtrace kernel             default 1
+ *   "arena_bytes_per_slot", "slots", "threads_per_pair"   generic kernel (one workgroup per pair)
+ *   "team_min_len"         pairs at least this long use the team kernel (0 = never)              default 8192
+ *   "team_wgs", "team_solo_max"   workgroups per team (0 = automatic), widest row done by one workgroup */
 int  wfahip_set_option(wfahip_ctx *ctx, const char *key, int64_t value);
 
 /* Debug / parity aid: align ONE pair and return every stored wavefront row.  rows[] receives
