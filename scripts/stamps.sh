@@ -12,8 +12,11 @@ import sys, numpy as np
 sys.path.insert(0, "/tmp/wfa_stamps")
 import wfa_amd as w
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
-data = w.generate_pairs(3, n, 1000, 0.05, n_threads=32)
-al = w.New(); al.AdaptiveReduction(w.DefaultAdaptiveOption)
+length = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+err = float(sys.argv[3]) if len(sys.argv) > 3 else 0.05
+data = w.generate_pairs(3, n, length, err, n_threads=32)
+al = w.New()
+if length >= 500: al.AdaptiveReduction(w.DefaultAdaptiveOption)
 r = al.align_arrays(*data); r = al.align_arrays(*data)
 print(al.last_timing())
 PY

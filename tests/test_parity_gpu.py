@@ -243,6 +243,51 @@ def test_forward_kernel_variants(built, opts, kind):
             al.close()
 
 
+@pytest.mark.parametrize("n_pairs", [1, 3, 9, 64, 1237])
+def test_short_read_batches(built, n_pairs):
+    """Short pairs (<= 240 bases) take the blocked kernel's batch mode: a group stages 8 queue entries at a time.
+    Ragged lengths, empty / 1-base / non-ACGT / lowercase entries inside batches, batch counts that do not
+    divide the number of pairs; the unbatched kernel must give the same records."""
+    import wfa_amd as w
+    from oracle import oracle as O
+    rng = np.random.default_rng(1000 + n_pairs)
+    qs, ts = [], []
+    for i in range(n_pairs):
+        L = int(rng.integers(1, 240))
+        q = bytes(b"ACGT"[c] for c in rng.integers(0, 4, L))
+        t = bytearray(q)
+        for _ in range(int(rng.integers(0, 1 + L // 12))):
+            pos = int(rng.integers(0, len(t)))
+            kind = int(rng.integers(0, 3))
+            if kind == 0:
+                t[pos] = b"ACGT"[int(rng.integers(0, 4))]
+            elif kind == 1:
+                t.insert(pos, b"ACGT"[int(rng.integers(0, 4))])
+            elif len(t) > 1:
+                del t[pos]
+        t = bytes(t[:240])
+        if i % 17 == 5:
+            q = b""
+        elif i % 17 == 9:
+            t = t.lower()
+        elif i % 17 == 13:
+            q = q[:len(q) // 2] + b"N" + q[len(q) // 2:]
+            q = q[:240]
+        elif i % 23 == 7:
+            q, t = b"A", b"CA"
+        qs.append(q), ts.append(t)
+    data = w.make_blob(qs, ts)
+    for ad in ((10, 50, 1), None):
+        want = O.align_batch(_oracle_params(True, ad), *data, n_threads=4)
+        for batch in (1, 0):
+            al = _aligner(True, ad)
+            al.set_option("blk_batch", batch)
+            got = al.align_arrays(*data)
+            assert al.last_timing().main_kernel_kind == 3
+            assert_batch_equal(got, want, f"short reads n={n_pairs} ad={ad} blk_batch={batch}")
+            al.close()
+
+
 def test_small_arena_forces_retry_ladder(built):
     """A deliberately tiny wavefront arena: pairs overflow, are re-run with 8x slots, results unchanged."""
     import wfa_amd as w

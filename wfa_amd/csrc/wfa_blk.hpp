@@ -124,7 +124,11 @@ constexpr int BK_BIG = 0x3FFFFFFF;
 #define WFA_BLK8_WAVES 2
 #endif
 
-template <int G>
+// BATCH > 1 (short reads: both sequences of a pair fit one staging pass of the group's own lanes): a group takes
+// BATCH consecutive queue entries at a time and stages all of them into its LDS slots, so the refill chain (queue
+// atomic -> lengths / offsets -> sequence bytes: three dependent memory round trips that stall all pairs of the
+// wave) is paid once per BATCH pairs; the following pairs of the batch start from LDS.
+template <int G, int BATCH>
 __global__ __launch_bounds__(64, (G == 16 ? 4 : WFA_BLK8_WAVES)) void wfa_blk_kernel(const KParams P) {
     constexpr int PP  = 64 / G;   // diagonals per lane
     constexpr int NG  = 64 / G;   // pairs per wave
@@ -142,9 +146,12 @@ __global__ __launch_bounds__(64, (G == 16 ? 4 : WFA_BLK8_WAVES)) void wfa_blk_ke
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int lane = threadIdx.x, j = lane & (G - 1), grp = lane / G;
 
-    const uint32_t        SW = P.lds_seq_words;
-    const uint32_t *const lq = lds + grp * 2 * SW;
-    const uint32_t *const lt = lq + SW;
+    const uint32_t  SW = P.lds_seq_words;
+    constexpr int   BM = 8;                                    // meta words per batch slot: wi, pr, nq, mt, q_off, t_off
+    const uint32_t  GW = BATCH > 1 ? BATCH * (2 * SW + BM) : 2 * SW;  // LDS words of one group
+    const uint32_t *lq = lds + grp * GW;                       // packed query / target of the group's current pair
+    const uint32_t *lt = lq + SW;
+    int             bslot = 0, bcnt = 0;                       // batch mode: next staged slot / staged slots
     const uint64_t        cap      = P.arena_words;
     const int             mdd      = (int)P.max_dist_diff;
     const int             minwf    = (int)P.min_wf_len;
@@ -200,7 +207,99 @@ __global__ __launch_bounds__(64, (G == 16 ? 4 : WFA_BLK8_WAVES)) void wfa_blk_ke
             // 2-bit pack the sequences: short pairs (one pass of the group's own lanes) all groups at once, long
             // pairs one group after the other with all 64 lanes (coalesced dword loads).
             const unsigned long long need = __ballot(st == 0);
-            if (need != 0ull) {
+            if constexpr (BATCH > 1) {
+                if (need != 0ull) {
+                    uint32_t *const gbase = lds + grp * GW;
+                    uint32_t *const gmeta = gbase + BATCH * 2 * SW;
+                    // ---- groups whose batch is used up take BATCH queue entries each (one atomic for all of them)
+                    const bool               fetch = st == 0 && bslot >= bcnt;
+                    const unsigned long long fneed = __ballot(fetch);
+                    if (fneed != 0ull) {
+                        uint32_t gbits = 0u;
+#pragma unroll
+                        for (int r = 0; r < NG; r++) gbits |= (uint32_t)((fneed >> (G * r)) & 1ull) << r;
+                        uint32_t base = 0;
+                        if (lane == 0) base = atomicAdd(P.queue_head, (uint32_t)(BATCH * __builtin_popcount(gbits)));
+                        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                        const uint32_t wi0 = base + (uint32_t)(BATCH * __builtin_popcount(gbits & ((1u << grp) - 1u)));
+                        // lane j < BATCH of a fetching group owns entry wi0 + j
+                        const uint32_t wi  = wi0 + (uint32_t)j;
+                        const bool     own = fetch && j < BATCH;
+                        const bool     got = own && wi < P.chunk_n;
+                        uint32_t pr = 0, nq = 0, mt = 0;
+                        uint64_t qo = 0, to = 0;
+                        if (got) {
+                            pr = P.work ? P.work[wi] : P.chunk_first + wi;
+                            nq = P.q_len[pr], mt = P.t_len[pr], qo = P.q_off[pr], to = P.t_off[pr];
+                        }
+                        uint32_t status = ST_PENDING;
+                        if (nq == 0 || mt == 0)
+                            status = ST_EMPTY;  // wfa.go:204-206
+                        else if (nq > 0x1FFFFFFFu || mt > 0x1FFFFFFFu)
+                            status = ST_TOO_LONG;  // wfa.go:207-209
+                        else if (((nq > mt ? nq : mt) + 15u) / 16u + 1u > SW || ((nq > mt ? nq : mt) + 15u) / 16u + 1u > (uint32_t)G)
+                            status = ST_REDO_LDS;
+                        if (got && status != ST_PENDING) {
+                            P.pair_meta[wi] = make_uint4(status, 0u, 0u, 0u);
+                            if (status >= ST_REDO_BYTES) push_redo(P, pr, status);
+                        }
+                        if (own) {
+                            uint32_t *const mw = gmeta + BM * j;
+                            mw[0] = wi, mw[1] = pr, mw[2] = (got && status == ST_PENDING) ? nq : 0u, mw[3] = mt;
+                            mw[4] = (uint32_t)qo, mw[5] = (uint32_t)(qo >> 32), mw[6] = (uint32_t)to, mw[7] = (uint32_t)(to >> 32);
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        // ---- every fetching group stages its BATCH pairs with its own lanes
+                        uint32_t badmask = 0u;
+#pragma unroll 1
+                        for (int sl = 0; sl < BATCH; sl++) {
+                            const uint32_t *const mw = gmeta + BM * sl;
+                            const uint32_t nq_s = fetch ? mw[2] : 0u, mt_s = mw[3];
+                            if (nq_s != 0u) {
+                                const uint64_t qo_s = (uint64_t)mw[4] | ((uint64_t)mw[5] << 32);
+                                const uint64_t to_s = (uint64_t)mw[6] | ((uint64_t)mw[7] << 32);
+                                uint32_t *const sq  = gbase + sl * 2 * SW;
+                                bool b = stage_pack<G>(P.blob, qo_s, nq_s, sq, j);
+                                b |= stage_pack<G>(P.blob, to_s, mt_s, sq + SW, j);
+                                badmask |= b ? (1u << sl) : 0u;
+                            }
+                        }
+                        badmask = (uint32_t)Red::or1((int)badmask);
+                        if (own && ((badmask >> j) & 1u) != 0u) {  // a byte outside ACGT: the byte-compare path takes it
+                            P.pair_meta[wi] = make_uint4(ST_REDO_BYTES, 0u, 0u, 0u);
+                            push_redo(P, pr, ST_REDO_BYTES);
+                            gmeta[BM * j + 2] = 0u;
+                        }
+                        if (fetch) {
+                            bslot = 0;
+                            bcnt  = wi0 >= P.chunk_n ? 0 : (int)imin2(BATCH, (int)(P.chunk_n - wi0));
+                            if (bcnt == 0) st = 2;
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    }
+                    // ---- idle groups with a staged pair start it (no global memory on this path)
+                    if (st == 0 && bslot < bcnt) {
+                        const uint32_t *const mw = gmeta + BM * bslot;
+                        const uint32_t nq = mw[2], mt = mw[3];
+                        if (nq != 0u) {
+                            pidx = mw[0], pair = mw[1];
+                            lq = gbase + bslot * 2 * SW, lt = lq + SW;
+                            n = (int)nq, m = (int)mt, Ak = m - n;
+                            si = 0, cells = 0, slow = false;
+                            kb   = -32 + PP * imax2(-24 / PP, imin2(24 / PP, Ak / (2 * PP)));
+                            rowp = P.arena + (uint64_t)pidx * cap;
+                            rows_left = (int)(cap / 64);
+                            first_eq = ((lq[0] ^ lt[0]) & 3u) == 0u;  // q[0] == t[0] (wfa.go:155)
+                            set_window();
+                            clear_rings();
+                            st = 1;
+                        }  // (a rejected entry: the group takes the next slot in the next round)
+                        bslot += 1;
+                    }
+                }
+            } else if (need != 0ull) {
                 uint32_t gbits = 0u;  // bit r: group r needs a pair (wave-uniform)
 #pragma unroll
                 for (int r = 0; r < NG; r++) gbits |= (uint32_t)((need >> (G * r)) & 1ull) << r;

@@ -40,6 +40,7 @@ struct DevBuf {
 
 // ctrl words (device): [0] queue_head [1] redo_count [2,3] ops_cursor (u64) [4,5] debug_info
 constexpr int CTRL_WORDS = 8;
+constexpr int BLK_BATCH  = 8;  // pairs a group of the blocked kernel stages at a time (short reads)
 
 }  // namespace
 
@@ -64,6 +65,7 @@ struct wfahip_ctx {
     int64_t       opt_packed               = 1;  // 0: never use the packed (sub-wave) kernels
     int64_t       opt_reg                  = 1;  // 0: never use the register-window kernel
     int64_t       opt_blk                  = 16; // blocked register-window kernel: lanes per pair (16 or 8), 0 = off
+    int64_t       opt_blk_batch            = 1;  // short reads: stage BLK_BATCH pairs per group at a time
     int64_t       opt_packed_arena_bytes   = 0;  // per pair, 0 = automatic
     int64_t       opt_chunk_pairs          = 0;  // 0 = automatic
     int64_t       opt_packed_waves_per_cu  = 0;  // 0 = automatic
@@ -274,6 +276,8 @@ extern "C" int wfahip_set_option(wfahip_ctx *ctx, const char *key, int64_t value
         ctx->opt_reg = value;
     else if (k == "blk")
         ctx->opt_blk = (value == 8 || value == 16) ? value : 0;
+    else if (k == "blk_batch")
+        ctx->opt_blk_batch = value;
     else if (k == "packed_arena_bytes")
         ctx->opt_packed_arena_bytes = value;
     else if (k == "chunk_pairs")
@@ -407,7 +411,10 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
                                 std::vector<uint64_t> &redo_out, bool detach_bt) -> int {
             DevBuf &arena_buf = ctx->bt_pending ? ctx->arena2 : ctx->arena;
             DevBuf &meta_buf  = ctx->bt_pending ? ctx->meta2 : ctx->meta;
-            const size_t   lds_bytes    = kind >= 3 ? lds_d : (kind == 2 ? lds_c : lds_b);
+            // short reads: the blocked kernel stages BLK_BATCH pairs per group at a time
+            const bool     blk_batch    = kind == 3 && seq_words <= 16 && ctx->opt_blk_batch != 0;
+            const size_t   lds_bytes    = blk_batch ? (size_t)4 * BLK_BATCH * (2 * seq_words + 8) * 4 + 16
+                                                    : (kind >= 3 ? lds_d : (kind == 2 ? lds_c : lds_b));
             const uint32_t pairs_wave   = kind == 4 ? 8 : (kind >= 2 ? 4 : 2);
             // blocked kernel: fixed-pitch arena (64 words per score, no directory), 16 words per base
             const uint64_t words        = kind >= 3 ? std::max<uint64_t>((words_dir * 2 + 63) & ~63ull, 2048) : words_dir;
@@ -461,9 +468,11 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
                 HIP_TRY(hipMemsetAsync(d_ctrl, 0, 4, st));  // queue_head only
                 HIP_TRY(hipEventRecord(evFa, st));
                 if (kind == 4)
-                    hipLaunchKernelGGL((wfa_blk_kernel<8>), dim3(grid), dim3(64), lds_bytes, st, P);
+                    hipLaunchKernelGGL((wfa_blk_kernel<8, 1>), dim3(grid), dim3(64), lds_bytes, st, P);
+                else if (kind == 3 && blk_batch)
+                    hipLaunchKernelGGL((wfa_blk_kernel<16, BLK_BATCH>), dim3(grid), dim3(64), lds_bytes, st, P);
                 else if (kind == 3)
-                    hipLaunchKernelGGL((wfa_blk_kernel<16>), dim3(grid), dim3(64), lds_bytes, st, P);
+                    hipLaunchKernelGGL((wfa_blk_kernel<16, 1>), dim3(grid), dim3(64), lds_bytes, st, P);
                 else if (kind == 2)
                     hipLaunchKernelGGL((wfa_reg_kernel<2, 4, 1>), dim3(grid), dim3(64), lds_bytes, st, P);
                 else
