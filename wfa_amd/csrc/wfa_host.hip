@@ -582,7 +582,7 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
         if (cr == 0 && !debug_single && ctx->opt_team_min_len > 0 && max_len >= (uint64_t)ctx->opt_team_min_len &&
             std::max(P.x, std::max(P.oe, P.e)) / P.g < (uint32_t)TEAM_RING) {
             const uint32_t cus = (uint32_t)std::max(1, ctx->num_cus);
-            uint32_t t0 = (uint32_t)std::min<uint64_t>(cus, std::max<uint64_t>(2, (2ull * max_len + 4095) / 4096));
+            uint32_t t0 = (uint32_t)std::min<uint64_t>(cus, std::max<uint64_t>(2, (2ull * max_len + 8191) / 8192));
             if (ctx->opt_team_wgs > 0) t0 = (uint32_t)std::min<int64_t>(cus, ctx->opt_team_wgs);
             team_n = (uint32_t)std::min<uint64_t>(n_work, std::max<uint32_t>(1, cus / t0));
             team_T = ctx->opt_team_wgs > 0 ? t0 : cus / team_n;
