@@ -288,6 +288,21 @@ def test_short_read_batches(built, n_pairs):
             al.close()
 
 
+@pytest.mark.parametrize("length,err,n", [(4000, 0.03, 120), (9000, 0.02, 40), (2500, 0.08, 120)])
+def test_mid_length_global(built, length, err, n):
+    """Global pairs of a few kbp: the blocked kernel near its LDS limit (offsets of several thousand, hundreds of
+    rows per pair); without wf-adaptive the bands outgrow the 64-diagonal window and the ladder takes over."""
+    import wfa_amd as w
+    from oracle import oracle as O
+    data = w.generate_pairs(seed=length, n_pairs=n, length=length, error_rate=err, n_threads=8)
+    for ad in ((10, 50, 1), None):
+        al = _aligner(True, ad)
+        got = al.align_arrays(*data)
+        assert al.last_timing().main_kernel_kind == 3
+        assert_batch_equal(got, O.align_batch(_oracle_params(True, ad), *data, n_threads=8), f"L={length} ad={ad}")
+        al.close()
+
+
 def test_small_arena_forces_retry_ladder(built):
     """A deliberately tiny wavefront arena: pairs overflow, are re-run with 8x slots, results unchanged."""
     import wfa_amd as w
