@@ -9,14 +9,17 @@
 #include "wfa_reg.hpp"
 #include "wfa_blk.hpp"
 #include "wfa_team.hpp"
+#include "wfa_finalize.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace wfa;
@@ -53,6 +56,9 @@ struct wfahip_ctx {
     std::vector<hipEvent_t> evpool;
     hipEvent_t    ev0 = nullptr, ev1 = nullptr, evA = nullptr, evB = nullptr, evC = nullptr;
     DevBuf        arena, ctrl, redo, work, meta;
+    DevBuf        fin;                       // device-side result arrays of the host entry (wfa_finalize.hpp)
+    void         *pin[2]     = {nullptr, nullptr};  // pinned staging for result downloads
+    hipEvent_t    pin_ev[2]  = {nullptr, nullptr};
     DevBuf        team_ctl;                  // barrier counters / reduction sets of the team kernel
     DevBuf        arena2, meta2;             // retry passes run beside the first pass's backtrace kernel
     hipEvent_t    evBtA = nullptr, evBtB = nullptr;
@@ -245,7 +251,11 @@ extern "C" int wfahip_create(int device_id, wfahip_ctx **out) {
 extern "C" void wfahip_destroy(wfahip_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    for (DevBuf *b : {&ctx->arena, &ctx->team_ctl, &ctx->arena2, &ctx->meta2, &ctx->ctrl, &ctx->redo, &ctx->work, &ctx->meta, &ctx->in_blob, &ctx->in_qoff, &ctx->in_qlen,
+    for (int i = 0; i < 2; i++) {
+        if (ctx->pin[i]) (void)hipHostFree(ctx->pin[i]);
+        if (ctx->pin_ev[i]) (void)hipEventDestroy(ctx->pin_ev[i]);
+    }
+    for (DevBuf *b : {&ctx->arena, &ctx->fin, &ctx->team_ctl, &ctx->arena2, &ctx->meta2, &ctx->ctrl, &ctx->redo, &ctx->work, &ctx->meta, &ctx->in_blob, &ctx->in_qoff, &ctx->in_qlen,
                       &ctx->in_toff, &ctx->in_tlen, &ctx->out_rec, &ctx->out_ops})
         release(*b);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -778,6 +788,50 @@ static int unpack_results(const std::vector<uint32_t> &rec, const std::vector<ui
     return WFAHIP_OK;
 }
 
+namespace {
+
+constexpr size_t PIN_CHUNK = 32u << 20;
+
+// Device -> pageable host memory: 32 MB pieces through two pinned buffers (full PCIe rate), copied out to their
+// destination by a few host threads while the next piece is in flight (first-touch page faults of freshly
+// malloc'd result arrays are what limits a plain hipMemcpy here).
+int download(wfahip_ctx *ctx, void *dst, const void *src, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return WFAHIP_OK;
+    for (int i = 0; i < 2; i++) {
+        if (!ctx->pin[i]) HIP_TRY(hipHostMalloc(&ctx->pin[i], PIN_CHUNK, hipHostMallocDefault));
+        if (!ctx->pin_ev[i]) HIP_TRY(hipEventCreateWithFlags(&ctx->pin_ev[i], hipEventDisableTiming));
+    }
+    const unsigned n_thr = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+    const size_t   n_chk = (bytes + PIN_CHUNK - 1) / PIN_CHUNK;
+    auto issue = [&](size_t c) -> hipError_t {
+        const size_t off = c * PIN_CHUNK, sz = std::min(PIN_CHUNK, bytes - off);
+        hipError_t   e   = hipMemcpyAsync(ctx->pin[c & 1], static_cast<const char *>(src) + off, sz, hipMemcpyDeviceToHost, st);
+        return e != hipSuccess ? e : hipEventRecord(ctx->pin_ev[c & 1], st);
+    };
+    HIP_TRY(issue(0));
+    for (size_t c = 0; c < n_chk; c++) {
+        HIP_TRY(hipEventSynchronize(ctx->pin_ev[c & 1]));
+        if (c + 1 < n_chk) HIP_TRY(issue(c + 1));
+        const size_t off = c * PIN_CHUNK, sz = std::min(PIN_CHUNK, bytes - off);
+        char        *d = static_cast<char *>(dst) + off;
+        const char  *p = static_cast<const char *>(ctx->pin[c & 1]);
+        if (sz < (4u << 20) || n_thr == 1) {
+            std::memcpy(d, p, sz);
+        } else {
+            std::vector<std::thread> th;
+            const size_t             part = ((sz / n_thr) + 4095) & ~size_t(4095);
+            for (unsigned t = 0; t < n_thr; t++) {
+                const size_t a = std::min(sz, (size_t)t * part), b = std::min(sz, a + part);
+                if (b > a) th.emplace_back([=] { std::memcpy(d + a, p + a, b - a); });
+            }
+            for (auto &t : th) t.join();
+        }
+    }
+    return WFAHIP_OK;
+}
+
+}  // namespace
+
 extern "C" int wfahip_align_batch(wfahip_ctx *ctx, const wfahip_params *p, const uint8_t *seq_blob,
                                   uint64_t blob_bytes, const uint64_t *q_off, const uint32_t *q_len,
                                   const uint64_t *t_off, const uint32_t *t_len, uint64_t n_pairs,
@@ -807,12 +861,20 @@ extern "C" int wfahip_align_batch(wfahip_ctx *ctx, const wfahip_params *p, const
     if ((rc = ensure(ctx, ctx->in_qlen, n_pairs * 4))) return rc;
     if ((rc = ensure(ctx, ctx->in_tlen, n_pairs * 4))) return rc;
     if ((rc = ensure(ctx, ctx->out_rec, n_pairs * REC_WORDS * 4))) return rc;
+    const bool dbg_t = std::getenv("WFAHIP_DEBUG_TIMING") != nullptr;
+    auto       now   = [] { return std::chrono::steady_clock::now(); };
+    auto       ms_of = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    const auto t_h2d = now();
     if (blob_bytes) HIP_TRY(hipMemcpyAsync(ctx->in_blob.p, seq_blob, blob_bytes, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(ctx->in_qoff.p, q_off, n_pairs * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(ctx->in_toff.p, t_off, n_pairs * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(ctx->in_qlen.p, q_len, n_pairs * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(ctx->in_tlen.p, t_len, n_pairs * 4, hipMemcpyHostToDevice, st));
 
+    if (dbg_t) HIP_TRY(hipStreamSynchronize(st));
+    const auto t_dev = now();
     // CIGAR ops are merged runs: a first guess of (n+m)/4 + 8 per pair, grown on demand (at most n+m+2 each)
     uint64_t ops_cap = sum_len / 4 + 8 * n_pairs + 1024;
     for (int attempt = 0; attempt < 3; attempt++) {
@@ -829,13 +891,76 @@ extern "C" int wfahip_align_batch(wfahip_ctx *ctx, const wfahip_params *p, const
     }
     if (rc) return rc;
 
-    std::vector<uint32_t> rec(n_pairs * REC_WORDS);
-    std::vector<uint64_t> ops(std::max<uint64_t>(ctx->timing.ops_written, 1));
-    HIP_TRY(hipMemcpy(rec.data(), ctx->out_rec.p, rec.size() * 4, hipMemcpyDeviceToHost));
-    if (ctx->timing.ops_written)
-        HIP_TRY(hipMemcpy(ops.data(), ctx->out_ops.p, ctx->timing.ops_written * 8, hipMemcpyDeviceToHost));
-    uint64_t cells = 0;
-    rc             = unpack_results(rec, ops, n_pairs, out, &cells);
+    const auto t_d2h = now();
+    // ---- assemble wfahip_results on the device (ops packed in pair order, one array per field), then download
+    const uint64_t n         = n_pairs;
+    const uint32_t n_blocks  = (uint32_t)((n + (uint64_t)FIN_BLOCK * FIN_ITEMS - 1) / ((uint64_t)FIN_BLOCK * FIN_ITEMS));
+    const uint64_t ops_total_cap = std::max<uint64_t>(ctx->timing.ops_written, 1);
+    auto           al8       = [](uint64_t v) { return (v + 7) & ~7ull; };
+    // layout of ctx->fin (bytes): totals[2] | blk_sum[n_blocks] | ops_off[n] | loc_off[n] | 11 x u32[n] | ops_out
+    uint64_t off = 0;
+    auto     take = [&](uint64_t bytes) {
+        const uint64_t o = off;
+        off += al8(bytes);
+        return o;
+    };
+    const uint64_t o_tot = take(16), o_blk = take(8ull * n_blocks), o_ooff = take(8ull * n), o_loc = take(4ull * n);
+    uint64_t       o_f[11];
+    for (int i = 0; i < 11; i++) o_f[i] = take(4ull * n);
+    const uint64_t o_ops = take(8ull * ops_total_cap);
+    if ((rc = ensure(ctx, ctx->fin, off))) return rc;
+    char *fb = static_cast<char *>(ctx->fin.p);
+    FinParams F{};
+    F.rec = static_cast<const uint32_t *>(ctx->out_rec.p), F.ops = static_cast<const uint64_t *>(ctx->out_ops.p), F.n = n;
+    F.totals  = reinterpret_cast<unsigned long long *>(fb + o_tot);
+    F.blk_sum = reinterpret_cast<uint64_t *>(fb + o_blk), F.ops_off = reinterpret_cast<uint64_t *>(fb + o_ooff);
+    F.loc_off = reinterpret_cast<uint32_t *>(fb + o_loc);
+    F.status = reinterpret_cast<int32_t *>(fb + o_f[0]), F.score = reinterpret_cast<uint32_t *>(fb + o_f[1]);
+    F.tbegin = reinterpret_cast<int32_t *>(fb + o_f[2]), F.tend = reinterpret_cast<int32_t *>(fb + o_f[3]);
+    F.qbegin = reinterpret_cast<int32_t *>(fb + o_f[4]), F.qend = reinterpret_cast<int32_t *>(fb + o_f[5]);
+    F.align_len = reinterpret_cast<uint32_t *>(fb + o_f[6]), F.matches = reinterpret_cast<uint32_t *>(fb + o_f[7]);
+    F.gaps = reinterpret_cast<uint32_t *>(fb + o_f[8]), F.gap_regions = reinterpret_cast<uint32_t *>(fb + o_f[9]);
+    F.ops_len = reinterpret_cast<uint32_t *>(fb + o_f[10]), F.ops_out = reinterpret_cast<uint64_t *>(fb + o_ops);
+    HIP_TRY(hipMemsetAsync(F.totals, 0, 16, st));
+    hipLaunchKernelGGL(fin_scan_blocks, dim3(n_blocks), dim3(FIN_BLOCK), 0, st, F);
+    hipLaunchKernelGGL(fin_scan_sums, dim3(1), dim3(1024), 0, st, F, n_blocks);
+    hipLaunchKernelGGL(fin_gather, dim3((uint32_t)((n + 3) / 4)), dim3(256), 0, st, F);
+    HIP_TRY(hipGetLastError());
+    unsigned long long totals[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(totals, F.totals, 16, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const auto t_unp = now();
+
+    results_zero(out);
+    out->n = n;
+    {
+        const size_t cnt = std::max<uint64_t>(n, 1);
+#define ALLOC(field, type)                                             \
+    out->field = static_cast<type *>(std::malloc(cnt * sizeof(type))); \
+    if (!out->field) {                                                 \
+        wfahip_results_free(out);                                      \
+        return WFAHIP_ERR_OOM;                                         \
+    }
+        ALLOC(status, int32_t) ALLOC(score, uint32_t) ALLOC(tbegin, int32_t) ALLOC(tend, int32_t)
+        ALLOC(qbegin, int32_t) ALLOC(qend, int32_t) ALLOC(align_len, uint32_t) ALLOC(matches, uint32_t)
+        ALLOC(gaps, uint32_t) ALLOC(gap_regions, uint32_t) ALLOC(ops_off, uint64_t) ALLOC(ops_len, uint32_t)
+#undef ALLOC
+        out->ops = static_cast<uint64_t *>(std::malloc(std::max<uint64_t>(totals[0], 1) * 8));
+        if (!out->ops) {
+            wfahip_results_free(out);
+            return WFAHIP_ERR_OOM;
+        }
+    }
+    out->n_ops = totals[0];
+    void *const       dsts[11] = {out->status, out->score, out->tbegin, out->tend, out->qbegin, out->qend,
+                                  out->align_len, out->matches, out->gaps, out->gap_regions, out->ops_len};
+    for (int i = 0; i < 11 && rc == WFAHIP_OK; i++) rc = download(ctx, dsts[i], fb + o_f[i], 4ull * n, st);
+    if (rc == WFAHIP_OK) rc = download(ctx, out->ops_off, fb + o_ooff, 8ull * n, st);
+    if (rc == WFAHIP_OK) rc = download(ctx, out->ops, fb + o_ops, 8ull * totals[0], st);
+    const uint64_t cells = totals[1];
+    if (dbg_t)
+        std::fprintf(stderr, "[wfahip] host entry: H2D %.1f ms, device %.1f ms, finalize %.1f ms, download %.1f ms\n",
+                     ms_of(t_h2d, t_dev), ms_of(t_dev, t_d2h), ms_of(t_d2h, t_unp), ms_of(t_unp, now()));
     ctx->timing.cells_stored = cells;
     if (rc) wfahip_results_free(out);
     return rc;
