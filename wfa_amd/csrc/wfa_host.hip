@@ -157,7 +157,7 @@ struct Job {
 constexpr size_t LDS_MAX_BYTES = 160 * 1024;
 
 // Launch configuration for one job.
-int make_cfg(wfahip_ctx *ctx, uint32_t max_len, int mode, int level, uint64_t n_work, LaunchCfg &c) {
+int make_cfg(wfahip_ctx *ctx, uint32_t max_len, int mode, int level, uint64_t n_work, bool semi_global, LaunchCfg &c) {
     int waves = max_len <= 4096 ? 1 : (max_len <= 65536 ? 4 : 16);
     if (ctx->opt_threads_per_pair > 0) {
         int64_t t = ctx->opt_threads_per_pair;
@@ -169,7 +169,8 @@ int make_cfg(wfahip_ctx *ctx, uint32_t max_len, int mode, int level, uint64_t n_
     c.lds_bytes     = (2ull * c.lds_seq_words + GEN_LDS_EXTRA_WORDS) * 4ull;
     if (c.lds_bytes > LDS_MAX_BYTES) return 1;  // caller must use mode 1
 
-    uint64_t base_words = std::max<uint64_t>(64 * 1024, 96ull * max_len);
+    // semi-global rows are n+m-1 wide until wf-adaptive collapses the band (a few dozen scores): ~4x the words
+    uint64_t base_words = std::max<uint64_t>(64 * 1024, (semi_global ? 384ull : 96ull) * max_len);
     if (ctx->opt_arena_bytes_per_slot > 0) base_words = std::max<uint64_t>(4096, ctx->opt_arena_bytes_per_slot / 4);
     uint64_t words = base_words;
     for (int i = 0; i < level; i++) words *= 8;
@@ -581,10 +582,10 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
         const uint64_t n_work = job.all ? n_pairs : job.pairs.size();
         if (n_work == 0) continue;
         LaunchCfg cfg;
-        int       cr = make_cfg(ctx, max_len, job.mode, job.level, n_work, cfg);
+        int       cr = make_cfg(ctx, max_len, job.mode, job.level, n_work, !P.global_alignment, cfg);
         if (cr == 1) {  // sequences do not fit LDS: byte path for the whole job
             job.mode = 1;
-            cr       = make_cfg(ctx, max_len, 1, job.level, n_work, cfg);
+            cr       = make_cfg(ctx, max_len, 1, job.level, n_work, !P.global_alignment, cfg);
         }
         if (debug_single) cfg.slots = 1;
         // Wide wavefronts: a team of workgroups per pair (wfa_team_kernel) instead of one workgroup per pair.
