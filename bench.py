@@ -148,8 +148,8 @@ def main():
     # gfx950: FETCH_SIZE counts half the bytes of the coalesced input reads (checked against the known 2.0 GB of
     # sequence bytes the forward kernel must read: it reports 1.12 GB), so it is doubled; WRITE_SIZE is taken as is.
     traffic, traffic_src = None, None
-    KNAMES = ["wfa_generic_kernel<1, 0>", "wfa_packed_kernel", "wfa_reg_kernel<2, 4, 1>", "wfa_blk_kernel<16>",
-              "wfa_blk_kernel<8>"]
+    KNAMES = ["wfa_generic_kernel<1, 0>", "wfa_packed_kernel", "wfa_reg_kernel<2, 4, 1>", "wfa_blk_kernel<16",
+              "wfa_blk_kernel<8"]
     kname = KNAMES[int(timing.main_kernel_kind)]
     default_workload = (n == 1_000_000 and args.length == 1000 and abs(args.error - 0.05) < 1e-9 and args.seed == 3
                         and not args.semi_global and not args.no_adaptive)
@@ -190,7 +190,7 @@ def main():
                "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                             "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
                             "algorithmic_bytes_per_launch": alg_bytes,
-                            "kernel": kname,
+                            "kernel": kname + (", 1>" if kname.endswith("16") or kname.endswith("<8") else ""),
                             "kernel_ms": main_k_ms, "all_kernels_ms": k_ms,
                             "note": "achieved = algorithmic bytes of one step / duration of the dominant "
                                     "(forward) kernel's launches in that step; peak = 8 TB/s HBM3E spec; the kernel "
