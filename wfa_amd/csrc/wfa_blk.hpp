@@ -606,12 +606,13 @@ __global__ __launch_bounds__(64, (G == 16 ? 4 : WFA_BLK8_WAVES)) void wfa_blk_ke
 
             // ------------------------------------------------------------ keep every kept row inside [kb+1, kb+62]
             {
-                const int  ulo = imin2(imin2(rlo[0], rlo[1]), imin2(rlo[2], rlo[3]));
-                const int  uhi = imax2(imax2(rhi[0], rhi[1]), imax2(rhi[2], rhi[3]));
-                const bool live    = run && !fin && uhi >= ulo;
-                const bool need_dn = live && ulo <= kb;
-                const bool need_up = live && uhi >= kb + W - 1;
+                // the older rows already lie inside: only the row just added can touch the window's edge
+                const bool live    = keepl && !fin;
+                const bool need_dn = live && ilo <= 0;
+                const bool need_up = live && ihi >= W - 1;
                 if (__ballot(need_dn || need_up) != 0ull) {
+                    const int  ulo  = imin2(imin2(rlo[0], rlo[1]), imin2(rlo[2], rlo[3]));
+                    const int  uhi  = imax2(imax2(rhi[0], rhi[1]), imax2(rhi[2], rhi[3]));
                     const bool wide = (need_dn && (need_up || uhi >= kb - 16 + W - 1)) || (need_up && ulo <= kb + 16);
                     const bool dn = need_dn && !wide, up = need_up && !wide;
 #pragma unroll
