@@ -197,7 +197,12 @@ __global__ __launch_bounds__(64, (G == 16 ? 4 : WFA_BLK8_WAVES)) void wfa_blk_ke
 
 #ifdef WFA_STAMPS
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
+    unsigned long long evt[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // wave-steps, slow steps, hit steps, reduce steps, found steps,
+                                                            // found pair-steps, continuation iterations, running pair-steps
+#define WFA_EVT(i, v) (evt[i] += (v))
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+#else
+#define WFA_EVT(i, v) ((void)0)
 #endif
     // refill of idle groups; returns true when the queue is exhausted and no pair is left
     const auto refill = [&]() __attribute__((always_inline)) -> bool {
@@ -382,6 +387,7 @@ __global__ __launch_bounds__(64, (G == 16 ? 4 : WFA_BLK8_WAVES)) void wfa_blk_ke
             const uint32_t a_edge = Ops::dn1(Mo[PP - 1], j), b_edge = Ops::dn1(I[PP - 1], j);
             const uint32_t c_edge = Ops::up1(Mo[0], j), d_edge = Ops::up1(D[0], j);
             const bool     slow_any = __ballot(run && slow) != 0ull;
+            WFA_EVT(0, 1), WFA_EVT(1, slow_any ? 1 : 0), WFA_EVT(7, __builtin_popcountll(__ballot(run)) / G);
             if (!slow_any) {
 #pragma unroll
                 for (int p = 0; p < PP; p++) {
@@ -463,6 +469,7 @@ __global__ __launch_bounds__(64, (G == 16 ? 4 : WFA_BLK8_WAVES)) void wfa_blk_ke
                 const int kd = k0 + psel;
                 bool      go = cmask != 0u;
                 do {
+                    WFA_EVT(6, 1);
                     const int      rem = lm - h;
                     const uint32_t xr  = SeqView<0>::win16(lq, h - kd) ^ SeqView<0>::win16(lt, h);
                     const uint32_t cnt = umin2(ffbl_raw(xr) >> 1, (uint32_t)imin2(imax2(rem, 0), 16));
@@ -482,6 +489,7 @@ __global__ __launch_bounds__(64, (G == 16 ? 4 : WFA_BLK8_WAVES)) void wfa_blk_ke
             for (int p = 0; p < PP; p++) nz[p] = nM[p] != 0u, hit[p] = nM[p] >= (uint32_t)lim[p], hitl |= hit[p];
             bool       term    = false;
             const bool hit_any = __ballot(hitl) != 0ull;
+            WFA_EVT(2, hit_any ? 1 : 0);
             if (hit_any) {
                 bool tl = false;
 #pragma unroll
@@ -508,6 +516,7 @@ __global__ __launch_bounds__(64, (G == 16 ? 4 : WFA_BLK8_WAVES)) void wfa_blk_ke
             // remaining distance (wfa.go:488) = max(m-h, n-v) = max(m, n+k) - h; an entry is usable iff h < min(m, n+k)
             const bool want_reduce = run && !term && adaptive && anyM && (ghi - glo + 1) >= minwf;
             if (__ballot(want_reduce) != 0ull) {
+                WFA_EVT(3, 1);
                 int  dd[PP], mind = BK_BIG, maxd = -BK_BIG;
                 bool vd[PP];
 #pragma unroll
@@ -521,6 +530,7 @@ __global__ __launch_bounds__(64, (G == 16 ? 4 : WFA_BLK8_WAVES)) void wfa_blk_ke
                 const int  thr   = mind + mdd;
                 const bool found = want_reduce && mind != BK_BIG && maxd > thr;  // some distance fails (wfa.go:507)
                 if (__ballot(found) != 0ull) {
+                    WFA_EVT(4, 1), WFA_EVT(5, __builtin_popcountll(__ballot(found)) / G);
                     int first_ok = BK_BIG, last_ok = -BK_BIG;
 #pragma unroll
                     for (int p = PP - 1; p >= 0; p--) first_ok = (vd[p] && dd[p] <= thr) ? PP * j + p : first_ok;
@@ -674,6 +684,7 @@ __global__ __launch_bounds__(64, (G == 16 ? 4 : WFA_BLK8_WAVES)) void wfa_blk_ke
     if (lane == 0 && P.debug_info) {
         unsigned long long *acc = reinterpret_cast<unsigned long long *>(P.debug_info);
         for (int i = 0; i < 8; i++) atomicAdd(acc + i, stamp_acc[i]);
+        for (int i = 0; i < 8; i++) atomicAdd(acc + 8 + i, evt[i]);
     }
 #endif
 }

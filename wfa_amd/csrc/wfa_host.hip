@@ -411,8 +411,8 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
         P.min_xe        = std::min(P.x, P.e);
 #ifdef WFA_STAMPS
         static DevBuf stampbuf;
-        if ((rc = ensure(ctx, stampbuf, 64))) return rc;
-        HIP_TRY(hipMemsetAsync(stampbuf.p, 0, 64, st));
+        if ((rc = ensure(ctx, stampbuf, 128))) return rc;
+        HIP_TRY(hipMemsetAsync(stampbuf.p, 0, 128, st));
         P.debug_info = static_cast<uint32_t *>(stampbuf.p);
 #endif
         // one pass over `count` pairs (identity range when list == nullptr); returns the {pair,status} redo entries
@@ -556,8 +556,11 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
             if (!jb.pairs.empty()) jobs.push_back(std::move(jb));
 #ifdef WFA_STAMPS
             {
-                unsigned long long acc[8];
-                HIP_TRY(hipMemcpy(acc, P.debug_info, 64, hipMemcpyDeviceToHost));
+                unsigned long long acc[16];
+                HIP_TRY(hipMemcpy(acc, P.debug_info, 128, hipMemcpyDeviceToHost));
+                std::fprintf(stderr, "[events] wave-steps %llu  slow %llu  hit %llu  reduce %llu  found %llu  found pair-steps %llu  "
+                             "continuation iterations %llu  running pair-steps %llu\n", acc[8], acc[9], acc[10], acc[11], acc[12],
+                             acc[13], acc[14], acc[15]);
                 unsigned long long tot = 0;
                 for (int i = 0; i < 6; i++) tot += acc[i];
                 const char *nm[6] = {"refill", "next", "extend", "ranges+reduce", "stores", "ring+finish+window"};
