@@ -170,3 +170,37 @@ def test_global_cigars_are_valid_alignments(ref_pairs, oracle_vectors):
         p = ref_pairs[ent["pair"]]
         q, t = p["q"].upper(), p["t"].upper()
         assert cigar_score(ent["cigar"], q, t) == ent["score"], p["source"]
+
+
+def _plot_cells(text):
+    return [[c.strip() for c in line.split("\t")] for line in text.rstrip("\n").split("\n")]
+
+
+def _oracle_wavefronts(ka):
+    al = O.Aligner(global_alignment=ka["mode"] == "global", adaptive=tuple(ka["adaptive"]))
+    al.align(ka["q"].encode(), ka["t"].encode())
+    return {c: {s: {lo + i: v for i, v in enumerate(raw) if v} for s, (lo, hi, raw) in d.items()}
+            for c, d in al.dump().items()}
+
+
+def test_plot_reproduces_readme_tables(known_answers):
+    """N3 of SURVEY.md section 8f: the host mirror of (*Aligner).Plot (wfa_component_plot.go:41-209) over the
+    oracle's final wavefronts prints the README's M-component tables (tests/golden/plot_tables.json, extracted
+    by scripts/make_plot_golden.py).  KA1 (README.md:101-114): every cell.  KA2 (README.md:128-140): the README
+    block predates v0.4.0 (caveat 3); the cells that differ are listed and must not grow."""
+    import json
+    import os
+    from wfa_amd.aligner import plot_component
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "plot_tables.json"), encoding="utf-8"))
+    ka1, ka2 = known_answers["vectors"][0], known_answers["vectors"][1]
+    got1 = _plot_cells(plot_component(ka1["q"].encode(), ka1["t"].encode(), _oracle_wavefronts(ka1)))
+    assert got1 == gold["ka1_global"]
+    got2 = _plot_cells(plot_component(ka2["q"].encode(), ka2["t"].encode(), _oracle_wavefronts(ka2)))
+    want2 = gold["ka2_semiglobal"]
+    assert len(got2) == len(want2) and all(len(a) == len(b) for a, b in zip(got2, want2))
+    diff = sorted((r - 1, c - 1) for r in range(len(want2)) for c in range(len(want2[r])) if got2[r][c] != want2[r][c])
+    assert diff == [tuple(x) for x in PLOT_KA2_STALE], diff
+
+
+# (query row, target column), 1-based, of the KA2 README cells that v0.4.0's rules do not reproduce
+PLOT_KA2_STALE = [(3, 10), (4, 6), (5, 5), (5, 10), (6, 6), (7, 3), (7, 5)]

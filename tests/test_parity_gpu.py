@@ -90,6 +90,32 @@ def test_wavefront_dumps_match_oracle(built, known_answers, oracle_vectors):
         al.close()
 
 
+def test_plot_from_device_wavefronts(built, known_answers):
+    """(*Aligner).Plot over the DEVICE wavefronts prints the README's KA1 M-component table
+    cell for cell, and for KA2 exactly what the oracle's wavefronts print (the README's KA2 block is stale in seven
+    cells, tests/test_oracle_golden.py)."""
+    import json
+    import os
+    from oracle import oracle as O
+    from wfa_amd.aligner import plot_component
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "plot_tables.json"), encoding="utf-8"))
+    cells = lambda text: [[c.strip() for c in line.split("\t")] for line in text.rstrip("\n").split("\n")]
+    for ka, want in ((known_answers["vectors"][0], gold["ka1_global"]), (known_answers["vectors"][1], None)):
+        al = _aligner(ka["mode"] == "global", tuple(ka["adaptive"]))
+        text = al.Plot(ka["q"].encode(), ka["t"].encode())
+        oa = O.Aligner(global_alignment=ka["mode"] == "global", adaptive=tuple(ka["adaptive"]))
+        oa.align(ka["q"].encode(), ka["t"].encode())
+        owf = {c: {s: {lo + i: v for i, v in enumerate(raw) if v} for s, (lo, hi, raw) in d.items()}
+               for c, d in oa.dump().items()}
+        assert text == plot_component(ka["q"].encode(), ka["t"].encode(), owf), ka["id"]
+        if want is not None:
+            assert cells(text) == want
+        for comp in "ID":  # the I and D components plot too (no extension logic there)
+            assert al.Plot(ka["q"].encode(), ka["t"].encode(), comp) == plot_component(
+                ka["q"].encode(), ka["t"].encode(), owf, comp)
+        al.close()
+
+
 @pytest.mark.parametrize("length,err,n", [(150, 0.02, 4000), (1000, 0.05, 3000), (1000, 0.2, 300), (37, 0.1, 2000)])
 @pytest.mark.parametrize("glob,adaptive", [(True, (10, 50, 1)), (True, None), (False, (10, 50, 1)), (False, None)])
 def test_synthetic_batches(built, length, err, n, glob, adaptive):

@@ -7,5 +7,5 @@ from .aligner import (  # noqa: F401
     AdaptiveReductionOption, Aligner, AlignmentResult, BatchResult, DefaultAdaptiveOption, DefaultOptions,
     DefaultPenalties, ErrEmptySeq, ErrSeqTooLong, MaskLower32, MaxSeqLen, New, Op, OpD, OpH, OpI, OpM, OpX,
     Options, Penalties, RecycleAligner, RecycleAlignmentResult, RecycleAlignmentText, WfaError, generate_pairs,
-    make_blob, trimOps,
+    make_blob, plot_component, trimOps,
 )

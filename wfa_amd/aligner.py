@@ -299,6 +299,11 @@ class Aligner:
             L.lib().wfahip_results_free(C.byref(res))
         return out, br.result(0)
 
+    def Plot(self, q: bytes, t: bytes, component: str = "M", notChangeToMatch: bool = False, maxScore: int = -1) -> str:
+        """(*Aligner).Plot (wfa_component_plot.go:41): the component table, from the DEVICE wavefronts of one pair."""
+        wf, _ = self.debug_wavefronts(q, t)
+        return plot_component(q, t, wf, component, self.p, notChangeToMatch, maxScore)
+
     def close(self):
         if getattr(self, "_ctx", None):
             L.lib().wfahip_destroy(self._ctx)
@@ -309,6 +314,86 @@ class Aligner:
             self.close()
         except Exception:
             pass
+
+
+WFA_ARROWS = "⊕⟼🠦↧🠧⬂⬊"  # wfa_backtrace_types.go:39: no type, InsOpen, InsExt, DelOpen, DelExt, Mismatch, Match
+
+
+def plot_component(q: bytes, t: bytes, wavefronts: dict, component: str = "M", penalties: Penalties = None,
+                   notChangeToMatch: bool = False, maxScore: int = -1) -> str:
+    """The text table of (*Aligner).Plot (wfa_component_plot.go:41-209) for one component, built from the stored
+    wavefront words {'M': {score: {k: raw}}, 'I': .., 'D': ..} (raw = offset<<3 | type) -- the form
+    Aligner.debug_wavefronts returns from the device and the oracle's dump has.
+
+    Every cell shows the first (lowest) score that reached it and the arrow of its type; with the M component,
+    cells reached by extension become matches and only the cell a run started from keeps its type
+    (wfa_component_plot.go:97-99,133-177)."""
+    p = penalties or DefaultPenalties
+    lenQ, lenT = len(q), len(t)
+    M, I, D = wavefronts["M"], wavefronts["I"], wavefronts["D"]
+    comp = wavefronts[component]
+    isM = component == "M"
+    m = [[-1] * lenT for _ in range(lenQ)]
+
+    def after_diff(c, s, diff, k):  # Component.GetAfterDiff (wfa_component.go:158-167): 0 when missing
+        if diff > s:
+            return 0
+        return c.get(s - diff, {}).get(k, 0) >> 3
+
+    vp = hp = 0  # the reference declares them outside the loops (wfa_component_plot.go:66)
+    for s in sorted(comp):
+        if maxScore >= 0 and s > maxScore:
+            break
+        row = comp[s]
+        for k in sorted(row):
+            raw = row[k]
+            offset, typ = raw >> 3, raw & 7
+            h = offset - 1
+            v = h - k
+            if v < 0 or h < 0 or v >= lenQ or h >= lenT:
+                continue
+            if m[v][h] >= 0:  # recorded with a lower score
+                continue
+            m[v][h] = (s << 3) | typ
+            if not isM or q[v] != t[h]:
+                continue
+            if typ == 2:  # InsExt
+                offset0 = max(after_diff(M, s, p.GapOpen + p.GapExt, k - 1), after_diff(I, s, p.GapExt, k - 1)) + 1
+            elif typ == 4:  # DelExt
+                offset0 = max(after_diff(M, s, p.GapOpen + p.GapExt, k + 1), after_diff(D, s, p.GapExt, k + 1))
+            else:
+                isk = max(after_diff(M, s, p.GapOpen + p.GapExt, k - 1), after_diff(I, s, p.GapExt, k - 1)) + 1
+                dsk = max(after_diff(M, s, p.GapOpen + p.GapExt, k + 1), after_diff(D, s, p.GapExt, k + 1))
+                offset0 = max(isk, dsk, after_diff(M, s, p.Mismatch, k) + 1)
+            h00 = offset0 - 1
+            if h == h00:  # not extended at all
+                continue
+            v0, h0 = v, h
+            if not notChangeToMatch:
+                m[v0][h0] = (s << 3) | 6
+            n = 0
+            while True:
+                h -= 1
+                v -= 1
+                if v < 0 or h < 0:
+                    break
+                n += 1
+                if m[v][h] >= 0:
+                    continue
+                m[v][h] = (s << 3) | (typ if notChangeToMatch else 6)
+                vp, hp = v, h
+                if q[v] != t[h] or h == h00:
+                    break
+            if n == 0:
+                vp, hp = v0, h0
+            if not notChangeToMatch:
+                m[vp][hp] = (s << 3) | typ  # the run's first cell keeps the original type
+    out = ["   \t " + "".join("\t%3d" % (h + 1) for h in range(lenT)),
+           "   \t " + "".join("\t%3s" % chr(b) for b in t)]
+    for v in range(lenQ):
+        cells = "".join("\t  ." if c < 0 else "\t%s%2d" % (WFA_ARROWS[c & 7], c >> 3) for c in m[v])
+        out.append("%3d\t%s%s" % (v + 1, chr(q[v]), cells))
+    return "\n".join(out) + "\n"
 
 
 @dataclass
