@@ -593,7 +593,10 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
         if (debug_single) cfg.slots = 1;
         // Wide wavefronts: a team of workgroups per pair (wfa_team_kernel) instead of one workgroup per pair.
         uint32_t team_T = 0, team_n = 0;
+        // It pays when one workgroup per pair cannot fill the GPU: few pairs, or arenas so large that only a few
+        // fit (cfg.slots is the number of pairs the generic kernel could run at once).
         if (cr == 0 && !debug_single && ctx->opt_team_min_len > 0 && max_len >= (uint64_t)ctx->opt_team_min_len &&
+            (cfg.slots < (uint32_t)std::max(1, ctx->num_cus / 2) || ctx->opt_team_wgs > 0) &&
             std::max(P.x, std::max(P.oe, P.e)) / P.g < (uint32_t)TEAM_RING) {
             const uint32_t cus = (uint32_t)std::max(1, ctx->num_cus);
             uint32_t t0 = (uint32_t)std::min<uint64_t>(cus, std::max<uint64_t>(2, (2ull * max_len + 8191) / 8192));
