@@ -146,6 +146,9 @@ int  wfahip_last_timing(const wfahip_ctx *ctx, wfahip_timing *out);
  *   "packed_arena_bytes"   per-pair arena of the sub-wave pipeline (0 = automatic)
  *   "chunk_pairs", "packed_waves_per_cu", "overlap"   chunking of the sub-wave pipeline
  *   "tail_overlap"  0|1    retry passes run beside the first pass's backtrace kernel             default 1
+ *   "pilot"  0|1           wf-adaptive off, reads >= 400 bases: 4 096 pairs go first and decide whether the
+ *                          rest uses the sub-wave kernels at all                                  default 1
+ *   "blk_batch"  0|1       short reads: a group of the blocked kernel stages 8 pairs per refill   default 1
  *   "arena_bytes_per_slot", "slots", "threads_per_pair"   generic kernel (one workgroup per pair)
  *   "team_min_len"         pairs at least this long use the team kernel (0 = never)              default 8192
  *   "team_wgs", "team_solo_max"   workgroups per team (0 = automatic), widest row done by one workgroup */

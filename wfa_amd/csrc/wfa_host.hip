@@ -79,6 +79,7 @@ struct wfahip_ctx {
                                                     // per pair) in the generic ladder; 0 = never
     int64_t       opt_team_wgs             = 0;     // workgroups per team, 0 = automatic
     int64_t       opt_team_solo_max        = TEAM_SOLO_MAX;  // rows up to this width are done by one workgroup
+    int64_t       opt_pilot                = 1;  // 1: a 4 096-pair pilot decides whether a large batch uses the sub-wave kernels
     int64_t       opt_tail_overlap         = 1;  // 1: retry passes overlap the backtrace kernel of the first pass
     int64_t       opt_overlap              = 0;  // 1: backtrace of chunk c on a second stream beside the forward kernel of chunk c+1 (measured: no gain)
     int           force_mode               = -1;  // debug: start the ladder in this mode
@@ -299,6 +300,8 @@ extern "C" int wfahip_set_option(wfahip_ctx *ctx, const char *key, int64_t value
         ctx->opt_overlap = value;
     else if (k == "tail_overlap")
         ctx->opt_tail_overlap = value;
+    else if (k == "pilot")
+        ctx->opt_pilot = value;
     else if (k == "team_min_len")
         ctx->opt_team_min_len = value;
     else if (k == "team_wgs")
@@ -418,7 +421,7 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
         // one pass over `count` pairs (identity range when list == nullptr); returns the {pair,status} redo entries
         // detach_bt: (first pass, one chunk) the backtrace kernel goes to stream2 and is only waited for at the very
         // end of the call, so the retry passes -- which use the second arena -- run beside it.
-        auto forward_pass = [&](int kind, const std::vector<uint32_t> *list, uint64_t count,
+        auto forward_pass = [&](int kind, const std::vector<uint32_t> *list, uint64_t first_pair, uint64_t count,
                                 std::vector<uint64_t> &redo_out, bool detach_bt) -> int {
             DevBuf &arena_buf = ctx->bt_pending ? ctx->arena2 : ctx->arena;
             DevBuf &meta_buf  = ctx->bt_pending ? ctx->meta2 : ctx->meta;
@@ -471,7 +474,7 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
                 const uint32_t buf = (uint32_t)(c % n_buf);
                 P.arena       = static_cast<uint32_t *>(arena_buf.p) + (uint64_t)buf * chunk * words;
                 P.pair_meta   = static_cast<uint4 *>(meta_buf.p) + (uint64_t)buf * chunk;
-                P.chunk_first = (uint32_t)c0, P.chunk_n = (uint32_t)cn;
+                P.chunk_first = (uint32_t)(first_pair + c0), P.chunk_n = (uint32_t)cn;
                 P.work        = list ? static_cast<const uint32_t *>(ctx->work.p) + c0 : nullptr;
                 const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)ctx->num_cus * waves_per_cu,
                                                                   (cn + pairs_wave - 1) / pairs_wave);
@@ -523,9 +526,25 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
         if (can_b || can_c || can_d) {
             std::vector<uint64_t> redo1, redo2;
             const int kind1 = can_d ? (ctx->opt_blk == 8 ? 4 : 3) : (can_c ? 2 : 1);
-            if ((rc = forward_pass(kind1, nullptr, n_pairs, redo1, true))) return rc;
+            // Pilot: on a large batch the first 4 096 pairs go first; when most of them leave the 64-diagonal window
+            // (wf-adaptive off on long reads, very divergent pairs) the rest skips the sub-wave kernels instead of
+            // starting every pair there only to hand it on.
+            uint64_t done_pairs = 0;
+            bool     skip_rest  = false;
+            if (n_pairs >= 32768 && !P.adaptive && max_len >= 400 && ctx->opt_pilot != 0) {  // (wf-adaptive or short reads: narrow bands)
+                const uint64_t pilot = 4096;
+                if ((rc = forward_pass(kind1, nullptr, 0, pilot, redo1, false))) return rc;
+                done_pairs = pilot;
+                skip_rest  = redo1.size() * 2 > pilot;
+            }
+            if (!skip_rest) {
+                std::vector<uint64_t> more;
+                if ((rc = forward_pass(kind1, nullptr, done_pairs, n_pairs - done_pairs, more, true))) return rc;
+                redo1.insert(redo1.end(), more.begin(), more.end());
+                done_pairs = n_pairs;
+            }
             ctx->timing.main_kernel_kind = (uint32_t)kind1;
-            ctx->timing.n_packed_pairs = (uint32_t)(n_pairs - redo1.size());
+            ctx->timing.n_packed_pairs = (uint32_t)(done_pairs - redo1.size());
             ctx->timing.n_retried_pairs += (uint32_t)redo1.size();
             Job jb, ja;
             jb.mode = 1, jb.level = 0, jb.all = false;
@@ -544,13 +563,15 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
                     else ja.pairs.push_back((uint32_t)e);
                 }
                 if (!lst.empty()) {
-                    if ((rc = forward_pass(1, &lst, lst.size(), redo2, false))) return rc;
+                    if ((rc = forward_pass(1, &lst, 0, lst.size(), redo2, false))) return rc;
                     ctx->timing.n_packed_pairs += (uint32_t)(lst.size() - redo2.size());
                     for (uint64_t e : redo2) ((uint32_t)(e >> 32) == ST_REDO_BYTES ? jb : ja).pairs.push_back((uint32_t)e);
                 }
             } else {
                 for (uint64_t e : redo1) ((uint32_t)(e >> 32) == ST_REDO_BYTES ? jb : ja).pairs.push_back((uint32_t)e);
             }
+            if (skip_rest)
+                for (uint64_t i = done_pairs; i < n_pairs; i++) ja.pairs.push_back((uint32_t)i);
             std::sort(ja.pairs.begin(), ja.pairs.end());
             if (!ja.pairs.empty()) jobs.push_back(std::move(ja));
             if (!jb.pairs.empty()) jobs.push_back(std::move(jb));
