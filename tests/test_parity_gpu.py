@@ -329,6 +329,27 @@ def test_mid_length_global(built, length, err, n):
         al.close()
 
 
+@pytest.mark.parametrize("err,expect_skip", [(0.12, True), (0.01, False)])
+def test_pilot_chunk(built, err, expect_skip):
+    """wf-adaptive off on a large batch of 400+ base reads: the first 4 096 pairs are a pilot; when most of them
+    outgrow the 64-diagonal window the rest goes straight to the generic kernel, else the blocked kernel takes
+    the rest.  Either way every record equals the oracle's."""
+    import os
+    import wfa_amd as w
+    from oracle import oracle as O
+    n = 33000
+    data = w.generate_pairs(seed=int(err * 1000), n_pairs=n, length=400, error_rate=err, n_threads=16)
+    al = _aligner(True, None)
+    got = al.align_arrays(*data)
+    t = al.last_timing()
+    assert (t.n_packed_pairs < 4096) == expect_skip, t
+    want = O.align_batch(_oracle_params(True, None), *data, n_threads=max(8, (os.cpu_count() or 8) // 2))
+    assert_batch_equal(got, want, f"pilot err={err}")
+    al.set_option("pilot", 0)
+    assert_batch_equal(al.align_arrays(*data), want, f"no pilot err={err}")
+    al.close()
+
+
 def test_small_arena_forces_retry_ladder(built):
     """A deliberately tiny wavefront arena: pairs overflow, are re-run with 8x slots, results unchanged."""
     import wfa_amd as w
