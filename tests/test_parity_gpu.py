@@ -350,6 +350,28 @@ def test_pilot_chunk(built, err, expect_skip):
     al.close()
 
 
+def test_mixed_lengths_keep_the_fast_path(built):
+    """A batch of short reads with a few long ones: the sub-wave pipeline is sized for the pairs that fit its LDS
+    budget, the kernels hand the long pairs on (ST_REDO_LDS) and the generic / team kernels finish them."""
+    import wfa_amd as w
+    from oracle import oracle as O
+    short = w.generate_pairs(seed=41, n_pairs=3000, length=300, error_rate=0.05)
+    longp = w.generate_pairs(seed=42, n_pairs=6, length=15000, error_rate=0.05)
+    blob = np.concatenate([short[0], longp[0]])
+    off = np.uint64(len(short[0]))
+    data = (blob, np.concatenate([short[1], longp[1] + off]), np.concatenate([short[2], longp[2]]),
+            np.concatenate([short[3], longp[3] + off]), np.concatenate([short[4], longp[4]]))
+    for ad in ((10, 50, 1), None):
+        al = _aligner(True, ad)
+        got = al.align_arrays(*data)
+        t = al.last_timing()
+        assert t.main_kernel_kind == 3, t
+        if ad is not None:  # (without wf-adaptive many 300-base pairs outgrow the 64-diagonal window on their own)
+            assert t.n_packed_pairs >= 2900, t
+        assert_batch_equal(got, O.align_batch(_oracle_params(True, ad), *data, n_threads=8), f"mixed lengths ad={ad}")
+        al.close()
+
+
 def test_small_arena_forces_retry_ladder(built):
     """A deliberately tiny wavefront arena: pairs overflow, are re-run with 8x slots, results unchanged."""
     import wfa_amd as w

@@ -395,16 +395,34 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
     if (ctx->opt_packed && !debug_single && ctx->force_mode < 0 && P.global_alignment) {
         const uint32_t dx = P.x / P.g, doe = P.oe / P.g, de = P.e / P.g;
         const uint32_t dm = std::max(dx, doe) + 1, di = de + 1;
-        const uint32_t seq_words = (max_len + 15) / 16 + 1;
+        // Mixed lengths: the sub-wave kernels keep both sequences of a pair in a few KB of LDS.  When the longest
+        // pair of the batch does not fit but most pairs do, the pipeline is sized for the longest pair that fits;
+        // the kernels hand the longer ones on themselves (ST_REDO_LDS) and the generic / team kernels take them.
+        constexpr uint32_t SUB_LEN_LIMIT = 10200;
+        uint32_t           sub_len       = max_len;
+        if (max_len > SUB_LEN_LIMIT && n_pairs >= 256) {
+            std::vector<uint32_t> ql(n_pairs), tl(n_pairs);
+            HIP_TRY(hipMemcpyAsync(ql.data(), d_q_len, n_pairs * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(tl.data(), d_t_len, n_pairs * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            uint64_t n_fit = 0;
+            uint32_t best  = 0;
+            for (uint64_t i = 0; i < n_pairs; i++) {
+                const uint32_t l = std::max(ql[i], tl[i]);
+                if (l <= SUB_LEN_LIMIT) n_fit++, best = std::max(best, l);
+            }
+            if (n_fit * 10 >= n_pairs * 9 && best > 0) sub_len = best;  // at least 90 % of the pairs fit
+        }
+        const uint32_t seq_words = (sub_len + 15) / 16 + 1;
         const uint64_t sub_words = packed_sub_lds_words(seq_words, dm, di);
         const size_t   lds_b     = (size_t)sub_words * 2 * 4;       // packed kernel: two halves
         const size_t   lds_c     = (size_t)seq_words * 2 * 4 * 4;   // register kernel: four rows, sequences only
         const size_t   lds_d     = (size_t)seq_words * 2 * 4 * (ctx->opt_blk == 8 ? 8 : 4) + 16;  // blocked kernel
         const bool     can_b     = lds_b <= 20 * 1024;
         const bool     can_c     = ctx->opt_reg && dx == 2 && doe == 4 && de == 1 && lds_c <= 20 * 1024;
-        const bool     can_d     = ctx->opt_blk && dx == 2 && doe == 4 && de == 1 && max_len < 32768 &&
+        const bool     can_d     = ctx->opt_blk && dx == 2 && doe == 4 && de == 1 && sub_len < 32768 &&
                                lds_d <= (ctx->opt_blk == 8 ? 40 : 20) * 1024;
-        uint64_t       words_dir = std::max<uint64_t>(1024, 8ull * max_len);  // compact rows: 1 word per diagonal
+        uint64_t       words_dir = std::max<uint64_t>(1024, 8ull * sub_len);  // compact rows: 1 word per diagonal
         if (ctx->opt_packed_arena_bytes > 0) words_dir = std::max<uint64_t>(1024, ctx->opt_packed_arena_bytes / 4);
         words_dir = (words_dir + 7) & ~7ull;
         P.arena_words   = words_dir;
