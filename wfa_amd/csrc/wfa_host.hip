@@ -153,6 +153,7 @@ struct Job {
     int                   level;  // arena size = base * 8^level
     bool                  all;    // identity work list over all pairs
     std::vector<uint32_t> pairs;
+    uint32_t              max_len = 0;  // length bound of these pairs (0 = the batch's)
 };
 
 constexpr size_t LDS_MAX_BYTES = 160 * 1024;
@@ -386,6 +387,8 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
 
     std::deque<Job> jobs;
     std::vector<uint32_t> no_memory;
+    std::vector<uint32_t> h_len;   // max(q_len, t_len) per pair, only when the batch mixes short and long pairs
+    uint32_t              sub_len_used = 0;
     const int             max_level = 6;
     bool                  first     = true;
 
@@ -407,11 +410,16 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
             HIP_TRY(hipStreamSynchronize(st));
             uint64_t n_fit = 0;
             uint32_t best  = 0;
+            h_len.resize(n_pairs);
             for (uint64_t i = 0; i < n_pairs; i++) {
                 const uint32_t l = std::max(ql[i], tl[i]);
+                h_len[i]         = l;
                 if (l <= SUB_LEN_LIMIT) n_fit++, best = std::max(best, l);
             }
-            if (n_fit * 10 >= n_pairs * 9 && best > 0) sub_len = best;  // at least 90 % of the pairs fit
+            if (n_fit * 10 >= n_pairs * 9 && best > 0)
+                sub_len = best, sub_len_used = best;  // at least 90 % of the pairs fit
+            else
+                h_len.clear();
         }
         const uint32_t seq_words = (sub_len + 15) / 16 + 1;
         const uint64_t sub_words = packed_sub_lds_words(seq_words, dm, di);
@@ -591,8 +599,20 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
             if (skip_rest)
                 for (uint64_t i = done_pairs; i < n_pairs; i++) ja.pairs.push_back((uint32_t)i);
             std::sort(ja.pairs.begin(), ja.pairs.end());
-            if (!ja.pairs.empty()) jobs.push_back(std::move(ja));
-            if (!jb.pairs.empty()) jobs.push_back(std::move(jb));
+            for (Job *jp : {&ja, &jb}) {
+                if (jp->pairs.empty()) continue;
+                if (sub_len_used == 0) {
+                    jobs.push_back(std::move(*jp));
+                    continue;
+                }
+                // mixed lengths: the leftovers that fit the short class keep its (small) arenas and LDS budget
+                Job js = *jp, jl = *jp;
+                js.pairs.clear(), jl.pairs.clear();
+                js.max_len = sub_len_used;
+                for (uint32_t pid : jp->pairs) (h_len[pid] <= sub_len_used ? js : jl).pairs.push_back(pid);
+                if (!js.pairs.empty()) jobs.push_back(std::move(js));
+                if (!jl.pairs.empty()) jobs.push_back(std::move(jl));
+            }
 #ifdef WFA_STAMPS
             {
                 unsigned long long acc[16];
@@ -623,6 +643,8 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
         jobs.pop_front();
         const uint64_t n_work = job.all ? n_pairs : job.pairs.size();
         if (n_work == 0) continue;
+        const uint32_t max_len_all = max_len;
+        const uint32_t max_len     = job.max_len ? job.max_len : max_len_all;  // (shadows the batch's bound for this job)
         LaunchCfg cfg;
         int       cr = make_cfg(ctx, max_len, job.mode, job.level, n_work, !P.global_alignment, cfg);
         if (cr == 1) {  // sequences do not fit LDS: byte path for the whole job
@@ -733,8 +755,8 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
             HIP_TRY(hipMemcpy(ent.data(), ctx->redo.p, n_redo * 8ull, hipMemcpyDeviceToHost));
             std::sort(ent.begin(), ent.end(), [](uint64_t a, uint64_t b) { return (uint32_t)a < (uint32_t)b; });
             Job jb, ja;
-            jb.mode = 1, jb.level = job.level, jb.all = false;
-            ja.mode = job.mode, ja.level = job.level + 1, ja.all = false;
+            jb.mode = 1, jb.level = job.level, jb.all = false, jb.max_len = job.max_len;
+            ja.mode = job.mode, ja.level = job.level + 1, ja.all = false, ja.max_len = job.max_len;
             for (uint32_t i = 0; i < n_redo; i++) {
                 const uint32_t stw = (uint32_t)(ent[i] >> 32);
                 (stw == ST_REDO_BYTES || stw == ST_REDO_LDS ? jb : ja).pairs.push_back((uint32_t)ent[i]);
