@@ -102,6 +102,19 @@ struct BlkRed {
                 : "+v"(a));                                                                               \
         return a;                                                                                         \
     }
+    // a <- min, b <- max, c <- min: three independent chains fill each other's DPP wait states, no s_nop
+    static WFA_DEV void min_max_min(int &a, int &b, int &c) {
+#define WFA_DPP_ST3(ctl)                                                                               \
+    "v_min_i32_dpp %0, %0, %0 " ctl "\n\tv_max_i32_dpp %1, %1, %1 " ctl "\n\tv_min_i32_dpp %2, %2, %2 " ctl "\n\t"
+        if constexpr (G == 16)
+            asm("s_nop 1\n\t" WFA_DPP_ST3(WFA_DPP_CTL_XOR1) WFA_DPP_ST3(WFA_DPP_CTL_XOR2) WFA_DPP_ST3(WFA_DPP_CTL_HMIR)
+                    WFA_DPP_ST3(WFA_DPP_CTL_MIR)
+                : "+v"(a), "+v"(b), "+v"(c));
+        else
+            asm("s_nop 1\n\t" WFA_DPP_ST3(WFA_DPP_CTL_XOR1) WFA_DPP_ST3(WFA_DPP_CTL_XOR2) WFA_DPP_ST3(WFA_DPP_CTL_HMIR)
+                : "+v"(a), "+v"(b), "+v"(c));
+#undef WFA_DPP_ST3
+    }
     WFA_RED2(min_max, "v_min_i32_dpp", "v_max_i32_dpp")
     WFA_RED2(max_add, "v_max_i32_dpp", "v_add_u32_dpp")
     WFA_RED1(max1, "v_max_i32_dpp")
@@ -499,65 +512,107 @@ __global__ __launch_bounds__(64, (G == 16 ? 4 : WFA_BLK8_WAVES)) void wfa_blk_ke
                 term = run && (r & 2) != 0;
             }
 
-            // ------------------------------------------------------------ tight range of the M cells = M.Lo/M.Hi
-            int glo = BK_BIG, ghi = -BK_BIG;  // window-relative index of the lane's first / last M cell
-#pragma unroll
-            for (int p = PP - 1; p >= 0; p--) glo = nz[p] ? PP * j + p : glo;
-#pragma unroll
-            for (int p = 0; p < PP; p++) ghi = nz[p] ? PP * j + p : ghi;
-            Red::min_max(glo, ghi);
-            const bool anyM = ghi >= 0;
-            int        ilo = glo, ihi = ghi;  // band to keep (window-relative)
-            uint32_t   csum = 0u;
-#pragma unroll
-            for (int p = 0; p < PP; p++) csum += cc[p];
-
-            // ------------------------------------------------------------ wf-adaptive (wfa.go:461-540)
+            // ------------------------------------------------------------ band of the row + wf-adaptive (wfa.go:461-540)
             // remaining distance (wfa.go:488) = max(m-h, n-v) = max(m, n+k) - h; an entry is usable iff h < min(m, n+k)
-            const bool want_reduce = run && !term && adaptive && anyM && (ghi - glo + 1) >= minwf;
-            if (__ballot(want_reduce) != 0ull) {
-                WFA_EVT(3, 1);
-                int  dd[PP], mind = BK_BIG, maxd = -BK_BIG;
-                bool vd[PP];
+            int      ilo = 0, ihi = -1;  // band to keep (window-relative)
+            bool     anyM = false;
+            uint32_t csum = 0u;
+            if (!hit_any) {
+                // No cell of the wave sits at a sequence end (97 % of the steps): every M cell is usable, so the
+                // tight range of M (M.Lo/M.Hi, the wf-adaptive trigger of wfa.go:242) is [first, last usable entry],
+                // and with the threshold at +infinity when wf-adaptive does not run, [first_ok, last_ok] IS the
+                // band to keep in every case (nothing fails -> it is the tight range; wfa.go:509-524 otherwise: the
+                // entries between the last leading failure and first_ok are holes).  Two reduction rounds, no
+                // branch: (first M, last M, min distance), then (first_ok, last_ok).
+                int glo = BK_BIG, ghi = -BK_BIG, mind = BK_BIG, dd[PP];
+#pragma unroll
+                for (int p = PP - 1; p >= 0; p--) glo = nz[p] ? PP * j + p : glo;
 #pragma unroll
                 for (int p = 0; p < PP; p++) {
-                    vd[p] = nz[p] && !hit[p];
+                    ghi   = nz[p] ? PP * j + p : ghi;
                     dd[p] = lmx[p] - (int)nM[p];
-                    mind  = vd[p] ? imin2(mind, dd[p]) : mind;
-                    maxd  = vd[p] ? imax2(maxd, dd[p]) : maxd;
+                    mind  = nz[p] ? imin2(mind, dd[p]) : mind;
                 }
-                Red::min_max(mind, maxd);
-                const int  thr   = mind + mdd;
-                const bool found = want_reduce && mind != BK_BIG && maxd > thr;  // some distance fails (wfa.go:507)
-                if (__ballot(found) != 0ull) {
-                    WFA_EVT(4, 1), WFA_EVT(5, __builtin_popcountll(__ballot(found)) / G);
-                    int first_ok = BK_BIG, last_ok = -BK_BIG;
+                Red::min_max_min(glo, ghi, mind);
+                anyM = ghi >= 0;
+                const bool want = run && adaptive && anyM && (ghi - glo + 1) >= minwf;
+                const int  thr  = want ? mind + mdd : BK_BIG;
+                int        first_ok = BK_BIG, last_ok = -BK_BIG;
 #pragma unroll
-                    for (int p = PP - 1; p >= 0; p--) first_ok = (vd[p] && dd[p] <= thr) ? PP * j + p : first_ok;
+                for (int p = PP - 1; p >= 0; p--) first_ok = (nz[p] && dd[p] <= thr) ? PP * j + p : first_ok;
 #pragma unroll
-                    for (int p = 0; p < PP; p++) last_ok = (vd[p] && dd[p] <= thr) ? PP * j + p : last_ok;
-                    Red::min_max(first_ok, last_ok);
-                    // wfa.go:509-511: _lo = one past the last failing entry before the first non-failing one.  The
-                    // entries between that one and first_ok are unusable ones: holes (absent cells) or cells at a
-                    // sequence end.  While no cell of the wave has reached an end they are all holes, and deleting
-                    // or keeping a hole is the same thing: _lo = first_ok gives the identical row.
-                    int newlo = first_ok;
-                    if (hit_any) {
-                        int leadp = -1;
+                for (int p = 0; p < PP; p++) last_ok = (nz[p] && dd[p] <= thr) ? PP * j + p : last_ok;
+                Red::min_max(first_ok, last_ok);
+                ilo = first_ok, ihi = last_ok;
 #pragma unroll
-                        for (int p = 0; p < PP; p++) leadp = (vd[p] && PP * j + p < first_ok) ? PP * j + p : leadp;
-                        leadp = Red::max1(leadp);
-                        newlo = leadp >= 0 ? leadp + 1 : glo;
+                for (int p = 0; p < PP; p++) {  // Delete of wfa.go:526-535: the words never exist
+                    const int  ix   = PP * j + p;
+                    const bool keep = ix >= ilo && ix <= ihi;
+                    nM[p] = keep ? nM[p] : 0u, nI[p] = keep ? nI[p] : 0u, nD[p] = keep ? nD[p] : 0u;
+                    wd[p] = keep ? wd[p] : 0u;
+                    csum += keep ? cc[p] : 0u;
+                }
+            } else {
+                // ------------------------------------------------------------ tight range of the M cells = M.Lo/M.Hi
+                int glo = BK_BIG, ghi = -BK_BIG;  // window-relative index of the lane's first / last M cell
+#pragma unroll
+                for (int p = PP - 1; p >= 0; p--) glo = nz[p] ? PP * j + p : glo;
+#pragma unroll
+                for (int p = 0; p < PP; p++) ghi = nz[p] ? PP * j + p : ghi;
+                Red::min_max(glo, ghi);
+                anyM = ghi >= 0;
+                ilo = glo, ihi = ghi;
+                csum = 0u;
+#pragma unroll
+                for (int p = 0; p < PP; p++) csum += cc[p];
+
+                // ------------------------------------------------------------ wf-adaptive (wfa.go:461-540)
+                // remaining distance (wfa.go:488) = max(m-h, n-v) = max(m, n+k) - h; an entry is usable iff h < min(m, n+k)
+                const bool want_reduce = run && !term && adaptive && anyM && (ghi - glo + 1) >= minwf;
+                if (__ballot(want_reduce) != 0ull) {
+                    WFA_EVT(3, 1);
+                    int  dd[PP], mind = BK_BIG, maxd = -BK_BIG;
+                    bool vd[PP];
+#pragma unroll
+                    for (int p = 0; p < PP; p++) {
+                        vd[p] = nz[p] && !hit[p];
+                        dd[p] = lmx[p] - (int)nM[p];
+                        mind  = vd[p] ? imin2(mind, dd[p]) : mind;
+                        maxd  = vd[p] ? imax2(maxd, dd[p]) : maxd;
                     }
-                    if (found) ilo = newlo, ihi = last_ok;  // wfa.go:517-524
-                    csum = 0u;
+                    Red::min_max(mind, maxd);
+                    const int  thr   = mind + mdd;
+                    const bool found = want_reduce && mind != BK_BIG && maxd > thr;  // some distance fails (wfa.go:507)
+                    if (__ballot(found) != 0ull) {
+                        WFA_EVT(4, 1), WFA_EVT(5, __builtin_popcountll(__ballot(found)) / G);
+                        int first_ok = BK_BIG, last_ok = -BK_BIG;
 #pragma unroll
-                    for (int p = 0; p < PP; p++) {  // Delete of wfa.go:526-535: the words never exist
-                        const int  ix   = PP * j + p;
-                        const bool keep = ix >= ilo && ix <= ihi;
-                        nM[p] = keep ? nM[p] : 0u, nI[p] = keep ? nI[p] : 0u, nD[p] = keep ? nD[p] : 0u;
-                        wd[p] = keep ? wd[p] : 0u;
-                        csum += keep ? cc[p] : 0u;
+                        for (int p = PP - 1; p >= 0; p--) first_ok = (vd[p] && dd[p] <= thr) ? PP * j + p : first_ok;
+#pragma unroll
+                        for (int p = 0; p < PP; p++) last_ok = (vd[p] && dd[p] <= thr) ? PP * j + p : last_ok;
+                        Red::min_max(first_ok, last_ok);
+                        // wfa.go:509-511: _lo = one past the last failing entry before the first non-failing one.  The
+                        // entries between that one and first_ok are unusable ones: holes (absent cells) or cells at a
+                        // sequence end.  While no cell of the wave has reached an end they are all holes, and deleting
+                        // or keeping a hole is the same thing: _lo = first_ok gives the identical row.
+                        int newlo = first_ok;
+                        if (hit_any) {
+                            int leadp = -1;
+#pragma unroll
+                            for (int p = 0; p < PP; p++) leadp = (vd[p] && PP * j + p < first_ok) ? PP * j + p : leadp;
+                            leadp = Red::max1(leadp);
+                            newlo = leadp >= 0 ? leadp + 1 : glo;
+                        }
+                        if (found) ilo = newlo, ihi = last_ok;  // wfa.go:517-524
+                        csum = 0u;
+#pragma unroll
+                        for (int p = 0; p < PP; p++) {  // Delete of wfa.go:526-535: the words never exist
+                            const int  ix   = PP * j + p;
+                            const bool keep = ix >= ilo && ix <= ihi;
+                            nM[p] = keep ? nM[p] : 0u, nI[p] = keep ? nI[p] : 0u, nD[p] = keep ? nD[p] : 0u;
+                            wd[p] = keep ? wd[p] : 0u;
+                            csum += keep ? cc[p] : 0u;
+                        }
                     }
                 }
             }
