@@ -456,7 +456,7 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
             const size_t   lds_bytes    = blk_batch ? (size_t)4 * BLK_BATCH * (2 * seq_words + 8) * 4 + 16
                                                     : (kind >= 3 ? lds_d : (kind == 2 ? lds_c : lds_b));
             const uint32_t pairs_wave   = kind == 4 ? 8 : (kind >= 2 ? 4 : 2);
-            // blocked kernel: fixed-pitch arena (64 words per score, no directory), 16 words per base
+            // blocked kernel: fixed-pitch arena (64 words per score, no directory), 16 words per base: 250 scores at 1 kbp
             const uint64_t words        = kind >= 3 ? std::max<uint64_t>((words_dir * 2 + 63) & ~63ull, 2048) : words_dir;
             P.arena_words = words, P.compact_fmt = kind >= 3 ? 1u : 0u;
             const uint32_t waves_lds    = (uint32_t)std::min<size_t>(32, LDS_MAX_BYTES / lds_bytes);
@@ -568,6 +568,13 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
                 if ((rc = forward_pass(kind1, nullptr, done_pairs, n_pairs - done_pairs, more, true))) return rc;
                 redo1.insert(redo1.end(), more.begin(), more.end());
                 done_pairs = n_pairs;
+            }
+            if (std::getenv("WFAHIP_DEBUG_TIMING")) {
+                uint64_t cnt[4] = {0, 0, 0, 0};
+                for (uint64_t e : redo1) cnt[std::min<uint32_t>(3, (uint32_t)(e >> 32) - ST_REDO_BYTES)]++;
+                std::fprintf(stderr, "[wfahip] handed on by the first pass: bytes %llu, arena %llu, lds %llu, band %llu\n",
+                             (unsigned long long)cnt[0], (unsigned long long)cnt[1], (unsigned long long)cnt[2],
+                             (unsigned long long)cnt[3]);
             }
             ctx->timing.main_kernel_kind = (uint32_t)kind1;
             ctx->timing.n_packed_pairs = (uint32_t)(done_pairs - redo1.size());
