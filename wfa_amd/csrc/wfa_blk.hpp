@@ -1,8 +1,8 @@
 // wfa_blk.hpp -- kernel D: blocked register-window forward kernel (64/G pairs per wave64).
 //
 // A group of G lanes (G = 16: one DPP row, or G = 8: half a row) owns one pair; lane j of the group holds the
-// PP = 64/G CONSECUTIVE diagonals kb + PP*j + p (p = 0..PP-1) of a 64-diagonal window that follows the band in
-// steps of 16.  Consequences of the blocked layout:
+// PP = 64/G CONSECUTIVE diagonals kb + PP*j + p (p = 0..PP-1) of a 64-diagonal window that follows the band one
+// lane (PP diagonals) at a time.  Consequences of the blocked layout:
 //   * the k-1 / k+1 sources of WF_NEXT (wfa.go:579,580,614,615) are the lane's own neighbouring registers for
 //     all but one position, so a score step needs four DPP lane shifts in total (Mo/I below, Mo/D above);
 //   * a lane's PP finished cells are adjacent in the arena: one 16-byte store per lane and row;
@@ -38,9 +38,14 @@ struct BlkOps<16> {
     // value held by lane j-1 / j+1 of the group; 0 beyond the group edge (bound_ctrl)
     static WFA_DEV uint32_t dn1(uint32_t x, int) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true); }
     static WFA_DEV uint32_t up1(uint32_t x, int) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x101, 0xf, 0xf, true); }
-    // window moves by 16 diagonals = 4 lanes: registers move towards higher (shr) / lower (shl) lanes
-    static WFA_DEV uint32_t shr(uint32_t x, int) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true); }
-    static WFA_DEV uint32_t shl(uint32_t x, int) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x104, 0xf, 0xf, true); }
+    // the window moves by WFA_BLK_SHIFT_LANES lanes: registers move towards higher (shr) / lower (shl) lanes
+    // (measured on 1e6 x 1 kbp: 4 lanes -> 3 316 pairs outgrow the window, 2 lanes -> 1 294, 1 lane -> 595, same speed)
+#ifndef WFA_BLK_SHIFT_LANES
+#define WFA_BLK_SHIFT_LANES 1
+#endif
+    static constexpr int SHIFT_D = 4 * WFA_BLK_SHIFT_LANES;  // diagonals per window shift
+    static WFA_DEV uint32_t shr(uint32_t x, int) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x110 + WFA_BLK_SHIFT_LANES, 0xf, 0xf, true); }
+    static WFA_DEV uint32_t shl(uint32_t x, int) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x100 + WFA_BLK_SHIFT_LANES, 0xf, 0xf, true); }
 };
 
 template <>
@@ -53,6 +58,7 @@ struct BlkOps<8> {
         const uint32_t r = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x101, 0xf, 0xf, true);
         return j == 7 ? 0u : r;
     }
+    static constexpr int SHIFT_D = 16;
     static WFA_DEV uint32_t shr(uint32_t x, int j) {  // 16 diagonals = 2 lanes
         const uint32_t r = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);
         return j < 2 ? 0u : r;
@@ -678,7 +684,7 @@ __global__ __launch_bounds__(64, (G == 16 ? 4 : WFA_BLK8_WAVES)) void wfa_blk_ke
                 if (__ballot(need_dn || need_up) != 0ull) {
                     const int  ulo  = imin2(imin2(rlo[0], rlo[1]), imin2(rlo[2], rlo[3]));
                     const int  uhi  = imax2(imax2(rhi[0], rhi[1]), imax2(rhi[2], rhi[3]));
-                    const bool wide = (need_dn && (need_up || uhi >= kb - 16 + W - 1)) || (need_up && ulo <= kb + 16);
+                    const bool wide = (need_dn && (need_up || uhi >= kb - Ops::SHIFT_D + W - 1)) || (need_up && ulo <= kb + Ops::SHIFT_D);
                     const bool dn = need_dn && !wide, up = need_up && !wide;
 #pragma unroll
                     for (int d = 0; d < 4; d++)
@@ -694,7 +700,7 @@ __global__ __launch_bounds__(64, (G == 16 ? 4 : WFA_BLK8_WAVES)) void wfa_blk_ke
                         I[p]             = dn ? a : (up ? b : I[p]);
                         D[p]             = dn ? c : (up ? d : D[p]);
                     }
-                    kb += dn ? -16 : (up ? 16 : 0);
+                    kb += dn ? -Ops::SHIFT_D : (up ? Ops::SHIFT_D : 0);
                     set_window();
                     if (__ballot(wide) != 0ull) {  // the band does not fit the window: hand the pair on
                         if (wide && j == 0) {
