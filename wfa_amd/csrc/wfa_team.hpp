@@ -34,8 +34,8 @@ namespace wfa {
 constexpr int TEAM_THREADS   = 1024;
 constexpr int TEAM_RING      = 64;   // directory entries every workgroup keeps in LDS (sources reach back < 64 scores)
 constexpr int TEAM_CTL_WORDS = 128;  // per team, in global memory: [0] barrier count [1] abort [2] work index
-                                     // [3] cells [4] command [5] score [6..7] arena top [8 + 8*set ..] three reduction sets
-                                     // [48..49] end-cell key (u64) [64..] diagnostic stamps
+                                     // [3] cells [4] command [5] score [6..7] arena top [8..9] end-cell key (u64) [10] end flags
+                                     // [16 + 16*set ..] three reduction sets [64..] diagnostic stamps
 constexpr uint32_t TEAM_SPIN_LIMIT = 1u << 24;
 #ifndef WFA_TEAM_U
 #define WFA_TEAM_U 2
@@ -44,8 +44,8 @@ constexpr int      TEAM_U          = WFA_TEAM_U;     // cells of a thread in fli
 constexpr uint32_t TEAM_SOLO_MAX   = 4096;  // default: rows up to this width are done by workgroup 0 alone
 enum : uint32_t { TEAM_CMD_NONE = 0, TEAM_CMD_RESUME = 1, TEAM_CMD_DONE = 2 };  // ctl[4]; ctl[5] = score, ctl[6..7] = top
 
-struct TeamRed {  // one reduction set (global memory)
-    int mlo, mhi, term, mind, first_ok, last_ok, anyfail, lead;
+struct TeamRed {  // one reduction set (global memory, 16 words)
+    int mlo, mhi, term, mind, first_ok, last_ok, anyfail, lead, hitmin, pad[7];
 };
 
 template <int MODE>
@@ -108,12 +108,12 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
     };
     const auto ald = [](const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     const auto ast = [](uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-    auto tred = [&](uint32_t set) { return reinterpret_cast<TeamRed *>(ctl + 8 + 8 * set); };
+    auto tred = [&](uint32_t set) { return reinterpret_cast<TeamRed *>(ctl + 16 + 16 * set); };
     auto reset_set = [&](TeamRed *r) {  // memory-side stores: the other workgroups' atomics must see them
         uint32_t *const w = reinterpret_cast<uint32_t *>(r);
-        const int       v[8] = {INT32_MAX, INT32_MIN, 0, INT32_MAX, INT32_MAX, INT32_MIN, 0, INT32_MIN};
+        const int       v[9] = {INT32_MAX, INT32_MIN, 0, INT32_MAX, INT32_MAX, INT32_MIN, 0, INT32_MIN, INT32_MAX};
 #pragma unroll
-        for (int i = 0; i < 8; i++) __hip_atomic_store(w + i, (uint32_t)v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = 0; i < 9; i++) __hip_atomic_store(w + i, (uint32_t)v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
 
     for (;;) {
@@ -123,8 +123,8 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
             __hip_atomic_store(&ctl[2], w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&ctl[3], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&ctl[4], (uint32_t)TEAM_CMD_NONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&ctl[48], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&ctl[49], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ctl[8], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ctl[9], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             reset_set(tred(0)), reset_set(tred(1)), reset_set(tred(2));
         }
         team_barrier(true);
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
                         const uint32_t cmd = ald(&ctl[4]);
                         if (cmd == TEAM_CMD_DONE) {  // how the pair ended: everybody takes part in the end-cell search
                             s_final = ald(&ctl[5]);
-                            const uint32_t fl = ald(&ctl[50]);
+                            const uint32_t fl = ald(&ctl[10]);
                             done = (fl & 1u) != 0u, overflow = (fl & 2u) != 0u;
                             break;
                         }
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
             uint32_t *const rowM = A + base, *const rowI = rowM + W, *const rowD = rowI + W;
             if (tid == 0) {
                 red[0] = INT32_MAX, red[1] = INT32_MIN, red[2] = 0, red[3] = INT32_MAX;
-                red[4] = INT32_MAX, red[5] = INT32_MIN, red[6] = 0, red[7] = INT32_MIN;
+                red[4] = INT32_MAX, red[5] = INT32_MIN, red[6] = 0, red[7] = INT32_MIN, red[11] = INT32_MAX;
             }
             __syncthreads();
             const int64_t i0 = teamed ? (int64_t)b * G + tid : tid, istep = teamed ? stripe : G;
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
             int nlo = mlo, nhi = mhi;  // surviving band: I and D only hold cells where M does
             if (P.adaptive && mhi >= mlo && (mhi - mlo + 1) >= (int)P.min_wf_len && mind != INT32_MAX) {
                 const int maxdiff = (int)P.max_dist_diff;
-                int       first_ok = INT32_MAX, last_ok = INT32_MIN, anyfail = 0;
+                int       first_ok = INT32_MAX, last_ok = INT32_MIN, anyfail = 0, hitmin = INT32_MAX;
                 auto p2cell = [&](uint32_t mw, int k) {
                     const int d = reduce_dist(mw, k, n, m);
                     if (d >= 0) {
@@ -391,30 +391,46 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
                             anyfail = 1;
                         else
                             first_ok = imin2(first_ok, k), last_ok = imax2(last_ok, k);
+                    } else if (mw != 0u) {
+                        hitmin = imin2(hitmin, k);  // a present cell at / past a sequence end
                     }
                 };
 #pragma unroll
                 for (int u = 0; u < TEAM_U; u++)
                     if (i0 + u * istep < W) p2cell(kM[u], lo + (int)(i0 + u * istep));
                 for (int64_t i = i_rest; i < W; i += istep) p2cell(ldw(rowM + i), lo + (int)i);
-                first_ok = wave_min(first_ok), last_ok = wave_max(last_ok);
+                first_ok = wave_min(first_ok), last_ok = wave_max(last_ok), hitmin = wave_min(hitmin);
                 anyfail  = __ballot(anyfail) != 0ull;
                 if (lane == 0) {
-                    atomicMin(&red[4], first_ok), atomicMax(&red[5], last_ok);
+                    atomicMin(&red[4], first_ok), atomicMax(&red[5], last_ok), atomicMin(&red[11], hitmin);
                     if (anyfail) red[6] = 1;
                 }
                 __syncthreads();
                 if (teamed) {
-                    team_min(&tr->first_ok, 4), team_max(&tr->last_ok, 5), team_or(&tr->anyfail, 6);
+                    team_min(&tr->first_ok, 4), team_max(&tr->last_ok, 5), team_or(&tr->anyfail, 6), team_min(&tr->hitmin, 11);
                     TEAM_STAMP(2);
                     team_barrier(false);  // B2
                     TEAM_STAMP(1);
                     if (aborted) return;
-                    team_get(&tr->first_ok, 4), team_get(&tr->last_ok, 5), team_get(&tr->anyfail, 6);
+                    team_get(&tr->first_ok, 4), team_get(&tr->last_ok, 5), team_get(&tr->anyfail, 6), team_get(&tr->hitmin, 11);
                     __syncthreads();
                 }
-                first_ok = red[4], last_ok = red[5], anyfail = red[6];
-                if (anyfail) {
+                first_ok = red[4], last_ok = red[5], anyfail = red[6], hitmin = red[11];
+                if (anyfail && hitmin >= first_ok) {
+                    // wfa.go:509-511: _lo = one past the last usable entry before the first non-failing one.  With no
+                    // present-but-unusable cell (a cell at a sequence end) below first_ok, the entries between that
+                    // one and first_ok are holes, and dropping or keeping a hole is the same row: _lo = first_ok --
+                    // one pass over the row and one team barrier less.
+                    nlo = first_ok, nhi = last_ok;
+                    auto fixcell = [&](uint32_t mw, uint32_t idw, int k) {
+                        if (k < nlo || k > nhi) my_cells -= (mw != 0u) + idw;
+                    };
+#pragma unroll
+                    for (int u = 0; u < TEAM_U; u++)
+                        if (i0 + u * istep < W) fixcell(kM[u], kF[u], lo + (int)(i0 + u * istep));
+                    for (int64_t i = i_rest; i < W; i += istep)
+                        fixcell(ldw(rowM + i), (ldw(rowI + i) != 0u) + (ldw(rowD + i) != 0u), lo + (int)i);
+                } else if (anyfail) {
                     // _lo: one past the last valid entry before the first non-failing one (wfa.go:503-516)
                     int lead = INT32_MIN;
 #pragma unroll
@@ -469,7 +485,7 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
         // ---- a pair that ends in solo mode: wake the parked workgroups
         if (!teamed && lead_wg) {
             if (tid == 0) {
-                ast(&ctl[5], s_final), ast(&ctl[50], (done ? 1u : 0u) | (overflow ? 2u : 0u));
+                ast(&ctl[5], s_final), ast(&ctl[10], (done ? 1u : 0u) | (overflow ? 2u : 0u));
                 ast(&ctl[4], (uint32_t)TEAM_CMD_DONE);
             }
             team_barrier(true);
@@ -533,11 +549,11 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
                     best = min(best, sc | (uint32_t)(Ak - (int)(keyD >> 1) + 0x40000000));
                 __syncthreads();
             }
-            if (tid == 0) atomicMin(reinterpret_cast<unsigned long long *>(ctl + 48), best);
+            if (tid == 0) atomicMin(reinterpret_cast<unsigned long long *>(ctl + 8), best);
             team_barrier(false);
             if (aborted) return;
             if (lead_wg) {
-                const uint32_t blo = ald(&ctl[48]), bhi = ald(&ctl[49]);
+                const uint32_t blo = ald(&ctl[8]), bhi = ald(&ctl[9]);
                 if (blo != 0xFFFFFFFFu) minS = bhi, lastK = (int)blo - 0x40000000;
             }
         }
