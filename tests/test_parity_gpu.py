@@ -372,6 +372,41 @@ def test_mixed_lengths_keep_the_fast_path(built):
         al.close()
 
 
+@pytest.mark.parametrize("seed", [101, 202, 303, 404])
+def test_fuzz_configs(built, seed):
+    """Seeded random configurations: penalties (the 2:4:1 shapes the blocked kernel takes and others), global /
+    semi-global, wf-adaptive parameters, ragged lengths from 1 to 1 500 bases, error rates up to 30 %."""
+    import wfa_amd as w
+    from oracle import oracle as O
+    rng = np.random.default_rng(seed)
+    pens = [(4, 6, 2), (2, 3, 1), (8, 12, 4), (6, 9, 3), (1, 1, 1), (3, 5, 2), (2, 6, 1), (5, 3, 3)]
+    for _ in range(6):
+        pen = pens[int(rng.integers(0, len(pens)))]
+        glob = bool(rng.integers(0, 4))  # mostly global
+        ad = None if rng.integers(0, 3) == 0 else (int(rng.integers(1, 24)), int(rng.integers(1, 120)), 1)
+        n = int(rng.integers(50, 400))
+        qs, ts = [], []
+        for i in range(n):
+            L = int(rng.integers(1, 1500 if glob else 400))
+            q = rng.integers(0, 4, L)
+            t = list(q)
+            for _e in range(int(L * rng.uniform(0, 0.3))):
+                kind, pos = int(rng.integers(0, 3)), int(rng.integers(0, max(1, len(t))))
+                if kind == 0 and t:
+                    t[pos] = int(rng.integers(0, 4))
+                elif kind == 1:
+                    t.insert(pos, int(rng.integers(0, 4)))
+                elif len(t) > 1:
+                    del t[pos]
+            qs.append(bytes(b"ACGT"[c] for c in q)), ts.append(bytes(b"ACGT"[c] for c in t) or b"G")
+        data = w.make_blob(qs, ts)
+        al = _aligner(glob, ad, pen)
+        got = al.align_arrays(*data)
+        want = O.align_batch(_oracle_params(glob, ad, pen), *data, n_threads=8)
+        assert_batch_equal(got, want, f"fuzz seed={seed} pen={pen} glob={glob} ad={ad} n={n}")
+        al.close()
+
+
 def test_small_arena_forces_retry_ladder(built):
     """A deliberately tiny wavefront arena: pairs overflow, are re-run with 8x slots, results unchanged."""
     import wfa_amd as w
