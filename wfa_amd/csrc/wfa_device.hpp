@@ -24,15 +24,23 @@ WFA_DEV void push_redo(const KParams &P, uint32_t pair, uint32_t status) {
 
 // ---------------------------------------------------------------------------------------------
 // wave64 reductions (DPP/ds_swizzle via __shfl_xor; 64 lanes, not 32)
+// Four DPP butterfly stages reduce each 16-lane row, row_bcast15 / row_bcast31 carry the row results up to lane 63
+// (the classic GCN wave reduction: no LDS round trips, unlike __shfl_xor = ds_bpermute), v_readlane broadcasts.
+#define WFA_WAVE_REDUCE(OP)                                                                                   \
+    asm("s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t" OP          \
+        " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t" OP                          \
+        " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t" OP                              \
+        " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t" OP                                   \
+        " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t" OP                                 \
+        " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"                                         \
+        : "+v"(v))
 WFA_DEV int wave_min(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = imin2(v, __shfl_xor(v, o, 64));
-    return v;
+    WFA_WAVE_REDUCE("v_min_i32_dpp");
+    return __builtin_amdgcn_readlane(v, 63);
 }
 WFA_DEV int wave_max(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = imax2(v, __shfl_xor(v, o, 64));
-    return v;
+    WFA_WAVE_REDUCE("v_max_i32_dpp");
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
 // ---------------------------------------------------------------------------------------------
