@@ -149,6 +149,8 @@ int  wfahip_last_timing(const wfahip_ctx *ctx, wfahip_timing *out);
  *   "pilot"  0|1           wf-adaptive off, reads >= 400 bases: 4 096 pairs go first and decide whether the
  *                          rest uses the sub-wave kernels at all                                  default 1
  *   "blk_batch"  0|1       short reads: a group of the blocked kernel stages 8 pairs per refill   default 1
+ *   "blk_wide"  0|1        pairs whose band leaves the 64-diagonal window retry on the same kernel with a
+ *                          wave per pair (256 diagonals) before the generic kernel takes them       default 1
  *   "arena_bytes_per_slot", "slots", "threads_per_pair"   generic kernel (one workgroup per pair)
  *   "team_min_len"         pairs at least this long use the team kernel (0 = never)              default 8192
  *   "team_wgs", "team_solo_max"   workgroups per team (0 = automatic), widest row done by one workgroup */

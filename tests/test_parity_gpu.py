@@ -329,6 +329,35 @@ def test_mid_length_global(built, length, err, n):
         al.close()
 
 
+def test_wide_band_retry_kernel(built):
+    """Pairs whose band leaves the 64-diagonal window retry on the wave-per-pair blocked kernel (256 diagonals);
+    what outgrows that too goes on to the generic kernel.  Same records with the rung switched off."""
+    import wfa_amd as w
+    from oracle import oracle as O
+    # without wf-adaptive a wavefront is about as wide as its score / gap_ext
+    parts = [w.generate_pairs(seed=5, n_pairs=300, length=400, error_rate=0.06, n_threads=8),    # ~100 diagonals
+             w.generate_pairs(seed=6, n_pairs=60, length=2500, error_rate=0.15, n_threads=8)]    # > 256 diagonals
+    qs, ts = [], []
+    for blob, q_off, q_len, t_off, t_len in parts:
+        for i in range(len(q_len)):
+            qs.append(bytes(blob[int(q_off[i]):int(q_off[i]) + int(q_len[i])]))
+            ts.append(bytes(blob[int(t_off[i]):int(t_off[i]) + int(t_len[i])]))
+    data = w.make_blob(qs, ts)
+    want = O.align_batch(_oracle_params(True, None), *data, n_threads=8)
+    packed = {}
+    for wide in (1, 0):
+        al = _aligner(True, None)
+        al.set_option("blk_wide", wide)
+        got = al.align_arrays(*data)
+        t = al.last_timing()
+        assert t.main_kernel_kind == 3
+        packed[wide] = t.n_packed_pairs
+        assert_batch_equal(got, want, f"blk_wide={wide}")
+        al.close()
+    assert packed[1] >= packed[0] + 100, packed   # the 256-diagonal rung finished most of the 400 bp pairs ...
+    assert packed[1] < len(qs)                    # ... and handed the widest ones on
+
+
 @pytest.mark.parametrize("err,expect_skip", [(0.12, True), (0.01, False)])
 def test_pilot_chunk(built, err, expect_skip):
     """wf-adaptive off on a large batch of 400+ base reads: the first 4 096 pairs are a pilot; when most of them

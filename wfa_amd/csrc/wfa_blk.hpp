@@ -20,15 +20,26 @@
 // pre-extension offset (wfa.go:766-817) equals the offset just computed.  A sticky per-pair flag, set by the
 // first cell that hits an end, switches the wave to the exact code (bit-for-bit the rules of next_cell()).
 //
-// Output: one compact backtrace word per diagonal (compact_word()) in the fixed-pitch arena layout (CompactView
-// fmt 1: 64 words per score, diagonal k at slot k & 63; the window base stays a multiple of PP so a lane's PP
-// words are one aligned 16/32-byte store), and pair_meta for wfa_backtrace_kernel.
+// Output: one compact backtrace word per diagonal (compact_word()) in a directory-free arena layout (CompactView
+// fmt 3: tiles of 8 scores x 64 diagonals; fmt 1 / 4: 64 / 256 words per score, diagonal k at slot k & (W-1); the
+// window base stays a multiple of PP so a lane's PP words are aligned 16-byte stores), and pair_meta for
+// wfa_backtrace_kernel.
+//
+// G = 64 (one pair per wave, PP = 4, a 256-diagonal window) is the retry rung for the pairs whose band outgrows
+// the 64-diagonal window: same code, wave-wide DPP shifts and readlane-combined reductions.
 #pragma once
 #include "wfa_device.hpp"
 #include "wfa_packed.hpp"
 #include <type_traits>
 
 namespace wfa {
+
+#ifndef WFA_BLK_TILED
+#define WFA_BLK_TILED 1  // 1: 64-diagonal arenas are tiled 8 scores x 64 diagonals (CompactView fmt 3); 0: plain rows (fmt 1)
+#endif
+#ifndef WFA_BLK_SC1
+#define WFA_BLK_SC1 0
+#endif
 
 template <int G>
 struct BlkOps;
@@ -67,6 +78,17 @@ struct BlkOps<8> {
         const uint32_t r = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x102, 0xf, 0xf, true);
         return j >= 6 ? 0u : r;
     }
+};
+
+// G = 64: the whole wave owns one pair (a 256-diagonal window; the retry rung for pairs whose band outgrew 64
+// diagonals).  Lane neighbours come from the wave-wide DPP shifts, which shift zeros in at lanes 0 / 63.
+template <>
+struct BlkOps<64> {
+    static WFA_DEV uint32_t dn1(uint32_t x, int) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xf, 0xf, true); }  // wave_shr:1
+    static WFA_DEV uint32_t up1(uint32_t x, int) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x130, 0xf, 0xf, true); }  // wave_shl:1
+    static constexpr int SHIFT_D = 4;
+    static WFA_DEV uint32_t shr(uint32_t x, int j) { return dn1(x, j); }
+    static WFA_DEV uint32_t shl(uint32_t x, int j) { return up1(x, j); }
 };
 
 // Butterfly reductions inside a group, written as DPP-fused VOP2 instructions (one instruction per stage and
@@ -129,6 +151,32 @@ struct BlkRed {
 #undef WFA_RED1
 };
 
+// 64 lanes: the four row results (BlkRed<16>) are combined through readlane + scalar ops; every result is
+// wave-uniform (it lives in an SGPR).
+template <>
+struct BlkRed<64> {
+    static WFA_DEV int rl(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+    static WFA_DEV int mn4(int v) { return imin2(imin2(rl(v, 0), rl(v, 16)), imin2(rl(v, 32), rl(v, 48))); }
+    static WFA_DEV int mx4(int v) { return imax2(imax2(rl(v, 0), rl(v, 16)), imax2(rl(v, 32), rl(v, 48))); }
+    static WFA_DEV void min_max(int &a, int &b) {
+        BlkRed<16>::min_max(a, b);
+        a = mn4(a), b = mx4(b);
+    }
+    static WFA_DEV void min_max_min(int &a, int &b, int &c) {
+        BlkRed<16>::min_max_min(a, b, c);
+        a = mn4(a), b = mx4(b), c = mn4(c);
+    }
+    static WFA_DEV void max_add(int &a, int &b) {
+        BlkRed<16>::max_add(a, b);
+        a = mx4(a), b = rl(b, 0) + rl(b, 16) + rl(b, 32) + rl(b, 48);
+    }
+    static WFA_DEV int max1(int a) { return mx4(BlkRed<16>::max1(a)); }
+    static WFA_DEV int or1(int a) {
+        a = BlkRed<16>::or1(a);
+        return rl(a, 0) | rl(a, 16) | rl(a, 32) | rl(a, 48);
+    }
+};
+
 WFA_DEV uint32_t ffbl_raw(uint32_t x) {  // index of the lowest set bit; 0xFFFFFFFF for x == 0
     uint32_t r;
     asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x));
@@ -148,14 +196,15 @@ constexpr int BK_BIG = 0x3FFFFFFF;
 // atomic -> lengths / offsets -> sequence bytes: three dependent memory round trips that stall all pairs of the
 // wave) is paid once per BATCH pairs; the following pairs of the batch start from LDS.
 template <int G, int BATCH>
-__global__ __launch_bounds__(64, (G == 16 ? 4 : WFA_BLK8_WAVES)) void wfa_blk_kernel(const KParams P) {
-    constexpr int PP  = 64 / G;   // diagonals per lane
-    constexpr int NG  = 64 / G;   // pairs per wave
+__global__ __launch_bounds__(64, (G == 8 ? WFA_BLK8_WAVES : 4)) void wfa_blk_kernel(const KParams P) {
+    constexpr int PP  = G == 64 ? 4 : 64 / G;  // diagonals per lane
+    constexpr int NG  = 64 / G;                // pairs per wave
 #ifdef WFA_BLK_W
     constexpr int W = WFA_BLK_W;  // experiment: pretend the window is narrower
 #else
-    constexpr int W   = 64;       // window width in diagonals
+    constexpr int W   = G * PP;   // window width in diagonals: 64 (G = 16, 8) or 256 (G = 64); also the arena's row pitch
 #endif
+    constexpr bool TILED = WFA_BLK_TILED != 0 && W == 64;  // arena layout: CompactView fmt 3 (else fmt 1 / 4: plain rows)
     using Ops         = BlkOps<G>;
 #ifdef WFA_MARKS
 #define WFA_MARK(i) asm volatile("; ##MARK " #i)
@@ -312,9 +361,9 @@ __global__ __launch_bounds__(64, (G == 16 ? 4 : WFA_BLK8_WAVES)) void wfa_blk_ke
                             lq = gbase + bslot * 2 * SW, lt = lq + SW;
                             n = (int)nq, m = (int)mt, Ak = m - n;
                             si = 0, cells = 0, slow = false;
-                            kb   = -32 + PP * imax2(-24 / PP, imin2(24 / PP, Ak / (2 * PP)));
+                            kb   = -(W / 2) + PP * imax2(-(3 * W / 8) / PP, imin2((3 * W / 8) / PP, Ak / (2 * PP)));
                             rowp = P.arena + (uint64_t)pidx * cap;
-                            rows_left = (int)(cap / 64);
+                            rows_left = (int)(cap / W);
                             first_eq = ((lq[0] ^ lt[0]) & 3u) == 0u;  // q[0] == t[0] (wfa.go:155)
                             set_window();
                             clear_rings();
@@ -358,7 +407,7 @@ __global__ __launch_bounds__(64, (G == 16 ? 4 : WFA_BLK8_WAVES)) void wfa_blk_ke
                 } else {
                     for (unsigned long long todo = __ballot(stage); todo != 0ull;) {
                         const int r = __builtin_ctzll(todo) / G;  // wave-uniform group index
-                        todo &= ~((G == 16 ? 0xFFFFull : 0xFFull) << (G * r));
+                        todo &= ~((G == 64 ? ~0ull : (1ull << (G & 63)) - 1ull) << ((G * r) & 63));
                         const uint64_t qo_r = ((uint64_t)__shfl((uint32_t)(qo >> 32), G * r, 64) << 32) | __shfl((uint32_t)qo, G * r, 64);
                         const uint64_t to_r = ((uint64_t)__shfl((uint32_t)(to >> 32), G * r, 64) << 32) | __shfl((uint32_t)to, G * r, 64);
                         const uint32_t nq_r = __shfl(nq, G * r, 64), mt_r = __shfl(mt, G * r, 64);
@@ -377,9 +426,9 @@ __global__ __launch_bounds__(64, (G == 16 ? 4 : WFA_BLK8_WAVES)) void wfa_blk_ke
                     pidx = wi, pair = pr;
                     n = (int)nq, m = (int)mt, Ak = m - n;
                     si = 0, cells = 0, slow = false;
-                    kb   = -32 + PP * imax2(-24 / PP, imin2(24 / PP, Ak / (2 * PP)));  // k = 0 (the seed) inside, biased towards Ak
+                    kb   = -(W / 2) + PP * imax2(-(3 * W / 8) / PP, imin2((3 * W / 8) / PP, Ak / (2 * PP)));  // k = 0 (the seed) inside, biased towards Ak
                     rowp = P.arena + (uint64_t)pidx * cap;
-                    rows_left = (int)(cap / 64);
+                    rows_left = (int)(cap / W);
                     first_eq = ((lq[0] ^ lt[0]) & 3u) == 0u;  // q[0] == t[0] (wfa.go:155)
                     set_window();
                     clear_rings();
@@ -633,15 +682,31 @@ __global__ __launch_bounds__(64, (G == 16 ? 4 : WFA_BLK8_WAVES)) void wfa_blk_ke
 #pragma unroll
             for (int p = 0; p < PP; p++) anyw |= wd[p];
             if (keepl && anyw != 0u) {
-                uint32_t *const row = rowp + ((uint32_t)k0 & 63u);
-                if constexpr (PP == 4) {
+                if constexpr (TILED) {
+                    // tile of 8 scores x 64 diagonals: [diagonal / 4][score & 7][diagonal & 3] (CompactView fmt 3)
+                    uint32_t *const row = rowp + (((uint32_t)k0 & 63u) << 3);
+#if WFA_BLK_SC1
+                    {
+                        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                        const u32x4 v4 = {wd[0], wd[1], wd[2], wd[3]};
+                        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(row), "v"(v4) : "memory");
+                    }
+#else
                     *reinterpret_cast<uint4 *>(row) = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+#endif
+                    if constexpr (PP == 8) *reinterpret_cast<uint4 *>(row + 32) = make_uint4(wd[4], wd[5], wd[6], wd[7]);
                 } else {
-                    *reinterpret_cast<uint4 *>(row)     = make_uint4(wd[0], wd[1], wd[2], wd[3]);
-                    *reinterpret_cast<uint4 *>(row + 4) = make_uint4(wd[4], wd[5], wd[6], wd[7]);
+                    uint32_t *const row = rowp + ((uint32_t)k0 & (uint32_t)(W - 1));
+                    *reinterpret_cast<uint4 *>(row) = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+                    if constexpr (PP == 8) *reinterpret_cast<uint4 *>(row + 4) = make_uint4(wd[4], wd[5], wd[6], wd[7]);
                 }
             }
-            rowp += 64;
+            if constexpr (TILED) {
+                rowp += 4;
+                rowp += (((uint32_t)(uintptr_t)rowp & 0x70u) == 0u) ? 480 : 0;  // past the tile's 8th score: next tile
+            } else {
+                rowp += W;
+            }
             rows_left -= 1;
             WFA_STAMP(4); WFA_MARK(4);  // stores
 

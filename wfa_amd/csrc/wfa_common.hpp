@@ -81,8 +81,9 @@ struct KParams {
     uint32_t  dm, di;                // ring depths: max(dx,doe)+1 (M), de+1 (I and D)
     uint32_t  sub_lds_words;         // LDS words owned by one 32-lane subgroup
     uint32_t  min_xe;                // min(x, e): bounds the number of CIGAR ops by 2*score/min_xe + 8
-    uint32_t  compact_fmt;           // compact arena layout: 0 = rows + directory, 1 = fixed pitch (64 words per score,
-                                     // diagonal k at slot k & 63, no directory)
+    uint32_t  compact_fmt;           // compact arena layout (CompactView): 0 = rows + directory; no directory: 1 = 64 words
+                                     // per score, diagonal k at slot k & 63; 3 = tiles of 8 scores x 64 diagonals;
+                                     // 4 = 256 words per score, slot k & 255
 };
 
 }  // namespace wfa

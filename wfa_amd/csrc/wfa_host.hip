@@ -44,6 +44,10 @@ struct DevBuf {
 // ctrl words (device): [0] queue_head [1] redo_count [2,3] ops_cursor (u64) [4,5] debug_info
 constexpr int CTRL_WORDS = 8;
 constexpr int BLK_BATCH  = 8;  // pairs a group of the blocked kernel stages at a time (short reads)
+// Pinned host block of a context (uint32 words).  Copies between pageable memory and the device are staged by the
+// runtime and cost 0.3-0.5 ms each even for a few bytes; the retry ladder sits on the critical path of a batch.
+constexpr size_t HPIN_CTRL = 0, HPIN_REDO = 16, HPIN_REDO_ENT = 4096, HPIN_WORK = HPIN_REDO + 2 * HPIN_REDO_ENT,
+                 HPIN_WORK_IDS = 16384, HPIN_WORDS = HPIN_WORK + HPIN_WORK_IDS;
 
 }  // namespace
 
@@ -59,6 +63,7 @@ struct wfahip_ctx {
     DevBuf        fin;                       // device-side result arrays of the host entry (wfa_finalize.hpp)
     void         *pin[2]     = {nullptr, nullptr};  // pinned staging for result downloads
     hipEvent_t    pin_ev[2]  = {nullptr, nullptr};
+    uint32_t     *hpin       = nullptr;  // small pinned block: control words, head of the redo list, work-list staging
     DevBuf        team_ctl;                  // barrier counters / reduction sets of the team kernel
     DevBuf        arena2, meta2;             // retry passes run beside the first pass's backtrace kernel
     hipEvent_t    evBtA = nullptr, evBtB = nullptr;
@@ -71,6 +76,7 @@ struct wfahip_ctx {
     int64_t       opt_packed               = 1;  // 0: never use the packed (sub-wave) kernels
     int64_t       opt_reg                  = 1;  // 0: never use the register-window kernel
     int64_t       opt_blk                  = 16; // blocked register-window kernel: lanes per pair (16 or 8), 0 = off
+    int64_t       opt_blk_wide             = 1;  // 1: pairs leaving the 64-diagonal window retry on the wave-per-pair blocked kernel (256 diagonals)
     int64_t       opt_blk_batch            = 1;  // short reads: stage BLK_BATCH pairs per group at a time
     int64_t       opt_packed_arena_bytes   = 0;  // per pair, 0 = automatic
     int64_t       opt_chunk_pairs          = 0;  // 0 = automatic
@@ -243,7 +249,8 @@ extern "C" int wfahip_create(int device_id, wfahip_ctx **out) {
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
         hipEventCreate(&ctx->evA) != hipSuccess || hipEventCreate(&ctx->evB) != hipSuccess ||
         hipEventCreate(&ctx->evC) != hipSuccess || hipEventCreate(&ctx->evBtA) != hipSuccess ||
-        hipEventCreate(&ctx->evBtB) != hipSuccess) {
+        hipEventCreate(&ctx->evBtB) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void **>(&ctx->hpin), HPIN_WORDS * 4, hipHostMallocDefault) != hipSuccess) {
         delete ctx;
         return WFAHIP_ERR_HIP;
     }
@@ -254,6 +261,7 @@ extern "C" int wfahip_create(int device_id, wfahip_ctx **out) {
 extern "C" void wfahip_destroy(wfahip_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    if (ctx->hpin) (void)hipHostFree(ctx->hpin);
     for (int i = 0; i < 2; i++) {
         if (ctx->pin[i]) (void)hipHostFree(ctx->pin[i]);
         if (ctx->pin_ev[i]) (void)hipEventDestroy(ctx->pin_ev[i]);
@@ -301,6 +309,8 @@ extern "C" int wfahip_set_option(wfahip_ctx *ctx, const char *key, int64_t value
         ctx->opt_overlap = value;
     else if (k == "tail_overlap")
         ctx->opt_tail_overlap = value;
+    else if (k == "blk_wide")
+        ctx->opt_blk_wide = value;
     else if (k == "pilot")
         ctx->opt_pilot = value;
     else if (k == "team_min_len")
@@ -365,6 +375,35 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
     rc = ensure(ctx, ctx->redo, n_pairs * 8);
     if (rc) return rc;
     uint32_t *d_ctrl = static_cast<uint32_t *>(ctx->ctrl.p);
+    // control words (+ the redo list, sorted by pair, when `ent` is given) in one round trip through pinned memory
+    const auto fetch_ctrl = [&](uint32_t *hc, std::vector<uint64_t> *ent) -> int {
+        HIP_TRY(hipMemcpyAsync(ctx->hpin + HPIN_CTRL, d_ctrl, CTRL_WORDS * 4, hipMemcpyDeviceToHost, st));
+        const size_t head = std::min<size_t>(HPIN_REDO_ENT * 8, ctx->redo.bytes);
+        if (ent) HIP_TRY(hipMemcpyAsync(ctx->hpin + HPIN_REDO, ctx->redo.p, head, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        std::memcpy(hc, ctx->hpin + HPIN_CTRL, CTRL_WORDS * 4);
+        if (ent) {
+            const size_t n = hc[1], nh = std::min<size_t>(n, head / 8);
+            ent->assign(n, 0);
+            if (nh) std::memcpy(ent->data(), ctx->hpin + HPIN_REDO, nh * 8);
+            if (n > nh)
+                HIP_TRY(hipMemcpy(ent->data() + nh, static_cast<const char *>(ctx->redo.p) + nh * 8, (n - nh) * 8, hipMemcpyDeviceToHost));
+            std::sort(ent->begin(), ent->end(), [](uint64_t a, uint64_t b) { return (uint32_t)a < (uint32_t)b; });
+        }
+        return WFAHIP_OK;
+    };
+    // work list of a retry pass -> ctx->work (short lists go through pinned memory; the caller syncs `st` before the next upload)
+    const auto upload_work = [&](const uint32_t *ids, size_t n) -> int {
+        int r = ensure(ctx, ctx->work, n * 4);
+        if (r) return r;
+        const void *src = ids;
+        if (n <= HPIN_WORK_IDS) {
+            std::memcpy(ctx->hpin + HPIN_WORK, ids, n * 4);
+            src = ctx->hpin + HPIN_WORK;
+        }
+        HIP_TRY(hipMemcpyAsync(ctx->work.p, src, n * 4, hipMemcpyHostToDevice, st));
+        return WFAHIP_OK;
+    };
 
     KParams P{};
     P.blob = static_cast<const uint8_t *>(d_blob), P.blob_bytes = blob_bytes;
@@ -454,11 +493,15 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
             // short reads: the blocked kernel stages BLK_BATCH pairs per group at a time
             const bool     blk_batch    = kind == 3 && seq_words <= 16 && ctx->opt_blk_batch != 0;
             const size_t   lds_bytes    = blk_batch ? (size_t)4 * BLK_BATCH * (2 * seq_words + 8) * 4 + 16
-                                                    : (kind >= 3 ? lds_d : (kind == 2 ? lds_c : lds_b));
-            const uint32_t pairs_wave   = kind == 4 ? 8 : (kind >= 2 ? 4 : 2);
-            // blocked kernel: fixed-pitch arena (64 words per score, no directory), 16 words per base: 250 scores at 1 kbp
-            const uint64_t words        = kind >= 3 ? std::max<uint64_t>((words_dir * 2 + 63) & ~63ull, 2048) : words_dir;
-            P.arena_words = words, P.compact_fmt = kind >= 3 ? 1u : 0u;
+                                          : kind == 5 ? (size_t)seq_words * 2 * 4 + 16
+                                                      : (kind >= 3 ? lds_d : (kind == 2 ? lds_c : lds_b));
+            const uint32_t pairs_wave   = kind == 5 ? 1 : (kind == 4 ? 8 : (kind >= 2 ? 4 : 2));
+            // blocked kernels: fixed-pitch arena, no directory.  64-diagonal window: 16 words per base = 250 scores at
+            // 1 kbp; 256-diagonal window (kind 5, the retry rung): 128 words per base = 500 scores at 1 kbp
+            const uint64_t words        = kind == 5   ? std::max<uint64_t>((words_dir * 16 + 511) & ~511ull, 8192)
+                                          : kind >= 3 ? std::max<uint64_t>((words_dir * 2 + 511) & ~511ull, 2048)
+                                                      : words_dir;
+            P.arena_words = words, P.compact_fmt = kind == 5 ? 4u : (kind >= 3 ? (WFA_BLK_TILED ? 3u : 1u) : 0u);
             const uint32_t waves_lds    = (uint32_t)std::min<size_t>(32, LDS_MAX_BYTES / lds_bytes);
             const bool     overlap      = ctx->opt_overlap != 0;
             uint32_t       waves_per_cu = kind == 4 ? std::min<uint32_t>(waves_lds, 12)
@@ -481,10 +524,7 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
             if ((rc2 = ensure(ctx, meta_buf, chunk * 16 * n_buf))) return rc2;
             detach_bt = detach_bt && n_chunks == 1 && ctx->opt_tail_overlap != 0;
             ctx->timing.arena_bytes = std::max<uint64_t>(ctx->timing.arena_bytes, words * 4ull * chunk * n_buf);
-            if (list) {
-                if ((rc2 = ensure(ctx, ctx->work, count * 4))) return rc2;
-                HIP_TRY(hipMemcpyAsync(ctx->work.p, list->data(), count * 4, hipMemcpyHostToDevice, st));
-            }
+            if (list && (rc2 = upload_work(list->data(), count))) return rc2;
             while (ctx->evpool.size() < 4 * n_chunks) {
                 hipEvent_t e;
                 HIP_TRY(hipEventCreate(&e));
@@ -507,7 +547,9 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
                 if (n_buf == 2 && c >= 2) HIP_TRY(hipStreamWaitEvent(st, ctx->evpool[4 * (c - 2) + 3], 0));  // buffer free
                 HIP_TRY(hipMemsetAsync(d_ctrl, 0, 4, st));  // queue_head only
                 HIP_TRY(hipEventRecord(evFa, st));
-                if (kind == 4)
+                if (kind == 5)
+                    hipLaunchKernelGGL((wfa_blk_kernel<64, 1>), dim3(grid), dim3(64), lds_bytes, st, P);
+                else if (kind == 4)
                     hipLaunchKernelGGL((wfa_blk_kernel<8, 1>), dim3(grid), dim3(64), lds_bytes, st, P);
                 else if (kind == 3 && blk_batch)
                     hipLaunchKernelGGL((wfa_blk_kernel<16, BLK_BATCH>), dim3(grid), dim3(64), lds_bytes, st, P);
@@ -529,8 +571,7 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
                 for (uint64_t c = (n_chunks >= 2 ? n_chunks - 2 : 0); c < n_chunks; c++)
                     HIP_TRY(hipStreamWaitEvent(st, ctx->evpool[4 * c + 3], 0));
             uint32_t hc[CTRL_WORDS];
-            HIP_TRY(hipMemcpyAsync(hc, d_ctrl, sizeof hc, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));  // (detach_bt: the forward kernel is done, the backtrace may still run)
+            if ((rc2 = fetch_ctrl(hc, &redo_out))) return rc2;  // (detach_bt: the forward kernel is done, the backtrace may still run)
             if (detach_bt) ctx->bt_pending = true;
             for (uint64_t c = 0; c < n_chunks; c++) {
                 float msF = 0, msB = 0;
@@ -541,11 +582,6 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
                 ctx->timing.n_launches += 2;
             }
             P.work = nullptr;
-            redo_out.assign(hc[1], 0);
-            if (hc[1]) {
-                HIP_TRY(hipMemcpy(redo_out.data(), ctx->redo.p, hc[1] * 8ull, hipMemcpyDeviceToHost));
-                std::sort(redo_out.begin(), redo_out.end(), [](uint64_t a, uint64_t b) { return (uint32_t)a < (uint32_t)b; });
-            }
             return WFAHIP_OK;
         };
 
@@ -586,6 +622,22 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
             // once, backtrace included) than through another forward + backtrace pass; beyond that the LDS-ring
             // kernel's throughput wins.
             const uint64_t resident_generic = (uint64_t)ctx->num_cus * 32;
+            if (kind1 >= 3 && ctx->opt_blk_wide != 0) {
+                // pairs whose band outgrew the 64-diagonal window: the same kernel with a wave per pair (256 diagonals)
+                std::vector<uint32_t> lst;
+                std::vector<uint64_t> rest;
+                for (uint64_t e : redo1) {
+                    if ((uint32_t)(e >> 32) == ST_REDO_BAND) lst.push_back((uint32_t)e);
+                    else rest.push_back(e);
+                }
+                if (!lst.empty()) {
+                    if ((rc = forward_pass(5, &lst, 0, lst.size(), redo2, false))) return rc;
+                    ctx->timing.n_packed_pairs += (uint32_t)(lst.size() - redo2.size());
+                    rest.insert(rest.end(), redo2.begin(), redo2.end());
+                    redo1.swap(rest);
+                    redo2.clear();
+                }
+            }
             if (kind1 >= 2 && can_b && redo1.size() > resident_generic) {
                 // second chance on the LDS-ring kernel (64-diagonal bands at any alignment) for band/arena misses
                 std::vector<uint32_t> lst;
@@ -709,9 +761,7 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
         if (job.all) {
             P.work = nullptr;
         } else {
-            rc = ensure(ctx, ctx->work, n_work * 4);
-            if (rc) return rc;
-            HIP_TRY(hipMemcpyAsync(ctx->work.p, job.pairs.data(), n_work * 4, hipMemcpyHostToDevice, st));
+            if ((rc = upload_work(job.pairs.data(), n_work))) return rc;
             P.work = static_cast<const uint32_t *>(ctx->work.p);
         }
         HIP_TRY(hipMemsetAsync(d_ctrl, 0, 8, st));  // queue_head, redo_count
@@ -730,9 +780,9 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
             HIP_TRY(launch_generic(P, cfg, st));
         }
         HIP_TRY(hipEventRecord(ctx->evB, st));
-        uint32_t hctrl[CTRL_WORDS];
-        HIP_TRY(hipMemcpyAsync(hctrl, d_ctrl, sizeof hctrl, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        uint32_t              hctrl[CTRL_WORDS];
+        std::vector<uint64_t> ent;  // {pair, status}, sorted by pair
+        if ((rc = fetch_ctrl(hctrl, &ent))) return rc;
         if (team_T > 0) {  // a team barrier that ran into its spin bound
             std::vector<uint32_t> tc((size_t)team_n * TEAM_CTL_WORDS);
             HIP_TRY(hipMemcpy(tc.data(), ctx->team_ctl.p, tc.size() * 4, hipMemcpyDeviceToHost));
@@ -758,9 +808,6 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
         const uint32_t n_redo = hctrl[1];
         if (n_redo) {
             ctx->timing.n_retried_pairs += n_redo;
-            std::vector<uint64_t> ent(n_redo);  // {pair, status}
-            HIP_TRY(hipMemcpy(ent.data(), ctx->redo.p, n_redo * 8ull, hipMemcpyDeviceToHost));
-            std::sort(ent.begin(), ent.end(), [](uint64_t a, uint64_t b) { return (uint32_t)a < (uint32_t)b; });
             Job jb, ja;
             jb.mode = 1, jb.level = job.level, jb.all = false, jb.max_len = job.max_len;
             ja.mode = job.mode, ja.level = job.level + 1, ja.all = false, ja.max_len = job.max_len;
@@ -782,8 +829,7 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
         HIP_TRY(hipMemcpyAsync(P.rec + (uint64_t)pid * REC_WORDS, recw, sizeof recw, hipMemcpyHostToDevice, st));
     }
     uint32_t hctrl[CTRL_WORDS];
-    HIP_TRY(hipMemcpyAsync(hctrl, d_ctrl, sizeof hctrl, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    if ((rc = fetch_ctrl(hctrl, nullptr))) return rc;
     float ms = 0;
     if (ctx->bt_pending) {
         HIP_TRY(hipEventElapsedTime(&ms, ctx->evBtA, ctx->evBtB));
@@ -1002,8 +1048,9 @@ extern "C" int wfahip_align_batch(wfahip_ctx *ctx, const wfahip_params *p, const
     hipLaunchKernelGGL(fin_gather, dim3((uint32_t)((n + 3) / 4)), dim3(256), 0, st, F);
     HIP_TRY(hipGetLastError());
     unsigned long long totals[2] = {0, 0};
-    HIP_TRY(hipMemcpyAsync(totals, F.totals, 16, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(ctx->hpin + HPIN_CTRL + CTRL_WORDS, F.totals, 16, hipMemcpyDeviceToHost, st));  // (pinned)
     HIP_TRY(hipStreamSynchronize(st));
+    std::memcpy(totals, ctx->hpin + HPIN_CTRL + CTRL_WORDS, 16);
     const auto t_unp = now();
 
     results_zero(out);
