@@ -149,6 +149,9 @@ int  wfahip_last_timing(const wfahip_ctx *ctx, wfahip_timing *out);
  *   "pilot"  0|1           wf-adaptive off, reads >= 400 bases: 4 096 pairs go first and decide whether the
  *                          rest uses the sub-wave kernels at all                                  default 1
  *   "blk_batch"  0|1       short reads: a group of the blocked kernel stages 8 pairs per refill   default 1
+ *   "bt_stream"  n         n waves of the first pass's launch backtrace finished pairs while the other
+ *                          waves are still aligning (0 = backtrace kernel after the forward kernel)  default 96
+ *   "bt_stream_min"        ... for batches of at least this many pairs                             default 65536
  *   "blk_wide"  0|1        pairs whose band leaves the 64-diagonal window retry on the same kernel with a
  *                          wave per pair (256 diagonals) before the generic kernel takes them       default 1
  *   "arena_bytes_per_slot", "slots", "threads_per_pair"   generic kernel (one workgroup per pair)

@@ -214,11 +214,13 @@ def test_unaligned_blob_offsets(built):
     al.close()
 
 
-@pytest.mark.parametrize("opts,kind", [({"blk": 16}, 3), ({"blk": 8}, 4), ({"blk": 0}, 2), ({"blk": 0, "reg": 0}, 1),
-                                       ({"packed": 0}, 0)])
+@pytest.mark.parametrize("opts,kind", [({"blk": 16}, 3), ({"blk": 16, "bt_stream_min": 1}, 3),
+                                       ({"blk": 16, "bt_stream_min": 1, "bt_stream": 4}, 3), ({"blk": 8}, 4),
+                                       ({"blk": 0}, 2), ({"blk": 0, "reg": 0}, 1), ({"packed": 0}, 0)])
 def test_forward_kernel_variants(built, opts, kind):
     """Every forward kernel (blocked register-window with 16 / 8 lanes per pair, strided register-window, LDS-ring
-    packed, generic) on one mixed batch: unequal lengths (the 64-diagonal window has to follow the band up and
+    packed, generic; the blocked kernel also with the streamed backtrace forced on for this small batch) on one
+    mixed batch: unequal lengths (the 64-diagonal window has to follow the band up and
     down), 15 % error (bands that outgrow the window are handed down the ladder), short reads, wf-adaptive on
     and off, and a per-pair arena too small for some pairs."""
     import wfa_amd as w
@@ -565,6 +567,11 @@ def test_full_size_parity_c3(built):
         cells = al.last_timing().cells_stored
         want = O.align_batch(_oracle_params(True, ad), *data, n_threads=thr)
         assert_batch_equal(got, want, f"full size L={length}")
+        # (1e6 pairs: the backtrace is streamed -- waves of the forward launch walk finished pairs while the others
+        # are still aligning; the hand-over between them must hold every time)
+        for rep in range(3):
+            assert_batch_equal(al.align_arrays(*data), want, f"full size L={length}, repeat {rep}")
+            assert al.last_timing().cells_stored == cells
         # the retry passes run beside the first pass's backtrace kernel: same records and same cell census as the
         # serial schedule
         al.set_option("tail_overlap", 0)

@@ -37,9 +37,6 @@ namespace wfa {
 #ifndef WFA_BLK_TILED
 #define WFA_BLK_TILED 1  // 1: 64-diagonal arenas are tiled 8 scores x 64 diagonals (CompactView fmt 3); 0: plain rows (fmt 1)
 #endif
-#ifndef WFA_BLK_SC1
-#define WFA_BLK_SC1 0
-#endif
 
 template <int G>
 struct BlkOps;
@@ -195,8 +192,27 @@ constexpr int BK_BIG = 0x3FFFFFFF;
 // BATCH consecutive queue entries at a time and stages all of them into its LDS slots, so the refill chain (queue
 // atomic -> lengths / offsets -> sequence bytes: three dependent memory round trips that stall all pairs of the
 // wave) is paid once per BATCH pairs; the following pairs of the batch start from LDS.
-template <int G, int BATCH>
+//
+// STREAM: finished pairs are handed to wfa_backtrace_stream_kernel while this kernel is still running.  The arena
+// rows are stored write-through (sc1); a finished pair's done_q entry {index + 1, score, end offset, cells} is
+// stored -- one 16-byte write-through store -- in the following refill, right after the queue atomic has returned
+// (vmcnt = 0: every earlier store of the wave has been acknowledged), so it costs no wait of its own.
+typedef uint32_t blk_u32x4 __attribute__((ext_vector_type(4)));
+
+WFA_DEV void blk_store_sc1(void *p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    const blk_u32x4 v = {a, b, c, d};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+
+// a pair that ends without a backtrace (rejected, handed on): its done_q entry only keeps the entry count complete
+WFA_DEV void blk_push_not_ok(const KParams &P, uint32_t pidx) {
+    const uint32_t t = atomicAdd(P.done_ctl, 1u);
+    blk_store_sc1(P.done_q + t, (pidx + 1u) | DONE_NOT_OK, 0u, 0u, 0u);
+}
+
+template <int G, int BATCH, bool STREAM = false>
 __global__ __launch_bounds__(64, (G == 8 ? WFA_BLK8_WAVES : 4)) void wfa_blk_kernel(const KParams P) {
+    static_assert(!STREAM || (G == 16 && BATCH == 1), "streamed backtrace: 16 lanes per pair, unbatched refill");
     constexpr int PP  = G == 64 ? 4 : 64 / G;  // diagonals per lane
     constexpr int NG  = 64 / G;                // pairs per wave
 #ifdef WFA_BLK_W
@@ -213,6 +229,12 @@ __global__ __launch_bounds__(64, (G == 8 ? WFA_BLK8_WAVES : 4)) void wfa_blk_ker
 #endif
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int lane = threadIdx.x, j = lane & (G - 1), grp = lane / G;
+    if constexpr (STREAM) {
+        if (blockIdx.x < P.n_stream_wgs) {  // (dispatched first: resident from the start)
+            stream_backtrace(P);
+            return;
+        }
+    }
 
     const uint32_t  SW = P.lds_seq_words;
     constexpr int   BM = 8;                                    // meta words per batch slot: wi, pr, nq, mt, q_off, t_off
@@ -233,6 +255,8 @@ __global__ __launch_bounds__(64, (G == 8 ? WFA_BLK8_WAVES : 4)) void wfa_blk_ker
     uint32_t   pidx = 0, pair = 0, si = 0, cells = 0;
     int        n = 0, m = 0, Ak = 0, kb = 0, k0 = 0, rows_left = 0;
     bool       slow = false, first_eq = false;
+    bool       pend = false;  // STREAM: the pair just finished still has to be pushed (its score index, end offset and
+                              // cell count wait in si, Ak and cells, which are dead until the next pair starts)
     uint32_t  *rowp = nullptr;  // row of the current score in the pair's arena slot (64 words per score)
 
     uint32_t M[4][PP], I[PP], D[PP];  // offsets, 0 = absent; M[i & 3] = row of step i
@@ -377,8 +401,27 @@ __global__ __launch_bounds__(64, (G == 8 ? WFA_BLK8_WAVES : 4)) void wfa_blk_ker
 #pragma unroll
                 for (int r = 0; r < NG; r++) gbits |= (uint32_t)((need >> (G * r)) & 1ull) << r;
                 uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(P.queue_head, (uint32_t)__builtin_popcount(gbits));
-                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if constexpr (STREAM) {
+                    // lane 0 takes the queue entries, lane 1 reserves the done_q entries of the groups that finished in
+                    // the step before: one atomic instruction, one round trip
+                    uint32_t pbits = 0u;
+                    const unsigned long long pb = __ballot(pend);
+#pragma unroll
+                    for (int r = 0; r < NG; r++) pbits |= (uint32_t)((pb >> (G * r)) & 1ull) << r;
+                    uint32_t *const aptr = lane == 0 ? P.queue_head : P.done_ctl;
+                    const uint32_t  aval = (uint32_t)__builtin_popcount(lane == 0 ? gbits : pbits);
+                    uint32_t        r2   = 0u;
+                    if (lane < 2 && aval != 0u) r2 = atomicAdd(aptr, aval);
+                    base              = (uint32_t)__builtin_amdgcn_readlane((int)r2, 0);
+                    const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)r2, 1);
+                    if (pend && j == 0)
+                        blk_store_sc1(P.done_q + (t0 + (uint32_t)__builtin_popcount(pbits & ((1u << grp) - 1u))), pidx + 1u,
+                                      si * P.g, (uint32_t)Ak, cells);
+                    pend = false;
+                } else {
+                    if (lane == 0) base = atomicAdd(P.queue_head, (uint32_t)__builtin_popcount(gbits));
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                }
                 const bool     want = st == 0;
                 const uint32_t wi   = base + (uint32_t)__builtin_popcount(gbits & ((1u << grp) - 1u));
                 const bool     got  = want && wi < P.chunk_n;
@@ -421,6 +464,7 @@ __global__ __launch_bounds__(64, (G == 8 ? WFA_BLK8_WAVES : 4)) void wfa_blk_ker
                 if (got && status != ST_PENDING && j == 0) {
                     P.pair_meta[wi] = make_uint4(status, 0u, 0u, 0u);
                     if (status >= ST_REDO_BYTES) push_redo(P, pr, status);
+                    if constexpr (STREAM) blk_push_not_ok(P, wi);
                 }  // (the group stays in state 0 and pulls another pair in the next round)
                 if (stage && !bad) {
                     pidx = wi, pair = pr;
@@ -685,19 +729,17 @@ __global__ __launch_bounds__(64, (G == 8 ? WFA_BLK8_WAVES : 4)) void wfa_blk_ker
                 if constexpr (TILED) {
                     // tile of 8 scores x 64 diagonals: [diagonal / 4][score & 7][diagonal & 3] (CompactView fmt 3)
                     uint32_t *const row = rowp + (((uint32_t)k0 & 63u) << 3);
-#if WFA_BLK_SC1
-                    {
-                        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                        const u32x4 v4 = {wd[0], wd[1], wd[2], wd[3]};
-                        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(row), "v"(v4) : "memory");
-                    }
-#else
-                    *reinterpret_cast<uint4 *>(row) = make_uint4(wd[0], wd[1], wd[2], wd[3]);
-#endif
+                    if constexpr (STREAM)
+                        blk_store_sc1(row, wd[0], wd[1], wd[2], wd[3]);
+                    else
+                        *reinterpret_cast<uint4 *>(row) = make_uint4(wd[0], wd[1], wd[2], wd[3]);
                     if constexpr (PP == 8) *reinterpret_cast<uint4 *>(row + 32) = make_uint4(wd[4], wd[5], wd[6], wd[7]);
                 } else {
                     uint32_t *const row = rowp + ((uint32_t)k0 & (uint32_t)(W - 1));
-                    *reinterpret_cast<uint4 *>(row) = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+                    if constexpr (STREAM)
+                        blk_store_sc1(row, wd[0], wd[1], wd[2], wd[3]);
+                    else
+                        *reinterpret_cast<uint4 *>(row) = make_uint4(wd[0], wd[1], wd[2], wd[3]);
                     if constexpr (PP == 8) *reinterpret_cast<uint4 *>(row + 4) = make_uint4(wd[4], wd[5], wd[6], wd[7]);
                 }
             }
@@ -729,11 +771,17 @@ __global__ __launch_bounds__(64, (G == 8 ? WFA_BLK8_WAVES : 4)) void wfa_blk_ker
                     if (no_room) {
                         P.pair_meta[pidx] = make_uint4(ST_REDO_ARENA, 0u, 0u, 0u);
                         push_redo(P, pair, ST_REDO_ARENA);
-                    } else {
+                        if constexpr (STREAM) blk_push_not_ok(P, pidx);
+                    } else if constexpr (!STREAM) {
                         P.pair_meta[pidx] = make_uint4(ST_OK, si * P.g, (uint32_t)hf, (uint32_t)ctot);
                     }
                 }
                 if (fin) {
+                    if constexpr (STREAM) {
+                        pend  = !no_room;  // pushed by the next refill; until then si / Ak / cells keep the entry's fields
+                        Ak    = hf;
+                        cells = (uint32_t)ctot;
+                    }
                     st = 0;
                     clear_rings();
                 }
@@ -771,6 +819,7 @@ __global__ __launch_bounds__(64, (G == 8 ? WFA_BLK8_WAVES : 4)) void wfa_blk_ker
                         if (wide && j == 0) {
                             P.pair_meta[pidx] = make_uint4(ST_REDO_BAND, 0u, 0u, 0u);
                             push_redo(P, pair, ST_REDO_BAND);
+                            if constexpr (STREAM) blk_push_not_ok(P, pidx);
                         }
                         if (wide) {
                             st = 0;
@@ -813,6 +862,11 @@ __global__ __launch_bounds__(64, (G == 8 ? WFA_BLK8_WAVES : 4)) void wfa_blk_ker
         for (int i = 0; i < 8; i++) atomicAdd(acc + 8 + i, evt[i]);
     }
 #endif
+    if constexpr (STREAM) {
+        // The queue is exhausted and this wave's pairs are done (the last refill pushed their entries): help with the
+        // backtrace of the pairs still in flight elsewhere.
+        stream_backtrace(P);
+    }
 }
 
 }  // namespace wfa

@@ -19,6 +19,8 @@ constexpr uint32_t TAG_BITS = 3, TAG_MASK = 7;
 enum : uint32_t {
     ST_OK = 0, ST_EMPTY = 1, ST_TOO_LONG = 2, ST_NO_MEMORY = 4,
     ST_PENDING = 0xFFFFFFFFu,  // not processed yet
+    DONE_NOT_OK = 0x80000000u, // done_q entry .x = (index in chunk + 1) | DONE_NOT_OK for pairs without a backtrace
+    DONE_TAKEN  = 0xFFFFFFFFu, // done_q entry .x after the streaming backtrace kernel has processed it
     ST_REDO_BYTES = 100,       // non-ACGT byte found: needs the byte-compare path
     ST_REDO_ARENA = 101,       // wavefront arena too small: needs a bigger slot
     ST_REDO_LDS   = 102,       // sequences do not fit this launch's LDS budget
@@ -81,6 +83,11 @@ struct KParams {
     uint32_t  dm, di;                // ring depths: max(dx,doe)+1 (M), de+1 (I and D)
     uint32_t  sub_lds_words;         // LDS words owned by one 32-lane subgroup
     uint32_t  min_xe;                // min(x, e): bounds the number of CIGAR ops by 2*score/min_xe + 8
+    // streamed backtrace (wfa_blk_kernel<.., STREAM = true> + wfa_backtrace_stream_kernel): finished pairs are pushed to
+    // done_q in completion order; done_ctl = {entries pushed, entries ticketed}
+    uint4    *done_q;
+    uint32_t *done_ctl;
+    uint32_t  n_stream_wgs;  // the first workgroups of the launch only backtrace
     uint32_t  compact_fmt;           // compact arena layout (CompactView): 0 = rows + directory; no directory: 1 = 64 words
                                      // per score, diagonal k at slot k & 63; 3 = tiles of 8 scores x 64 diagonals;
                                      // 4 = 256 words per score, slot k & 255

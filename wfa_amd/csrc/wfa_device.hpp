@@ -394,13 +394,17 @@ struct CompactView {
     const uint32_t *A;
     uint64_t        cap;
     uint32_t        g, n_ent, fmt;
+    bool            coherent = false;  // the producer kernel is still running: agent-scope loads (never a stale L2 line)
+    WFA_DEV uint32_t ld(uint64_t i) const {
+        return coherent ? __hip_atomic_load(A + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : A[i];
+    }
     WFA_DEV uint32_t word(uint32_t s, int k) const {
         if (s % g != 0u) return 0u;
         const uint32_t idx = s / g;
         if (idx >= n_ent) return 0u;
-        if (fmt == 1u) return A[64u * idx + ((uint32_t)k & 63u)];
-        if (fmt == 4u) return A[256ull * idx + ((uint32_t)k & 255u)];
-        if (fmt == 3u) return A[512ull * (idx >> 3) + (((uint32_t)k & 60u) << 3) + ((idx & 7u) << 2) + ((uint32_t)k & 3u)];
+        if (fmt == 3u) return ld(512ull * (idx >> 3) + (((uint32_t)k & 60u) << 3) + ((idx & 7u) << 2) + ((uint32_t)k & 3u));
+        if (fmt == 1u) return ld(64ull * idx + ((uint32_t)k & 63u));
+        if (fmt == 4u) return ld(256ull * idx + ((uint32_t)k & 255u));
         const uint4 e = *reinterpret_cast<const uint4 *>(A + cap - 4ull * (idx + 1));
         const int   lo = (int)e.y, w = (int)e.z;
         if (w <= 0 || k < lo || k >= lo + w) return 0u;

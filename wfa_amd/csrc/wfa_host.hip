@@ -66,6 +66,7 @@ struct wfahip_ctx {
     uint32_t     *hpin       = nullptr;  // small pinned block: control words, head of the redo list, work-list staging
     DevBuf        team_ctl;                  // barrier counters / reduction sets of the team kernel
     DevBuf        arena2, meta2;             // retry passes run beside the first pass's backtrace kernel
+    DevBuf        doneq;                     // streamed backtrace: 256 bytes of counters + one 16-byte entry per pair
     hipEvent_t    evBtA = nullptr, evBtB = nullptr;
     bool          bt_pending = false;        // the first pass's backtrace kernel is still running on stream2
     DevBuf        in_blob, in_qoff, in_qlen, in_toff, in_tlen, out_rec, out_ops;  // host-entry staging
@@ -76,6 +77,8 @@ struct wfahip_ctx {
     int64_t       opt_packed               = 1;  // 0: never use the packed (sub-wave) kernels
     int64_t       opt_reg                  = 1;  // 0: never use the register-window kernel
     int64_t       opt_blk                  = 16; // blocked register-window kernel: lanes per pair (16 or 8), 0 = off
+    int64_t       opt_bt_stream            = 96; // > 0: that many waves of the first pass's launch backtrace finished pairs while the others go on
+    int64_t       opt_bt_stream_min        = 65536;  // ... for batches of at least this many pairs
     int64_t       opt_blk_wide             = 1;  // 1: pairs leaving the 64-diagonal window retry on the wave-per-pair blocked kernel (256 diagonals)
     int64_t       opt_blk_batch            = 1;  // short reads: stage BLK_BATCH pairs per group at a time
     int64_t       opt_packed_arena_bytes   = 0;  // per pair, 0 = automatic
@@ -266,7 +269,7 @@ extern "C" void wfahip_destroy(wfahip_ctx *ctx) {
         if (ctx->pin[i]) (void)hipHostFree(ctx->pin[i]);
         if (ctx->pin_ev[i]) (void)hipEventDestroy(ctx->pin_ev[i]);
     }
-    for (DevBuf *b : {&ctx->arena, &ctx->fin, &ctx->team_ctl, &ctx->arena2, &ctx->meta2, &ctx->ctrl, &ctx->redo, &ctx->work, &ctx->meta, &ctx->in_blob, &ctx->in_qoff, &ctx->in_qlen,
+    for (DevBuf *b : {&ctx->arena, &ctx->fin, &ctx->team_ctl, &ctx->arena2, &ctx->meta2, &ctx->doneq, &ctx->ctrl, &ctx->redo, &ctx->work, &ctx->meta, &ctx->in_blob, &ctx->in_qoff, &ctx->in_qlen,
                       &ctx->in_toff, &ctx->in_tlen, &ctx->out_rec, &ctx->out_ops})
         release(*b);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -311,6 +314,10 @@ extern "C" int wfahip_set_option(wfahip_ctx *ctx, const char *key, int64_t value
         ctx->opt_tail_overlap = value;
     else if (k == "blk_wide")
         ctx->opt_blk_wide = value;
+    else if (k == "bt_stream")
+        ctx->opt_bt_stream = value;
+    else if (k == "bt_stream_min")
+        ctx->opt_bt_stream_min = value;
     else if (k == "pilot")
         ctx->opt_pilot = value;
     else if (k == "team_min_len")
@@ -523,6 +530,14 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
             if (rc2) return rc2;
             if ((rc2 = ensure(ctx, meta_buf, chunk * 16 * n_buf))) return rc2;
             detach_bt = detach_bt && n_chunks == 1 && ctx->opt_tail_overlap != 0;
+            // streamed backtrace: a few waves walk finished pairs while the forward kernel is still running
+            const bool stream_bt = detach_bt && kind == 3 && !blk_batch && ctx->opt_bt_stream > 0 && (int64_t)count >= ctx->opt_bt_stream_min;
+            P.done_q = nullptr, P.done_ctl = nullptr, P.n_stream_wgs = 0;
+            if (stream_bt) {
+                if ((rc2 = ensure(ctx, ctx->doneq, 256 + 16 * chunk))) return rc2;
+                P.done_ctl = static_cast<uint32_t *>(ctx->doneq.p);
+                P.done_q   = reinterpret_cast<uint4 *>(static_cast<char *>(ctx->doneq.p) + 256);
+            }
             ctx->timing.arena_bytes = std::max<uint64_t>(ctx->timing.arena_bytes, words * 4ull * chunk * n_buf);
             if (list && (rc2 = upload_work(list->data(), count))) return rc2;
             while (ctx->evpool.size() < 4 * n_chunks) {
@@ -542,8 +557,17 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
                 P.pair_meta   = static_cast<uint4 *>(meta_buf.p) + (uint64_t)buf * chunk;
                 P.chunk_first = (uint32_t)(first_pair + c0), P.chunk_n = (uint32_t)cn;
                 P.work        = list ? static_cast<const uint32_t *>(ctx->work.p) + c0 : nullptr;
-                const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)ctx->num_cus * waves_per_cu,
-                                                                  (cn + pairs_wave - 1) / pairs_wave);
+                uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)ctx->num_cus * waves_per_cu,
+                                                            (cn + pairs_wave - 1) / pairs_wave);
+                const uint32_t n_bt = stream_bt ? (uint32_t)std::min<int64_t>(ctx->opt_bt_stream, grid / 4) : 0u;
+                if (stream_bt) {
+                    // the first n_bt workgroups of the launch only backtrace; they take the place of forward waves when
+                    // the launch fills the GPU
+                    if (grid < (uint32_t)ctx->num_cus * waves_per_cu) grid = std::min<uint32_t>(grid + n_bt, (uint32_t)ctx->num_cus * waves_per_cu);
+                    P.n_stream_wgs = n_bt;
+                    HIP_TRY(hipMemsetAsync(ctx->doneq.p, 0, 256 + 16 * cn, st));
+                    HIP_TRY(hipMemsetAsync(P.pair_meta, 0xFF, 16 * cn, st));  // ST_PENDING: only pairs without a backtrace get a status
+                }
                 if (n_buf == 2 && c >= 2) HIP_TRY(hipStreamWaitEvent(st, ctx->evpool[4 * (c - 2) + 3], 0));  // buffer free
                 HIP_TRY(hipMemsetAsync(d_ctrl, 0, 4, st));  // queue_head only
                 HIP_TRY(hipEventRecord(evFa, st));
@@ -553,6 +577,8 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
                     hipLaunchKernelGGL((wfa_blk_kernel<8, 1>), dim3(grid), dim3(64), lds_bytes, st, P);
                 else if (kind == 3 && blk_batch)
                     hipLaunchKernelGGL((wfa_blk_kernel<16, BLK_BATCH>), dim3(grid), dim3(64), lds_bytes, st, P);
+                else if (kind == 3 && stream_bt)
+                    hipLaunchKernelGGL((wfa_blk_kernel<16, 1, true>), dim3(grid), dim3(64), lds_bytes, st, P);
                 else if (kind == 3)
                     hipLaunchKernelGGL((wfa_blk_kernel<16, 1>), dim3(grid), dim3(64), lds_bytes, st, P);
                 else if (kind == 2)
@@ -604,6 +630,12 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
                 if ((rc = forward_pass(kind1, nullptr, done_pairs, n_pairs - done_pairs, more, true))) return rc;
                 redo1.insert(redo1.end(), more.begin(), more.end());
                 done_pairs = n_pairs;
+            }
+            if (std::getenv("WFAHIP_DEBUG_TIMING") && P.done_ctl) {
+                uint32_t dc[2];
+                HIP_TRY(hipStreamSynchronize(ctx->stream2));
+                HIP_TRY(hipMemcpy(dc, P.done_ctl, sizeof dc, hipMemcpyDeviceToHost));
+                std::fprintf(stderr, "[wfahip] streamed backtrace: %u entries pushed, %u ticketed\n", dc[0], dc[1]);
             }
             if (std::getenv("WFAHIP_DEBUG_TIMING")) {
                 uint64_t cnt[4] = {0, 0, 0, 0};

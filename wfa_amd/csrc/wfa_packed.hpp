@@ -292,30 +292,16 @@ __global__ __launch_bounds__(64, 7) void wfa_packed_kernel(const KParams P) {
 #endif
 }
 
-// Lane-per-pair backtrace (wfa.go:703-983) + process() statistics + result record for the pairs the packed
-// kernel finished.  Global alignment only (the packed kernel's scope).
-__global__ __launch_bounds__(256) void wfa_backtrace_kernel(const KParams P) {
-    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= P.chunk_n) return;
-    const uint32_t pair = P.work ? P.work[idx] : P.chunk_first + idx;
-    const uint4    meta = P.pair_meta[idx];
-    uint32_t *const rec = P.rec + (uint64_t)pair * REC_WORDS;
-    if (meta.x != ST_OK) {
-        // Final statuses (empty / too long) are recorded here.  A pair that was handed on (ST_REDO_*) gets its
-        // record from the pass that finishes it -- which may already be running beside this kernel, so this
-        // kernel must not touch that record.
-        if (meta.x < ST_REDO_BYTES) {
-            const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-            uint4 *r4     = reinterpret_cast<uint4 *>(rec);
-            r4[0] = make_uint4(meta.x, 0u, 0u, 0u), r4[1] = z, r4[2] = z, r4[3] = z;
-        }
-        return;
-    }
-    const int n = (int)P.q_len[pair], m = (int)P.t_len[pair];
-    const uint32_t s_final = meta.y;
+// Backtrace (wfa.go:703-983) + process() statistics + result record of ONE finished pair of the sub-wave pipeline
+// (global alignment only): idx = the pair's index in the chunk (= its arena slot), h_end = extended offset of the
+// end cell M[s_final][m - n].
+WFA_DEV void backtrace_one(const KParams &P, uint32_t idx, uint32_t s_final, uint32_t h_end, uint32_t cells, bool coherent) {
+    const uint32_t  pair = P.work ? P.work[idx] : P.chunk_first + idx;
+    uint32_t *const rec  = P.rec + (uint64_t)pair * REC_WORDS;
+    const int       n = (int)P.q_len[pair], m = (int)P.t_len[pair];
     CompactView cv;
     cv.A = P.arena + (uint64_t)idx * P.arena_words, cv.cap = P.arena_words, cv.g = P.g, cv.n_ent = s_final / P.g + 1u;
-    cv.fmt = P.compact_fmt;
+    cv.fmt = P.compact_fmt, cv.coherent = coherent;
 
     // ops region: bound = 2 * score / min(x, e) + 8 entries, carved from the shared ops buffer
     const uint32_t bound = 2u * (s_final / P.min_xe) + 8u;
@@ -324,7 +310,7 @@ __global__ __launch_bounds__(256) void wfa_backtrace_kernel(const KParams P) {
     const bool     fits = off + bound <= P.ops_cap;
     ow.init(P.ops + off, fits ? bound : 0u);
     TraceOut to;
-    back_trace_compact(cv, n, m, s_final, m - n, meta.z, P.x, P.o, P.e, ow, to);
+    back_trace_compact(cv, n, m, s_final, m - n, h_end, P.x, P.o, P.e, ow, to);
     ow.finish();
     // (when the ops buffer is too small the host sees ops_cursor > ops_cap and re-runs with a bigger one)
     const uint64_t first = off + bound - ow.n;
@@ -332,7 +318,76 @@ __global__ __launch_bounds__(256) void wfa_backtrace_kernel(const KParams P) {
     r4[0] = make_uint4(ST_OK, to.score, (uint32_t)to.tbegin, (uint32_t)to.tend);
     r4[1] = make_uint4((uint32_t)to.qbegin, (uint32_t)to.qend, ow.alen, ow.matches);
     r4[2] = make_uint4(ow.gaps, ow.regions, ow.n, (uint32_t)first);
-    r4[3] = make_uint4((uint32_t)(first >> 32), meta.w, 0u, s_final);
+    r4[3] = make_uint4((uint32_t)(first >> 32), cells, 0u, s_final);
+}
+
+// Lane-per-pair backtrace of a chunk the forward kernel has finished.  Final statuses (empty / too long) are recorded
+// here.  A pair that was handed on (ST_REDO_*) gets its record from the pass that finishes it -- which may already
+// be running beside this kernel, so this kernel must not touch that record.
+// Streamed mode (P.done_q != nullptr): the finished pairs are the done_q entries the streaming kernel has not taken.
+__global__ __launch_bounds__(256) void wfa_backtrace_kernel(const KParams P) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P.chunk_n) return;
+    const uint4 meta = P.pair_meta[idx];
+    if (meta.x != ST_OK && meta.x < ST_REDO_BYTES) {
+        const uint32_t pair = P.work ? P.work[idx] : P.chunk_first + idx;
+        const uint4    z    = make_uint4(0u, 0u, 0u, 0u);
+        uint4 *r4           = reinterpret_cast<uint4 *>(P.rec + (uint64_t)pair * REC_WORDS);
+        r4[0] = make_uint4(meta.x, 0u, 0u, 0u), r4[1] = z, r4[2] = z, r4[3] = z;
+    }
+    if (P.done_q) {
+        const uint4 e = P.done_q[idx];
+        if (e.x != 0u && e.x != DONE_TAKEN && (e.x & DONE_NOT_OK) == 0u) {
+            backtrace_one(P, e.x - 1u, e.y, e.z, e.w, false);
+        }
+    } else if (meta.x == ST_OK) {
+        backtrace_one(P, idx, meta.y, meta.z, meta.w, false);
+    }
+}
+
+// Streaming backtrace (called by waves of wfa_blk_kernel<.., STREAM = true>): the done_q entries are taken in
+// completion order while the forward waves of the same launch are still running.  The walk is a chain of dependent
+// DRAM reads: ~100 waves keep up with the whole forward kernel, while the same work costs ~1.8 ms of the whole GPU
+// when it runs afterwards.  The first n_stream_wgs workgroups of the launch do nothing else; a forward wave joins in
+// when the pair queue is exhausted, so the last pairs in flight are walked by the whole GPU.
+// A wave takes 64 consecutive entries -- pairs that finished at about the same time -- waits until all of them are
+// written, and walks them lane per pair with agent-scope loads (the producer's stores are write-through, its entry
+// is stored after them).  Every pair of the chunk pushes exactly one entry, so the tickets run out when all pairs
+// are done.  A wave never waits for long: when an entry does not show up within 20 ms it leaves, and
+// wfa_backtrace_kernel, launched afterwards, sweeps up every entry not taken.
+WFA_DEV void stream_backtrace(const KParams &P) {
+    const int      lane = threadIdx.x;
+    uint32_t *const ctl = P.done_ctl;
+    for (;;) {
+        uint32_t base = 0u;
+        if (lane == 0) base = atomicAdd(ctl + 1, 64u);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (base >= P.chunk_n) break;
+        const uint32_t idx   = base + (uint32_t)lane;
+        const bool     valid = idx < P.chunk_n;
+        uint32_t *const ew   = reinterpret_cast<uint32_t *>(P.done_q + idx);
+        bool            ok   = !valid;
+        const uint64_t  t0   = wall_clock64();
+        bool            late = false;
+        for (;;) {
+            if (!ok) ok = __hip_atomic_load(ew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+            if (__ballot(!ok) == 0ull) break;
+            __builtin_amdgcn_s_sleep(32);
+            if (wall_clock64() - t0 > 2000000ull) {  // 100 MHz clock: 20 ms
+                late = true;
+                break;
+            }
+        }
+        if (late) break;  // (the entries stay untaken: the sweep kernel does them)
+        if (valid) {
+            const uint32_t ex = __hip_atomic_load(ew + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t ey = __hip_atomic_load(ew + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t ez = __hip_atomic_load(ew + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t e3 = __hip_atomic_load(ew + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((ex & DONE_NOT_OK) == 0u) backtrace_one(P, ex - 1u, ey, ez, e3, true);
+            ew[0] = DONE_TAKEN;
+        }
+    }
 }
 
 }  // namespace wfa
