@@ -147,7 +147,7 @@ def main():
     # (profiles/*_pmc_hbm.json, made by scripts/profile_bench.sh; PMC cannot be collected from inside the bench).
     # gfx950: FETCH_SIZE counts half the bytes of the coalesced input reads (checked against the known 2.0 GB of
     # sequence bytes the forward kernel must read: it reports 1.12 GB), so it is doubled; WRITE_SIZE is taken as is.
-    traffic, traffic_src = None, None
+    traffic, traffic_src, traffic_kernel = None, None, None
     KNAMES = ["wfa_generic_kernel<1, 0>", "wfa_packed_kernel", "wfa_reg_kernel<2, 4, 1>", "wfa_blk_kernel<16",
               "wfa_blk_kernel<8"]
     kname = KNAMES[int(timing.main_kernel_kind)]
@@ -166,6 +166,7 @@ def main():
                     if "FETCH_SIZE_KB" in g0 and "WRITE_SIZE_KB" in g0:
                         traffic = (2.0 * g0["FETCH_SIZE_KB"] + g0["WRITE_SIZE_KB"]) * 1024.0
                         traffic_src = os.path.basename(f)
+                        traffic_kernel = name.replace("void wfa::", "").split("(")[0]
             if traffic is not None:
                 break
 
@@ -190,10 +191,11 @@ def main():
                "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                             "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
                             "algorithmic_bytes_per_launch": alg_bytes,
-                            "kernel": kname + (", 1>" if kname.endswith("16") or kname.endswith("<8") else ""),
+                            "kernel": traffic_kernel or (kname + (", 1>" if kname.endswith("16") or kname.endswith("<8") else "")),
                             "kernel_ms": main_k_ms, "all_kernels_ms": k_ms,
                             "note": "achieved = algorithmic bytes of one step / duration of the dominant "
-                                    "(forward) kernel's launches in that step; peak = 8 TB/s HBM3E spec; the kernel "
+                                    "kernel's launches in that step (forward pass; on large batches the same launch "
+                                    "also streams the backtrace); peak = 8 TB/s HBM3E spec; the kernel "
                                     "is integer-VALU-issue bound, not HBM bound (DESIGN.md section 5)"}}
         # ---- CPU baseline: the oracle (a literal port of the reference's algorithm) on a bounded sample of the
         # same dataset, on this box's host cores.  Reported baseline, not the target.
