@@ -331,6 +331,25 @@ def test_mid_length_global(built, length, err, n):
         al.close()
 
 
+@pytest.mark.parametrize("wait_us", [20000, 0])
+def test_streamed_backtrace_mid_length(built, wait_us):
+    """Streamed backtrace forced on for a small batch of 4 kbp pairs (hundreds of score steps per pair, streaming
+    waves that wait for their entries).  wait_us = 0: every streaming wave gives up at its first wait, so the sweep
+    kernel after the launch has to find and walk what they left behind."""
+    import wfa_amd as w
+    from oracle import oracle as O
+    data = w.generate_pairs(seed=44, n_pairs=3000, length=4000, error_rate=0.04, n_threads=8)
+    want = O.align_batch(_oracle_params(True, (10, 50, 1)), *data, n_threads=8)
+    al = _aligner(True, (10, 50, 1))
+    al.set_option("bt_stream_min", 1)
+    al.set_option("bt_stream_wait_us", wait_us)
+    for rep in range(2):
+        got = al.align_arrays(*data)
+        assert al.last_timing().main_kernel_kind == 3
+        assert_batch_equal(got, want, f"wait_us={wait_us} repeat {rep}")
+    al.close()
+
+
 def test_wide_band_retry_kernel(built):
     """Pairs whose band leaves the 64-diagonal window retry on the wave-per-pair blocked kernel (256 diagonals);
     what outgrows that too goes on to the generic kernel.  Same records with the rung switched off."""

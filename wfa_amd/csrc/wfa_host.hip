@@ -79,6 +79,7 @@ struct wfahip_ctx {
     int64_t       opt_blk                  = 16; // blocked register-window kernel: lanes per pair (16 or 8), 0 = off
     int64_t       opt_bt_stream            = 96; // > 0: that many waves of the first pass's launch backtrace finished pairs while the others go on
     int64_t       opt_bt_stream_min        = 65536;  // ... for batches of at least this many pairs
+    int64_t       opt_bt_stream_wait_us    = 20000;  // a streaming wave gives up on a queue entry after this long
     int64_t       opt_blk_wide             = 1;  // 1: pairs leaving the 64-diagonal window retry on the wave-per-pair blocked kernel (256 diagonals)
     int64_t       opt_blk_batch            = 1;  // short reads: stage BLK_BATCH pairs per group at a time
     int64_t       opt_packed_arena_bytes   = 0;  // per pair, 0 = automatic
@@ -318,6 +319,8 @@ extern "C" int wfahip_set_option(wfahip_ctx *ctx, const char *key, int64_t value
         ctx->opt_bt_stream = value;
     else if (k == "bt_stream_min")
         ctx->opt_bt_stream_min = value;
+    else if (k == "bt_stream_wait_us")
+        ctx->opt_bt_stream_wait_us = value;
     else if (k == "pilot")
         ctx->opt_pilot = value;
     else if (k == "team_min_len")
@@ -565,6 +568,7 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
                     // the launch fills the GPU
                     if (grid < (uint32_t)ctx->num_cus * waves_per_cu) grid = std::min<uint32_t>(grid + n_bt, (uint32_t)ctx->num_cus * waves_per_cu);
                     P.n_stream_wgs = n_bt;
+                    P.stream_wait  = (uint32_t)std::min<int64_t>(std::max<int64_t>(ctx->opt_bt_stream_wait_us, 0) * 100, 0x7FFFFFFF);
                     HIP_TRY(hipMemsetAsync(ctx->doneq.p, 0, 256 + 16 * cn, st));
                     HIP_TRY(hipMemsetAsync(P.pair_meta, 0xFF, 16 * cn, st));  // ST_PENDING: only pairs without a backtrace get a status
                 }

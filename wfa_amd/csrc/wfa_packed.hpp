@@ -373,7 +373,7 @@ WFA_DEV void stream_backtrace(const KParams &P) {
             if (!ok) ok = __hip_atomic_load(ew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
             if (__ballot(!ok) == 0ull) break;
             __builtin_amdgcn_s_sleep(32);
-            if (wall_clock64() - t0 > 2000000ull) {  // 100 MHz clock: 20 ms
+            if (wall_clock64() - t0 > (uint64_t)P.stream_wait) {  // (20 ms unless the host says otherwise)
                 late = true;
                 break;
             }
