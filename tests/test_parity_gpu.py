@@ -331,11 +331,12 @@ def test_mid_length_global(built, length, err, n):
         al.close()
 
 
-@pytest.mark.parametrize("wait_us", [20000, 0])
-def test_streamed_backtrace_mid_length(built, wait_us):
+@pytest.mark.parametrize("wait_us,chunk_pairs", [(20000, 0), (0, 0), (20000, 1000)])
+def test_streamed_backtrace_mid_length(built, wait_us, chunk_pairs):
     """Streamed backtrace forced on for a small batch of 4 kbp pairs (hundreds of score steps per pair, streaming
     waves that wait for their entries).  wait_us = 0: every streaming wave gives up at its first wait, so the sweep
-    kernel after the launch has to find and walk what they left behind."""
+    kernel after the launch has to find and walk what they left behind.  chunk_pairs = 1000: three chunks, each with
+    its own queue."""
     import wfa_amd as w
     from oracle import oracle as O
     data = w.generate_pairs(seed=44, n_pairs=3000, length=4000, error_rate=0.04, n_threads=8)
@@ -343,10 +344,11 @@ def test_streamed_backtrace_mid_length(built, wait_us):
     al = _aligner(True, (10, 50, 1))
     al.set_option("bt_stream_min", 1)
     al.set_option("bt_stream_wait_us", wait_us)
+    al.set_option("chunk_pairs", chunk_pairs)
     for rep in range(2):
         got = al.align_arrays(*data)
         assert al.last_timing().main_kernel_kind == 3
-        assert_batch_equal(got, want, f"wait_us={wait_us} repeat {rep}")
+        assert_batch_equal(got, want, f"wait_us={wait_us} chunk_pairs={chunk_pairs} repeat {rep}")
     al.close()
 
 

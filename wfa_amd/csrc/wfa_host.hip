@@ -534,7 +534,7 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
             if ((rc2 = ensure(ctx, meta_buf, chunk * 16 * n_buf))) return rc2;
             detach_bt = detach_bt && n_chunks == 1 && ctx->opt_tail_overlap != 0;
             // streamed backtrace: a few waves walk finished pairs while the forward kernel is still running
-            const bool stream_bt = detach_bt && kind == 3 && !blk_batch && ctx->opt_bt_stream > 0 && (int64_t)count >= ctx->opt_bt_stream_min;
+            const bool stream_bt = kind == 3 && !blk_batch && n_buf == 1 && ctx->opt_bt_stream > 0 && (int64_t)chunk >= ctx->opt_bt_stream_min;
             P.done_q = nullptr, P.done_ctl = nullptr, P.n_stream_wgs = 0;
             if (stream_bt) {
                 if ((rc2 = ensure(ctx, ctx->doneq, 256 + 16 * chunk))) return rc2;
