@@ -151,7 +151,7 @@ int  wfahip_last_timing(const wfahip_ctx *ctx, wfahip_timing *out);
  *   "blk_batch"  0|1       short reads: a group of the blocked kernel stages 8 pairs per refill   default 1
  *   "bt_stream"  n         n waves of the first pass's launch backtrace finished pairs while the other
  *                          waves are still aligning (0 = backtrace kernel after the forward kernel)  default 96
- *   "bt_stream_min"        ... for batches of at least this many pairs                             default 65536
+ *   "bt_stream_min"        ... for chunks of at least this many pairs                              default 393216
  *   "bt_stream_wait_us"    a streaming wave that waits longer than this for a finished pair leaves the
  *                          rest to the backtrace kernel that follows the launch                     default 20000
  *   "blk_wide"  0|1        pairs whose band leaves the 64-diagonal window retry on the same kernel with a
