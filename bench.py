@@ -6,7 +6,9 @@ per GPU, global alignment, wf-adaptive 10/50/1, penalties 4/6/2, seed 3.  A "ste
 over the rank's batch: raw byte sequences already resident in HBM -> result records + CIGAR ops in HBM.
 Multi-GPU (torchrun, one rank per GPU): pairs are sharded over ranks (weak scaling: 1e6 pairs per GPU, rank r
 owns dataset indices [r*n, (r+1)*n)), no data-path collective; the only RCCL traffic is the gather of the
-result records and CIGAR ops onto rank 0 at the end of every step.
+64-byte result records (score, region, statistics) onto rank 0 at the end of every step.  Like on one GPU the
+CIGAR ops stay in the HBM of the GPU that produced them; --gather-ops ships them to rank 0 as well (0.74 GB per
+rank and step at 1 kbp).
 
 Prints ONE JSON line (rank 0).  `value` = pairs aligned by all ranks / max-over-ranks wall time of K steps.
 """
@@ -39,6 +41,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=150_000, help="pairs timed on one host core (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=1)
     ap.add_argument("--opt", action="append", default=[], help="library option key=value (experiments)")
+    ap.add_argument("--gather-ops", action="store_true", help="multi-GPU: gather the CIGAR op arrays onto rank 0 too")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -97,12 +100,13 @@ def main():
         lib.wfahip_last_timing(al._ctx, C.byref(timing))
         n_ops = int(needed.value)
         if world > 1:
-            # Result gather onto rank 0 over RCCL/xGMI (fixed-size records, then padded op arrays).  It is started
+            # Result gather onto rank 0 over RCCL/xGMI (fixed-size records; with --gather-ops the padded op arrays
+            # too).  It is started
             # here and completed before the next one starts (or at the end of the timed region), so the exchange
             # of batch i runs beside the alignment of batch i+1; the send buffers are private copies.
             if pending[0] is not None:
                 pending[0].wait()
-            pending[0] = gather_results_async(d_rec, d_ops, n_ops, dst=0)
+            pending[0] = gather_results_async(d_rec, d_ops, n_ops, dst=0, with_ops=args.gather_ops)
         return n_ops
 
     def drain():
@@ -179,6 +183,7 @@ def main():
                            f"wf-adaptive {'off' if args.no_adaptive else '10/50/1'}, seed {args.seed}",
                "pairs_per_gpu": n, "length": args.length, "error_rate": args.error,
                "parallelism": f"pair-sharded x{world}", "status_ok": int(ok.sum()),
+               "gather": "none (1 GPU)" if world == 1 else ("records + CIGAR ops" if args.gather_ops else "records"),
                "gcells_per_s": value * args.length * args.length / 1e9,
                "kernel_ms_per_step": k_ms, "main_kernel_ms": main_k_ms, "launches_per_step": int(timing.n_launches),
                "packed_pairs": int(timing.n_packed_pairs),

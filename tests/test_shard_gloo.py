@@ -44,9 +44,14 @@ def _worker(rank, world, port, n_total, out_path):
     t_rec.zero_(), t_ops.zero_()
     got = pend.wait()
     again = gather_results(torch.from_numpy(rec), torch.from_numpy(ops), len(r.ops), dst=0)
+    only_rec = gather_results(torch.from_numpy(rec), torch.from_numpy(ops), len(r.ops), dst=0, with_ops=False)
     if rank == 0:
         assert all(torch.equal(a, b) for a, b in zip(got[0], again[0]))
         assert all(torch.equal(a, b) for a, b in zip(got[1], again[1]))
+        assert all(torch.equal(a, b) for a, b in zip(got[0], only_rec[0]))  # records only: same records, no ops
+        assert all(o.numel() == 0 for o in only_rec[1])
+    else:
+        assert only_rec is None
     if rank == 0:
         recs, opss = got
         scores, cigars = [], []
