@@ -148,7 +148,8 @@ int  wfahip_last_timing(const wfahip_ctx *ctx, wfahip_timing *out);
  *   "tail_overlap"  0|1    retry passes run beside the first pass's backtrace kernel             default 1
  *   "pilot"  0|1           wf-adaptive off, reads >= 400 bases: 4 096 pairs go first and decide whether the
  *                          rest uses the sub-wave kernels at all                                  default 1
- *   "blk_batch"  0|1       short reads: a group of the blocked kernel stages 8 pairs per refill   default 1
+ *   "blk_batch"  0..8      short reads: a group of the blocked kernel stages several pairs per refill
+ *                          (1 = as many as spreads the chunk evenly, at most 8; 2..8 = that many)  default 1
  *   "bt_stream"  n         n waves of the first pass's launch backtrace finished pairs while the other
  *                          waves are still aligning (0 = backtrace kernel after the forward kernel)  default 96
  *   "bt_stream_min"        ... for chunks of at least this many pairs                              default 393216

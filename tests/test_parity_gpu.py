@@ -307,7 +307,7 @@ def test_short_read_batches(built, n_pairs):
     data = w.make_blob(qs, ts)
     for ad in ((10, 50, 1), None):
         want = O.align_batch(_oracle_params(True, ad), *data, n_threads=4)
-        for batch in (1, 0):
+        for batch in (1, 8, 3, 0):
             al = _aligner(True, ad)
             al.set_option("blk_batch", batch)
             got = al.align_arrays(*data)

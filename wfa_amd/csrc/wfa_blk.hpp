@@ -316,12 +316,15 @@ __global__ __launch_bounds__(64, (G == 8 ? WFA_BLK8_WAVES : 4)) void wfa_blk_ker
 #pragma unroll
                         for (int r = 0; r < NG; r++) gbits |= (uint32_t)((fneed >> (G * r)) & 1ull) << r;
                         uint32_t base = 0;
-                        if (lane == 0) base = atomicAdd(P.queue_head, (uint32_t)(BATCH * __builtin_popcount(gbits)));
+                        // (bn <= BATCH entries per grab: the host picks it so that a small chunk spreads evenly over
+                        // the resident groups instead of leaving a quarter of them without a batch)
+                        const int bn = (int)P.blk_batch_n;
+                        if (lane == 0) base = atomicAdd(P.queue_head, (uint32_t)(bn * __builtin_popcount(gbits)));
                         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                        const uint32_t wi0 = base + (uint32_t)(BATCH * __builtin_popcount(gbits & ((1u << grp) - 1u)));
-                        // lane j < BATCH of a fetching group owns entry wi0 + j
+                        const uint32_t wi0 = base + (uint32_t)(bn * __builtin_popcount(gbits & ((1u << grp) - 1u)));
+                        // lane j < bn of a fetching group owns entry wi0 + j
                         const uint32_t wi  = wi0 + (uint32_t)j;
-                        const bool     own = fetch && j < BATCH;
+                        const bool     own = fetch && j < bn;
                         const bool     got = own && wi < P.chunk_n;
                         uint32_t pr = 0, nq = 0, mt = 0;
                         uint64_t qo = 0, to = 0;
@@ -350,7 +353,7 @@ __global__ __launch_bounds__(64, (G == 8 ? WFA_BLK8_WAVES : 4)) void wfa_blk_ker
                         // ---- every fetching group stages its BATCH pairs with its own lanes
                         uint32_t badmask = 0u;
 #pragma unroll 1
-                        for (int sl = 0; sl < BATCH; sl++) {
+                        for (int sl = 0; sl < bn; sl++) {
                             const uint32_t *const mw = gmeta + BM * sl;
                             const uint32_t nq_s = fetch ? mw[2] : 0u, mt_s = mw[3];
                             if (nq_s != 0u) {
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(64, (G == 8 ? WFA_BLK8_WAVES : 4)) void wfa_blk_ker
                         }
                         if (fetch) {
                             bslot = 0;
-                            bcnt  = wi0 >= P.chunk_n ? 0 : (int)imin2(BATCH, (int)(P.chunk_n - wi0));
+                            bcnt  = wi0 >= P.chunk_n ? 0 : (int)imin2(bn, (int)(P.chunk_n - wi0));
                             if (bcnt == 0) st = 2;
                         }
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -81,7 +81,7 @@ struct wfahip_ctx {
     int64_t       opt_bt_stream_min        = 393216; // ... for chunks of at least this many pairs (measured at 1 kbp: -0.13 ms at 262 144 pairs, +0.26 ms at 524 288)
     int64_t       opt_bt_stream_wait_us    = 20000;  // a streaming wave gives up on a queue entry after this long
     int64_t       opt_blk_wide             = 1;  // 1: pairs leaving the 64-diagonal window retry on the wave-per-pair blocked kernel (256 diagonals)
-    int64_t       opt_blk_batch            = 1;  // short reads: stage BLK_BATCH pairs per group at a time
+    int64_t       opt_blk_batch            = 1;  // short reads: stage up to BLK_BATCH pairs per group at a time (1 = automatic count, 2..8 = that many, 0 = off)
     int64_t       opt_packed_arena_bytes   = 0;  // per pair, 0 = automatic
     int64_t       opt_chunk_pairs          = 0;  // 0 = automatic
     int64_t       opt_packed_waves_per_cu  = 0;  // 0 = automatic
@@ -579,8 +579,15 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
                     hipLaunchKernelGGL((wfa_blk_kernel<64, 1>), dim3(grid), dim3(64), lds_bytes, st, P);
                 else if (kind == 4)
                     hipLaunchKernelGGL((wfa_blk_kernel<8, 1>), dim3(grid), dim3(64), lds_bytes, st, P);
-                else if (kind == 3 && blk_batch)
+                else if (kind == 3 && blk_batch) {
+                    // entries per grab: the chunk's share of one resident group, cut into the fewest rounds of <= 8
+                    const uint64_t groups = (uint64_t)ctx->num_cus * 16 * 4;  // 4 waves per SIMD x 4 pairs
+                    const uint64_t share  = (cn + groups - 1) / groups;
+                    const uint64_t rounds = (share + BLK_BATCH - 1) / BLK_BATCH;
+                    P.blk_batch_n = (uint32_t)std::min<uint64_t>(BLK_BATCH, std::max<uint64_t>(1, (share + rounds - 1) / std::max<uint64_t>(1, rounds)));
+                    if (ctx->opt_blk_batch > 1) P.blk_batch_n = (uint32_t)std::min<int64_t>(BLK_BATCH, ctx->opt_blk_batch);
                     hipLaunchKernelGGL((wfa_blk_kernel<16, BLK_BATCH>), dim3(grid), dim3(64), lds_bytes, st, P);
+                }
                 else if (kind == 3 && stream_bt)
                     hipLaunchKernelGGL((wfa_blk_kernel<16, 1, true>), dim3(grid), dim3(64), lds_bytes, st, P);
                 else if (kind == 3)
