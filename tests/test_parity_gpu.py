@@ -1,5 +1,7 @@
 """GPU: the HIP path (through the C-ABI) against the oracle and the golden fixtures.  Bit-exact: score,
 CIGAR ops, match region, statistics."""
+import os
+
 import numpy as np
 import pytest
 
@@ -13,6 +15,11 @@ def _aligner(global_alignment=True, adaptive=(10, 50, 1), penalties=(4, 6, 2)):
     al = w.New(w.Penalties(*penalties), w.Options(GlobalAlignment=global_alignment), device=0)
     if adaptive is not None:
         assert al.AdaptiveReduction(w.AdaptiveReductionOption(*adaptive)) is None
+    # WFA_TEST_OPTS="key=value,..." runs the whole suite with library options forced (e.g. bt_stream_min=1: the
+    # streamed backtrace on every batch the blocked kernel takes)
+    for kv in filter(None, os.environ.get("WFA_TEST_OPTS", "").split(",")):
+        k, v = kv.split("=")
+        al.set_option(k, int(v))
     return al
 
 
