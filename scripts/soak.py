@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""GPU box: full-size parity soak.  For several seeds / lengths / error rates: the HIP path on a large batch against the
+oracle on all host cores, bit-exact on every field and every CIGAR op; each batch is aligned twice (streamed
+backtrace: the hand-over between forward and backtrace waves must hold every time).
+Usage: scripts/soak.py [n_pairs]"""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+import numpy as np
+import wfa_amd as w
+from oracle import oracle as O
+import test_parity_gpu as T
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+thr = max(8, (os.cpu_count() or 8) // 2)
+bad = 0
+for seed, length, err, ad in ((101, 1000, 0.05, (10, 50, 1)), (102, 1000, 0.08, (10, 50, 1)), (103, 600, 0.03, (10, 50, 1)),
+                              (104, 2000, 0.05, (10, 50, 1)), (105, 1000, 0.05, (20, 100, 1)), (106, 300, 0.10, None)):
+    nn = n * 1000 // length if length > 1000 else n
+    data = w.generate_pairs(seed=seed, n_pairs=nn, length=length, error_rate=err, n_threads=32)
+    t0 = time.perf_counter()
+    want = O.align_batch(T._oracle_params(True, ad), *data, n_threads=thr)
+    t1 = time.perf_counter()
+    al = T._aligner(True, ad)
+    for rep in range(2):
+        got = al.align_arrays(*data)
+        t = al.last_timing()
+        try:
+            T.assert_batch_equal(got, want, f"seed={seed} L={length} err={err} ad={ad} rep={rep}")
+            print(f"ok   seed={seed} n={nn} L={length} err={err} ad={ad} rep={rep}: lib {t.total_ms:.1f} ms, kind {t.main_kernel_kind}, "
+                  f"retried {t.n_retried_pairs}, oracle {t1 - t0:.1f} s on {thr} threads", flush=True)
+        except AssertionError as e:
+            bad += 1
+            print("FAIL", str(e)[:300], flush=True)
+    al.close()
+print("soak done, failures:", bad)
+sys.exit(1 if bad else 0)
