@@ -318,6 +318,9 @@ struct OpsWriter {
 // wfa_cigar.go:142-146, becomes a no-op) at buf[cap-n .. cap).  The statistics of process()
 // (wfa_cigar.go:168-211: span first-M .. last-M) are accumulated while emitting: in emission order the
 // span runs from the first emitted M to the last emitted M.
+#ifndef WFA_OPS_PAIRED
+#define WFA_OPS_PAIRED 1
+#endif
 struct OpsWriterRev {
     uint64_t *buf;
     uint32_t  cap;
@@ -327,9 +330,11 @@ struct OpsWriterRev {
     bool      seenM;
     uint32_t  alen, matches, gaps, regions;      // committed (up to the latest M)
     uint32_t  p_len, p_gaps, p_regions;          // pending since the latest M
-    uint64_t  last;                              // last flushed op (for the no-M case)
+    uint64_t  last;                              // last flushed op (for the no-M case, and the partner of a paired store)
+    bool      paired;                            // entries go out two at a time as aligned 16-byte stores
     WFA_DEV void init(uint64_t *b, uint32_t c) {
         buf = b, cap = c, n = 0, cur = 0, overflow = false, seenM = false;
+        paired = WFA_OPS_PAIRED != 0 && (reinterpret_cast<uintptr_t>(b + c) & 15u) == 0u;
         alen = matches = gaps = regions = 0;
         p_len = p_gaps = p_regions = 0;
         last = 0;
@@ -344,10 +349,16 @@ struct OpsWriterRev {
     }
     WFA_DEV void flush() {
         if (cur == 0) return;
-        if (n < cap)
-            buf[cap - 1 - n] = cur;
-        else
+        if (n < cap) {
+            // paired: entry cap-1-n with n odd sits on a 16-byte boundary; it goes out together with the entry
+            // before it (`last`, one slot higher), whose own store was skipped
+            if (!paired)
+                buf[cap - 1 - n] = cur;
+            else if (n & 1u)
+                *reinterpret_cast<ulonglong2 *>(buf + (cap - 1 - n)) = make_ulonglong2(cur, last);
+        } else {
             overflow = true;
+        }
         n++;
         const uint32_t letter = (uint32_t)(cur >> 32), cnt = (uint32_t)cur;
         if (letter == 'M') {
@@ -367,6 +378,7 @@ struct OpsWriterRev {
     }
     // process() with no M op at all: begin = end = 0 -> only the first op of the forward list counts
     WFA_DEV void finish() {
+        if (paired && (n & 1u) && n <= cap) buf[cap - n] = last;  // the last entry has no partner
         if (!seenM && n > 0) {
             const uint32_t letter = (uint32_t)(last >> 32), cnt = (uint32_t)last;
             alen = cnt, matches = 0;
