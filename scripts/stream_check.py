@@ -15,6 +15,8 @@ for name, opt in (("base", 0), ("stream", waves)):
     al = w.New()
     al.AdaptiveReduction(w.DefaultAdaptiveOption)
     al.set_option("bt_stream", opt)
+    al.set_option("bt_stream_single", 1)
+    al.set_option("bt_stream_min", 1)
     al.align_arrays(*data)
     t0 = time.perf_counter()
     r = al.align_arrays(*data)

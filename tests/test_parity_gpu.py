@@ -15,8 +15,8 @@ def _aligner(global_alignment=True, adaptive=(10, 50, 1), penalties=(4, 6, 2)):
     al = w.New(w.Penalties(*penalties), w.Options(GlobalAlignment=global_alignment), device=0)
     if adaptive is not None:
         assert al.AdaptiveReduction(w.AdaptiveReductionOption(*adaptive)) is None
-    # WFA_TEST_OPTS="key=value,..." runs the whole suite with library options forced (e.g. bt_stream_min=1: the
-    # streamed backtrace on every batch the blocked kernel takes)
+    # WFA_TEST_OPTS="key=value,..." runs the whole suite with library options forced (e.g.
+    # bt_stream_min=1,bt_stream_single=1: the streamed backtrace on every batch the blocked kernel takes)
     for kv in filter(None, os.environ.get("WFA_TEST_OPTS", "").split(",")):
         k, v = kv.split("=")
         al.set_option(k, int(v))
@@ -221,8 +221,8 @@ def test_unaligned_blob_offsets(built):
     al.close()
 
 
-@pytest.mark.parametrize("opts,kind", [({"blk": 16}, 3), ({"blk": 16, "bt_stream_min": 1}, 3),
-                                       ({"blk": 16, "bt_stream_min": 1, "bt_stream": 4}, 3), ({"blk": 8}, 4),
+@pytest.mark.parametrize("opts,kind", [({"blk": 16}, 3), ({"blk": 16, "bt_stream_min": 1, "bt_stream_single": 1}, 3),
+                                       ({"blk": 16, "bt_stream_min": 1, "bt_stream_single": 1, "bt_stream": 4}, 3), ({"blk": 8}, 4),
                                        ({"blk": 0}, 2), ({"blk": 0, "reg": 0}, 1), ({"packed": 0}, 0)])
 def test_forward_kernel_variants(built, opts, kind):
     """Every forward kernel (blocked register-window with 16 / 8 lanes per pair, strided register-window, LDS-ring
@@ -350,6 +350,7 @@ def test_streamed_backtrace_mid_length(built, wait_us, chunk_pairs):
     want = O.align_batch(_oracle_params(True, (10, 50, 1)), *data, n_threads=8)
     al = _aligner(True, (10, 50, 1))
     al.set_option("bt_stream_min", 1)
+    al.set_option("bt_stream_single", 1)
     al.set_option("bt_stream_wait_us", wait_us)
     al.set_option("chunk_pairs", chunk_pairs)
     for rep in range(2):
@@ -595,11 +596,13 @@ def test_full_size_parity_c3(built):
         cells = al.last_timing().cells_stored
         want = O.align_batch(_oracle_params(True, ad), *data, n_threads=thr)
         assert_batch_equal(got, want, f"full size L={length}")
-        # (1e6 pairs: the backtrace is streamed -- waves of the forward launch walk finished pairs while the others
-        # are still aligning; the hand-over between them must hold every time)
+        # streamed backtrace -- waves of the forward launch walk finished pairs while the others are still aligning;
+        # the hand-over between them must hold every time
+        al.set_option("bt_stream_single", 1)
         for rep in range(3):
-            assert_batch_equal(al.align_arrays(*data), want, f"full size L={length}, repeat {rep}")
+            assert_batch_equal(al.align_arrays(*data), want, f"full size L={length}, streamed, repeat {rep}")
             assert al.last_timing().cells_stored == cells
+        al.set_option("bt_stream_single", 0)
         # the retry passes run beside the first pass's backtrace kernel: same records and same cell census as the
         # serial schedule
         al.set_option("tail_overlap", 0)

@@ -78,7 +78,9 @@ struct wfahip_ctx {
     int64_t       opt_reg                  = 1;  // 0: never use the register-window kernel
     int64_t       opt_blk                  = 16; // blocked register-window kernel: lanes per pair (16 or 8), 0 = off
     int64_t       opt_bt_stream            = 96; // > 0: that many waves of the first pass's launch backtrace finished pairs while the others go on
-    int64_t       opt_bt_stream_min        = 393216; // ... for chunks of at least this many pairs (measured at 1 kbp: -0.13 ms at 262 144 pairs, +0.26 ms at 524 288)
+    int64_t       opt_bt_stream_min        = 393216; // ... for chunks of at least this many pairs
+    int64_t       opt_bt_stream_single     = 0;      // 1: also when the pass is a single chunk (there the backtrace kernel already runs beside the
+                                                     // retry passes and, since its op stores are combined, costs less than the streaming: 25.35 vs 25.55 ms)
     int64_t       opt_bt_stream_wait_us    = 20000;  // a streaming wave gives up on a queue entry after this long
     int64_t       opt_blk_wide             = 1;  // 1: pairs leaving the 64-diagonal window retry on the wave-per-pair blocked kernel (256 diagonals)
     int64_t       opt_blk_batch            = 1;  // short reads: stage up to BLK_BATCH pairs per group at a time (1 = automatic count, 2..8 = that many, 0 = off)
@@ -319,6 +321,8 @@ extern "C" int wfahip_set_option(wfahip_ctx *ctx, const char *key, int64_t value
         ctx->opt_bt_stream = value;
     else if (k == "bt_stream_min")
         ctx->opt_bt_stream_min = value;
+    else if (k == "bt_stream_single")
+        ctx->opt_bt_stream_single = value;
     else if (k == "bt_stream_wait_us")
         ctx->opt_bt_stream_wait_us = value;
     else if (k == "pilot")
@@ -534,7 +538,8 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
             if ((rc2 = ensure(ctx, meta_buf, chunk * 16 * n_buf))) return rc2;
             detach_bt = detach_bt && n_chunks == 1 && ctx->opt_tail_overlap != 0;
             // streamed backtrace: a few waves walk finished pairs while the forward kernel is still running
-            const bool stream_bt = kind == 3 && !blk_batch && n_buf == 1 && ctx->opt_bt_stream > 0 && (int64_t)chunk >= ctx->opt_bt_stream_min;
+            const bool stream_bt = kind == 3 && !blk_batch && n_buf == 1 && ctx->opt_bt_stream > 0 && (int64_t)chunk >= ctx->opt_bt_stream_min &&
+                                   (n_chunks > 1 || ctx->opt_bt_stream_single != 0);
             P.done_q = nullptr, P.done_ctl = nullptr, P.n_stream_wgs = 0;
             if (stream_bt) {
                 if ((rc2 = ensure(ctx, ctx->doneq, 256 + 16 * chunk))) return rc2;

@@ -304,7 +304,8 @@ WFA_DEV void backtrace_one(const KParams &P, uint32_t idx, uint32_t s_final, uin
     cv.fmt = P.compact_fmt, cv.coherent = coherent;
 
     // ops region: bound = 2 * score / min(x, e) + 8 entries, carved from the shared ops buffer
-    const uint32_t bound = 2u * (s_final / P.min_xe) + 8u;
+    // (a multiple of the writer's store group: with the buffer aligned every region ends on a store boundary)
+    const uint32_t bound = (2u * (s_final / P.min_xe) + 8u + OpsWriterRev::GROUP - 1u) & ~(OpsWriterRev::GROUP - 1u);
     const uint64_t off   = atomicAdd(P.ops_cursor, (unsigned long long)bound);
     OpsWriterRev   ow;
     const bool     fits = off + bound <= P.ops_cap;
