@@ -204,7 +204,7 @@ def main():
                                     "is integer-VALU-issue bound, not HBM bound (DESIGN.md section 5)"}}
         # ---- CPU baseline: the oracle (a literal port of the reference's algorithm) on a bounded sample of the
         # same dataset, on this box's host cores.  Reported baseline, not the target.
-        if args.cpu_sample > 0:
+        if args.cpu_sample > 0 and world == 1:  # (N = 1 only: the other ranks would sit in the barrier meanwhile)
             from oracle import oracle as O
             ns = min(args.cpu_sample, n)
             p = O.make_params(global_alignment=not args.semi_global,
