@@ -101,7 +101,8 @@ typedef struct {
                                   ran, else the first generic launch) */
     uint32_t n_main_launches;  /* launches of that kernel (one per chunk) */
     uint32_t n_packed_pairs;   /* pairs finished by the sub-wave forward + backtrace kernels */
-    uint32_t main_kernel_kind; /* 0 = wfa_generic_kernel, 1 = wfa_packed_kernel, 2 = wfa_reg_kernel, 3 = wfa_blk_kernel<16>, 4 = wfa_blk_kernel<8> */
+    uint32_t main_kernel_kind; /* 0 = wfa_generic_kernel, 1 = wfa_packed_kernel, 2 = wfa_reg_kernel, 3 = wfa_blk_kernel<16>, 4 = wfa_blk_kernel<8>,
+                                  5 = wfa_blk_kernel<64> */
     uint32_t reserved;
 } wfahip_timing;
 
@@ -146,8 +147,9 @@ int  wfahip_last_timing(const wfahip_ctx *ctx, wfahip_timing *out);
  *   "packed_arena_bytes"   per-pair arena of the sub-wave pipeline (0 = automatic)
  *   "chunk_pairs", "packed_waves_per_cu", "overlap"   chunking of the sub-wave pipeline
  *   "tail_overlap"  0|1    retry passes run beside the first pass's backtrace kernel             default 1
- *   "pilot"  0|1           wf-adaptive off, reads >= 400 bases: 4 096 pairs go first and decide whether the
- *                          rest uses the sub-wave kernels at all                                  default 1
+ *   "pilot"  0|1           wf-adaptive off, >= 65 536 pairs of >= 200 bases: 4 096 pairs go first and decide whether
+ *                          the rest starts on the 64-diagonal kernel, on the 256-diagonal one, or on the
+ *                          generic kernel                                                          default 1
  *   "blk_batch"  0..8      short reads: a group of the blocked kernel stages several pairs per refill
  *                          (1 = as many as spreads the chunk evenly, at most 8; 2..8 = that many)  default 1
  *   "bt_stream"  n         n waves of the first pass's launch backtrace finished pairs while the other

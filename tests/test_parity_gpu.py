@@ -389,24 +389,30 @@ def test_wide_band_retry_kernel(built):
     assert packed[1] < len(qs)                    # ... and handed the widest ones on
 
 
-@pytest.mark.parametrize("err,expect_skip", [(0.12, True), (0.01, False)])
-def test_pilot_chunk(built, err, expect_skip):
-    """wf-adaptive off on a large batch of 400+ base reads: the first 4 096 pairs are a pilot; when most of them
-    outgrow the 64-diagonal window the rest goes straight to the generic kernel, else the blocked kernel takes
-    the rest.  Either way every record equals the oracle's."""
+@pytest.mark.parametrize("length,err,route", [(400, 0.12, "generic"), (400, 0.01, "blk"), (300, 0.08, "wide")])
+def test_pilot_chunk(built, length, err, route):
+    """wf-adaptive off on a large batch of 200+ base reads: the first 4 096 pairs are a pilot.  When most of them
+    outgrow the 64-diagonal window the rest goes straight to the wave-per-pair kernel (256 diagonals) if that one
+    takes the pilot's leftovers, else to the generic kernel; otherwise the blocked kernel takes the rest.  Either
+    way every record equals the oracle's."""
     import os
     import wfa_amd as w
     from oracle import oracle as O
-    n = 33000
-    data = w.generate_pairs(seed=int(err * 1000), n_pairs=n, length=400, error_rate=err, n_threads=16)
+    n = 70000
+    data = w.generate_pairs(seed=int(err * 1000), n_pairs=n, length=length, error_rate=err, n_threads=16)
     al = _aligner(True, None)
     got = al.align_arrays(*data)
     t = al.last_timing()
-    assert (t.n_packed_pairs < 4096) == expect_skip, t
+    if route == "generic":
+        assert t.main_kernel_kind == 3 and t.n_packed_pairs < 4096, t
+    elif route == "wide":
+        assert t.main_kernel_kind == 5 and t.n_packed_pairs > n - n // 10, t
+    else:
+        assert t.main_kernel_kind == 3 and t.n_packed_pairs > n - n // 10, t
     want = O.align_batch(_oracle_params(True, None), *data, n_threads=max(8, (os.cpu_count() or 8) // 2))
-    assert_batch_equal(got, want, f"pilot err={err}")
+    assert_batch_equal(got, want, f"pilot L={length} err={err}")
     al.set_option("pilot", 0)
-    assert_batch_equal(al.align_arrays(*data), want, f"no pilot err={err}")
+    assert_batch_equal(al.align_arrays(*data), want, f"no pilot L={length} err={err}")
     al.close()
 
 

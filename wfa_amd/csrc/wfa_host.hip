@@ -630,21 +630,48 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
         if (can_b || can_c || can_d) {
             std::vector<uint64_t> redo1, redo2;
             const int kind1 = can_d ? (ctx->opt_blk == 8 ? 4 : 3) : (can_c ? 2 : 1);
-            // Pilot: on a large batch the first 4 096 pairs go first; when most of them leave the 64-diagonal window
-            // (wf-adaptive off on long reads, very divergent pairs) the rest skips the sub-wave kernels instead of
-            // starting every pair there only to hand it on.
+            // Pilot: on a large batch with wf-adaptive off the first 4 096 pairs go first.  When most of them leave the
+            // 64-diagonal window the rest does not start there only to be handed on: it goes straight to the
+            // wave-per-pair kernel (256 diagonals) if that one takes most of the pilot's leftovers, else to the
+            // generic ladder.  (wf-adaptive or short reads: narrow bands, no pilot.)
             uint64_t done_pairs = 0;
             bool     skip_rest  = false;
-            if (n_pairs >= 32768 && !P.adaptive && max_len >= 400 && ctx->opt_pilot != 0) {  // (wf-adaptive or short reads: narrow bands)
+            int      kind_rest  = kind1;
+            const bool wide_ok  = kind1 >= 3 && ctx->opt_blk_wide != 0;
+            std::vector<uint64_t> redo_w;  // handed on by the 256-diagonal kernel, or not eligible for it
+            const auto wide_pass = [&](std::vector<uint64_t> &from) -> int {  // band failures of `from` -> kind 5; the rest -> redo_w
+                std::vector<uint32_t> lst;
+                for (uint64_t e : from) {
+                    if ((uint32_t)(e >> 32) == ST_REDO_BAND) lst.push_back((uint32_t)e);
+                    else redo_w.push_back(e);
+                }
+                from.clear();
+                if (lst.empty()) return 0;
+                std::vector<uint64_t> r2;
+                int rcw = forward_pass(5, &lst, 0, lst.size(), r2, false);
+                if (rcw) return -rcw;
+                ctx->timing.n_packed_pairs += (uint32_t)(lst.size() - r2.size());
+                redo_w.insert(redo_w.end(), r2.begin(), r2.end());
+                return r2.size() * 2 > lst.size() ? 2 : 1;  // 2: the wide kernel does not take most of them either
+            };
+            uint64_t n_first_fail = 0;  // pairs the first-pass kernel(s) handed on
+            if (n_pairs >= 65536 && !P.adaptive && max_len >= 200 && ctx->opt_pilot != 0) {  // (the pilot costs one extra pass, ~0.1 ms)
                 const uint64_t pilot = 4096;
                 if ((rc = forward_pass(kind1, nullptr, 0, pilot, redo1, false))) return rc;
-                done_pairs = pilot;
-                skip_rest  = redo1.size() * 2 > pilot;
+                done_pairs   = pilot;
+                n_first_fail = redo1.size();
+                if (redo1.size() * 2 > pilot) {
+                    const int wv = wide_ok ? wide_pass(redo1) : 2;
+                    if (wv < 0) return -wv;
+                    if (wv == 1) kind_rest = 5;
+                    else skip_rest = true;
+                }
             }
             if (!skip_rest) {
                 std::vector<uint64_t> more;
-                if ((rc = forward_pass(kind1, nullptr, done_pairs, n_pairs - done_pairs, more, true))) return rc;
-                redo1.insert(redo1.end(), more.begin(), more.end());
+                if ((rc = forward_pass(kind_rest, nullptr, done_pairs, n_pairs - done_pairs, more, true))) return rc;
+                n_first_fail += more.size();
+                (kind_rest == 5 ? redo_w : redo1).insert((kind_rest == 5 ? redo_w : redo1).end(), more.begin(), more.end());
                 done_pairs = n_pairs;
             }
             if (std::getenv("WFAHIP_DEBUG_TIMING") && P.done_ctl) {
@@ -660,9 +687,9 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
                              (unsigned long long)cnt[0], (unsigned long long)cnt[1], (unsigned long long)cnt[2],
                              (unsigned long long)cnt[3]);
             }
-            ctx->timing.main_kernel_kind = (uint32_t)kind1;
-            ctx->timing.n_packed_pairs = (uint32_t)(done_pairs - redo1.size());
-            ctx->timing.n_retried_pairs += (uint32_t)redo1.size();
+            ctx->timing.main_kernel_kind = (uint32_t)kind_rest;
+            ctx->timing.n_packed_pairs += (uint32_t)(done_pairs - n_first_fail);
+            ctx->timing.n_retried_pairs += (uint32_t)n_first_fail;
             Job jb, ja;
             jb.mode = 1, jb.level = 0, jb.all = false;
             ja.mode = 0, ja.level = 0, ja.all = false;
@@ -670,23 +697,14 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
             // once, backtrace included) than through another forward + backtrace pass; beyond that the LDS-ring
             // kernel's throughput wins.
             const uint64_t resident_generic = (uint64_t)ctx->num_cus * 32;
-            if (kind1 >= 3 && ctx->opt_blk_wide != 0) {
+            if (wide_ok) {
                 // pairs whose band outgrew the 64-diagonal window: the same kernel with a wave per pair (256 diagonals)
-                std::vector<uint32_t> lst;
-                std::vector<uint64_t> rest;
-                for (uint64_t e : redo1) {
-                    if ((uint32_t)(e >> 32) == ST_REDO_BAND) lst.push_back((uint32_t)e);
-                    else rest.push_back(e);
-                }
-                if (!lst.empty()) {
-                    if ((rc = forward_pass(5, &lst, 0, lst.size(), redo2, false))) return rc;
-                    ctx->timing.n_packed_pairs += (uint32_t)(lst.size() - redo2.size());
-                    rest.insert(rest.end(), redo2.begin(), redo2.end());
-                    redo1.swap(rest);
-                    redo2.clear();
-                }
+                const int wv = wide_pass(redo1);
+                if (wv < 0) return -wv;
             }
-            if (kind1 >= 2 && can_b && redo1.size() > resident_generic) {
+            redo1.insert(redo1.end(), redo_w.begin(), redo_w.end());
+            redo_w.clear();
+            if (kind1 >= 2 && can_b && !wide_ok && redo1.size() > resident_generic) {
                 // second chance on the LDS-ring kernel (64-diagonal bands at any alignment) for band/arena misses
                 std::vector<uint32_t> lst;
                 for (uint64_t e : redo1) {
