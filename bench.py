@@ -153,7 +153,7 @@ def main():
     # sequence bytes the forward kernel must read: it reports 1.12 GB), so it is doubled; WRITE_SIZE is taken as is.
     traffic, traffic_src, traffic_kernel = None, None, None
     KNAMES = ["wfa_generic_kernel<1, 0>", "wfa_packed_kernel", "wfa_reg_kernel<2, 4, 1>", "wfa_blk_kernel<16",
-              "wfa_blk_kernel<8", "wfa_blk_kernel<64"]
+              "wfa_blk_kernel<8", "wfa_blk_kernel<64", "wfa_blk_kernel<8, 8, false, 4"]
     kname = KNAMES[int(timing.main_kernel_kind)]
     default_workload = (n == 1_000_000 and args.length == 1000 and abs(args.error - 0.05) < 1e-9 and args.seed == 3
                         and not args.semi_global and not args.no_adaptive)
@@ -196,7 +196,7 @@ def main():
                "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                             "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
                             "algorithmic_bytes_per_launch": alg_bytes,
-                            "kernel": traffic_kernel or (kname + (", 1>" if kname.endswith("16") or kname.endswith("<8") or kname.endswith("64") else "")),
+                            "kernel": traffic_kernel or (kname + (", ..>" if kname.startswith("wfa_blk_kernel") else "")),
                             "kernel_ms": main_k_ms, "all_kernels_ms": k_ms,
                             "note": "achieved = algorithmic bytes of one step / duration of the dominant "
                                     "kernel's launches in that step (forward pass; on large batches the same launch "

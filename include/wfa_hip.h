@@ -102,7 +102,7 @@ typedef struct {
     uint32_t n_main_launches;  /* launches of that kernel (one per chunk) */
     uint32_t n_packed_pairs;   /* pairs finished by the sub-wave forward + backtrace kernels */
     uint32_t main_kernel_kind; /* 0 = wfa_generic_kernel, 1 = wfa_packed_kernel, 2 = wfa_reg_kernel, 3 = wfa_blk_kernel<16>, 4 = wfa_blk_kernel<8>,
-                                  5 = wfa_blk_kernel<64> */
+                                  5 = wfa_blk_kernel<64>, 6 = wfa_blk_kernel<8, 8, false, 4> (short reads) */
     uint32_t reserved;
 } wfahip_timing;
 
@@ -159,6 +159,8 @@ int  wfahip_last_timing(const wfahip_ctx *ctx, wfahip_timing *out);
  *                          stream: a single chunk's backtrace kernel already runs beside the retries)  default 0
  *   "bt_stream_wait_us"    a streaming wave that waits longer than this for a finished pair leaves the
  *                          rest to the backtrace kernel that follows the launch                     default 20000
+ *   "blk_narrow"  0|1      reads under 200 bases start with eight pairs per wave (8 lanes, 32 diagonals each);
+ *                          what outgrows that retries on the 16-lane instance                         default 1
  *   "blk_wide"  0|1        pairs whose band leaves the 64-diagonal window retry on the same kernel with a
  *                          wave per pair (256 diagonals) before the generic kernel takes them       default 1
  *   "arena_bytes_per_slot", "slots", "threads_per_pair"   generic kernel (one workgroup per pair)

@@ -278,8 +278,8 @@ def test_forward_kernel_variants(built, opts, kind):
             al.close()
 
 
-@pytest.mark.parametrize("n_pairs", [1, 3, 9, 64, 1237])
-def test_short_read_batches(built, n_pairs):
+@pytest.mark.parametrize("n_pairs,max_l", [(1, 240), (3, 240), (9, 240), (64, 240), (1237, 240), (9, 190), (1237, 190), (20000, 120)])
+def test_short_read_batches(built, n_pairs, max_l):
     """Short pairs (<= 240 bases) take the blocked kernel's batch mode: a group stages 8 queue entries at a time.
     Ragged lengths, empty / 1-base / non-ACGT / lowercase entries inside batches, batch counts that do not
     divide the number of pairs; the unbatched kernel must give the same records."""
@@ -288,7 +288,7 @@ def test_short_read_batches(built, n_pairs):
     rng = np.random.default_rng(1000 + n_pairs)
     qs, ts = [], []
     for i in range(n_pairs):
-        L = int(rng.integers(1, 240))
+        L = int(rng.integers(1, max_l))
         q = bytes(b"ACGT"[c] for c in rng.integers(0, 4, L))
         t = bytearray(q)
         for _ in range(int(rng.integers(0, 1 + L // 12))):
@@ -300,26 +300,30 @@ def test_short_read_batches(built, n_pairs):
                 t.insert(pos, b"ACGT"[int(rng.integers(0, 4))])
             elif len(t) > 1:
                 del t[pos]
-        t = bytes(t[:240])
+        t = bytes(t[:max_l])
         if i % 17 == 5:
             q = b""
         elif i % 17 == 9:
             t = t.lower()
         elif i % 17 == 13:
             q = q[:len(q) // 2] + b"N" + q[len(q) // 2:]
-            q = q[:240]
+            q = q[:max_l]
         elif i % 23 == 7:
             q, t = b"A", b"CA"
         qs.append(q), ts.append(t)
     data = w.make_blob(qs, ts)
+    max_len = max(max(len(q), len(t)) for q, t in zip(qs, ts))
     for ad in ((10, 50, 1), None):
         want = O.align_batch(_oracle_params(True, ad), *data, n_threads=4)
-        for batch in (1, 8, 3, 0):
+        for batch, narrow in ((1, 1), (8, 1), (3, 1), (1, 0), (8, 0), (0, 1)):
             al = _aligner(True, ad)
             al.set_option("blk_batch", batch)
+            al.set_option("blk_narrow", narrow)
             got = al.align_arrays(*data)
-            assert al.last_timing().main_kernel_kind == 3
-            assert_batch_equal(got, want, f"short reads n={n_pairs} ad={ad} blk_batch={batch}")
+            # reads under 200 bases start with eight pairs per wave (32-diagonal windows); pairs that outgrow them
+            # (here: up to 240 bases with up to 8 % edits) move on to the 16-lane instance
+            assert al.last_timing().main_kernel_kind == (6 if (batch and narrow and max_len < 200) else 3)
+            assert_batch_equal(got, want, f"short reads n={n_pairs} ad={ad} blk_batch={batch} blk_narrow={narrow}")
             al.close()
 
 

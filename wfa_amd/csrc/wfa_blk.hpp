@@ -77,6 +77,16 @@ struct BlkOps<8> {
     }
 };
 
+// G = 8 with FOUR diagonals per lane: a 32-diagonal window, eight pairs per wave (short reads); the window moves by
+// one lane.
+struct BlkOps8n {
+    static WFA_DEV uint32_t dn1(uint32_t x, int j) { return BlkOps<8>::dn1(x, j); }
+    static WFA_DEV uint32_t up1(uint32_t x, int j) { return BlkOps<8>::up1(x, j); }
+    static constexpr int SHIFT_D = 4;
+    static WFA_DEV uint32_t shr(uint32_t x, int j) { return dn1(x, j); }
+    static WFA_DEV uint32_t shl(uint32_t x, int j) { return up1(x, j); }
+};
+
 // G = 64: the whole wave owns one pair (a 256-diagonal window; the retry rung for pairs whose band outgrew 64
 // diagonals).  Lane neighbours come from the wave-wide DPP shifts, which shift zeros in at lanes 0 / 63.
 template <>
@@ -210,10 +220,11 @@ WFA_DEV void blk_push_not_ok(const KParams &P, uint32_t pidx) {
     blk_store_sc1(P.done_q + t, (pidx + 1u) | DONE_NOT_OK, 0u, 0u, 0u);
 }
 
-template <int G, int BATCH, bool STREAM = false>
-__global__ __launch_bounds__(64, (G == 8 ? WFA_BLK8_WAVES : 4)) void wfa_blk_kernel(const KParams P) {
+template <int G, int BATCH, bool STREAM = false, int PPT = 0>
+__global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : 4)) void wfa_blk_kernel(const KParams P) {
     static_assert(!STREAM || (G == 16 && BATCH == 1), "streamed backtrace: 16 lanes per pair, unbatched refill");
-    constexpr int PP  = G == 64 ? 4 : 64 / G;  // diagonals per lane
+    static_assert(PPT == 0 || (G == 8 && PPT == 4), "diagonals per lane can only be overridden for the 8-lane narrow instance");
+    constexpr int PP  = PPT ? PPT : (G == 64 ? 4 : 64 / G);  // diagonals per lane
     constexpr int NG  = 64 / G;                // pairs per wave
 #ifdef WFA_BLK_W
     constexpr int W = WFA_BLK_W;  // experiment: pretend the window is narrower
@@ -221,7 +232,7 @@ __global__ __launch_bounds__(64, (G == 8 ? WFA_BLK8_WAVES : 4)) void wfa_blk_ker
     constexpr int W   = G * PP;   // window width in diagonals: 64 (G = 16, 8) or 256 (G = 64); also the arena's row pitch
 #endif
     constexpr bool TILED = WFA_BLK_TILED != 0 && W == 64;  // arena layout: CompactView fmt 3 (else fmt 1 / 4: plain rows)
-    using Ops         = BlkOps<G>;
+    using Ops         = typename std::conditional<(G == 8 && PP == 4), BlkOps8n, BlkOps<G>>::type;
 #ifdef WFA_MARKS
 #define WFA_MARK(i) asm volatile("; ##MARK " #i)
 #else
@@ -337,8 +348,8 @@ __global__ __launch_bounds__(64, (G == 8 ? WFA_BLK8_WAVES : 4)) void wfa_blk_ker
                             status = ST_EMPTY;  // wfa.go:204-206
                         else if (nq > 0x1FFFFFFFu || mt > 0x1FFFFFFFu)
                             status = ST_TOO_LONG;  // wfa.go:207-209
-                        else if (((nq > mt ? nq : mt) + 15u) / 16u + 1u > SW || ((nq > mt ? nq : mt) + 15u) / 16u + 1u > (uint32_t)G)
-                            status = ST_REDO_LDS;
+                        else if (((nq > mt ? nq : mt) + 15u) / 16u + 1u > SW || ((nq > mt ? nq : mt) + 15u) / 16u + 1u > 16u)
+                            status = ST_REDO_LDS;  // (batch mode is for reads of at most 240 bases: 1-2 staging passes of the group)
                         if (got && status != ST_PENDING) {
                             P.pair_meta[wi] = make_uint4(status, 0u, 0u, 0u);
                             if (status >= ST_REDO_BYTES) push_redo(P, pr, status);

@@ -82,6 +82,7 @@ struct wfahip_ctx {
     int64_t       opt_bt_stream_single     = 0;      // 1: also when the pass is a single chunk (there the backtrace kernel already runs beside the
                                                      // retry passes and, since its op stores are combined, costs less than the streaming: 25.35 vs 25.55 ms)
     int64_t       opt_bt_stream_wait_us    = 20000;  // a streaming wave gives up on a queue entry after this long
+    int64_t       opt_blk_narrow           = 1;  // 1: reads under 200 bases start on the 8-lanes-per-pair instance (32-diagonal window, 8 pairs per wave)
     int64_t       opt_blk_wide             = 1;  // 1: pairs leaving the 64-diagonal window retry on the wave-per-pair blocked kernel (256 diagonals)
     int64_t       opt_blk_batch            = 1;  // short reads: stage up to BLK_BATCH pairs per group at a time (1 = automatic count, 2..8 = that many, 0 = off)
     int64_t       opt_packed_arena_bytes   = 0;  // per pair, 0 = automatic
@@ -317,6 +318,8 @@ extern "C" int wfahip_set_option(wfahip_ctx *ctx, const char *key, int64_t value
         ctx->opt_tail_overlap = value;
     else if (k == "blk_wide")
         ctx->opt_blk_wide = value;
+    else if (k == "blk_narrow")
+        ctx->opt_blk_narrow = value;
     else if (k == "bt_stream")
         ctx->opt_bt_stream = value;
     else if (k == "bt_stream_min")
@@ -505,17 +508,19 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
             DevBuf &arena_buf = ctx->bt_pending ? ctx->arena2 : ctx->arena;
             DevBuf &meta_buf  = ctx->bt_pending ? ctx->meta2 : ctx->meta;
             // short reads: the blocked kernel stages BLK_BATCH pairs per group at a time
-            const bool     blk_batch    = kind == 3 && seq_words <= 16 && ctx->opt_blk_batch != 0;
-            const size_t   lds_bytes    = blk_batch ? (size_t)4 * BLK_BATCH * (2 * seq_words + 8) * 4 + 16
+            // (kind 6: eight pairs per wave, 32-diagonal window; only with the batched refill)
+            const bool     blk_batch    = (kind == 3 || kind == 6) && seq_words <= 16 && ctx->opt_blk_batch != 0;
+            if (kind == 6 && !blk_batch) return WFAHIP_ERR_INTERNAL;
+            const size_t   lds_bytes    = blk_batch ? (size_t)(kind == 6 ? 8 : 4) * BLK_BATCH * (2 * seq_words + 8) * 4 + 16
                                           : kind == 5 ? (size_t)seq_words * 2 * 4 + 16
                                                       : (kind >= 3 ? lds_d : (kind == 2 ? lds_c : lds_b));
-            const uint32_t pairs_wave   = kind == 5 ? 1 : (kind == 4 ? 8 : (kind >= 2 ? 4 : 2));
+            const uint32_t pairs_wave   = kind == 5 ? 1 : (kind == 4 || kind == 6 ? 8 : (kind >= 2 ? 4 : 2));
             // blocked kernels: fixed-pitch arena, no directory.  64-diagonal window: 16 words per base = 250 scores at
             // 1 kbp; 256-diagonal window (kind 5, the retry rung): 128 words per base = 500 scores at 1 kbp
             const uint64_t words        = kind == 5   ? std::max<uint64_t>((words_dir * 16 + 511) & ~511ull, 8192)
                                           : kind >= 3 ? std::max<uint64_t>((words_dir * 2 + 511) & ~511ull, 2048)
                                                       : words_dir;
-            P.arena_words = words, P.compact_fmt = kind == 5 ? 4u : (kind >= 3 ? (WFA_BLK_TILED ? 3u : 1u) : 0u);
+            P.arena_words = words, P.compact_fmt = kind == 6 ? 5u : kind == 5 ? 4u : (kind >= 3 ? (WFA_BLK_TILED ? 3u : 1u) : 0u);
             const uint32_t waves_lds    = (uint32_t)std::min<size_t>(32, LDS_MAX_BYTES / lds_bytes);
             const bool     overlap      = ctx->opt_overlap != 0;
             uint32_t       waves_per_cu = kind == 4 ? std::min<uint32_t>(waves_lds, 12)
@@ -584,14 +589,17 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
                     hipLaunchKernelGGL((wfa_blk_kernel<64, 1>), dim3(grid), dim3(64), lds_bytes, st, P);
                 else if (kind == 4)
                     hipLaunchKernelGGL((wfa_blk_kernel<8, 1>), dim3(grid), dim3(64), lds_bytes, st, P);
-                else if (kind == 3 && blk_batch) {
+                else if (blk_batch) {
                     // entries per grab: the chunk's share of one resident group, cut into the fewest rounds of <= 8
-                    const uint64_t groups = (uint64_t)ctx->num_cus * 16 * 4;  // 4 waves per SIMD x 4 pairs
+                    const uint64_t groups = (uint64_t)ctx->num_cus * 16 * pairs_wave;  // 4 waves per SIMD x 4 (8) pairs
                     const uint64_t share  = (cn + groups - 1) / groups;
                     const uint64_t rounds = (share + BLK_BATCH - 1) / BLK_BATCH;
                     P.blk_batch_n = (uint32_t)std::min<uint64_t>(BLK_BATCH, std::max<uint64_t>(1, (share + rounds - 1) / std::max<uint64_t>(1, rounds)));
                     if (ctx->opt_blk_batch > 1) P.blk_batch_n = (uint32_t)std::min<int64_t>(BLK_BATCH, ctx->opt_blk_batch);
-                    hipLaunchKernelGGL((wfa_blk_kernel<16, BLK_BATCH>), dim3(grid), dim3(64), lds_bytes, st, P);
+                    if (kind == 6)
+                        hipLaunchKernelGGL((wfa_blk_kernel<8, BLK_BATCH, false, 4>), dim3(grid), dim3(64), lds_bytes, st, P);
+                    else
+                        hipLaunchKernelGGL((wfa_blk_kernel<16, BLK_BATCH>), dim3(grid), dim3(64), lds_bytes, st, P);
                 }
                 else if (kind == 3 && stream_bt)
                     hipLaunchKernelGGL((wfa_blk_kernel<16, 1, true>), dim3(grid), dim3(64), lds_bytes, st, P);
@@ -629,7 +637,11 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
 
         if (can_b || can_c || can_d) {
             std::vector<uint64_t> redo1, redo2;
-            const int kind1 = can_d ? (ctx->opt_blk == 8 ? 4 : 3) : (can_c ? 2 : 1);
+            // short reads (< 200 bases, batched refill): eight pairs per wave in 32-diagonal windows first; what outgrows
+            // them retries on the 16-lane instance below
+            const bool narrow1 = can_d && ctx->opt_blk == 16 && ctx->opt_blk_narrow != 0 && ctx->opt_blk_batch != 0 && max_len < 200 &&
+                                 seq_words <= 16;
+            const int  kind1   = narrow1 ? 6 : (can_d ? (ctx->opt_blk == 8 ? 4 : 3) : (can_c ? 2 : 1));
             // Pilot: on a large batch with wf-adaptive off the first 4 096 pairs go first.  When most of them leave the
             // 64-diagonal window the rest does not start there only to be handed on: it goes straight to the
             // wave-per-pair kernel (256 diagonals) if that one takes most of the pilot's leftovers, else to the
@@ -697,6 +709,21 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
             // once, backtrace included) than through another forward + backtrace pass; beyond that the LDS-ring
             // kernel's throughput wins.
             const uint64_t resident_generic = (uint64_t)ctx->num_cus * 32;
+            if (kind1 == 6) {  // band / arena failures of the 32-diagonal instance -> the 64-diagonal one
+                std::vector<uint32_t> lst;
+                std::vector<uint64_t> keep, r2;
+                for (uint64_t e : redo1) {
+                    const uint32_t stw = (uint32_t)(e >> 32);
+                    if (stw == ST_REDO_BAND || stw == ST_REDO_ARENA) lst.push_back((uint32_t)e);
+                    else keep.push_back(e);
+                }
+                if (!lst.empty()) {
+                    if ((rc = forward_pass(3, &lst, 0, lst.size(), r2, false))) return rc;
+                    ctx->timing.n_packed_pairs += (uint32_t)(lst.size() - r2.size());
+                    keep.insert(keep.end(), r2.begin(), r2.end());
+                    redo1.swap(keep);
+                }
+            }
             if (wide_ok) {
                 // pairs whose band outgrew the 64-diagonal window: the same kernel with a wave per pair (256 diagonals)
                 const int wv = wide_pass(redo1);
