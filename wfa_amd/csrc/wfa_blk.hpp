@@ -253,6 +253,7 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : 4)) void
     const uint32_t *lq = lds + grp * GW;                       // packed query / target of the group's current pair
     const uint32_t *lt = lq + SW;
     int             bslot = 0, bcnt = 0;                       // batch mode: next staged slot / staged slots
+    bool            dry   = false;                             // batch mode: this wave has seen the end of the queue
     const uint64_t        cap      = P.arena_words;
     const int             mdd      = (int)P.max_dist_diff;
     const int             minwf    = (int)P.min_wf_len;
@@ -322,7 +323,9 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : 4)) void
                     // ---- groups whose batch is used up take BATCH queue entries each (one atomic for all of them)
                     const bool               fetch = st == 0 && bslot >= bcnt;
                     const unsigned long long fneed = __ballot(fetch);
-                    if (fneed != 0ull) {
+                    if (fneed != 0ull && dry) {  // nothing left to take: no round trip to find that out again
+                        if (fetch) st = 2;
+                    } else if (fneed != 0ull) {
                         uint32_t gbits = 0u;
 #pragma unroll
                         for (int r = 0; r < NG; r++) gbits |= (uint32_t)((fneed >> (G * r)) & 1ull) << r;
@@ -332,6 +335,7 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : 4)) void
                         const int bn = (int)P.blk_batch_n;
                         if (lane == 0) base = atomicAdd(P.queue_head, (uint32_t)(bn * __builtin_popcount(gbits)));
                         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                        dry  = base + (uint32_t)(bn * __builtin_popcount(gbits)) >= P.chunk_n;
                         const uint32_t wi0 = base + (uint32_t)(bn * __builtin_popcount(gbits & ((1u << grp) - 1u)));
                         // lane j < bn of a fetching group owns entry wi0 + j
                         const uint32_t wi  = wi0 + (uint32_t)j;
@@ -361,22 +365,58 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : 4)) void
                         }
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        // ---- every fetching group stages its BATCH pairs with its own lanes
-                        uint32_t badmask = 0u;
+                        // ---- staging: the fetching groups one after the other, each with ALL 64 lanes in one round --
+                        // eight lanes per batch slot, four per sequence, up to four packed words per lane (a sequence
+                        // of this mode has at most 16 words), all loads of a round independent.  Staged slot by slot
+                        // with a group's own lanes, the dependent load rounds of a batch (8 slots x 2 sequences x 1-2
+                        // passes) were half of a short-read wave's time.
+                        // When most groups of the wave fetch at once (the start of the kernel) the groups stage their
+                        // own batches side by side instead: the same number of load rounds, no serialisation by group.
+                        static_assert(BATCH <= 8, "one staging round covers eight slots");
+                        uint32_t   badmask = 0u;
+                        const bool side_by_side = 2 * __builtin_popcount(gbits) > NG;
+                        if (side_by_side) {
 #pragma unroll 1
-                        for (int sl = 0; sl < bn; sl++) {
-                            const uint32_t *const mw = gmeta + BM * sl;
-                            const uint32_t nq_s = fetch ? mw[2] : 0u, mt_s = mw[3];
-                            if (nq_s != 0u) {
-                                const uint64_t qo_s = (uint64_t)mw[4] | ((uint64_t)mw[5] << 32);
-                                const uint64_t to_s = (uint64_t)mw[6] | ((uint64_t)mw[7] << 32);
-                                uint32_t *const sq  = gbase + sl * 2 * SW;
-                                bool b = stage_pack<G>(P.blob, qo_s, nq_s, sq, j);
-                                b |= stage_pack<G>(P.blob, to_s, mt_s, sq + SW, j);
-                                badmask |= b ? (1u << sl) : 0u;
+                            for (int sl = 0; sl < bn; sl++) {
+                                const uint32_t *const mw = gmeta + BM * sl;
+                                const uint32_t nq_s = fetch ? mw[2] : 0u, mt_s = mw[3];
+                                if (nq_s != 0u) {
+                                    const uint64_t qo_s = (uint64_t)mw[4] | ((uint64_t)mw[5] << 32);
+                                    const uint64_t to_s = (uint64_t)mw[6] | ((uint64_t)mw[7] << 32);
+                                    uint32_t *const sq  = gbase + sl * 2 * SW;
+                                    bool b = stage_pack<G>(P.blob, qo_s, nq_s, sq, j);
+                                    b |= stage_pack<G>(P.blob, to_s, mt_s, sq + SW, j);
+                                    badmask |= b ? (1u << sl) : 0u;
+                                }
                             }
+                            badmask = (uint32_t)Red::or1((int)badmask);
                         }
-                        badmask = (uint32_t)Red::or1((int)badmask);
+#pragma unroll 1
+                        for (uint32_t gb = side_by_side ? 0u : gbits; gb != 0u; gb &= gb - 1u) {
+                            const int             r     = __builtin_ctz(gb);  // wave-uniform
+                            uint32_t *const       rbase = lds + r * GW;
+                            const uint32_t *const rmeta = rbase + BATCH * 2 * SW;
+                            uint32_t              badl  = 0u;
+                            const int             sl = lane >> 3, sq = (lane >> 2) & 1;
+                            if (sl < bn) {
+                                const uint32_t *const mw = rmeta + BM * sl;
+                                const uint32_t nq_s = mw[2];
+                                const uint32_t len  = sq ? mw[3] : nq_s;
+                                const uint32_t nw   = (len + 15u) >> 4;
+                                const uint64_t off  = (uint64_t)mw[4 + 2 * sq] | ((uint64_t)mw[5 + 2 * sq] << 32);
+                                bool           b    = false;
+                                if (nq_s != 0u) {
+#pragma unroll 1
+                                    for (uint32_t jw = (uint32_t)lane & 3u; jw <= nw; jw += 4u)
+                                        rbase[sl * 2 * SW + sq * SW + jw] = stage_word(P.blob, off, len, jw, b);
+                                }
+                                badl |= b ? (1u << sl) : 0u;
+                            }
+                            uint32_t wb = 0u;
+#pragma unroll
+                            for (int sl = 0; sl < BATCH; sl++) wb |= (__ballot((badl >> sl) & 1u) != 0ull ? 1u : 0u) << sl;
+                            if (grp == r) badmask = wb;
+                        }
                         if (own && ((badmask >> j) & 1u) != 0u) {  // a byte outside ACGT: the byte-compare path takes it
                             P.pair_meta[wi] = make_uint4(ST_REDO_BYTES, 0u, 0u, 0u);
                             push_redo(P, pr, ST_REDO_BYTES);

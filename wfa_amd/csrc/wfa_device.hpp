@@ -95,38 +95,42 @@ struct SeqView<1> {
 // Pack `len` bytes at blob[off..) into 2-bit words dst[0..ceil(len/16)] (last index = zero pad word).
 // Threads tid, tid+G, ... each produce one word from up to five aligned dword loads (coalesced across
 // the group).  Returns true if this thread saw a byte outside {A,C,G,T}.
+// word j (bases 16j .. 16j+15; 0 past the end) of a sequence, 2-bit packed; bad |= a byte outside {A,C,G,T}
+WFA_DEV uint32_t stage_word(const uint8_t *blob, uint64_t off, uint32_t len, uint32_t j, bool &bad) {
+    const uint32_t nw   = (len + 15u) >> 4;
+    uint32_t       word = 0;
+    if (j < nw) {
+        const uintptr_t a  = (uintptr_t)(blob + off) + 16ull * j;
+        const uint32_t *p  = (const uint32_t *)(a & ~(uintptr_t)3);
+        const uint32_t  sh = (uint32_t)(a & 3) * 8u;
+        const uint32_t  nb = (len - 16u * j) < 16u ? (len - 16u * j) : 16u;
+        const uint32_t  nd = ((uint32_t)(a & 3) + nb + 3u) >> 2;  // dwords that hold valid bytes: 1..5
+        uint32_t        d[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) d[i] = ((uint32_t)i < nd) ? p[i] : 0u;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            uint32_t w = __funnelshift_r(d[i], d[i + 1], sh);
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                uint32_t idx = 4u * i + b;
+                uint32_t c   = (w >> (8 * b)) & 0xFFu;
+                bool     ok  = (c == 'A') | (c == 'C') | (c == 'G') | (c == 'T');
+                if (idx < nb) {
+                    bad |= !ok;
+                    word |= ((c >> 1) & 3u) << (2u * idx);
+                }
+            }
+        }
+    }
+    return word;
+}
+
 template <int G>
 WFA_DEV bool stage_pack(const uint8_t *blob, uint64_t off, uint32_t len, uint32_t *dst, int tid) {
     const uint32_t nw  = (len + 15u) >> 4;
     bool           bad = false;
-    for (uint32_t j = tid; j <= nw; j += G) {
-        uint32_t word = 0;
-        if (j < nw) {
-            const uintptr_t a  = (uintptr_t)(blob + off) + 16ull * j;
-            const uint32_t *p  = (const uint32_t *)(a & ~(uintptr_t)3);
-            const uint32_t  sh = (uint32_t)(a & 3) * 8u;
-            const uint32_t  nb = (len - 16u * j) < 16u ? (len - 16u * j) : 16u;
-            const uint32_t  nd = ((uint32_t)(a & 3) + nb + 3u) >> 2;  // dwords that hold valid bytes: 1..5
-            uint32_t        d[5];
-#pragma unroll
-            for (int i = 0; i < 5; i++) d[i] = ((uint32_t)i < nd) ? p[i] : 0u;
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                uint32_t w = __funnelshift_r(d[i], d[i + 1], sh);
-#pragma unroll
-                for (int b = 0; b < 4; b++) {
-                    uint32_t idx = 4u * i + b;
-                    uint32_t c   = (w >> (8 * b)) & 0xFFu;
-                    bool     ok  = (c == 'A') | (c == 'C') | (c == 'G') | (c == 'T');
-                    if (idx < nb) {
-                        bad |= !ok;
-                        word |= ((c >> 1) & 3u) << (2u * idx);
-                    }
-                }
-            }
-        }
-        dst[j] = word;
-    }
+    for (uint32_t j = tid; j <= nw; j += G) dst[j] = stage_word(blob, off, len, j, bad);
     return bad;
 }
 
