@@ -15,7 +15,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 thr = max(8, (os.cpu_count() or 8) // 2)
 bad = 0
 for seed, length, err, ad in ((101, 1000, 0.05, (10, 50, 1)), (102, 1000, 0.08, (10, 50, 1)), (103, 600, 0.03, (10, 50, 1)),
-                              (104, 2000, 0.05, (10, 50, 1)), (105, 1000, 0.05, (20, 100, 1)), (106, 300, 0.10, None)):
+                              (104, 2000, 0.05, (10, 50, 1)), (105, 1000, 0.05, (20, 100, 1)), (106, 300, 0.10, None),
+                              (107, 150, 0.03, None), (108, 100, 0.06, (10, 50, 1)), (109, 230, 0.04, None)):
     nn = n * 1000 // length if length > 1000 else n
     data = w.generate_pairs(seed=seed, n_pairs=nn, length=length, error_rate=err, n_threads=32)
     t0 = time.perf_counter()

@@ -327,6 +327,21 @@ def test_short_read_batches(built, n_pairs, max_l):
             al.close()
 
 
+def test_hand_over_does_not_depend_on_wave_mates(built):
+    """Which pairs a forward kernel hands on (band touching the window edge) must be a property of the pair, not of
+    the pairs that happen to share its wave: the queue order varies from run to run, the count must not."""
+    import wfa_amd as w
+    data = w.generate_pairs(seed=108, n_pairs=300000, length=100, error_rate=0.06, n_threads=16)
+    al = _aligner(True, (10, 50, 1))
+    seen = set()
+    for _ in range(4):
+        al.align_arrays(*data)
+        t = al.last_timing()
+        seen.add((t.n_retried_pairs, t.cells_stored))
+    assert len(seen) == 1 and next(iter(seen))[0] > 0, seen
+    al.close()
+
+
 @pytest.mark.parametrize("length,err,n", [(4000, 0.03, 120), (9000, 0.02, 40), (2500, 0.08, 120)])
 def test_mid_length_global(built, length, err, n):
     """Global pairs of a few kbp: the blocked kernel near its LDS limit (offsets of several thousand, hundreds of

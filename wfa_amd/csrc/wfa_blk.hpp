@@ -655,13 +655,15 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : 4)) void
             for (int p = 0; p < PP; p++) nz[p] = nM[p] != 0u, hit[p] = nM[p] >= (uint32_t)lim[p], hitl |= hit[p];
             bool       term    = false;
             const bool hit_any = __ballot(hitl) != 0ull;
+            bool       ghit    = false;  // this pair has a cell at a sequence end in this step
             WFA_EVT(2, hit_any ? 1 : 0);
             if (hit_any) {
                 bool tl = false;
 #pragma unroll
                 for (int p = 0; p < PP; p++) tl |= (k0 + p == Ak && nz[p] && (int)nM[p] >= m);
                 const int r = Red::or1((hitl ? 1 : 0) | (tl ? 2 : 0));
-                slow |= (r & 1) != 0;
+                ghit = (r & 1) != 0;
+                slow |= ghit;
                 term = run && (r & 2) != 0;
             }
 
@@ -746,15 +748,18 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : 4)) void
                         Red::min_max(first_ok, last_ok);
                         // wfa.go:509-511: _lo = one past the last failing entry before the first non-failing one.  The
                         // entries between that one and first_ok are unusable ones: holes (absent cells) or cells at a
-                        // sequence end.  While no cell of the wave has reached an end they are all holes, and deleting
-                        // or keeping a hole is the same thing: _lo = first_ok gives the identical row.
+                        // sequence end.  While no cell of the PAIR has reached an end they are all holes, and deleting
+                        // or keeping a hole is the same thing: _lo = first_ok gives the identical row.  (The test is per
+                        // pair, not per wave: a band that keeps leading holes because a neighbour pair sits at an end
+                        // would make the window bookkeeping -- and with it the rare hand-over of a pair whose band
+                        // touches the window edge -- depend on which pairs share a wave.)
                         int newlo = first_ok;
                         if (hit_any) {
                             int leadp = -1;
 #pragma unroll
                             for (int p = 0; p < PP; p++) leadp = (vd[p] && PP * j + p < first_ok) ? PP * j + p : leadp;
                             leadp = Red::max1(leadp);
-                            newlo = leadp >= 0 ? leadp + 1 : glo;
+                            newlo = ghit ? (leadp >= 0 ? leadp + 1 : glo) : first_ok;
                         }
                         if (found) ilo = newlo, ihi = last_ok;  // wfa.go:517-524
                         csum = 0u;
