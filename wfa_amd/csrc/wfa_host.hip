@@ -583,7 +583,7 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
                     HIP_TRY(hipMemsetAsync(P.pair_meta, 0xFF, 16 * cn, st));  // ST_PENDING: only pairs without a backtrace get a status
                 }
                 if (n_buf == 2 && c >= 2) HIP_TRY(hipStreamWaitEvent(st, ctx->evpool[4 * (c - 2) + 3], 0));  // buffer free
-                HIP_TRY(hipMemsetAsync(d_ctrl, 0, 4, st));  // queue_head only
+                if (c > 0) HIP_TRY(hipMemsetAsync(d_ctrl, 0, 4, st));  // queue_head only (chunk 0: cleared with redo_count above)
                 HIP_TRY(hipEventRecord(evFa, st));
                 if (kind == 5)
                     hipLaunchKernelGGL((wfa_blk_kernel<64, 1>), dim3(grid), dim3(64), lds_bytes, st, P);
