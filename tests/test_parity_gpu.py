@@ -635,3 +635,44 @@ def test_full_size_parity_c3(built):
         assert_batch_equal(again, want, f"full size L={length}, serial schedule")
         assert al.last_timing().cells_stored == cells
         al.close()
+
+
+def test_device_entry_with_an_unaligned_ops_buffer(built):
+    """wfahip_align_batch_device with caller-owned device buffers: the backtrace combines eight CIGAR ops per 64-byte
+    store when the ops buffer allows it; a buffer that is only 8-byte aligned must give the same result (single
+    stores), and a buffer that is too small must be reported with the capacity that is needed."""
+    import ctypes as C
+    import torch
+    import wfa_amd as w
+    from wfa_amd import _lib as L
+    from oracle import oracle as O
+    n = 20000
+    blob, q_off, q_len, t_off, t_len = w.generate_pairs(seed=77, n_pairs=n, length=500, error_rate=0.05, n_threads=8)
+    want = O.align_batch(_oracle_params(True, (10, 50, 1)), blob, q_off, q_len, t_off, t_len, n_threads=8)
+    dev = torch.device("cuda:0")
+    d = [torch.from_numpy(a).to(dev) for a in (blob, q_off.view(np.int64), q_len.view(np.int32), t_off.view(np.int64),
+                                               t_len.view(np.int32))]
+    al = _aligner(True, (10, 50, 1))
+    prm = al._params()
+    cap = int(want.ops_len.astype(np.int64).sum()) * 4 + 16 * n
+    d_ops_all = torch.zeros(cap + 8, dtype=torch.int64, device=dev)
+    d_rec = torch.zeros((n, L.REC_WORDS), dtype=torch.int32, device=dev)
+    for shift in (0, 1, 3):  # ops buffer 64-byte aligned / 8 bytes off / 24 bytes off
+        d_ops = d_ops_all[shift:shift + cap]
+        needed = C.c_uint64()
+        rc = L.lib().wfahip_align_batch_device(al._ctx, C.byref(prm), d[0].data_ptr(), blob.size, d[1].data_ptr(), d[2].data_ptr(),
+                                               d[3].data_ptr(), d[4].data_ptr(), n, 0, d_rec.data_ptr(), d_ops.data_ptr(), cap,
+                                               C.byref(needed), None)
+        L.check(rc, "wfahip_align_batch_device")
+        rec = d_rec.cpu().numpy().view(np.uint32)
+        ops = d_ops.cpu().numpy().view(np.uint64)
+        assert np.array_equal(rec[:, L.REC_SCORE], want.score) and np.array_equal(rec[:, L.REC_OPS_LEN], want.ops_len), shift
+        off = rec[:, L.REC_OPS_OFF_LO].astype(np.uint64) | (rec[:, L.REC_OPS_OFF_HI].astype(np.uint64) << np.uint64(32))
+        for i in range(0, n, 97):
+            assert np.array_equal(ops[int(off[i]):int(off[i]) + int(rec[i, L.REC_OPS_LEN])], want.pair_ops(i)), (shift, i)
+    needed = C.c_uint64()
+    rc = L.lib().wfahip_align_batch_device(al._ctx, C.byref(prm), d[0].data_ptr(), blob.size, d[1].data_ptr(), d[2].data_ptr(),
+                                           d[3].data_ptr(), d[4].data_ptr(), n, 0, d_rec.data_ptr(), d_ops_all.data_ptr(), 1000,
+                                           C.byref(needed), None)
+    assert rc == L.ERR_OOM and needed.value > 1000, (rc, needed.value)
+    al.close()
