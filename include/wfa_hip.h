@@ -119,7 +119,8 @@ void wfahip_destroy(wfahip_ctx *ctx);
 /* The cgo entry: host inputs, host outputs, synchronous.  seq_blob holds all sequences; pair i is
  * query seq_blob[q_off[i] .. +q_len[i]) vs target seq_blob[t_off[i] .. +t_len[i]).  Inputs are
  * borrowed for the duration of the call only.  out is filled with malloc'd arrays; release with
- * wfahip_results_free.  Replaces Aligner.Align (wfa.go:196). */
+ * wfahip_results_free, which keeps the large blocks for the next call (RecycleAlignmentResult,
+ * wfa_cigar.go:92: fresh pages cost more than the download).  Replaces Aligner.Align (wfa.go:196). */
 int  wfahip_align_batch(wfahip_ctx *ctx, const wfahip_params *p, const uint8_t *seq_blob,
                         uint64_t blob_bytes, const uint64_t *q_off, const uint32_t *q_len,
                         const uint64_t *t_off, const uint32_t *t_len, uint64_t n_pairs,

@@ -17,6 +17,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <malloc.h>
+#include <mutex>
 #include <numeric>
 #include <string>
 #include <thread>
@@ -950,11 +952,54 @@ extern "C" int wfahip_align_batch_device(wfahip_ctx *ctx, const wfahip_params *p
 
 static void results_zero(wfahip_results *r) { std::memset(r, 0, sizeof *r); }
 
+// Result arrays are plain malloc blocks (a binding may free() them itself), but wfahip_results_free keeps the large
+// ones for the next call instead of returning them to the system: a fresh 0.7 GB ops array costs its download
+// twice over in first-touch page faults (the reference recycles its results the same way, wfa_cigar.go:92).
+namespace {
+struct ResBlock { void *p; size_t bytes; };
+std::mutex            g_res_mu;
+std::vector<ResBlock> g_res_cache;
+size_t                g_res_cached_bytes = 0;
+constexpr size_t      RES_CACHE_MIN = 1u << 20, RES_CACHE_MAX_BYTES = 4ull << 30, RES_CACHE_MAX_BLOCKS = 32;
+
+void *res_alloc(size_t bytes) {
+    if (bytes >= RES_CACHE_MIN) {
+        std::lock_guard<std::mutex> lk(g_res_mu);
+        size_t best = g_res_cache.size();
+        for (size_t i = 0; i < g_res_cache.size(); i++)
+            if (g_res_cache[i].bytes >= bytes && g_res_cache[i].bytes <= 2 * bytes &&
+                (best == g_res_cache.size() || g_res_cache[i].bytes < g_res_cache[best].bytes))
+                best = i;
+        if (best != g_res_cache.size()) {
+            void *p = g_res_cache[best].p;
+            g_res_cached_bytes -= g_res_cache[best].bytes;
+            g_res_cache.erase(g_res_cache.begin() + (long)best);
+            return p;
+        }
+    }
+    return std::malloc(bytes);
+}
+void res_release(void *p) {
+    if (!p) return;
+    const size_t bytes = malloc_usable_size(p);  // (the block's real capacity, whatever the caller did to n / n_ops)
+    if (bytes >= RES_CACHE_MIN) {
+        std::lock_guard<std::mutex> lk(g_res_mu);
+        if (g_res_cache.size() < RES_CACHE_MAX_BLOCKS && g_res_cached_bytes + bytes <= RES_CACHE_MAX_BYTES) {
+            g_res_cache.push_back({p, bytes});
+            g_res_cached_bytes += bytes;
+            return;
+        }
+    }
+    std::free(p);
+}
+}  // namespace
+
 extern "C" void wfahip_results_free(wfahip_results *r) {
     if (!r) return;
-    std::free(r->status), std::free(r->score), std::free(r->tbegin), std::free(r->tend), std::free(r->qbegin);
-    std::free(r->qend), std::free(r->align_len), std::free(r->matches), std::free(r->gaps);
-    std::free(r->gap_regions), std::free(r->ops_off), std::free(r->ops_len), std::free(r->ops);
+    for (void *p : {(void *)r->status, (void *)r->score, (void *)r->tbegin, (void *)r->tend, (void *)r->qbegin, (void *)r->qend,
+                    (void *)r->align_len, (void *)r->matches, (void *)r->gaps, (void *)r->gap_regions, (void *)r->ops_len,
+                    (void *)r->ops_off, (void *)r->ops})
+        res_release(p);
     results_zero(r);
 }
 
@@ -1152,23 +1197,23 @@ extern "C" int wfahip_align_batch(wfahip_ctx *ctx, const wfahip_params *p, const
     out->n = n;
     {
         const size_t cnt = std::max<uint64_t>(n, 1);
-#define ALLOC(field, type)                                             \
-    out->field = static_cast<type *>(std::malloc(cnt * sizeof(type))); \
-    if (!out->field) {                                                 \
-        wfahip_results_free(out);                                      \
-        return WFAHIP_ERR_OOM;                                         \
+#define ALLOC(field, type)                                          \
+    out->field = static_cast<type *>(res_alloc(cnt * sizeof(type))); \
+    if (!out->field) {                                               \
+        wfahip_results_free(out);                                    \
+        return WFAHIP_ERR_OOM;                                       \
     }
         ALLOC(status, int32_t) ALLOC(score, uint32_t) ALLOC(tbegin, int32_t) ALLOC(tend, int32_t)
         ALLOC(qbegin, int32_t) ALLOC(qend, int32_t) ALLOC(align_len, uint32_t) ALLOC(matches, uint32_t)
         ALLOC(gaps, uint32_t) ALLOC(gap_regions, uint32_t) ALLOC(ops_off, uint64_t) ALLOC(ops_len, uint32_t)
 #undef ALLOC
-        out->ops = static_cast<uint64_t *>(std::malloc(std::max<uint64_t>(totals[0], 1) * 8));
+        out->n_ops = totals[0];
+        out->ops   = static_cast<uint64_t *>(res_alloc(std::max<uint64_t>(totals[0], 1) * 8));
         if (!out->ops) {
             wfahip_results_free(out);
             return WFAHIP_ERR_OOM;
         }
     }
-    out->n_ops = totals[0];
     void *const       dsts[11] = {out->status, out->score, out->tbegin, out->tend, out->qbegin, out->qend,
                                   out->align_len, out->matches, out->gaps, out->gap_regions, out->ops_len};
     for (int i = 0; i < 11 && rc == WFAHIP_OK; i++) rc = download(ctx, dsts[i], fb + o_f[i], 4ull * n, st);
