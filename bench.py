@@ -6,7 +6,8 @@ per GPU, global alignment, wf-adaptive 10/50/1, penalties 4/6/2, seed 3.  A "ste
 over the rank's batch: raw byte sequences already resident in HBM -> result records + CIGAR ops in HBM.
 Multi-GPU (torchrun, one rank per GPU): pairs are sharded over ranks (weak scaling: 1e6 pairs per GPU, rank r
 owns dataset indices [r*n, (r+1)*n)), no data-path collective; the only RCCL traffic is the gather of the
-64-byte result records (score, region, statistics) onto rank 0 at the end of every step.  Like on one GPU the
+result records (44 bytes per pair: status, score, region, statistics, op count) onto rank 0 at the end of every
+step.  Like on one GPU the
 CIGAR ops stay in the HBM of the GPU that produced them; --gather-ops ships them to rank 0 as well (0.74 GB per
 rank and step at 1 kbp).
 
@@ -106,7 +107,10 @@ def main():
             # of batch i runs beside the alignment of batch i+1; the send buffers are private copies.
             if pending[0] is not None:
                 pending[0].wait()
-            pending[0] = gather_results_async(d_rec, d_ops, n_ops, dst=0, with_ops=args.gather_ops)
+            # (records only: the first 11 words -- status, score, region, statistics, op count; the op offsets, cell
+            # census and score count that follow only mean something next to the rank's own op array)
+            rec_out = d_rec if args.gather_ops else d_rec[:, :L.REC_OPS_OFF_LO]
+            pending[0] = gather_results_async(rec_out, d_ops, n_ops, dst=0, with_ops=args.gather_ops)
         return n_ops
 
     def drain():
