@@ -12,6 +12,7 @@
 #include "wfa_finalize.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -66,6 +67,8 @@ struct wfahip_ctx {
     void         *pin[2]     = {nullptr, nullptr};  // pinned staging for result downloads
     hipEvent_t    pin_ev[2]  = {nullptr, nullptr};
     uint32_t     *hpin       = nullptr;  // small pinned block: control words, head of the redo list, work-list staging
+    hipStream_t   stream_up  = nullptr;  // host entry: the blob upload runs ahead of the alignment of earlier pairs
+    std::vector<hipEvent_t> ev_up;
     DevBuf        team_ctl;                  // barrier counters / reduction sets of the team kernel
     DevBuf        arena2, meta2;             // retry passes run beside the first pass's backtrace kernel
     DevBuf        doneq;                     // streamed backtrace: 256 bytes of counters + one 16-byte entry per pair
@@ -271,6 +274,8 @@ extern "C" void wfahip_destroy(wfahip_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->hpin) (void)hipHostFree(ctx->hpin);
+    if (ctx->stream_up) (void)hipStreamDestroy(ctx->stream_up);
+    for (hipEvent_t e : ctx->ev_up) (void)hipEventDestroy(e);
     for (int i = 0; i < 2; i++) {
         if (ctx->pin[i]) (void)hipHostFree(ctx->pin[i]);
         if (ctx->pin_ev[i]) (void)hipEventDestroy(ctx->pin_ev[i]);
@@ -362,7 +367,9 @@ static int check_params(const wfahip_params *p) {
 static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_blob, uint64_t blob_bytes,
                         const void *d_q_off, const void *d_q_len, const void *d_t_off, const void *d_t_len,
                         uint64_t n_pairs, uint32_t max_len, void *d_rec, void *d_ops, uint64_t ops_cap,
-                        uint64_t *ops_needed, hipStream_t st, bool debug_single) {
+                        uint64_t *ops_needed, hipStream_t st, bool debug_single, uint64_t ops_cursor0 = 0) {
+    // (ops_cursor0: where this call's ops start in d_ops -- the host entry aligns a batch in several calls that
+    // share one op buffer)
     int rc = check_params(p);
     if (rc != WFAHIP_OK) return rc;
     if (n_pairs > 0xFFFFFFF0ull) return WFAHIP_ERR_BAD_ARG;
@@ -441,6 +448,10 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
     P.ops = static_cast<uint64_t *>(d_ops), P.ops_cap = ops_cap;
 
     HIP_TRY(hipMemsetAsync(d_ctrl, 0, CTRL_WORDS * 4, st));
+    if (ops_cursor0) {
+        HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_ctrl + 2), (int)(uint32_t)ops_cursor0, 1, st));
+        HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_ctrl + 3), (int)(uint32_t)(ops_cursor0 >> 32), 1, st));
+    }
     HIP_TRY(hipEventRecord(ctx->ev0, st));
 
     std::deque<Job> jobs;
@@ -1128,7 +1139,37 @@ extern "C" int wfahip_align_batch(wfahip_ctx *ctx, const wfahip_params *p, const
         return std::chrono::duration<double, std::milli>(b - a).count();
     };
     const auto t_h2d = now();
-    if (blob_bytes) HIP_TRY(hipMemcpyAsync(ctx->in_blob.p, seq_blob, blob_bytes, hipMemcpyHostToDevice, st));
+    // Large batches: the pairs are aligned in a few slices, each as soon as the part of the blob it refers to has
+    // arrived (an uploader thread feeds a copy stream), so most of the alignment time hides behind the upload.
+    // Needs the blob ranges of consecutive slices to be disjoint enough (pairs laid out in order, the usual case).
+    constexpr int     UP_SLICES = 4;
+    uint64_t          sl_first[UP_SLICES + 1], sl_lo[UP_SLICES], sl_hi[UP_SLICES];
+    bool              sliced = n_pairs >= 200000 && blob_bytes >= (64u << 20) && !std::getenv("WFAHIP_NO_UPLOAD_OVERLAP");
+    if (sliced) {
+        uint64_t covered = 0;
+        for (int k = 0; k <= UP_SLICES; k++) sl_first[k] = n_pairs * k / UP_SLICES;
+        for (int k = 0; k < UP_SLICES && sliced; k++) {
+            uint64_t lo = blob_bytes, hi = 0;
+            for (uint64_t i = sl_first[k]; i < sl_first[k + 1]; i++) {
+                if (!(q_len[i] <= WFAHIP_MAX_SEQ_LEN && t_len[i] <= WFAHIP_MAX_SEQ_LEN && q_len[i] && t_len[i])) continue;
+                lo = std::min(lo, std::min(q_off[i], t_off[i]));
+                hi = std::max(hi, std::max(q_off[i] + q_len[i], t_off[i] + t_len[i]));
+            }
+            if (hi <= lo) lo = hi = 0;
+            lo &= ~15ull;  // (whole aligned dwords of the first sequence; the tail padding of in_blob covers the end)
+            sl_lo[k] = lo, sl_hi[k] = hi, covered += hi - lo;
+        }
+        sliced = covered <= blob_bytes + blob_bytes / 4;
+    }
+    if (sliced) {
+        if (!ctx->stream_up) HIP_TRY(hipStreamCreateWithFlags(&ctx->stream_up, hipStreamNonBlocking));
+        while (ctx->ev_up.size() < (size_t)UP_SLICES) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ctx->ev_up.push_back(e);
+        }
+    }
+    if (blob_bytes && !sliced) HIP_TRY(hipMemcpyAsync(ctx->in_blob.p, seq_blob, blob_bytes, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(ctx->in_qoff.p, q_off, n_pairs * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(ctx->in_toff.p, t_off, n_pairs * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(ctx->in_qlen.p, q_len, n_pairs * 4, hipMemcpyHostToDevice, st));
@@ -1141,6 +1182,57 @@ extern "C" int wfahip_align_batch(wfahip_ctx *ctx, const wfahip_params *p, const
     for (int attempt = 0; attempt < 3; attempt++) {
         if ((rc = ensure(ctx, ctx->out_ops, ops_cap * 8))) return rc;
         uint64_t needed = 0;
+        if (sliced && attempt == 0) {
+            std::atomic<int> recorded{0}, up_err{0};
+            std::thread uploader([&] {
+                if (hipSetDevice(ctx->device) != hipSuccess) up_err = 1;
+                for (int k = 0; k < UP_SLICES; k++) {
+                    if (!up_err && sl_hi[k] > sl_lo[k] &&
+                        hipMemcpyAsync(static_cast<char *>(ctx->in_blob.p) + sl_lo[k], seq_blob + sl_lo[k], sl_hi[k] - sl_lo[k],
+                                       hipMemcpyHostToDevice, ctx->stream_up) != hipSuccess)
+                        up_err = 1;
+                    if (hipEventRecord(ctx->ev_up[k], ctx->stream_up) != hipSuccess) up_err = 1;
+                    recorded = k + 1;
+                }
+            });
+            wfahip_timing acc{};
+            uint64_t      cursor = 0;
+            for (int k = 0; k < UP_SLICES && rc == WFAHIP_OK; k++) {
+                while (recorded.load() <= k) std::this_thread::yield();  // (the event must have been recorded before the wait)
+                if (up_err) {
+                    rc = WFAHIP_ERR_HIP;
+                    break;
+                }
+                if (hipStreamWaitEvent(st, ctx->ev_up[k], 0) != hipSuccess) {
+                    rc = WFAHIP_ERR_HIP;
+                    break;
+                }
+                const uint64_t k0 = sl_first[k], nk = sl_first[k + 1] - k0;
+                if (nk == 0) continue;
+                rc = align_device(ctx, p, ctx->in_blob.p, blob_bytes, static_cast<char *>(ctx->in_qoff.p) + 8 * k0,
+                                  static_cast<char *>(ctx->in_qlen.p) + 4 * k0, static_cast<char *>(ctx->in_toff.p) + 8 * k0,
+                                  static_cast<char *>(ctx->in_tlen.p) + 4 * k0, nk, max_len,
+                                  static_cast<char *>(ctx->out_rec.p) + (size_t)REC_WORDS * 4 * k0, ctx->out_ops.p, ops_cap, &needed, st,
+                                  false, cursor);
+                cursor = ctx->timing.ops_written;
+                acc.kernel_ms += ctx->timing.kernel_ms, acc.total_ms += ctx->timing.total_ms, acc.n_launches += ctx->timing.n_launches;
+                acc.n_retried_pairs += ctx->timing.n_retried_pairs, acc.main_kernel_ms += ctx->timing.main_kernel_ms;
+                acc.n_main_launches += ctx->timing.n_main_launches, acc.n_packed_pairs += ctx->timing.n_packed_pairs;
+                acc.arena_bytes      = std::max(acc.arena_bytes, ctx->timing.arena_bytes);
+                acc.main_kernel_kind = ctx->timing.main_kernel_kind;
+            }
+            uploader.join();
+            if (rc == WFAHIP_OK || rc == WFAHIP_ERR_OOM) {
+                acc.ops_written = ctx->timing.ops_written;
+                ctx->timing     = acc;
+            }
+            if (rc == WFAHIP_ERR_OOM) {  // the op buffer was too small: the whole blob is resident now, one plain call redoes it
+                HIP_TRY(hipStreamSynchronize(ctx->stream_up));
+                ops_cap = std::max(needed, ops_cap) + ops_cap / 2 + 1024;
+                continue;
+            }
+            break;
+        }
         rc = align_device(ctx, p, ctx->in_blob.p, blob_bytes, ctx->in_qoff.p, ctx->in_qlen.p, ctx->in_toff.p,
                           ctx->in_tlen.p, n_pairs, max_len, ctx->out_rec.p, ctx->out_ops.p, ops_cap, &needed, st,
                           false);
