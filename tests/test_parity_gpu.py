@@ -676,3 +676,33 @@ def test_device_entry_with_an_unaligned_ops_buffer(built):
                                            C.byref(needed), None)
     assert rc == L.ERR_OOM and needed.value > 1000, (rc, needed.value)
     al.close()
+
+
+def test_host_entry_slices_agree_with_the_plain_call(built):
+    """wfahip_align_batch aligns a large batch in four slices while the rest of the blob is still uploading, when the
+    slices refer to (nearly) disjoint parts of the blob.  Same pairs in shuffled order (every slice then refers to
+    the whole blob: plain upload-then-align) and with the overlap switched off: identical results pair by pair."""
+    import os
+    import wfa_amd as w
+    from oracle import oracle as O
+    n = 240000
+    blob, q_off, q_len, t_off, t_len = w.generate_pairs(seed=91, n_pairs=n, length=300, error_rate=0.05, n_threads=16)
+    assert blob.size >= (64 << 20)
+    al = _aligner(True, (10, 50, 1))
+    a = al.align_arrays(blob, q_off, q_len, t_off, t_len)                      # sliced
+    perm = np.random.default_rng(5).permutation(n)
+    b = al.align_arrays(blob, q_off[perm], q_len[perm], t_off[perm], t_len[perm])  # not sliced: ranges overlap
+    os.environ["WFAHIP_NO_UPLOAD_OVERLAP"] = "1"
+    try:
+        c = al.align_arrays(blob, q_off, q_len, t_off, t_len)                  # not sliced: switched off
+    finally:
+        del os.environ["WFAHIP_NO_UPLOAD_OVERLAP"]
+    assert_batch_equal(a, c, "sliced vs plain")
+    for f in ("status",) + FIELDS:
+        assert np.array_equal(getattr(a, f)[perm], getattr(b, f)), f
+    for i in range(0, n, 1013):
+        assert np.array_equal(a.pair_ops(int(perm[i])), b.pair_ops(i)), i
+    sample = slice(0, 20000)
+    want = O.align_batch(_oracle_params(True, (10, 50, 1)), blob, q_off[sample], q_len[sample], t_off[sample], t_len[sample], n_threads=8)
+    assert np.array_equal(a.score[sample], want.score) and np.array_equal(a.ops_len[sample], want.ops_len)
+    al.close()
