@@ -2,6 +2,7 @@
 """GPU box: a batch that needs several chunks (3e6 x 1 kbp: the arenas of one chunk take 35 % of HBM), which is where
 the streamed backtrace runs by default -- against the oracle on all host cores, bit-exact, twice."""
 import os, sys, time
+os.environ["WFAHIP_NO_UPLOAD_OVERLAP"] = "1"  # one device call for the whole batch (the sliced host entry would make four single-chunk calls)
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import wfa_amd as w
