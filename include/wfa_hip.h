@@ -120,7 +120,11 @@ void wfahip_destroy(wfahip_ctx *ctx);
  * query seq_blob[q_off[i] .. +q_len[i]) vs target seq_blob[t_off[i] .. +t_len[i]).  Inputs are
  * borrowed for the duration of the call only.  out is filled with malloc'd arrays; release with
  * wfahip_results_free, which keeps the large blocks for the next call (RecycleAlignmentResult,
- * wfa_cigar.go:92: fresh pages cost more than the download).  Replaces Aligner.Align (wfa.go:196). */
+ * wfa_cigar.go:92: fresh pages cost more than the download).  Replaces Aligner.Align (wfa.go:196).
+ * Batches of >= 200 000 pairs whose pairs lie in order in the blob are aligned in four slices while the rest of
+ * the blob is still uploading.  Environment (diagnostics): WFAHIP_NO_UPLOAD_OVERLAP=1 switches that off,
+ * WFAHIP_DL_THREADS=n sets the number of copy-out threads of the result download, WFAHIP_DEBUG_TIMING=1 prints
+ * the phases of a call to stderr. */
 int  wfahip_align_batch(wfahip_ctx *ctx, const wfahip_params *p, const uint8_t *seq_blob,
                         uint64_t blob_bytes, const uint64_t *q_off, const uint32_t *q_len,
                         const uint64_t *t_off, const uint32_t *t_len, uint64_t n_pairs,
