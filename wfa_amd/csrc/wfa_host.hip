@@ -1094,7 +1094,12 @@ int download(wfahip_ctx *ctx, void *dst, const void *src, size_t bytes, hipStrea
             const size_t             part = ((sz / n_thr) + 4095) & ~size_t(4095);
             for (unsigned t = 0; t < n_thr; t++) {
                 const size_t a = std::min(sz, (size_t)t * part), b = std::min(sz, a + part);
-                if (b > a) th.emplace_back([=] { std::memcpy(d + a, p + a, b - a); });
+                if (b <= a) continue;
+                try {
+                    th.emplace_back([=] { std::memcpy(d + a, p + a, b - a); });
+                } catch (...) {  // no more threads: this part is copied here
+                    std::memcpy(d + a, p + a, b - a);
+                }
             }
             for (auto &t : th) t.join();
         }
@@ -1184,7 +1189,7 @@ extern "C" int wfahip_align_batch(wfahip_ctx *ctx, const wfahip_params *p, const
         uint64_t needed = 0;
         if (sliced && attempt == 0) {
             std::atomic<int> recorded{0}, up_err{0};
-            std::thread uploader([&] {
+            const auto upload_all = [&] {
                 if (hipSetDevice(ctx->device) != hipSuccess) up_err = 1;
                 for (int k = 0; k < UP_SLICES; k++) {
                     if (!up_err && sl_hi[k] > sl_lo[k] &&
@@ -1194,7 +1199,13 @@ extern "C" int wfahip_align_batch(wfahip_ctx *ctx, const wfahip_params *p, const
                     if (hipEventRecord(ctx->ev_up[k], ctx->stream_up) != hipSuccess) up_err = 1;
                     recorded = k + 1;
                 }
-            });
+            };
+            std::thread uploader;
+            try {
+                uploader = std::thread(upload_all);
+            } catch (...) {  // no thread to be had: upload here, then align (no overlap, same result)
+                upload_all();
+            }
             wfahip_timing acc{};
             uint64_t      cursor = 0;
             for (int k = 0; k < UP_SLICES && rc == WFAHIP_OK; k++) {
@@ -1221,7 +1232,7 @@ extern "C" int wfahip_align_batch(wfahip_ctx *ctx, const wfahip_params *p, const
                 acc.arena_bytes      = std::max(acc.arena_bytes, ctx->timing.arena_bytes);
                 acc.main_kernel_kind = ctx->timing.main_kernel_kind;
             }
-            uploader.join();
+            if (uploader.joinable()) uploader.join();
             if (rc == WFAHIP_OK || rc == WFAHIP_ERR_OOM) {
                 acc.ops_written = ctx->timing.ops_written;
                 ctx->timing     = acc;
