@@ -122,7 +122,7 @@ void wfahip_destroy(wfahip_ctx *ctx);
  * wfahip_results_free, which keeps the large blocks for the next call (RecycleAlignmentResult,
  * wfa_cigar.go:92: fresh pages cost more than the download).  Replaces Aligner.Align (wfa.go:196).
  * Batches of >= 200 000 pairs whose pairs lie in order in the blob are aligned in four slices while the rest of
- * the blob is still uploading.  Environment (diagnostics): WFAHIP_NO_UPLOAD_OVERLAP=1 switches that off,
+ * the blob is still uploading and the results of earlier slices are already downloading.  Environment (diagnostics): WFAHIP_NO_UPLOAD_OVERLAP=1 switches that off,
  * WFAHIP_DL_THREADS=n sets the number of copy-out threads of the result download, WFAHIP_DEBUG_TIMING=1 prints
  * the phases of a call to stderr. */
 int  wfahip_align_batch(wfahip_ctx *ctx, const wfahip_params *p, const uint8_t *seq_blob,

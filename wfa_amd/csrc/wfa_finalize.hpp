@@ -28,6 +28,7 @@ struct FinParams {
     uint64_t *ops_off;
     uint32_t *ops_len;
     uint64_t *ops_out;
+    uint64_t  ops_base;          // added to every ops_off (a slice of a batch: ops_out points ops_base entries into the final array)
     unsigned long long *totals;  // [0] total ops, [1] total cells
 };
 
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(256) void fin_gather(const FinParams F) {
         F.gaps[i]        = ok ? r[REC_GAPS] : 0u;
         F.gap_regions[i] = ok ? r[REC_GAP_REGIONS] : 0u;
         F.ops_len[i]     = len;
-        F.ops_off[i]     = ok ? dst : 0ull;
+        F.ops_off[i]     = ok ? F.ops_base + dst : 0ull;
     }
     if (len == 0u) return;
     const uint64_t src = (uint64_t)r[REC_OPS_OFF_LO] | ((uint64_t)r[REC_OPS_OFF_HI] << 32);

@@ -68,6 +68,7 @@ struct wfahip_ctx {
     hipEvent_t    pin_ev[2]  = {nullptr, nullptr};
     uint32_t     *hpin       = nullptr;  // small pinned block: control words, head of the redo list, work-list staging
     hipStream_t   stream_up  = nullptr;  // host entry: the blob upload runs ahead of the alignment of earlier pairs
+    hipStream_t   stream_dn  = nullptr;  // host entry: the results of a slice are downloaded beside the next slice's alignment
     std::vector<hipEvent_t> ev_up;
     DevBuf        team_ctl;                  // barrier counters / reduction sets of the team kernel
     DevBuf        arena2, meta2;             // retry passes run beside the first pass's backtrace kernel
@@ -275,6 +276,7 @@ extern "C" void wfahip_destroy(wfahip_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->hpin) (void)hipHostFree(ctx->hpin);
     if (ctx->stream_up) (void)hipStreamDestroy(ctx->stream_up);
+    if (ctx->stream_dn) (void)hipStreamDestroy(ctx->stream_dn);
     for (hipEvent_t e : ctx->ev_up) (void)hipEventDestroy(e);
     for (int i = 0; i < 2; i++) {
         if (ctx->pin[i]) (void)hipHostFree(ctx->pin[i]);
@@ -1168,6 +1170,7 @@ extern "C" int wfahip_align_batch(wfahip_ctx *ctx, const wfahip_params *p, const
     }
     if (sliced) {
         if (!ctx->stream_up) HIP_TRY(hipStreamCreateWithFlags(&ctx->stream_up, hipStreamNonBlocking));
+        if (!ctx->stream_dn) HIP_TRY(hipStreamCreateWithFlags(&ctx->stream_dn, hipStreamNonBlocking));
         while (ctx->ev_up.size() < (size_t)UP_SLICES) {
             hipEvent_t e;
             HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1208,6 +1211,78 @@ extern "C" int wfahip_align_batch(wfahip_ctx *ctx, const wfahip_params *p, const
             }
             wfahip_timing acc{};
             uint64_t      cursor = 0;
+            // ---- per-slice assembly (wfa_finalize.hpp) and download beside the next slice's alignment
+            const uint64_t n = n_pairs;
+            const uint64_t per_blk = (uint64_t)FIN_BLOCK * FIN_ITEMS;
+            auto           al8s    = [](uint64_t v) { return (v + 7) & ~7ull; };
+            uint64_t       foff    = 0;
+            auto           takes   = [&](uint64_t bytes) {
+                const uint64_t o = foff;
+                foff += al8s(bytes);
+                return o;
+            };
+            const uint64_t so_tot = takes(16 * UP_SLICES), so_blk = takes(8ull * (n / per_blk + UP_SLICES + 1)), so_ooff = takes(8ull * n),
+                           so_loc = takes(4ull * n);
+            uint64_t so_f[11];
+            for (int i = 0; i < 11; i++) so_f[i] = takes(4ull * n);
+            const uint64_t so_ops = takes(8ull * ops_cap);
+            if ((rc = ensure(ctx, ctx->fin, foff))) {
+                if (uploader.joinable()) uploader.join();
+                return rc;
+            }
+            char *const sfb = static_cast<char *>(ctx->fin.p);
+            results_zero(out);
+            out->n = n;
+            bool alloc_ok = true;
+            {
+                const size_t cnt = std::max<uint64_t>(n, 1);
+#define ALLOCS(field, type) alloc_ok = alloc_ok && (out->field = static_cast<type *>(res_alloc(cnt * sizeof(type)))) != nullptr;
+                ALLOCS(status, int32_t) ALLOCS(score, uint32_t) ALLOCS(tbegin, int32_t) ALLOCS(tend, int32_t)
+                ALLOCS(qbegin, int32_t) ALLOCS(qend, int32_t) ALLOCS(align_len, uint32_t) ALLOCS(matches, uint32_t)
+                ALLOCS(gaps, uint32_t) ALLOCS(gap_regions, uint32_t) ALLOCS(ops_off, uint64_t) ALLOCS(ops_len, uint32_t)
+#undef ALLOCS
+            }
+            uint64_t         ops_done = 0, cells_done = 0, host_ops_cap = 0, blk_done = 0;
+            uint64_t         deferred_at = ~0ull;  // ops from this offset on did not fit the estimated host array: downloaded at the end
+            // one downloader thread takes the slices in order as the main thread marks them ready (state 1 = ready,
+            // 2 = nothing to download, skip)
+            struct DlTask { uint64_t k0, nk, o0, ops_k; bool with_ops; };
+            DlTask           dl_tasks[UP_SLICES] = {};
+            std::atomic<int> dl_state[UP_SLICES];
+            for (auto &a : dl_state) a = 0;
+            std::atomic<int> dl_err{0};
+            const auto dl_run = [&] {
+                if (hipSetDevice(ctx->device) != hipSuccess) dl_err = 1;
+                for (int k = 0; k < UP_SLICES; k++) {
+                    while (dl_state[k].load() == 0) std::this_thread::yield();
+                    if (dl_state[k].load() == 2 || dl_err) continue;
+                    const DlTask t       = dl_tasks[k];
+                    void *const dsts[11] = {out->status, out->score, out->tbegin, out->tend, out->qbegin, out->qend,
+                                            out->align_len, out->matches, out->gaps, out->gap_regions, out->ops_len};
+                    int r2 = WFAHIP_OK;
+                    for (int i = 0; i < 11 && r2 == WFAHIP_OK; i++)
+                        r2 = download(ctx, static_cast<char *>(dsts[i]) + 4 * t.k0, sfb + so_f[i] + 4 * t.k0, 4ull * t.nk, ctx->stream_dn);
+                    if (r2 == WFAHIP_OK) r2 = download(ctx, out->ops_off + t.k0, sfb + so_ooff + 8 * t.k0, 8ull * t.nk, ctx->stream_dn);
+                    if (r2 == WFAHIP_OK && t.with_ops) r2 = download(ctx, out->ops + t.o0, sfb + so_ops + 8 * t.o0, 8ull * t.ops_k, ctx->stream_dn);
+                    if (r2 != WFAHIP_OK) dl_err = 1;
+                }
+            };
+            std::thread dl_thread;
+            bool        dl_inline = false;
+            try {
+                dl_thread = std::thread(dl_run);
+            } catch (...) {
+                dl_inline = true;  // no thread: everything is downloaded after the last slice
+            }
+            const auto dl_finish = [&] {  // slices never marked (early exit) are skipped; then the downloads are waited for / run here
+                for (auto &a : dl_state) {
+                    int z = 0;
+                    a.compare_exchange_strong(z, 2);
+                }
+                if (dl_thread.joinable()) dl_thread.join();
+                else if (dl_inline) dl_run();
+            };
+            if (!alloc_ok) rc = WFAHIP_ERR_OOM;
             for (int k = 0; k < UP_SLICES && rc == WFAHIP_OK; k++) {
                 while (recorded.load() <= k) std::this_thread::yield();  // (the event must have been recorded before the wait)
                 if (up_err) {
@@ -1219,7 +1294,14 @@ extern "C" int wfahip_align_batch(wfahip_ctx *ctx, const wfahip_params *p, const
                     break;
                 }
                 const uint64_t k0 = sl_first[k], nk = sl_first[k + 1] - k0;
-                if (nk == 0) continue;
+                if (nk == 0) {
+                    dl_state[k] = 2;
+                    continue;
+                }
+                if (dbg_t) {
+                    (void)hipEventSynchronize(ctx->ev_up[k]);
+                    std::fprintf(stderr, "[wfahip]   slice %d: blob part here at +%.1f ms\n", k, ms_of(t_dev, now()));
+                }
                 rc = align_device(ctx, p, ctx->in_blob.p, blob_bytes, static_cast<char *>(ctx->in_qoff.p) + 8 * k0,
                                   static_cast<char *>(ctx->in_qlen.p) + 4 * k0, static_cast<char *>(ctx->in_toff.p) + 8 * k0,
                                   static_cast<char *>(ctx->in_tlen.p) + 4 * k0, nk, max_len,
@@ -1231,18 +1313,86 @@ extern "C" int wfahip_align_batch(wfahip_ctx *ctx, const wfahip_params *p, const
                 acc.n_main_launches += ctx->timing.n_main_launches, acc.n_packed_pairs += ctx->timing.n_packed_pairs;
                 acc.arena_bytes      = std::max(acc.arena_bytes, ctx->timing.arena_bytes);
                 acc.main_kernel_kind = ctx->timing.main_kernel_kind;
+                if (rc != WFAHIP_OK) break;
+                // assemble this slice's part of the result arrays
+                const uint32_t nb_k = (uint32_t)((nk + per_blk - 1) / per_blk);
+                FinParams F{};
+                F.rec = static_cast<const uint32_t *>(ctx->out_rec.p) + (size_t)REC_WORDS * k0;
+                F.ops = static_cast<const uint64_t *>(ctx->out_ops.p), F.n = nk;
+                F.totals  = reinterpret_cast<unsigned long long *>(sfb + so_tot) + 2 * k;
+                F.blk_sum = reinterpret_cast<uint64_t *>(sfb + so_blk) + blk_done;
+                F.loc_off = reinterpret_cast<uint32_t *>(sfb + so_loc) + k0;
+                F.ops_off = reinterpret_cast<uint64_t *>(sfb + so_ooff) + k0;
+                F.status = reinterpret_cast<int32_t *>(sfb + so_f[0]) + k0, F.score = reinterpret_cast<uint32_t *>(sfb + so_f[1]) + k0;
+                F.tbegin = reinterpret_cast<int32_t *>(sfb + so_f[2]) + k0, F.tend = reinterpret_cast<int32_t *>(sfb + so_f[3]) + k0;
+                F.qbegin = reinterpret_cast<int32_t *>(sfb + so_f[4]) + k0, F.qend = reinterpret_cast<int32_t *>(sfb + so_f[5]) + k0;
+                F.align_len = reinterpret_cast<uint32_t *>(sfb + so_f[6]) + k0, F.matches = reinterpret_cast<uint32_t *>(sfb + so_f[7]) + k0;
+                F.gaps = reinterpret_cast<uint32_t *>(sfb + so_f[8]) + k0, F.gap_regions = reinterpret_cast<uint32_t *>(sfb + so_f[9]) + k0;
+                F.ops_len = reinterpret_cast<uint32_t *>(sfb + so_f[10]) + k0;
+                F.ops_out = reinterpret_cast<uint64_t *>(sfb + so_ops) + ops_done, F.ops_base = ops_done;
+                bool hip_ok = hipMemsetAsync(F.totals, 0, 16, st) == hipSuccess;
+                hipLaunchKernelGGL(fin_scan_blocks, dim3(nb_k), dim3(FIN_BLOCK), 0, st, F);
+                hipLaunchKernelGGL(fin_scan_sums, dim3(1), dim3(1024), 0, st, F, nb_k);
+                hipLaunchKernelGGL(fin_gather, dim3((uint32_t)((nk + 3) / 4)), dim3(256), 0, st, F);
+                hip_ok = hip_ok && hipGetLastError() == hipSuccess &&
+                         hipMemcpyAsync(ctx->hpin + HPIN_CTRL + CTRL_WORDS, F.totals, 16, hipMemcpyDeviceToHost, st) == hipSuccess &&
+                         hipStreamSynchronize(st) == hipSuccess;
+                if (!hip_ok) {
+                    rc = WFAHIP_ERR_HIP;
+                    break;
+                }
+                unsigned long long tk[2];
+                std::memcpy(tk, ctx->hpin + HPIN_CTRL + CTRL_WORDS, 16);
+                const uint64_t ops_k = tk[0];
+                cells_done += tk[1], blk_done += nb_k;
+                if (!out->ops) {  // size the host op array from the first slice: ops per pair x pairs + 15 %
+                    host_ops_cap = std::min<uint64_t>(ops_cap, (uint64_t)((double)ops_k / (double)nk * (double)n * 1.15) + 65536);
+                    out->ops     = static_cast<uint64_t *>(res_alloc(std::max<uint64_t>(host_ops_cap, 1) * 8));
+                    if (!out->ops) {
+                        rc = WFAHIP_ERR_OOM;
+                        break;
+                    }
+                }
+                if (deferred_at == ~0ull && ops_done + ops_k > host_ops_cap) deferred_at = ops_done;
+                if (dbg_t) std::fprintf(stderr, "[wfahip]   slice %d: aligned + assembled at +%.1f ms\n", k, ms_of(t_dev, now()));
+                dl_tasks[k] = DlTask{k0, nk, ops_done, ops_k, deferred_at == ~0ull};
+                dl_state[k] = 1;
+                ops_done += ops_k;
             }
             if (uploader.joinable()) uploader.join();
+            dl_finish();
+            if (rc == WFAHIP_OK && dl_err) rc = WFAHIP_ERR_HIP;
             if (rc == WFAHIP_OK || rc == WFAHIP_ERR_OOM) {
                 acc.ops_written = ctx->timing.ops_written;
                 ctx->timing     = acc;
             }
-            if (rc == WFAHIP_ERR_OOM) {  // the op buffer was too small: the whole blob is resident now, one plain call redoes it
+            if (rc == WFAHIP_ERR_OOM && alloc_ok && needed > ops_cap) {  // the op buffer was too small: the whole blob is resident now, one plain call redoes it
+                wfahip_results_free(out);
                 HIP_TRY(hipStreamSynchronize(ctx->stream_up));
                 ops_cap = std::max(needed, ops_cap) + ops_cap / 2 + 1024;
                 continue;
             }
-            break;
+            if (rc == WFAHIP_OK && deferred_at != ~0ull) {  // more ops than estimated: an array of the exact size takes what is there + the rest
+                uint64_t *full = static_cast<uint64_t *>(res_alloc(std::max<uint64_t>(ops_done, 1) * 8));
+                if (!full) {
+                    rc = WFAHIP_ERR_OOM;
+                } else {
+                    std::memcpy(full, out->ops, deferred_at * 8);
+                    res_release(out->ops);
+                    out->ops = full;
+                    rc = download(ctx, out->ops + deferred_at, sfb + so_ops + 8 * deferred_at, 8ull * (ops_done - deferred_at), st);
+                }
+            }
+            if (rc != WFAHIP_OK) {
+                wfahip_results_free(out);
+                return rc;
+            }
+            out->n_ops               = ops_done;
+            ctx->timing.cells_stored = cells_done;
+            if (dbg_t)
+                std::fprintf(stderr, "[wfahip] host entry (sliced): small arrays %.1f ms, upload + alignment + assembly + download %.1f ms\n",
+                             ms_of(t_h2d, t_dev), ms_of(t_dev, now()));
+            return WFAHIP_OK;
         }
         rc = align_device(ctx, p, ctx->in_blob.p, blob_bytes, ctx->in_qoff.p, ctx->in_qlen.p, ctx->in_toff.p,
                           ctx->in_tlen.p, n_pairs, max_len, ctx->out_rec.p, ctx->out_ops.p, ops_cap, &needed, st,
