@@ -705,4 +705,18 @@ def test_host_entry_slices_agree_with_the_plain_call(built):
     sample = slice(0, 20000)
     want = O.align_batch(_oracle_params(True, (10, 50, 1)), blob, q_off[sample], q_len[sample], t_off[sample], t_len[sample], n_threads=8)
     assert np.array_equal(a.score[sample], want.score) and np.array_equal(a.ops_len[sample], want.ops_len)
+    # the host op array is sized from the first slice; here the later slices have five times as many ops per pair,
+    # so what does not fit is fetched at the end into an array of the exact size
+    p1 = w.generate_pairs(seed=92, n_pairs=n // 4, length=300, error_rate=0.01, n_threads=16)
+    p2 = w.generate_pairs(seed=93, n_pairs=n - n // 4, length=300, error_rate=0.10, n_threads=16)
+    off = np.uint64(len(p1[0]))
+    mixed = (np.concatenate([p1[0], p2[0]]), np.concatenate([p1[1], p2[1] + off]), np.concatenate([p1[2], p2[2]]),
+             np.concatenate([p1[3], p2[3] + off]), np.concatenate([p1[4], p2[4]]))
+    d = al.align_arrays(*mixed)
+    os.environ["WFAHIP_NO_UPLOAD_OVERLAP"] = "1"
+    try:
+        e = al.align_arrays(*mixed)
+    finally:
+        del os.environ["WFAHIP_NO_UPLOAD_OVERLAP"]
+    assert_batch_equal(d, e, "sliced vs plain, op-count estimate too low")
     al.close()
