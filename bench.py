@@ -1,58 +1,144 @@
 #!/usr/bin/env python3
 """bench.py -- aligned pairs/s of the HIP wavefront-alignment hot path on MI355X.
 
-Workload (BASELINE.json configs[2], the one `metric` is quoted on): 1e6 synthetic 1 kbp DNA pairs at 5 % error
-per GPU, global alignment, wf-adaptive 10/50/1, penalties 4/6/2, seed 3.  A "step" is one pass of the hot path
-over the rank's batch: raw byte sequences already resident in HBM -> result records + CIGAR ops in HBM.
-Multi-GPU (torchrun, one rank per GPU): pairs are sharded over ranks (weak scaling: 1e6 pairs per GPU, rank r
-owns dataset indices [r*n, (r+1)*n)), no data-path collective; the only RCCL traffic is the gather of the
-result records (44 bytes per pair: status, score, region, statistics, op count) onto rank 0 at the end of every
-step.  Like on one GPU the
-CIGAR ops stay in the HBM of the GPU that produced them; --gather-ops ships them to rank 0 as well (0.74 GB per
-rank and step at 1 kbp).
+Default workload (BASELINE.json configs[2], the one `metric` is quoted on; --config c3): 1e6 synthetic 1 kbp DNA
+pairs at 5 % error per GPU, global alignment, wf-adaptive 10/50/1, penalties 4/6/2, seed 3.  A "step" is one pass of
+the hot path over the rank's batch: raw byte sequences already resident in HBM -> result records + CIGAR ops in HBM.
+
+Other workloads of BASELINE.json, each printing its own JSON line:
+  --config c2    configs[1]: 1e5 x 150 bp @2 %, global, wf-adaptive off, seed 2
+  --config c4    configs[3]: 1e7 x 1 kbp @5 % IN TOTAL (strong scaling: --total-pairs 10000000), seed 4
+  --config c5s   configs[4] sample: 8 x 100 kbp @10 %, semi-global, wf-adaptive 10/50/1, seed 5
+
+Multi-GPU: one rank per GPU, pairs sharded over ranks, no data-path collective; the only RCCL traffic is the gather of
+the result records (44 bytes per pair) onto rank 0 after every step (--gather-ops ships the CIGAR op arrays too).
+`--gpus N` with WORLD_SIZE unset starts the N ranks itself (a torch.distributed.run child process, started before
+this process touches a GPU); under torchrun (WORLD_SIZE set) the process is one of the ranks.  Weak scaling by
+default (--pairs per GPU); --total-pairs T shards T pairs over the ranks (strong scaling).
+
+--backend gloo --dry runs the same multi-rank control flow on CPU tensors without the kernels (tests/test_bench_gloo.py).
 
 Prints ONE JSON line (rank 0).  `value` = pairs aligned by all ranks / max-over-ranks wall time of K steps.
 """
 import argparse
-import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
-import torch.distributed as dist
+METRIC = "aligned pairs/sec (and Gcells/s) on 1e6 synthetic 1 kbp pairs @5% error"
+
+CONFIGS = {
+    # name: (pairs, length, error, seed, semi_global, adaptive, total_pairs, cpu_sample)
+    "c3": dict(pairs=1_000_000, length=1000, error=0.05, seed=3, semi_global=False, adaptive=True, total=0, cpu=150_000),
+    "c2": dict(pairs=100_000, length=150, error=0.02, seed=2, semi_global=False, adaptive=False, total=0, cpu=100_000),
+    "c4": dict(pairs=0, length=1000, error=0.05, seed=4, semi_global=False, adaptive=True, total=10_000_000, cpu=150_000),
+    "c5s": dict(pairs=8, length=100_000, error=0.10, seed=5, semi_global=True, adaptive=True, total=0, cpu=0),
+}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pairs", type=int, default=1_000_000, help="pairs per GPU")
-    ap.add_argument("--length", type=int, default=1000)
-    ap.add_argument("--error", type=float, default=0.05)
-    ap.add_argument("--seed", type=int, default=3)
-    ap.add_argument("--semi-global", action="store_true")
-    ap.add_argument("--no-adaptive", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=150_000, help="pairs timed on one host core (0 = skip)")
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: enough for ~5 s on the default workload)")
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c3")
+    ap.add_argument("--pairs", type=int, default=None, help="pairs per GPU (weak scaling)")
+    ap.add_argument("--total-pairs", type=int, default=None, help="pairs over all GPUs (strong scaling)")
+    ap.add_argument("--length", type=int, default=None)
+    ap.add_argument("--error", type=float, default=None)
+    ap.add_argument("--seed", type=int, default=None)
+    ap.add_argument("--semi-global", action="store_true", default=None)
+    ap.add_argument("--no-adaptive", action="store_true", default=None)
+    ap.add_argument("--cpu-sample", type=int, default=None, help="pairs timed on host cores (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=1)
+    ap.add_argument("--cpu-all-cores", type=int, default=1, help="1: also time the oracle on every host core (N = 1 only)")
+    ap.add_argument("--host-entry", type=int, default=1, help="1: also time wfahip_align_batch (host blobs -> host results), N = 1 only")
+    ap.add_argument("--latency", type=int, default=1, help="1: also time single-pair Align round trips, N = 1 only")
     ap.add_argument("--opt", action="append", default=[], help="library option key=value (experiments)")
     ap.add_argument("--gather-ops", action="store_true", help="multi-GPU: gather the CIGAR op arrays onto rank 0 too")
-    args = ap.parse_args()
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl")
+    ap.add_argument("--dry", action="store_true", help="no kernels, CPU tensors: exercises the multi-rank control flow only")
+    ap.add_argument("--master-port", type=int, default=0)
+    args = ap.parse_args(argv)
+    c = CONFIGS[args.config]
+    if args.pairs is None:
+        args.pairs = c["pairs"]
+    if args.total_pairs is None:
+        args.total_pairs = c["total"]
+    if args.length is None:
+        args.length = c["length"]
+    if args.error is None:
+        args.error = c["error"]
+    if args.seed is None:
+        args.seed = c["seed"]
+    if args.semi_global is None:
+        args.semi_global = c["semi_global"]
+    if args.no_adaptive is None:
+        args.no_adaptive = not c["adaptive"]
+    if args.cpu_sample is None:
+        args.cpu_sample = c["cpu"]
+    if args.steps is None:
+        args.steps = {"c3": 200, "c2": 2000, "c4": 20, "c5s": 3}[args.config]
+    if args.warmup is None:
+        args.warmup = 1 if args.config == "c5s" else 3
+    return args
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(args, argv):
+    """--gpus N without a launcher: start the N ranks as children of a torch.distributed.run process.  Nothing in this
+    process has touched a GPU yet (no torch.cuda / HIP call), and it is never re-exec'd: it waits for the child and
+    leaves with its return code."""
+    port = args.master_port or free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args, argv))
+    run_rank(args)
+
+
+def run_rank(args):
+    import ctypes as C
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    dry = args.dry
+    if dry:
+        dev = torch.device("cpu")
+    else:
+        dev = torch.device(f"cuda:{local_rank}")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device(f"cuda:{local_rank}")
+        if args.backend == "nccl" and not dry:
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+    if not dry:
+        torch.cuda.set_device(local_rank)
 
     import __graft_entry__ as entry
     if rank == 0:  # one rank builds (a no-op when the in-tree library is current), the others wait for it
@@ -63,74 +149,99 @@ def main():
         entry.build()
     import wfa_amd as w
     from wfa_amd import _lib as L
-    from wfa_amd.shard import gather_results_async
+    from wfa_amd.shard import gather_results_async, shard_range
 
-    n = args.pairs
+    # ---- this rank's shard
+    if args.total_pairs > 0:
+        first, end = shard_range(args.total_pairs, rank, world)
+        scaling = "strong"
+    else:
+        first, end = rank * args.pairs, (rank + 1) * args.pairs
+        scaling = "weak"
+    n = end - first
+    n_all = args.total_pairs if args.total_pairs > 0 else args.pairs * world
+
     # ---- synthetic input (host generation, then H2D: outside the timed region)
-    blob, q_off, q_len, t_off, t_len = w.generate_pairs(args.seed, n, args.length, args.error,
-                                                        first_index=rank * n, n_threads=min(32, os.cpu_count() or 8))
-    d_blob = torch.from_numpy(blob).to(dev)
-    d_qoff = torch.from_numpy(q_off.view(np.int64)).to(dev)
-    d_toff = torch.from_numpy(t_off.view(np.int64)).to(dev)
-    d_qlen = torch.from_numpy(q_len.view(np.int32)).to(dev)
-    d_tlen = torch.from_numpy(t_len.view(np.int32)).to(dev)
-    max_len = int(max(q_len.max(), t_len.max()))
+    blob, q_off, q_len, t_off, t_len = w.generate_pairs(args.seed, n, args.length, args.error, first_index=first,
+                                                        n_threads=min(32, os.cpu_count() or 8))
+    max_len = int(max(q_len.max(), t_len.max())) if n else 1
     sum_len = int(q_len.astype(np.int64).sum() + t_len.astype(np.int64).sum())
     ops_cap = sum_len // 4 + 8 * n + 1024
-    d_rec = torch.empty((n, L.REC_WORDS), dtype=torch.int32, device=dev)
-    d_ops = torch.empty(ops_cap, dtype=torch.int64, device=dev)
+    if args.semi_global or args.length >= 20000:
+        ops_cap = sum_len + 2 * n + 1024
+    d_rec = torch.zeros((max(n, 1), L.REC_WORDS), dtype=torch.int32, device=dev)[:n]
+    d_ops = torch.zeros(ops_cap if not dry else 64 * n + 16, dtype=torch.int64, device=dev)
 
-    al = w.New(w.DefaultPenalties, w.Options(GlobalAlignment=not args.semi_global), device=local_rank)
-    if not args.no_adaptive:
-        assert al.AdaptiveReduction(w.DefaultAdaptiveOption) is None
-    for kv in args.opt:
-        key, val = kv.split("=")
-        L.check(L.lib().wfahip_set_option(al._ctx, key.encode(), int(val)), "wfahip_set_option")
-    prm = al._params()
-    lib = L.lib()
-    stream = torch.cuda.current_stream(dev).cuda_stream
     timing = L.Timing()
+    al = None
+    if not dry:
+        d_blob = torch.from_numpy(blob).to(dev)
+        d_qoff = torch.from_numpy(q_off.view(np.int64)).to(dev)
+        d_toff = torch.from_numpy(t_off.view(np.int64)).to(dev)
+        d_qlen = torch.from_numpy(q_len.view(np.int32)).to(dev)
+        d_tlen = torch.from_numpy(t_len.view(np.int32)).to(dev)
+        al = w.New(w.DefaultPenalties, w.Options(GlobalAlignment=not args.semi_global), device=local_rank)
+        if not args.no_adaptive:
+            assert al.AdaptiveReduction(w.DefaultAdaptiveOption) is None
+        for kv in args.opt:
+            key, val = kv.split("=")
+            L.check(L.lib().wfahip_set_option(al._ctx, key.encode(), int(val)), "wfahip_set_option")
+        prm = al._params()
+        lib = L.lib()
+        stream = torch.cuda.current_stream(dev).cuda_stream
     pending = [None]  # the result gather in flight (multi-GPU)
+    gather_bytes = [0]
 
     def step():
-        needed = C.c_uint64()
-        rc = lib.wfahip_align_batch_device(al._ctx, C.byref(prm), d_blob.data_ptr(), blob.size, d_qoff.data_ptr(),
-                                           d_qlen.data_ptr(), d_toff.data_ptr(), d_tlen.data_ptr(), n, max_len,
-                                           d_rec.data_ptr(), d_ops.data_ptr(), ops_cap, C.byref(needed), stream)
-        L.check(rc, "wfahip_align_batch_device")
-        lib.wfahip_last_timing(al._ctx, C.byref(timing))
-        n_ops = int(needed.value)
+        if dry:
+            # stand-in for the kernels: a deterministic record per pair (score field = global pair index)
+            d_rec[:, L.REC_STATUS] = 0
+            d_rec[:, L.REC_SCORE] = torch.arange(first, end, dtype=torch.int32)
+            d_rec[:, L.REC_OPS_LEN] = 1
+            n_ops = n
+        else:
+            needed = C.c_uint64()
+            rc = lib.wfahip_align_batch_device(al._ctx, C.byref(prm), d_blob.data_ptr(), blob.size, d_qoff.data_ptr(),
+                                               d_qlen.data_ptr(), d_toff.data_ptr(), d_tlen.data_ptr(), n, max_len,
+                                               d_rec.data_ptr(), d_ops.data_ptr(), ops_cap, C.byref(needed), stream)
+            L.check(rc, "wfahip_align_batch_device")
+            lib.wfahip_last_timing(al._ctx, C.byref(timing))
+            n_ops = int(needed.value)
         if world > 1:
             # Result gather onto rank 0 over RCCL/xGMI (fixed-size records; with --gather-ops the padded op arrays
-            # too).  It is started
-            # here and completed before the next one starts (or at the end of the timed region), so the exchange
-            # of batch i runs beside the alignment of batch i+1; the send buffers are private copies.
+            # too).  It is started here and completed before the next one starts (or at the end of the timed
+            # region), so the exchange of batch i runs beside the alignment of batch i+1; the send buffers are
+            # private copies.  (records only: the first 11 words -- status, score, region, statistics, op count; the
+            # op offsets, cell census and score count that follow only mean something next to the rank's own ops)
             if pending[0] is not None:
                 pending[0].wait()
-            # (records only: the first 11 words -- status, score, region, statistics, op count; the op offsets, cell
-            # census and score count that follow only mean something next to the rank's own op array)
             rec_out = d_rec if args.gather_ops else d_rec[:, :L.REC_OPS_OFF_LO]
+            gather_bytes[0] = rec_out.shape[0] * rec_out.shape[1] * 4 + (8 * n_ops if args.gather_ops else 0)
             pending[0] = gather_results_async(rec_out, d_ops, n_ops, dst=0, with_ops=args.gather_ops)
         return n_ops
 
+    last_gather = [None]
+
     def drain():
         if pending[0] is not None:
-            pending[0].wait()
+            last_gather[0] = pending[0].wait()
             pending[0] = None
 
     def sync_all():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        if not dry:
+            torch.cuda.synchronize(dev)
 
     # Setup, outside the timed region like the input upload: the first call of a context allocates its device buffers
-    # (61 GiB of wavefront arenas for this workload: seconds of hipMalloc).  With --warmup >= 1 the warm-up steps do
-    # that; with --warmup 0 one extra untimed call does, reported as config.setup_steps.
+    # (61 GiB of wavefront arenas for the default workload: seconds of hipMalloc).  With --warmup >= 1 the warm-up
+    # steps do that; with --warmup 0 one extra untimed call does, reported as config.setup_steps.
     setup_steps = 1 if args.warmup == 0 else 0
     for _ in range(args.warmup + setup_steps):
         step()
     drain()
     kernel_ms, main_ms = [], []
+    n_ops = 0
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -145,94 +256,206 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     elapsed = float(tt.item())
 
+    # one more gather on its own, timed (how long the exchange takes when nothing hides it)
+    gather_ms = None
+    if world > 1:
+        sync_all()
+        t1 = time.perf_counter()
+        rec_out = d_rec if args.gather_ops else d_rec[:, :L.REC_OPS_OFF_LO]
+        gather_results_async(rec_out, d_ops, n_ops, dst=0, with_ops=args.gather_ops).wait()
+        sync_all()
+        gather_ms = (time.perf_counter() - t1) * 1e3
+        # per-rank pair counts as the collective saw them
+        cnt = torch.tensor([n], dtype=torch.int64, device=dev)
+        cnts = [torch.empty_like(cnt) for _ in range(world)]
+        dist.all_gather(cnts, cnt)
+        pairs_per_rank = [int(c.item()) for c in cnts]
+        n_seen = dist.get_world_size()
+        gathered_ok = None
+        if rank == 0 and last_gather[0] is not None:
+            recs = last_gather[0][0]
+            gathered_ok = [int(r.shape[0]) for r in recs] == pairs_per_rank
+            if dry:  # the records of every rank arrived, in rank order, untouched
+                scores = torch.cat([r[:, L.REC_SCORE] for r in recs]).cpu()
+                gathered_ok = gathered_ok and bool(torch.equal(scores, torch.arange(n_all, dtype=torch.int32)))
+    else:
+        pairs_per_rank, n_seen, gathered_ok = [n], 1, None
+
     # ---- accounting for the roofline (algorithmic bytes)
     rec = d_rec.cpu().numpy().view(np.uint32)
     ok = rec[:, L.REC_STATUS] == 0
-    cells = int(rec[:, L.REC_CELLS_LO].astype(np.uint64).sum())
+    cells = int(rec[:, L.REC_CELLS_LO].astype(np.uint64).sum()) + (int(rec[:, L.REC_CELLS_HI].astype(np.uint64).sum()) << 32)
     n_ops_total = int(rec[:, L.REC_OPS_LEN].astype(np.uint64).sum())
     alg_bytes = 4 * cells + sum_len + 64 * n + 8 * n_ops_total
-    k_ms = float(np.mean(kernel_ms))
-    main_k_ms = float(np.mean(main_ms))
-    achieved = alg_bytes / (main_k_ms * 1e-3) / 1e9  # GB/s over the dominant kernel's launches of one step
+    k_ms = float(np.mean(kernel_ms)) if kernel_ms else 0.0
+    main_k_ms = float(np.mean(main_ms)) if main_ms else 0.0
+    achieved = alg_bytes / (main_k_ms * 1e-3) / 1e9 if main_k_ms > 0 else 0.0  # GB/s over the dominant kernel's launches of one step
 
-    # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    # (profiles/*_pmc_hbm.json, made by scripts/profile_bench.sh; PMC cannot be collected from inside the bench).
-    # gfx950: FETCH_SIZE counts half the bytes of the coalesced input reads (checked against the known 2.0 GB of
-    # sequence bytes the forward kernel must read: it reports 1.12 GB), so it is doubled; WRITE_SIZE is taken as is.
-    traffic, traffic_src, traffic_kernel = None, None, None
     KNAMES = ["wfa_generic_kernel<1, 0>", "wfa_packed_kernel", "wfa_reg_kernel<2, 4, 1>", "wfa_blk_kernel<16",
-              "wfa_blk_kernel<8", "wfa_blk_kernel<64", "wfa_blk_kernel<8, 8, false, 4"]
-    kname = KNAMES[int(timing.main_kernel_kind)]
-    default_workload = (n == 1_000_000 and args.length == 1000 and abs(args.error - 0.05) < 1e-9 and args.seed == 3
-                        and not args.semi_global and not args.no_adaptive)
-    if default_workload:
-        import glob
-        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json")), reverse=True):
-            try:
-                pm = json.load(open(f))["kernels"]
-            except Exception:
-                continue
-            for name, grids in pm.items():
-                if kname in name:
-                    g0 = max(grids.values(), key=lambda d: d.get("WRITE_SIZE_KB", 0))
-                    if "FETCH_SIZE_KB" in g0 and "WRITE_SIZE_KB" in g0:
-                        traffic = (2.0 * g0["FETCH_SIZE_KB"] + g0["WRITE_SIZE_KB"]) * 1024.0
-                        traffic_src = os.path.basename(f)
-                        traffic_kernel = name.replace("void wfa::", "").split("(")[0]
-            if traffic is not None:
-                break
+              "wfa_blk_kernel<8", "wfa_blk_kernel<64", "wfa_blk_kernel<8, 8, false, 4", "wfa_team_kernel"]
+    kname = KNAMES[min(int(timing.main_kernel_kind), len(KNAMES) - 1)]
 
     out = None
     if rank == 0:
-        total_pairs = n * world * args.steps
+        # HBM traffic + instruction counts of the dominant kernel from the committed rocprofv3 PMC passes of this
+        # same command (profiles/*_pmc.json, made by scripts/profile_bench.sh; PMC cannot be collected from inside the
+        # bench).  gfx950: FETCH_SIZE counts half the bytes of the coalesced input reads (checked against the known
+        # 2.0 GB of sequence bytes the forward kernel must read: it reports 1.12 GB), so it is doubled; WRITE_SIZE is
+        # taken as is.  `stale` says whether the profile was taken on another build of the kernels.
+        pm = find_profile(args.config, kname) if (not dry and n == CONFIGS[args.config]["pairs"] and not args.opt) else None
+        traffic = pm["traffic"] if pm else None
+        total_pairs = n_all * args.steps
         value = total_pairs / elapsed
-        cfg = {"workload": f"{n} x {args.length} bp pairs/GPU @{args.error:.0%} error, "
-                           f"{'semi-global' if args.semi_global else 'global'} gap-affine 4/6/2, "
+        cfg = {"workload": f"{n_all if scaling == 'strong' else n} x {args.length} bp pairs{'' if scaling == 'strong' else '/GPU'} "
+                           f"@{args.error:.0%} error, {'semi-global' if args.semi_global else 'global'} gap-affine 4/6/2, "
                            f"wf-adaptive {'off' if args.no_adaptive else '10/50/1'}, seed {args.seed}",
-               "pairs_per_gpu": n, "length": args.length, "error_rate": args.error,
-               "parallelism": f"pair-sharded x{world}", "status_ok": int(ok.sum()), "setup_steps": setup_steps,
+               "config": args.config, "pairs_per_gpu": n, "pairs_per_rank": pairs_per_rank, "total_pairs_per_step": n_all,
+               "length": args.length, "error_rate": args.error,
+               "parallelism": f"pair-sharded x{world}", "ranks_seen_by_collective": n_seen, "backend": "none (1 GPU)" if world == 1 else args.backend,
+               "status_ok": int(ok.sum()), "setup_steps": setup_steps,
                "gather": "none (1 GPU)" if world == 1 else ("records + CIGAR ops" if args.gather_ops else "records"),
+               "gather_bytes_per_rank_step": gather_bytes[0] if world > 1 else 0, "gather_ms_standalone": gather_ms,
+               "gathered_records_complete": gathered_ok,
                "gcells_per_s": value * args.length * args.length / 1e9,
                "kernel_ms_per_step": k_ms, "main_kernel_ms": main_k_ms, "launches_per_step": int(timing.n_launches),
                "packed_pairs": int(timing.n_packed_pairs),
                "retried_pairs": int(timing.n_retried_pairs), "arena_gib": timing.arena_bytes / 2 ** 30,
-               "wf_cells_per_pair": cells / n, "cigar_ops_per_pair": n_ops_total / n}
-        out = {"metric": "aligned pairs/sec (and Gcells/s) on 1e6 synthetic 1 kbp pairs @5% error",
-               "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "u32", "data": "synthetic", "config": cfg,
-               "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                            "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
-                            "algorithmic_bytes_per_launch": alg_bytes,
-                            "kernel": traffic_kernel or (kname + (", ..>" if kname.startswith("wfa_blk_kernel") else "")),
-                            "kernel_ms": main_k_ms, "all_kernels_ms": k_ms,
-                            "note": "achieved = algorithmic bytes of one step / duration of the dominant "
-                                    "kernel's launches in that step (forward pass; on large batches the same launch "
-                                    "also streams the backtrace); peak = 8 TB/s HBM3E spec; the kernel "
-                                    "is integer-VALU-issue bound, not HBM bound (DESIGN.md section 5)"}}
-        # ---- CPU baseline: the oracle (a literal port of the reference's algorithm) on a bounded sample of the
-        # same dataset, on this box's host cores.  Reported baseline, not the target.
-        if args.cpu_sample > 0 and world == 1:  # (N = 1 only: the other ranks would sit in the barrier meanwhile)
-            from oracle import oracle as O
-            ns = min(args.cpu_sample, n)
-            p = O.make_params(global_alignment=not args.semi_global,
-                              adaptive=None if args.no_adaptive else (10, 50, 1))
-            t1 = time.perf_counter()
-            ref = O.align_batch(p, blob, q_off[:ns], q_len[:ns], t_off[:ns], t_len[:ns], n_threads=args.cpu_threads,
-                                want_ops=False)
-            dt = time.perf_counter() - t1
-            same = bool(np.array_equal(ref.score, rec[:ns, L.REC_SCORE]) and
-                        np.array_equal(ref.align_len, rec[:ns, L.REC_ALIGN_LEN]))
-            out["cpu_baseline"] = {"value": ns / dt, "unit": "pairs/s", "cores": args.cpu_threads, "kind": "port",
-                                   "sample": f"first {ns} pairs of the same dataset, oracle/wfa_oracle.c "
-                                             f"(C restatement of the Go reference; Go itself is not installed), "
-                                             f"{dt:.1f} s", "scores_match_gpu": same,
-                                   "published_reference": "6483 pairs/s (wfa-go, laptop, 1 thread; README.md:330)"}
+               "wf_cells_per_pair": cells / max(n, 1), "cigar_ops_per_pair": n_ops_total / max(n, 1),
+               "timed_region_s": elapsed}
+        if dry:
+            cfg["dry"] = True
+        out = {"metric": METRIC, "value": value, "unit": "pairs/s", "n_gpus": n_seen, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
+               "vs_baseline": None, "dtype": "u32", "data": "synthetic", "config": cfg}
+        if not dry:
+            roof = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                    "frac": achieved / 8000.0, "traffic": traffic,
+                    "traffic_source": pm["source"] if pm else None, "traffic_stale": pm["stale"] if pm else None,
+                    "frac_on_traffic": (traffic / (main_k_ms * 1e-3) / 8e12) if (traffic and main_k_ms > 0) else None,
+                    "algorithmic_bytes_per_launch": alg_bytes,
+                    "kernel": (pm["kernel"] if pm else None) or (kname + (", ..>" if kname.startswith("wfa_blk_kernel") else "")),
+                    "kernel_ms": main_k_ms, "all_kernels_ms": k_ms,
+                    "note": "achieved = algorithmic bytes of one step / duration of the dominant kernel's launches in "
+                            "that step (HIP events on the launch stream); peak = 8 TB/s HBM3E spec; the forward kernel is "
+                            "integer-VALU-issue bound, not HBM bound: see `secondary` (DESIGN.md section 5)"}
+            if pm and pm.get("valu_insts") and main_k_ms > 0:
+                # second ceiling: vector-instruction issue.  1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction
+                # (MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles on a SIMD-32)
+                peak = 256 * 4 * 2.4e9 / 2 / 1e9
+                ach = pm["valu_insts"] / (main_k_ms * 1e-3) / 1e9
+                roof["secondary"] = {"bound": "valu-issue", "achieved": ach, "peak": peak, "unit": "G wave-instr/s",
+                                     "frac": ach / peak, "valu_wave_insts_per_launch": pm["valu_insts"],
+                                     "source": pm["source"], "stale": pm["stale"]}
+            out["roofline"] = roof
+        if not dry and world == 1:
+            extras(args, out, w, L, al, blob, q_off, q_len, t_off, t_len, rec, n)
         print(json.dumps(out), flush=True)
-    w.RecycleAligner(al)
+    if al is not None:
+        w.RecycleAligner(al)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def find_profile(config, kname):
+    """Newest profiles/*_<config>_pmc.json (or, for c3, *_pmc_hbm.json) that holds the dominant kernel."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{config}_pmc.json")), reverse=True)
+    if config == "c3":
+        cands += sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json")), reverse=True)
+    src_sha = kernel_sources_sha()
+    for f in cands:
+        try:
+            doc = json.load(open(f))
+            pm = doc["kernels"]
+        except Exception:
+            continue
+        for name, grids in pm.items():
+            if kname in name:
+                g0 = max(grids.values(), key=lambda d: d.get("WRITE_SIZE_KB", 0))
+                if "FETCH_SIZE_KB" in g0 and "WRITE_SIZE_KB" in g0:
+                    return {"traffic": (2.0 * g0["FETCH_SIZE_KB"] + g0["WRITE_SIZE_KB"]) * 1024.0,
+                            "valu_insts": g0.get("SQ_INSTS_VALU"), "source": os.path.basename(f),
+                            "kernel": name.replace("void wfa::", "").split("(")[0],
+                            "stale": doc.get("kernel_sources_sha") != src_sha}
+    return None
+
+
+def kernel_sources_sha():
+    """Hash of wfa_amd/csrc + include: tells whether a committed PMC profile belongs to this build of the kernels."""
+    import hashlib
+    h = hashlib.sha1()
+    for d in ("wfa_amd/csrc", "include"):
+        for f in sorted(os.listdir(os.path.join(ROOT, d))):
+            with open(os.path.join(ROOT, d, f), "rb") as fh:
+                h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
+def extras(args, out, w, L, al, blob, q_off, q_len, t_off, t_len, rec, n):
+    """N = 1 only, after the timed region: the CPU baseline (oracle = C restatement of the reference) on one core and
+    on all host cores, the host-to-host entry (wfahip_align_batch: what the cgo binding calls), single-pair latency."""
+    import numpy as np
+    cfg = out["config"]
+    if args.cpu_sample > 0:
+        from oracle import oracle as O
+        ns = min(args.cpu_sample, n)
+        p = O.make_params(global_alignment=not args.semi_global, adaptive=None if args.no_adaptive else (10, 50, 1))
+        t1 = time.perf_counter()
+        ref = O.align_batch(p, blob, q_off[:ns], q_len[:ns], t_off[:ns], t_len[:ns], n_threads=args.cpu_threads,
+                            want_ops=False)
+        dt = time.perf_counter() - t1
+        same = bool(np.array_equal(ref.score, rec[:ns, L.REC_SCORE]) and
+                    np.array_equal(ref.align_len, rec[:ns, L.REC_ALIGN_LEN]))
+        out["cpu_baseline"] = {"value": ns / dt, "unit": "pairs/s", "cores": args.cpu_threads, "kind": "port",
+                               "sample": f"first {ns} pairs of the same dataset, oracle/wfa_oracle.c "
+                                         f"(C restatement of the Go reference; Go itself is not installed), "
+                                         f"{dt:.1f} s", "scores_match_gpu": same,
+                               "published_reference": "6483 pairs/s (wfa-go, laptop, 1 thread; README.md:330)"}
+        if args.cpu_all_cores >= 2 or (args.cpu_all_cores == 1 and args.length < 20000):  # (long reads: minutes per pair)
+            cores = os.cpu_count() or 1
+            na = min(n, max(ns, int(ns / dt * 0.5 * cores * 8)))  # ~8 s of work if it scaled at 50 %
+            t1 = time.perf_counter()
+            ref = O.align_batch(p, blob, q_off[:na], q_len[:na], t_off[:na], t_len[:na], n_threads=cores, want_ops=False)
+            dta = time.perf_counter() - t1
+            out["cpu_baseline"]["all_cores"] = {"value": na / dta, "unit": "pairs/s", "cores": cores,
+                                                "sample": f"first {na} pairs, one oracle aligner per thread, {dta:.1f} s",
+                                                "scores_match_gpu": bool(np.array_equal(ref.score, rec[:na, L.REC_SCORE]))}
+    if args.host_entry:
+        # SURVEY.md section 8d timing (b): host byte blobs -> host result arrays through wfahip_align_batch
+        # (PCIe-inclusive; never `value`).  First call allocates staging buffers: untimed.
+        import ctypes as C
+        prm = al._params()
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        ts = []
+        reps = 1 if n * args.length >= 400_000_000 else 3
+        for i in range(reps + 1):
+            res = L.Results()
+            t1 = time.perf_counter()
+            L.check(L.lib().wfahip_align_batch(al._ctx, C.byref(prm), vp(blob), blob.size, vp(q_off), vp(q_len), vp(t_off),
+                                               vp(t_len), n, C.byref(res)), "wfahip_align_batch")
+            dt = time.perf_counter() - t1
+            if i == reps:
+                sc = np.ctypeslib.as_array(res.score, shape=(n,))
+                cfg["host_to_host_scores_match_device_entry"] = bool(np.array_equal(sc, rec[:, L.REC_SCORE]))
+            L.lib().wfahip_results_free(C.byref(res))
+            if i > 0:
+                ts.append(dt * 1e3)
+        cfg["host_to_host_ms"] = min(ts)
+        cfg["host_to_host_pairs_per_s"] = n / (min(ts) * 1e-3)
+        cfg["host_to_host_note"] = ("wfahip_align_batch: pageable host blobs -> malloc'd host result arrays, "
+                                    f"min of {reps} calls after one untimed call; PCIe-inclusive, never `value`")
+    if args.latency:
+        # single-pair round trip through the drop-in API (Aligner.Align = a batch of one)
+        k = min(n, 200)
+        qs = [bytes(blob[int(q_off[i]):int(q_off[i]) + int(q_len[i])]) for i in range(k)]
+        tsq = [bytes(blob[int(t_off[i]):int(t_off[i]) + int(t_len[i])]) for i in range(k)]
+        al.Align(qs[0], tsq[0])
+        t1 = time.perf_counter()
+        for i in range(k):
+            al.Align(qs[i], tsq[i])
+        cfg["single_pair_align_us"] = (time.perf_counter() - t1) / k * 1e6
+        cfg["single_pair_note"] = f"mean over {k} Aligner.Align calls (python ctypes mirror; batch of one per call)"
 
 
 if __name__ == "__main__":

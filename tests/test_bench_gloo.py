@@ -1,0 +1,61 @@
+"""bench.py's own multi-rank branch, run on CPU: `--gpus 2` with WORLD_SIZE unset makes bench.py start the two ranks
+itself (a torch.distributed.run child), `--backend gloo --dry` replaces the kernels by a deterministic record per pair
+so that everything else -- process-group init, barriers, the asynchronous record gather after every step, the
+max-over-ranks reduction of the elapsed time, the JSON line -- is the code the GPU run executes."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra, timeout=280):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--backend", "gloo", "--dry", "--length", "60",
+                        "--steps", "3", "--warmup", "1"] + extra, env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout  # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(300)
+def test_gpus_flag_starts_the_ranks_weak(built):
+    out = _run(["--gpus", "2", "--pairs", "1000"])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak"
+    c = out["config"]
+    assert c["ranks_seen_by_collective"] == 2 and c["pairs_per_rank"] == [1000, 1000]
+    assert c["total_pairs_per_step"] == 2000 and c["gathered_records_complete"] is True
+    assert c["gather_bytes_per_rank_step"] == 1000 * 11 * 4 and c["gather_ms_standalone"] > 0
+    assert out["steps"] == 3 and out["value"] == pytest.approx(2000 * 3 / (out["ms_per_step"] * 3e-3), rel=1e-6)
+
+
+@pytest.mark.timeout(300)
+def test_total_pairs_is_strong_scaling_with_uneven_shards(built):
+    out = _run(["--gpus", "2", "--total-pairs", "2001", "--gather-ops"])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong"
+    c = out["config"]
+    assert c["pairs_per_rank"] == [1001, 1000] and c["total_pairs_per_step"] == 2001
+    assert c["gathered_records_complete"] is True and c["gather"] == "records + CIGAR ops"
+
+
+@pytest.mark.timeout(300)
+def test_single_rank_dry_line(built):
+    out = _run(["--gpus", "1", "--pairs", "500"])
+    assert out["n_gpus"] == 1 and out["config"]["pairs_per_rank"] == [500] and out["config"]["dry"] is True
+
+
+def test_configs_name_the_baseline_workloads():
+    sys.path.insert(0, ROOT)
+    import bench
+    a = bench.parse_args([])
+    assert (a.pairs, a.length, a.error, a.seed, a.semi_global, a.no_adaptive, a.total_pairs) == (1_000_000, 1000, 0.05, 3, False, False, 0)
+    a = bench.parse_args(["--config", "c2"])
+    assert (a.pairs, a.length, a.error, a.seed, a.no_adaptive) == (100_000, 150, 0.02, 2, True)
+    a = bench.parse_args(["--config", "c4", "--gpus", "8"])
+    assert (a.total_pairs, a.length, a.seed) == (10_000_000, 1000, 4)
+    a = bench.parse_args(["--config", "c5s"])
+    assert (a.pairs, a.length, a.error, a.semi_global, a.no_adaptive) == (8, 100_000, 0.10, True, False)

@@ -138,7 +138,10 @@ def test_synthetic_batches(built, length, err, n, glob, adaptive):
     al.close()
 
 
-@pytest.mark.parametrize("pen", [(4, 6, 2), (1, 1, 1), (2, 3, 1), (5, 0, 3), (3, 7, 2), (6, 5, 4), (2, 12, 1)])
+# (6,4,2), (3,1,2): x == o+e; (2,4,2), (2,2,2): x == e; (4,2,2): o+e == 2e -- the shapes in which two of next()'s
+# sources come from the same earlier score
+@pytest.mark.parametrize("pen", [(4, 6, 2), (1, 1, 1), (2, 3, 1), (5, 0, 3), (3, 7, 2), (6, 5, 4), (2, 12, 1),
+                                 (6, 4, 2), (2, 4, 2), (4, 2, 2), (3, 1, 2), (2, 2, 2)])
 def test_other_penalties(built, pen):
     import wfa_amd as w
     from oracle import oracle as O
@@ -573,6 +576,42 @@ def test_config5_sample(built):
     al.set_option("team_min_len", 0)  # wfa_generic_kernel<16,0>
     assert_batch_equal(al.align_arrays(*data), want, "C5 sample, one workgroup per pair")
     assert al.last_timing().cells_stored == cells
+    al.close()
+
+
+@pytest.mark.timeout(1500)
+def test_config5_full_length_pair(built):
+    """BASELINE configs[4] at its stated length: 100 kbp pairs @10 %, semi-global + wf-adaptive 10/50/1 (seed 5, the
+    bench's --config c5s dataset), every record and every CIGAR op against the oracle (minutes of one host core per
+    pair)."""
+    import wfa_amd as w
+    from oracle import oracle as O
+    data = w.generate_pairs(seed=5, n_pairs=2, length=100_000, error_rate=0.10)
+    al = _aligner(False, (10, 50, 1))
+    got = al.align_arrays(*data)
+    want = O.align_batch(_oracle_params(False), *data, n_threads=2)
+    assert_batch_equal(got, want, "C5 full length")
+    assert (got.status == 0).all() and got.score.min() > 10_000
+    al.close()
+
+
+def test_failed_retry_pass_fails_the_call(built):
+    """A sub-wave retry pass that cannot get its arena (injected: option fail_pass = 5, the 256-diagonal rung) must
+    fail the whole call with its error code -- not drop the pairs it was given and report success."""
+    import ctypes as C
+    import wfa_amd as w
+    from wfa_amd import _lib as L
+    data = w.generate_pairs(seed=5, n_pairs=300, length=400, error_rate=0.06, n_threads=8)  # bands of ~100 diagonals
+    al = _aligner(True, None)
+    ok = al.align_arrays(*data)
+    assert al.last_timing().n_retried_pairs > 0
+    al.set_option("fail_pass", 5)
+    with pytest.raises(L.WfaHipError) as ei:
+        al.align_arrays(*data)
+    assert ei.value.code == L.ERR_OOM
+    al.set_option("fail_pass", 0)
+    again = al.align_arrays(*data)
+    assert_batch_equal(again, ok, "after the injected failure")
     al.close()
 
 

@@ -18,7 +18,7 @@ struct FinParams {
     const uint32_t *rec;      // [n][REC_WORDS]
     const uint64_t *ops;      // shared op buffer of the alignment kernels
     uint64_t        n;
-    uint32_t       *loc_off;  // [n] exclusive offset inside the pair's scan block
+    uint64_t       *loc_off;  // [n] exclusive offset inside the pair's scan block (64-bit: 4 096 long pairs can hold > 2^32 ops)
     uint64_t       *blk_sum;  // [n_blocks] ops per scan block, then exclusive bases
     // outputs (struct of arrays, device)
     int32_t  *status;
@@ -39,11 +39,11 @@ __device__ __forceinline__ uint32_t fin_len(const FinParams &F, uint64_t i) {
 
 // pass 1: per-pair offsets inside a block of FIN_BLOCK*FIN_ITEMS pairs + the block's total
 __global__ __launch_bounds__(FIN_BLOCK) void fin_scan_blocks(const FinParams F) {
-    __shared__ uint32_t wsum[FIN_BLOCK / 64];
+    __shared__ unsigned long long wsum[FIN_BLOCK / 64];
     const int      tid  = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint64_t i0   = ((uint64_t)blockIdx.x * FIN_BLOCK + tid) * FIN_ITEMS;
-    uint32_t           v[FIN_ITEMS], mine = 0;
-    unsigned long long cells = 0ull;
+    uint32_t           v[FIN_ITEMS];
+    unsigned long long mine = 0ull, cells = 0ull;
 #pragma unroll
     for (int k = 0; k < FIN_ITEMS; k++) {
         v[k] = fin_len(F, i0 + k), mine += v[k];
@@ -54,17 +54,17 @@ __global__ __launch_bounds__(FIN_BLOCK) void fin_scan_blocks(const FinParams F) 
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cells += __shfl_xor(cells, o, 64);
     if (lane == 0 && cells != 0ull) atomicAdd(&F.totals[1], cells);
-    uint32_t incl = mine;  // inclusive scan inside the wave
+    unsigned long long incl = mine;  // inclusive scan inside the wave
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(incl, o, 64);
+        const unsigned long long t = __shfl_up(incl, o, 64);
         if (lane >= o) incl += t;
     }
     if (lane == 63) wsum[wv] = incl;
     __syncthreads();
-    uint32_t wbase = 0;
+    unsigned long long wbase = 0ull;
     for (int w = 0; w < wv; w++) wbase += wsum[w];
-    uint32_t run = wbase + incl - mine;
+    unsigned long long run = wbase + incl - mine;
 #pragma unroll
     for (int k = 0; k < FIN_ITEMS; k++) {
         if (i0 + k < F.n) F.loc_off[i0 + k] = run;

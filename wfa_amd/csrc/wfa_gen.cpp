@@ -92,14 +92,24 @@ extern "C" int wfahip_generate_pairs(uint64_t seed, uint64_t first_index, uint64
     if (n_threads < 1) n_threads = 1;
     if ((uint64_t)n_threads > n_pairs) n_threads = n_pairs ? (int)n_pairs : 1;
     std::vector<std::thread> th;
+    try {
+        th.reserve((size_t)n_threads);
+    } catch (...) {
+        n_threads = 1;
+    }
     const uint64_t           per = (n_pairs + n_threads - 1) / n_threads;
     for (int i = 0; i < n_threads; i++) {
         uint64_t b = std::min<uint64_t>(n_pairs, (uint64_t)i * per), e = std::min<uint64_t>(n_pairs, b + per);
-        if (n_threads == 1)
-            gen_range(seed, first_index, b, e, length, error_rate, stride, blob, q_off, q_len, t_off, t_len);
-        else
-            th.emplace_back(gen_range, seed, first_index, b, e, length, error_rate, stride, blob, q_off, q_len,
-                            t_off, t_len);
+        bool inline_run = n_threads == 1;
+        if (!inline_run) {
+            try {
+                th.emplace_back(gen_range, seed, first_index, b, e, length, error_rate, stride, blob, q_off, q_len,
+                                t_off, t_len);
+            } catch (...) {  // no thread to be had: this range is generated here (no exception crosses the C-ABI,
+                inline_run = true;  // and no joinable thread is destroyed)
+            }
+        }
+        if (inline_run) gen_range(seed, first_index, b, e, length, error_rate, stride, blob, q_off, q_len, t_off, t_len);
     }
     for (auto &t : th) t.join();
     return WFAHIP_OK;

@@ -20,6 +20,7 @@
 #include <deque>
 #include <malloc.h>
 #include <mutex>
+#include <new>
 #include <numeric>
 #include <string>
 #include <thread>
@@ -36,6 +37,17 @@ using namespace wfa;
             return (_e == hipErrorOutOfMemory) ? WFAHIP_ERR_OOM : WFAHIP_ERR_HIP;                      \
         }                                                                                              \
     } while (0)
+
+// No C++ exception may cross the C-ABI (a cgo / ctypes caller cannot unwind): every extern "C" body with an
+// allocation in it runs inside this guard.
+#define WFAHIP_GUARD(expr)                  \
+    try {                                   \
+        return (expr);                      \
+    } catch (const std::bad_alloc &) {      \
+        return WFAHIP_ERR_OOM;              \
+    } catch (...) {                         \
+        return WFAHIP_ERR_INTERNAL;         \
+    }
 
 namespace {
 
@@ -101,6 +113,7 @@ struct wfahip_ctx {
     int64_t       opt_pilot                = 1;  // 1: a 4 096-pair pilot decides whether a large batch uses the sub-wave kernels
     int64_t       opt_tail_overlap         = 1;  // 1: retry passes overlap the backtrace kernel of the first pass
     int64_t       opt_overlap              = 0;  // 1: backtrace of chunk c on a second stream beside the forward kernel of chunk c+1 (measured: no gain)
+    int64_t       opt_fail_pass            = 0;   // test aid (fault injection): the sub-wave pass of this kind reports WFAHIP_ERR_OOM
     int           force_mode               = -1;  // debug: start the ladder in this mode
     wfahip_timing timing{};
     char          last_error[256] = {0};
@@ -238,7 +251,7 @@ extern "C" int wfahip_device_count(void) {
     return n;
 }
 
-extern "C" int wfahip_create(int device_id, wfahip_ctx **out) {
+static int create_impl(int device_id, wfahip_ctx **out) {
     if (!out) return WFAHIP_ERR_BAD_ARG;
     *out = nullptr;
     int n = wfahip_device_count();
@@ -264,12 +277,14 @@ extern "C" int wfahip_create(int device_id, wfahip_ctx **out) {
         hipEventCreate(&ctx->evC) != hipSuccess || hipEventCreate(&ctx->evBtA) != hipSuccess ||
         hipEventCreate(&ctx->evBtB) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void **>(&ctx->hpin), HPIN_WORDS * 4, hipHostMallocDefault) != hipSuccess) {
-        delete ctx;
+        wfahip_destroy(ctx);  // (releases whichever streams / events were created)
         return WFAHIP_ERR_HIP;
     }
     *out = ctx;
     return WFAHIP_OK;
 }
+
+extern "C" int wfahip_create(int device_id, wfahip_ctx **out) { WFAHIP_GUARD(create_impl(device_id, out)) }
 
 extern "C" void wfahip_destroy(wfahip_ctx *ctx) {
     if (!ctx) return;
@@ -298,7 +313,7 @@ extern "C" void wfahip_destroy(wfahip_ctx *ctx) {
     delete ctx;
 }
 
-extern "C" int wfahip_set_option(wfahip_ctx *ctx, const char *key, int64_t value) {
+static int set_option_impl(wfahip_ctx *ctx, const char *key, int64_t value) {
     if (!ctx || !key) return WFAHIP_ERR_BAD_ARG;
     std::string k(key);
     if (k == "arena_bytes_per_slot")
@@ -345,10 +360,14 @@ extern "C" int wfahip_set_option(wfahip_ctx *ctx, const char *key, int64_t value
         ctx->opt_team_wgs = value;
     else if (k == "team_solo_max")
         ctx->opt_team_solo_max = value;
+    else if (k == "fail_pass")
+        ctx->opt_fail_pass = value;
     else
         return WFAHIP_ERR_BAD_ARG;
     return WFAHIP_OK;
 }
+
+extern "C" int wfahip_set_option(wfahip_ctx *ctx, const char *key, int64_t value) { WFAHIP_GUARD(set_option_impl(ctx, key, value)) }
 
 extern "C" int wfahip_last_timing(const wfahip_ctx *ctx, wfahip_timing *out) {
     if (!ctx || !out) return WFAHIP_ERR_BAD_ARG;
@@ -366,10 +385,10 @@ static int check_params(const wfahip_params *p) {
 }
 
 // Core: everything device-resident.  keep_debug: run with one slot and keep ctrl debug words.
-static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_blob, uint64_t blob_bytes,
-                        const void *d_q_off, const void *d_q_len, const void *d_t_off, const void *d_t_len,
-                        uint64_t n_pairs, uint32_t max_len, void *d_rec, void *d_ops, uint64_t ops_cap,
-                        uint64_t *ops_needed, hipStream_t st, bool debug_single, uint64_t ops_cursor0 = 0) {
+static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void *d_blob, uint64_t blob_bytes,
+                             const void *d_q_off, const void *d_q_len, const void *d_t_off, const void *d_t_len,
+                             uint64_t n_pairs, uint32_t max_len, void *d_rec, void *d_ops, uint64_t ops_cap,
+                             uint64_t *ops_needed, hipStream_t st, bool debug_single, uint64_t ops_cursor0) {
     // (ops_cursor0: where this call's ops start in d_ops -- the host entry aligns a batch in several calls that
     // share one op buffer)
     int rc = check_params(p);
@@ -526,6 +545,7 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
             // (kind 6: eight pairs per wave, 32-diagonal window; only with the batched refill)
             const bool     blk_batch    = (kind == 3 || kind == 6) && seq_words <= 16 && ctx->opt_blk_batch != 0;
             if (kind == 6 && !blk_batch) return WFAHIP_ERR_INTERNAL;
+            if (ctx->opt_fail_pass == kind) return WFAHIP_ERR_OOM;  // (fault injection, tests only)
             const size_t   lds_bytes    = blk_batch ? (size_t)(kind == 6 ? 8 : 4) * BLK_BATCH * (2 * seq_words + 8) * 4 + 16
                                           : kind == 5 ? (size_t)seq_words * 2 * 4 + 16
                                                       : (kind >= 3 ? lds_d : (kind == 2 ? lds_c : lds_b));
@@ -675,8 +695,8 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
                 from.clear();
                 if (lst.empty()) return 0;
                 std::vector<uint64_t> r2;
-                int rcw = forward_pass(5, &lst, 0, lst.size(), r2, false);
-                if (rcw) return -rcw;
+                const int rcw = forward_pass(5, &lst, 0, lst.size(), r2, false);
+                if (rcw) return rcw;  // WFAHIP_ERR_* (negative): the whole call fails, no pair is silently dropped
                 ctx->timing.n_packed_pairs += (uint32_t)(lst.size() - r2.size());
                 redo_w.insert(redo_w.end(), r2.begin(), r2.end());
                 return r2.size() * 2 > lst.size() ? 2 : 1;  // 2: the wide kernel does not take most of them either
@@ -689,7 +709,7 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
                 n_first_fail = redo1.size();
                 if (redo1.size() * 2 > pilot) {
                     const int wv = wide_ok ? wide_pass(redo1) : 2;
-                    if (wv < 0) return -wv;
+                    if (wv < 0) return wv;
                     if (wv == 1) kind_rest = 5;
                     else skip_rest = true;
                 }
@@ -742,7 +762,7 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
             if (wide_ok) {
                 // pairs whose band outgrew the 64-diagonal window: the same kernel with a wave per pair (256 diagonals)
                 const int wv = wide_pass(redo1);
-                if (wv < 0) return -wv;
+                if (wv < 0) return wv;
             }
             redo1.insert(redo1.end(), redo_w.begin(), redo_w.end());
             redo_w.clear();
@@ -953,6 +973,15 @@ static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_b
     return WFAHIP_OK;
 }
 
+// (exception-safe: the host entry calls this while its upload / download threads are joinable)
+static int align_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_blob, uint64_t blob_bytes,
+                        const void *d_q_off, const void *d_q_len, const void *d_t_off, const void *d_t_len,
+                        uint64_t n_pairs, uint32_t max_len, void *d_rec, void *d_ops, uint64_t ops_cap,
+                        uint64_t *ops_needed, hipStream_t st, bool debug_single, uint64_t ops_cursor0 = 0) {
+    WFAHIP_GUARD(align_device_impl(ctx, p, d_blob, blob_bytes, d_q_off, d_q_len, d_t_off, d_t_len, n_pairs, max_len, d_rec, d_ops,
+                                   ops_cap, ops_needed, st, debug_single, ops_cursor0))
+}
+
 extern "C" int wfahip_align_batch_device(wfahip_ctx *ctx, const wfahip_params *p, const void *d_seq_blob,
                                          uint64_t blob_bytes, const void *d_q_off, const void *d_q_len,
                                          const void *d_t_off, const void *d_t_len, uint64_t n_pairs,
@@ -1111,10 +1140,10 @@ int download(wfahip_ctx *ctx, void *dst, const void *src, size_t bytes, hipStrea
 
 }  // namespace
 
-extern "C" int wfahip_align_batch(wfahip_ctx *ctx, const wfahip_params *p, const uint8_t *seq_blob,
-                                  uint64_t blob_bytes, const uint64_t *q_off, const uint32_t *q_len,
-                                  const uint64_t *t_off, const uint32_t *t_len, uint64_t n_pairs,
-                                  wfahip_results *out) {
+static int align_batch_impl(wfahip_ctx *ctx, const wfahip_params *p, const uint8_t *seq_blob,
+                            uint64_t blob_bytes, const uint64_t *q_off, const uint32_t *q_len,
+                            const uint64_t *t_off, const uint32_t *t_len, uint64_t n_pairs,
+                            wfahip_results *out) {
     if (!ctx || !out) return WFAHIP_ERR_BAD_ARG;
     results_zero(out);
     int rc = check_params(p);
@@ -1222,7 +1251,7 @@ extern "C" int wfahip_align_batch(wfahip_ctx *ctx, const wfahip_params *p, const
                 return o;
             };
             const uint64_t so_tot = takes(16 * UP_SLICES), so_blk = takes(8ull * (n / per_blk + UP_SLICES + 1)), so_ooff = takes(8ull * n),
-                           so_loc = takes(4ull * n);
+                           so_loc = takes(8ull * n);
             uint64_t so_f[11];
             for (int i = 0; i < 11; i++) so_f[i] = takes(4ull * n);
             const uint64_t so_ops = takes(8ull * ops_cap);
@@ -1321,7 +1350,7 @@ extern "C" int wfahip_align_batch(wfahip_ctx *ctx, const wfahip_params *p, const
                 F.ops = static_cast<const uint64_t *>(ctx->out_ops.p), F.n = nk;
                 F.totals  = reinterpret_cast<unsigned long long *>(sfb + so_tot) + 2 * k;
                 F.blk_sum = reinterpret_cast<uint64_t *>(sfb + so_blk) + blk_done;
-                F.loc_off = reinterpret_cast<uint32_t *>(sfb + so_loc) + k0;
+                F.loc_off = reinterpret_cast<uint64_t *>(sfb + so_loc) + k0;
                 F.ops_off = reinterpret_cast<uint64_t *>(sfb + so_ooff) + k0;
                 F.status = reinterpret_cast<int32_t *>(sfb + so_f[0]) + k0, F.score = reinterpret_cast<uint32_t *>(sfb + so_f[1]) + k0;
                 F.tbegin = reinterpret_cast<int32_t *>(sfb + so_f[2]) + k0, F.tend = reinterpret_cast<int32_t *>(sfb + so_f[3]) + k0;
@@ -1418,7 +1447,7 @@ extern "C" int wfahip_align_batch(wfahip_ctx *ctx, const wfahip_params *p, const
         off += al8(bytes);
         return o;
     };
-    const uint64_t o_tot = take(16), o_blk = take(8ull * n_blocks), o_ooff = take(8ull * n), o_loc = take(4ull * n);
+    const uint64_t o_tot = take(16), o_blk = take(8ull * n_blocks), o_ooff = take(8ull * n), o_loc = take(8ull * n);
     uint64_t       o_f[11];
     for (int i = 0; i < 11; i++) o_f[i] = take(4ull * n);
     const uint64_t o_ops = take(8ull * ops_total_cap);
@@ -1428,7 +1457,7 @@ extern "C" int wfahip_align_batch(wfahip_ctx *ctx, const wfahip_params *p, const
     F.rec = static_cast<const uint32_t *>(ctx->out_rec.p), F.ops = static_cast<const uint64_t *>(ctx->out_ops.p), F.n = n;
     F.totals  = reinterpret_cast<unsigned long long *>(fb + o_tot);
     F.blk_sum = reinterpret_cast<uint64_t *>(fb + o_blk), F.ops_off = reinterpret_cast<uint64_t *>(fb + o_ooff);
-    F.loc_off = reinterpret_cast<uint32_t *>(fb + o_loc);
+    F.loc_off = reinterpret_cast<uint64_t *>(fb + o_loc);
     F.status = reinterpret_cast<int32_t *>(fb + o_f[0]), F.score = reinterpret_cast<uint32_t *>(fb + o_f[1]);
     F.tbegin = reinterpret_cast<int32_t *>(fb + o_f[2]), F.tend = reinterpret_cast<int32_t *>(fb + o_f[3]);
     F.qbegin = reinterpret_cast<int32_t *>(fb + o_f[4]), F.qend = reinterpret_cast<int32_t *>(fb + o_f[5]);
@@ -1481,9 +1510,16 @@ extern "C" int wfahip_align_batch(wfahip_ctx *ctx, const wfahip_params *p, const
     return rc;
 }
 
-extern "C" int wfahip_debug_wavefronts(wfahip_ctx *ctx, const wfahip_params *p, const uint8_t *q, uint32_t n,
-                                       const uint8_t *t, uint32_t m, wfahip_row **rows, uint64_t *n_rows,
-                                       uint32_t **words, uint64_t *n_words, wfahip_results *res) {
+extern "C" int wfahip_align_batch(wfahip_ctx *ctx, const wfahip_params *p, const uint8_t *seq_blob,
+                                  uint64_t blob_bytes, const uint64_t *q_off, const uint32_t *q_len,
+                                  const uint64_t *t_off, const uint32_t *t_len, uint64_t n_pairs,
+                                  wfahip_results *out) {
+    WFAHIP_GUARD(align_batch_impl(ctx, p, seq_blob, blob_bytes, q_off, q_len, t_off, t_len, n_pairs, out))
+}
+
+static int debug_wavefronts_impl(wfahip_ctx *ctx, const wfahip_params *p, const uint8_t *q, uint32_t n,
+                                 const uint8_t *t, uint32_t m, wfahip_row **rows, uint64_t *n_rows,
+                                 uint32_t **words, uint64_t *n_words, wfahip_results *res) {
     if (!ctx || !rows || !n_rows || !words || !n_words || !q || !t || n == 0 || m == 0) return WFAHIP_ERR_BAD_ARG;
     *rows = nullptr, *words = nullptr, *n_rows = 0, *n_words = 0;
     if (res) results_zero(res);
@@ -1575,4 +1611,10 @@ extern "C" int wfahip_debug_wavefronts(wfahip_ctx *ctx, const wfahip_params *p, 
         rc = unpack_results(rec, ops, 1, res, nullptr);
     }
     return rc;
+}
+
+extern "C" int wfahip_debug_wavefronts(wfahip_ctx *ctx, const wfahip_params *p, const uint8_t *q, uint32_t n,
+                                       const uint8_t *t, uint32_t m, wfahip_row **rows, uint64_t *n_rows,
+                                       uint32_t **words, uint64_t *n_words, wfahip_results *res) {
+    WFAHIP_GUARD(debug_wavefronts_impl(ctx, p, q, n, t, m, rows, n_rows, words, n_words, res))
 }
