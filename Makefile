@@ -3,7 +3,7 @@ HIPCC   ?= hipcc
 ARCH    ?= gfx950
 HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function
 LIB     := wfa_amd/lib/libwfahip.so
-SRC     := wfa_amd/csrc/wfa_host.hip wfa_amd/csrc/wfa_gen.cpp
+SRC     := wfa_amd/csrc/wfa_host.hip wfa_amd/csrc/wfa_gen.cpp wfa_amd/csrc/wfa_multi.cpp
 HDR     := $(wildcard wfa_amd/csrc/*.hpp) include/wfa_hip.h
 
 all: $(LIB) oracle

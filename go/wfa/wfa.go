@@ -60,10 +60,15 @@ var ErrSeqTooLong error = fmt.Errorf("wfa: sequences longer than %d are not supp
 // Aligner holds one device context.  Like the reference's (wfa.go:73-78) it must not be used from several
 // goroutines at once; create one per goroutine (different Aligners may run concurrently).
 type Aligner struct {
-	p   *Penalties
-	ad  *AdaptiveReductionOption
-	opt *Options
-	ctx *C.wfahip_ctx
+	p     *Penalties
+	ad    *AdaptiveReductionOption
+	opt   *Options
+	ctx   *C.wfahip_ctx
+	multi *C.wfahip_multi // NewMulti: AlignBatch shards over several GPUs
+
+	// M, I, D: the reference exports its three components (wfa.go:86) for Plot and its test (wfa_test.go:154).
+	// On the GPU path the wavefronts live in HBM and are released per batch; Plot below fetches one pair's
+	// stored rows on demand (wfahip_debug_wavefronts) instead of keeping these fields.
 }
 
 // New returns a new Aligner bound to the current HIP device.  (wfa.go:120)
@@ -75,9 +80,35 @@ func New(p *Penalties, opt *Options) *Aligner {
 	return algn
 }
 
-// RecycleAligner releases the device context.  (wfa.go:102)
+// NewMulti returns an Aligner whose AlignBatch shards the pairs over the given GPUs (nil = every GPU): one context
+// and one host thread per GPU inside the library, results merged in pair order.  The reference's model is one
+// Aligner per goroutine (wfa.go:73-78); this is that model behind one call.  Align / Submit use the first GPU.
+func NewMulti(p *Penalties, opt *Options, devices []int) *Aligner {
+	algn := &Aligner{p: p, opt: opt}
+	var ids *C.int
+	cids := make([]C.int, len(devices))
+	for i, d := range devices {
+		cids[i] = C.int(d)
+	}
+	if len(cids) > 0 {
+		ids = &cids[0]
+	}
+	if rc := C.wfahip_create_multi(ids, C.int(len(cids)), &algn.multi); rc != 0 {
+		panic(fmt.Sprintf("wfa: %s", C.GoString(C.wfahip_strerror(rc))))
+	}
+	algn.ctx = C.wfahip_multi_ctx(algn.multi, 0) // owned by the set
+	return algn
+}
+
+// RecycleAligner releases the device context(s).  (wfa.go:102)
 func RecycleAligner(algn *Aligner) {
-	if algn != nil && algn.ctx != nil {
+	if algn == nil {
+		return
+	}
+	if algn.multi != nil {
+		C.wfahip_destroy_multi(algn.multi)
+		algn.multi, algn.ctx = nil, nil
+	} else if algn.ctx != nil {
 		C.wfahip_destroy(algn.ctx)
 		algn.ctx = nil
 	}
@@ -150,9 +181,22 @@ func (algn *Aligner) AlignBatch(qs, ts [][]byte) ([]*AlignmentResult, []error) {
 	}
 	p := algn.params()
 	var out C.wfahip_results
-	rc := C.wfahip_align_batch(algn.ctx, &p, (*C.uint8_t)(unsafe.Pointer(&blob[0])), C.uint64_t(len(blob)),
-		&qOff[0], &qLen[0], &tOff[0], &tLen[0], C.uint64_t(n), &out)
+	var rc C.int
+	if algn.multi != nil { // a context set over several GPUs: contiguous shards, one host thread per GPU inside the library
+		rc = C.wfahip_align_batch_multi(algn.multi, &p, (*C.uint8_t)(unsafe.Pointer(&blob[0])), C.uint64_t(len(blob)),
+			&qOff[0], &qLen[0], &tOff[0], &tLen[0], C.uint64_t(n), &out)
+	} else {
+		rc = C.wfahip_align_batch(algn.ctx, &p, (*C.uint8_t)(unsafe.Pointer(&blob[0])), C.uint64_t(len(blob)),
+			&qOff[0], &qLen[0], &tOff[0], &tLen[0], C.uint64_t(n), &out)
+	}
 	runtime.KeepAlive(blob)
+	return algn.unpack(rc, &out, n)
+}
+
+// unpack copies a wfahip_results into pool-owned AlignmentResults and hands the C arrays back to the library.
+func (algn *Aligner) unpack(rc C.int, out *C.wfahip_results, n int) ([]*AlignmentResult, []error) {
+	results := make([]*AlignmentResult, n)
+	errs := make([]error, n)
 	if rc != 0 {
 		err := fmt.Errorf("wfa: %s", C.GoString(C.wfahip_strerror(rc)))
 		for i := range errs {
@@ -160,7 +204,7 @@ func (algn *Aligner) AlignBatch(qs, ts [][]byte) ([]*AlignmentResult, []error) {
 		}
 		return results, errs
 	}
-	defer C.wfahip_results_free(&out)
+	defer C.wfahip_results_free(out)
 	status := unsafe.Slice((*int32)(unsafe.Pointer(out.status)), n)
 	score := unsafe.Slice((*uint32)(unsafe.Pointer(out.score)), n)
 	tb := unsafe.Slice((*int32)(unsafe.Pointer(out.tbegin)), n)
@@ -196,4 +240,66 @@ func (algn *Aligner) AlignBatch(qs, ts [][]byte) ([]*AlignmentResult, []error) {
 		}
 	}
 	return results, errs
+}
+
+// Submit hands in one pair (the bytes are copied) and returns its ticket; Collect aligns everything submitted since
+// the last Collect as ONE batch.  A per-pair loop like the reference's CLI (wfa-go/wfa-go.go:166-178) keeps its shape --
+// Submit where it called Align, one Collect at the end -- and runs at batch throughput instead of one device round
+// trip per pair.
+func (algn *Aligner) Submit(q, t []byte) uint64 {
+	var ticket C.uint64_t
+	var qp, tp *C.uint8_t
+	if len(q) > 0 {
+		qp = (*C.uint8_t)(unsafe.Pointer(&q[0]))
+	}
+	if len(t) > 0 {
+		tp = (*C.uint8_t)(unsafe.Pointer(&t[0]))
+	}
+	C.wfahip_submit(algn.ctx, qp, C.uint32_t(len(q)), tp, C.uint32_t(len(t)), &ticket)
+	runtime.KeepAlive(q)
+	runtime.KeepAlive(t)
+	return uint64(ticket)
+}
+
+// Collect returns results[ticket], errs[ticket] for every pair submitted since the last Collect.
+func (algn *Aligner) Collect() ([]*AlignmentResult, []error) {
+	n := int(C.wfahip_pending(algn.ctx))
+	p := algn.params()
+	var out C.wfahip_results
+	rc := C.wfahip_collect(algn.ctx, &p, &out)
+	return algn.unpack(rc, &out, n)
+}
+
+// Wavefronts returns every stored M, I and D word (offset<<3 | type, wfa_wavefront.go:93) of one alignment, keyed by
+// component, score and diagonal: what the reference keeps in Aligner.M/I/D (wfa.go:86) after Align.  A maintainer's
+// Plot (wfa_component_plot.go:41) iterates exactly this; wfa_amd/aligner.py:plot_component is that function over the
+// same data and reproduces the README tables from device wavefronts (tests/test_parity_gpu.py).
+func (algn *Aligner) Wavefronts(q, t []byte) (map[byte]map[uint32]map[int]uint32, error) {
+	var rows *C.wfahip_row
+	var words *C.uint32_t
+	var nRows, nWords C.uint64_t
+	p := algn.params()
+	rc := C.wfahip_debug_wavefronts(algn.ctx, &p, (*C.uint8_t)(unsafe.Pointer(&q[0])), C.uint32_t(len(q)),
+		(*C.uint8_t)(unsafe.Pointer(&t[0])), C.uint32_t(len(t)), &rows, &nRows, &words, &nWords, nil)
+	if rc != 0 {
+		return nil, fmt.Errorf("wfa: %s", C.GoString(C.wfahip_strerror(rc)))
+	}
+	defer C.wfahip_free(unsafe.Pointer(rows))
+	defer C.wfahip_free(unsafe.Pointer(words))
+	out := map[byte]map[uint32]map[int]uint32{'M': {}, 'I': {}, 'D': {}}
+	rs := unsafe.Slice(rows, int(nRows))
+	ws := unsafe.Slice((*uint32)(unsafe.Pointer(words)), int(nWords))
+	for _, r := range rs {
+		for ci, name := range []byte("MID") {
+			for j := 0; j < int(r.width); j++ {
+				if w := ws[int(r.word_off)+ci*int(r.width)+j]; w != 0 {
+					if out[name][uint32(r.score)] == nil {
+						out[name][uint32(r.score)] = map[int]uint32{}
+					}
+					out[name][uint32(r.score)][int(r.lo)+j] = w
+				}
+			}
+		}
+	}
+	return out, nil
 }

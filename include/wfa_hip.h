@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define WFAHIP_VERSION 100 /* 0.1.0 */
+#define WFAHIP_VERSION 200 /* 0.2.0 */
 
 /* whole-call return codes (0 = success, negative = failure) */
 enum {
@@ -144,6 +144,45 @@ int  wfahip_align_batch_device(wfahip_ctx *ctx, const wfahip_params *p, const vo
                                uint32_t max_len, void *d_rec, void *d_ops, uint64_t ops_cap,
                                uint64_t *ops_needed, void *stream);
 
+/* Pre-packed input: the sequences arrive 2-bit packed, 16 bases per uint32 (base i of a
+ * sequence in bits 2(i%16).. of word i/16, code = (ascii >> 1) & 3: A 0, C 1, T 2, G 3), every sequence starting at a
+ * word boundary and followed by one pad word; pair i is packed[q_woff[i] ..] (q_len[i] bases) vs packed[t_woff[i] ..].
+ * A quarter of the bytes cross PCIe; the device expands them into the byte blob the kernels read.  Valid only for
+ * pure uppercase ACGT input -- the reference compares raw bytes (wfa.go:408-454), so anything else must use
+ * wfahip_align_batch.  wfahip_pack_pairs is the host-side packer (n_threads host threads; returns
+ * WFAHIP_ERR_UNSUPPORTED if a byte outside ACGT is found); packed must hold the sum over all sequences of
+ * wfahip_packed_words(len) words.  Results are identical to wfahip_align_batch on the unpacked bytes. */
+uint64_t wfahip_packed_words(uint32_t len);
+int  wfahip_pack_pairs(const uint8_t *seq_blob, const uint64_t *q_off, const uint32_t *q_len, const uint64_t *t_off,
+                       const uint32_t *t_len, uint64_t n_pairs, int n_threads, uint32_t *packed, uint64_t *q_woff,
+                       uint64_t *t_woff, uint64_t *n_words);
+int  wfahip_align_batch_packed(wfahip_ctx *ctx, const wfahip_params *p, const uint32_t *packed, uint64_t n_words,
+                               const uint64_t *q_woff, const uint32_t *q_len, const uint64_t *t_woff,
+                               const uint32_t *t_len, uint64_t n_pairs, wfahip_results *out);
+
+/* One pair at a time behind the batch: a caller that loops over pairs like the reference's CLI
+ * (wfa-go/wfa-go.go:166-178: one Align per ">"/"<" record) submits each pair -- the bytes are copied, the call returns
+ * at once with the pair's ticket (0, 1, 2, ... since the last collect) -- and collects all results with ONE batch
+ * alignment: out->...[ticket] is the result of that submission.  Same thread rule as every other call on a context. */
+int      wfahip_submit(wfahip_ctx *ctx, const uint8_t *q, uint32_t n, const uint8_t *t, uint32_t m, uint64_t *ticket);
+uint64_t wfahip_pending(const wfahip_ctx *ctx);
+int      wfahip_collect(wfahip_ctx *ctx, const wfahip_params *p, wfahip_results *out);
+
+/* A set of contexts, one per GPU, behind one call (wfahip_create(device_ids, n_devices)).
+ * wfahip_align_batch_multi cuts the batch into contiguous shards of pairs balanced by sequence bytes, aligns every
+ * shard on its own GPU from its own host thread (alignments share no state: one Aligner per goroutine in the
+ * reference, wfa.go:73-78) and merges the results in pair order.  device_ids == NULL: devices 0 .. n_devices-1
+ * (n_devices <= 0: every device).  The same id may appear more than once (several contexts on one GPU). */
+typedef struct wfahip_multi wfahip_multi;
+int         wfahip_create_multi(const int *device_ids, int n_devices, wfahip_multi **out);
+void        wfahip_destroy_multi(wfahip_multi *m);
+int         wfahip_multi_size(const wfahip_multi *m);
+wfahip_ctx *wfahip_multi_ctx(wfahip_multi *m, int i); /* for wfahip_set_option / wfahip_last_timing; owned by m */
+int         wfahip_align_batch_multi(wfahip_multi *m, const wfahip_params *p, const uint8_t *seq_blob,
+                                     uint64_t blob_bytes, const uint64_t *q_off, const uint32_t *q_len,
+                                     const uint64_t *t_off, const uint32_t *t_len, uint64_t n_pairs,
+                                     wfahip_results *out);
+
 int  wfahip_last_timing(const wfahip_ctx *ctx, wfahip_timing *out);
 
 /* Tuning knobs (optional; results never depend on them).  Keys:
@@ -182,6 +221,16 @@ int  wfahip_debug_wavefronts(wfahip_ctx *ctx, const wfahip_params *p, const uint
                              const uint8_t *t, uint32_t m, wfahip_row **rows, uint64_t *n_rows,
                              uint32_t **words, uint64_t *n_words, wfahip_results *res);
 void wfahip_free(void *p);
+
+/* Debug / parity aid: the compact backtrace arena of pair `pair` (an index of the most recent batch, inside its first
+ * chunk) exactly as the first-pass sub-wave forward kernel left it in HBM, + the pair's meta words {status, final
+ * score, end offset, cells}.  One word per diagonal and score: bits 0-2 M tag, 3-4 I tag (0 none, 1 open, 2 ext),
+ * 5-6 D tag, 7-31 the pre-extension offset backTrace recomputes (wfa.go:766-817).  *fmt = layout: 1 = 64 words per
+ * score index (score / gcd), diagonal k at slot k & 63; 3 = tiles of 8 score indices x 64 diagonals,
+ * [(k & 63) / 4][index & 7][k & 3]; 4 = 256 words per index, slot k & 255; 5 = 32 words per index, slot k & 31.
+ * Slots the kernel never wrote hold stale bytes.  Caller frees *words with wfahip_free. */
+int  wfahip_debug_compact_arena(wfahip_ctx *ctx, uint64_t pair, uint32_t **words, uint64_t *n_words, uint32_t *fmt,
+                                uint32_t *meta4);
 
 /* Synthetic input generator (host): the seeded dataset spec of DESIGN.md (mirrors what
  * WFA's generate_dataset, used by README.md:298-306, produces: random ACGT pattern of length

@@ -19,7 +19,7 @@ def test_exports_match_header(built):
     L = _lib.lib()
     for name in declared:
         assert getattr(L, name) is not None
-    assert L.wfahip_version() == 100
+    assert L.wfahip_version() == 200
 
 
 def test_struct_layouts(built):
@@ -84,3 +84,34 @@ def test_reference_api_surface(built):
     assert r.CIGAR(False) == "2I3M1X2M1H"
     assert r.CIGAR(True) == "3M1X2M"
     assert str(w.ErrEmptySeq) == "wfa: invalid empty sequence"
+
+
+def test_host_packer(built):
+    """wfahip_pack_pairs (host only): 16 bases per word, code (ascii >> 1) & 3, every sequence at a word boundary with
+    one pad word; anything outside uppercase ACGT is refused (the byte entry must take it: wfa.go:408-454 compares
+    raw bytes)."""
+    import wfa_amd
+    from wfa_amd import _lib
+    data = wfa_amd.generate_pairs(seed=4, n_pairs=300, length=77, error_rate=0.1, n_threads=2)
+    blob, q_off, q_len, t_off, t_len = data
+    for thr in (1, 3):
+        packed, q_woff, t_woff = wfa_amd.pack_pairs(*data, n_threads=thr)
+        code = {ord("A"): 0, ord("C"): 1, ord("T"): 2, ord("G"): 3}
+        pos = 0
+        for i in range(300):
+            for off, ln, woff in ((q_off, q_len, q_woff), (t_off, t_len, t_woff)):
+                assert int(woff[i]) == pos
+                seq = blob[int(off[i]):int(off[i]) + int(ln[i])]
+                nw = (int(ln[i]) + 15) // 16
+                for w in range(nw):
+                    want = 0
+                    for k, c in enumerate(seq[16 * w:16 * w + 16]):
+                        want |= code[int(c)] << (2 * k)
+                    assert int(packed[pos + w]) == want
+                assert int(packed[pos + nw]) == 0
+                pos += nw + 1
+        assert pos == packed.size
+    bad = wfa_amd.make_blob([b"ACGTN", b"acgt"], [b"ACGT", b"ACGT"])
+    with pytest.raises(_lib.WfaHipError) as ei:
+        wfa_amd.pack_pairs(*bad)
+    assert ei.value.code == _lib.ERR_UNSUPPORTED

@@ -12,7 +12,7 @@ def _build():
     os.makedirs(os.path.dirname(EXE), exist_ok=True)
     lib = os.path.join(ROOT, "wfa_amd", "lib")
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-o", EXE, os.path.join(ROOT, "tests", "cpp_host_test.cpp"),
-                           f"-L{lib}", "-lwfahip", f"-Wl,-rpath,{lib}", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+                           "-pthread", f"-L{lib}", "-lwfahip", f"-Wl,-rpath,{lib}", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
 
 
 def test_cpp_host_builds_and_fails_loudly_without_gpu(built):

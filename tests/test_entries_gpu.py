@@ -1,0 +1,105 @@
+"""GPU: the round-2 entry points of the C-ABI -- pre-packed 2-bit input, per-pair submit / collect, the context set
+over several GPUs -- each against the plain batch entry and the oracle."""
+import numpy as np
+import pytest
+
+from test_parity_gpu import _aligner, _oracle_params, assert_batch_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def test_packed_entry_matches_byte_entry_and_oracle(built):
+    import wfa_amd as w
+    from oracle import oracle as O
+    data = w.generate_pairs(seed=17, n_pairs=6000, length=300, error_rate=0.06, n_threads=8)
+    # ragged: cut some sequences short so that word boundaries and pad words fall everywhere
+    blob, q_off, q_len, t_off, t_len = data
+    rng = np.random.default_rng(3)
+    q_len = np.maximum(1, q_len - rng.integers(0, 200, len(q_len)).astype(np.uint32)).astype(np.uint32)
+    t_len = np.maximum(1, t_len - rng.integers(0, 200, len(t_len)).astype(np.uint32)).astype(np.uint32)
+    data = (blob, q_off, q_len, t_off, t_len)
+    packed = w.pack_pairs(*data)
+    for glob, ad in ((True, (10, 50, 1)), (True, None), (False, (10, 50, 1))):
+        al = _aligner(glob, ad)
+        got = al.align_arrays_packed(packed[0], packed[1], q_len, packed[2], t_len)
+        want = O.align_batch(_oracle_params(glob, ad), *data, n_threads=8)
+        assert_batch_equal(got, want, f"packed entry glob={glob} ad={ad}")
+        assert_batch_equal(al.align_arrays(*data), want, "byte entry")
+        al.close()
+
+
+def test_packed_entry_sliced_upload(built):
+    """A batch large enough for the sliced pipeline (upload of slice k+1 and its unpack kernel beside the alignment of
+    slice k): same results as the byte entry, pair by pair."""
+    import wfa_amd as w
+    n = 300_000
+    data = w.generate_pairs(seed=23, n_pairs=n, length=1000, error_rate=0.05, n_threads=32)
+    packed, q_woff, t_woff = w.pack_pairs(*data, n_threads=32)
+    assert packed.size * 16 >= (256 << 20)
+    al = _aligner(True, (10, 50, 1))
+    a = al.align_arrays(*data)
+    b = al.align_arrays_packed(packed, q_woff, data[2], t_woff, data[4])
+    assert_batch_equal(b, a, "packed (sliced) vs bytes")
+    al.close()
+
+
+def test_submit_collect_is_the_batch(built):
+    import wfa_amd as w
+    data = w.generate_pairs(seed=29, n_pairs=500, length=200, error_rate=0.08, n_threads=4)
+    blob, q_off, q_len, t_off, t_len = data
+    qs = [bytes(blob[int(q_off[i]):int(q_off[i]) + int(q_len[i])]) for i in range(500)]
+    ts = [bytes(blob[int(t_off[i]):int(t_off[i]) + int(t_len[i])]) for i in range(500)]
+    qs[7], ts[9] = b"", b""          # ErrEmptySeq keeps its ticket
+    qs[11] = b"ACGTNNNNACGT"         # byte path inside the batch
+    al = _aligner(True, (10, 50, 1))
+    want, werr = al.AlignBatch(qs, ts)
+    assert al.Pending() == 0
+    for i in range(500):
+        assert al.Submit(qs[i], ts[i]) == i
+    assert al.Pending() == 500
+    got, gerr = al.Collect()
+    assert al.Pending() == 0
+    assert len(got) == 500
+    for i in range(500):
+        assert (gerr[i] is werr[i])
+        if werr[i] is None:
+            assert got[i].key() == want[i].key(), i
+    assert gerr[7] is w.ErrEmptySeq and gerr[9] is w.ErrEmptySeq
+    # tickets restart after a collect; an empty collect is fine
+    assert al.Submit(b"ACCATACTCG", b"AGGATGCTCG") == 0
+    r, e = al.Collect()
+    assert e == [None] and r[0].CIGAR(False) == "1M2X2M1X4M"
+    assert al.Collect() == ([], [])
+    al.close()
+
+
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0], None])
+def test_context_set_shards_and_merges_in_pair_order(built, devices):
+    """wfahip_create_multi / wfahip_align_batch_multi: contiguous shards balanced by sequence bytes, one host thread
+    and one context per shard (here several contexts on the one GPU of the box; None = every device), merged in pair
+    order with the op offsets re-based."""
+    import wfa_amd as w
+    from oracle import oracle as O
+    parts = [w.generate_pairs(seed=31, n_pairs=4000, length=100, error_rate=0.05, n_threads=8),
+             w.generate_pairs(seed=32, n_pairs=700, length=1500, error_rate=0.05, n_threads=8)]
+    qs, ts = [], []
+    for blob, q_off, q_len, t_off, t_len in parts:
+        for i in range(len(q_len)):
+            qs.append(bytes(blob[int(q_off[i]):int(q_off[i]) + int(q_len[i])]))
+            ts.append(bytes(blob[int(t_off[i]):int(t_off[i]) + int(t_len[i])]))
+    qs[0] = b""            # first pair of the first shard
+    ts[len(qs) - 1] = b""  # last pair of the last shard
+    qs[100] = b"ACGTRYACGT"
+    data = w.make_blob(qs, ts)
+    want = O.align_batch(_oracle_params(True, (10, 50, 1)), *data, n_threads=8)
+    m = w.MultiAligner(w.DefaultPenalties, w.DefaultOptions, devices=devices)
+    assert m.AdaptiveReduction(w.DefaultAdaptiveOption) is None
+    assert m.size() == (len(devices) if devices else max(1, __import__("torch").cuda.device_count()))
+    got = m.align_arrays(*data)
+    assert_batch_equal(got, want, f"context set {devices}")
+    # few pairs: fewer than two per context -> one context takes them all
+    small = w.make_blob(qs[1:4], ts[1:4])
+    assert_batch_equal(m.align_arrays(*small), O.align_batch(_oracle_params(True, (10, 50, 1)), *small), "small batch")
+    results, errors = m.AlignBatch(qs[:3], ts[:3])
+    assert errors[0] is w.ErrEmptySeq and errors[1] is None
+    m.close()

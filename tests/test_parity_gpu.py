@@ -759,3 +759,84 @@ def test_host_entry_slices_agree_with_the_plain_call(built):
         del os.environ["WFAHIP_NO_UPLOAD_OVERLAP"]
     assert_batch_equal(d, e, "sliced vs plain, op-count estimate too low")
     al.close()
+
+
+def _expected_compact_words(dump, x, o, e):
+    """{(s, k): compact word} from the oracle's final wavefronts: M tag, I / D tag codes, and the pre-extension offset
+    exactly as the reference's backTrace recomputes it from the UNBOUNDED sources (wfa.go:766-817)."""
+    M, I, D = ({s: {lo + i: v for i, v in enumerate(raw) if v} for s, (lo, hi, raw) in dump[c].items()} for c in "MID")
+
+    def get(C, s, k):  # Component.Get: 0 when the score underflows or nothing is stored (wfa_component.go:158-167)
+        return (C.get(s, {}).get(k, 0) >> 3) if s >= 0 else 0
+
+    out = {}
+    for s, row in M.items():
+        for k, raw in row.items():
+            tag = raw & 7
+            a0, b0 = get(M, s - o - e, k - 1), get(I, s - e, k - 1)
+            c0, d0 = get(M, s - o - e, k + 1), get(D, s - e, k + 1)
+            x0 = get(M, s - x, k)
+            isk = max(a0, b0) + 1 if (a0 or b0) else 0   # wfa.go:768-776 / 790-797
+            dsk = max(c0, d0)                             # wfa.go:779-787 / 799-806
+            if tag == 2:
+                off0 = isk
+            elif tag == 4:
+                off0 = dsk
+            else:
+                off0 = max(isk, dsk, x0 + 1) if (isk or dsk or x0) else 0  # wfa.go:808-813 (else: fromItself)
+            ic = I.get(s, {}).get(k, 0) & 7               # 0 / InsOpen 1 / InsExt 2
+            dt = D.get(s, {}).get(k, 0) & 7               # 0 / DelOpen 3 / DelExt 4
+            out[(s, k)] = (off0 << 7) | ((dt - 2 if dt else 0) << 5) | (ic << 3) | tag
+    return out
+
+
+def _arena_slot(fmt, i, k):
+    if fmt == 3:
+        return (i >> 3) * 512 + (((k & 63) >> 2) << 5) + ((i & 7) << 2) + (k & 3)
+    return i * {1: 64, 4: 256, 5: 32}[fmt] + (k & ({1: 63, 4: 255, 5: 31}[fmt]))
+
+
+@pytest.mark.parametrize("length,err,pen,ad,fmt", [(1000, 0.05, (4, 6, 2), (10, 50, 1), 3), (400, 0.08, (4, 6, 2), (10, 50, 1), 3),
+                                                   (300, 0.03, (2, 3, 1), None, 3), (600, 0.05, (8, 12, 4), (4, 10, 1), 3),
+                                                   (150, 0.02, (4, 6, 2), None, 5), (120, 0.06, (4, 6, 2), (10, 50, 1), 5)])
+def test_blocked_kernel_arena_word_for_word(built, length, err, pen, ad, fmt):
+    """The dominant kernel's stored state, not only its results: every compact backtrace word wfa_blk_kernel leaves in
+    HBM (M tag, I and D tag bits, pre-extension offset) against what the oracle's wavefronts imply -- visited by the
+    backtrace or not.  Covers wf-adaptive pruning (deleted cells must not be there with a source role), ragged lengths
+    (cells at sequence ends: the exact WF_NEXT with its rejections, where the stored offset is the UNBOUNDED
+    recomputation), both tile formats (8 x 64 tiles of the 16-lane instance, 32-word rows of the 8-lane one)."""
+    import wfa_amd as w
+    from oracle import oracle as O
+    n = 160
+    blob, q_off, q_len, t_off, t_len = w.generate_pairs(seed=length + int(err * 1000), n_pairs=n, length=length, error_rate=err)
+    rng = np.random.default_rng(length)
+    cut = rng.integers(0, 4, n) == 0  # a quarter of the pairs lose a piece of one sequence: overhangs, early sequence ends
+    q_len = np.where(cut & (np.arange(n) % 2 == 0), np.maximum(1, q_len - rng.integers(1, 25, n)), q_len).astype(np.uint32)
+    t_len = np.where(cut & (np.arange(n) % 2 == 1), np.maximum(1, t_len - rng.integers(1, 25, n)), t_len).astype(np.uint32)
+    al = _aligner(True, ad, pen)
+    got = al.align_arrays(blob, q_off, q_len, t_off, t_len)
+    assert al.last_timing().main_kernel_kind == (6 if fmt == 5 else 3)
+    g = np.gcd.reduce([pen[0], pen[1] + pen[2], pen[2]])
+    oa = O.Aligner(O.make_params(*pen, global_alignment=True, adaptive=ad))
+    checked = pairs = 0
+    for i in range(n):
+        words, f, meta = al.debug_compact_arena(i)
+        assert f == fmt
+        if meta[0] != 0:  # handed on to another kernel (band / arena): its slot is not the final state
+            continue
+        q = bytes(blob[int(q_off[i]):int(q_off[i]) + int(q_len[i])])
+        t = bytes(blob[int(t_off[i]):int(t_off[i]) + int(t_len[i])])
+        r = oa.align(q, t)
+        assert meta[1] == r.score == int(got.score[i])
+        exp = _expected_compact_words(oa.dump(), *pen)
+        assert meta[3] == sum(r.cells), (i, meta, r.cells)  # the census: every stored M, I and D word
+        for (s, k), wv in exp.items():
+            if s > r.score:
+                continue
+            have = int(words[_arena_slot(f, s // g, k)])
+            assert have == wv, (f"pair {i} score {s} diagonal {k}: arena {have:#x} = off {have >> 7} D{(have >> 5) & 3} "
+                                f"I{(have >> 3) & 3} tag {have & 7}, expected off {wv >> 7} D{(wv >> 5) & 3} I{(wv >> 3) & 3} tag {wv & 7}")
+            checked += 1
+        pairs += 1
+    assert pairs >= n * 3 // 4 and checked > 50 * pairs, (pairs, checked)
+    al.close()

@@ -21,7 +21,9 @@ EXPORTS = [
     "wfahip_version", "wfahip_strerror", "wfahip_device_count", "wfahip_create", "wfahip_destroy",
     "wfahip_align_batch", "wfahip_results_free", "wfahip_align_batch_device", "wfahip_last_timing",
     "wfahip_set_option", "wfahip_debug_wavefronts", "wfahip_free", "wfahip_gen_stride",
-    "wfahip_generate_pairs",
+    "wfahip_generate_pairs", "wfahip_packed_words", "wfahip_pack_pairs", "wfahip_align_batch_packed", "wfahip_submit",
+    "wfahip_pending", "wfahip_collect", "wfahip_create_multi", "wfahip_destroy_multi", "wfahip_multi_size",
+    "wfahip_multi_ctx", "wfahip_align_batch_multi", "wfahip_debug_compact_arena",
 ]
 
 
@@ -91,6 +93,30 @@ def lib():
         L.wfahip_gen_stride.argtypes = [u32, C.c_double]
         L.wfahip_generate_pairs.restype = C.c_int
         L.wfahip_generate_pairs.argtypes = [u64, u64, u64, u32, C.c_double, C.c_int, vp, vp, vp, vp, vp]
+        L.wfahip_packed_words.restype = u64
+        L.wfahip_packed_words.argtypes = [u32]
+        L.wfahip_pack_pairs.restype = C.c_int
+        L.wfahip_pack_pairs.argtypes = [vp, vp, vp, vp, vp, u64, C.c_int, vp, vp, vp, C.POINTER(u64)]
+        L.wfahip_align_batch_packed.restype = C.c_int
+        L.wfahip_align_batch_packed.argtypes = [vp, C.POINTER(Params), vp, u64, vp, vp, vp, vp, u64, C.POINTER(Results)]
+        L.wfahip_submit.restype = C.c_int
+        L.wfahip_submit.argtypes = [vp, C.c_char_p, u32, C.c_char_p, u32, C.POINTER(u64)]
+        L.wfahip_pending.restype = u64
+        L.wfahip_pending.argtypes = [vp]
+        L.wfahip_collect.restype = C.c_int
+        L.wfahip_collect.argtypes = [vp, C.POINTER(Params), C.POINTER(Results)]
+        L.wfahip_create_multi.restype = C.c_int
+        L.wfahip_create_multi.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
+        L.wfahip_destroy_multi.argtypes = [vp]
+        L.wfahip_multi_size.restype = C.c_int
+        L.wfahip_multi_size.argtypes = [vp]
+        L.wfahip_multi_ctx.restype = vp
+        L.wfahip_multi_ctx.argtypes = [vp, C.c_int]
+        L.wfahip_align_batch_multi.restype = C.c_int
+        L.wfahip_align_batch_multi.argtypes = [vp, C.POINTER(Params), vp, u64, vp, vp, vp, vp, u64, C.POINTER(Results)]
+        L.wfahip_debug_compact_arena.restype = C.c_int
+        L.wfahip_debug_compact_arena.argtypes = [vp, u64, C.POINTER(C.POINTER(u32)), C.POINTER(u64), C.POINTER(u32),
+                                                 C.POINTER(u32 * 4)]
         _lib = L
     return _lib
 

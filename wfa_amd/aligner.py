@@ -224,22 +224,42 @@ class Aligner:
         vp = lambda a: a.ctypes.data_as(C.c_void_p)
         L.check(L.lib().wfahip_align_batch(self._ctx, C.byref(prm), vp(blob), blob.size, vp(q_off), vp(q_len),
                                            vp(t_off), vp(t_len), n, C.byref(res)), "wfahip_align_batch")
-        try:
-            def arr(ptr, dt, cnt):
-                if cnt == 0:
-                    return np.zeros(0, dtype=dt)
-                return np.ctypeslib.as_array(ptr, shape=(cnt,)).astype(dt, copy=True)
-            out = BatchResult(
-                status=arr(res.status, np.int32, n), score=arr(res.score, np.uint32, n),
-                tbegin=arr(res.tbegin, np.int32, n), tend=arr(res.tend, np.int32, n),
-                qbegin=arr(res.qbegin, np.int32, n), qend=arr(res.qend, np.int32, n),
-                align_len=arr(res.align_len, np.uint32, n), matches=arr(res.matches, np.uint32, n),
-                gaps=arr(res.gaps, np.uint32, n), gap_regions=arr(res.gap_regions, np.uint32, n),
-                ops_off=arr(res.ops_off, np.uint64, n), ops_len=arr(res.ops_len, np.uint32, n),
-                ops=arr(res.ops, np.uint64, int(res.n_ops)))
-        finally:
-            L.lib().wfahip_results_free(C.byref(res))
-        return out
+        return _take_results(res, n)
+
+    def align_arrays_packed(self, packed, q_woff, q_len, t_woff, t_len) -> "BatchResult":
+        """Batch alignment of pre-packed 2-bit input (include/wfa_hip.h: wfahip_align_batch_packed); pack with
+        pack_pairs().  A quarter of the bytes cross PCIe; results are those of align_arrays on the unpacked bytes."""
+        n = int(len(q_len))
+        packed = np.ascontiguousarray(packed, dtype=np.uint32)
+        q_woff = np.ascontiguousarray(q_woff, dtype=np.uint64)
+        t_woff = np.ascontiguousarray(t_woff, dtype=np.uint64)
+        q_len = np.ascontiguousarray(q_len, dtype=np.uint32)
+        t_len = np.ascontiguousarray(t_len, dtype=np.uint32)
+        res = L.Results()
+        prm = self._params()
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        L.check(L.lib().wfahip_align_batch_packed(self._ctx, C.byref(prm), vp(packed), packed.size, vp(q_woff), vp(q_len),
+                                                  vp(t_woff), vp(t_len), n, C.byref(res)), "wfahip_align_batch_packed")
+        return _take_results(res, n)
+
+    # -- new: one pair at a time behind the batch ----------------------------------------------------
+    def Submit(self, q: bytes, t: bytes) -> int:
+        """Hand in one pair (copied) and return its ticket; Collect() aligns everything submitted as ONE batch.  This is
+        how a per-pair loop like the reference's CLI (wfa-go/wfa-go.go:166-178) is served at batch throughput."""
+        ticket = C.c_uint64()
+        L.check(L.lib().wfahip_submit(self._ctx, q, len(q), t, len(t), C.byref(ticket)), "wfahip_submit")
+        return int(ticket.value)
+
+    def Pending(self) -> int:
+        return int(L.lib().wfahip_pending(self._ctx))
+
+    def Collect(self):
+        """([]*AlignmentResult, []error) of the pairs submitted since the last Collect, indexed by ticket."""
+        n = self.Pending()
+        res = L.Results()
+        prm = self._params()
+        L.check(L.lib().wfahip_collect(self._ctx, C.byref(prm), C.byref(res)), "wfahip_collect")
+        return _results_and_errors(_take_results(res, n))
 
     def AlignBatch(self, qs: Sequence[bytes], ts: Sequence[bytes]):
         """([]*AlignmentResult, []error): per-pair results and per-pair errors (None = ok)."""
@@ -247,19 +267,7 @@ class Aligner:
             raise ValueError("qs and ts differ in length")
         if not qs:
             return [], []
-        br = self.align_arrays(*make_blob(qs, ts))
-        results: List[Optional[AlignmentResult]] = []
-        errors: List[Optional[Exception]] = []
-        for i in range(len(qs)):
-            st = int(br.status[i])
-            if st == L.PAIR_OK:
-                results.append(br.result(i))
-                errors.append(None)
-            else:
-                results.append(None)
-                errors.append(ErrEmptySeq if st == L.PAIR_EMPTY else ErrSeqTooLong if st == L.PAIR_TOO_LONG
-                              else WfaError("wfa: out of device memory for this pair"))
-        return results, errors
+        return _results_and_errors(self.align_arrays(*make_blob(qs, ts)))
 
     # -- diagnostics ----------------------------------------------------------------------------
     def last_timing(self) -> Timing:
@@ -299,6 +307,19 @@ class Aligner:
             L.lib().wfahip_results_free(C.byref(res))
         return out, br.result(0)
 
+    def debug_compact_arena(self, pair: int):
+        """(words, fmt, meta) of pair `pair` of the most recent batch: the compact backtrace arena as the first-pass
+        forward kernel left it (include/wfa_hip.h: wfahip_debug_compact_arena)."""
+        words = C.POINTER(C.c_uint32)()
+        n_words, fmt, meta = C.c_uint64(), C.c_uint32(), (C.c_uint32 * 4)()
+        L.check(L.lib().wfahip_debug_compact_arena(self._ctx, pair, C.byref(words), C.byref(n_words), C.byref(fmt),
+                                                   C.byref(meta)), "wfahip_debug_compact_arena")
+        try:
+            arr = np.ctypeslib.as_array(words, shape=(int(n_words.value),)).copy()
+        finally:
+            L.lib().wfahip_free(words)
+        return arr, int(fmt.value), tuple(int(x) for x in meta)
+
     def Plot(self, q: bytes, t: bytes, component: str = "M", notChangeToMatch: bool = False, maxScore: int = -1) -> str:
         """(*Aligner).Plot (wfa_component_plot.go:41): the component table, from the DEVICE wavefronts of one pair."""
         wf, _ = self.debug_wavefronts(q, t)
@@ -308,6 +329,109 @@ class Aligner:
         if getattr(self, "_ctx", None):
             L.lib().wfahip_destroy(self._ctx)
             self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _take_results(res: "L.Results", n: int) -> "BatchResult":
+    """numpy copies of a wfahip_results, which is then handed back to the library."""
+    try:
+        return BatchResult.from_c(res, n)
+    finally:
+        L.lib().wfahip_results_free(C.byref(res))
+
+
+def _results_and_errors(br: "BatchResult"):
+    results: List[Optional[AlignmentResult]] = []
+    errors: List[Optional[Exception]] = []
+    for i in range(len(br.status)):
+        st = int(br.status[i])
+        if st == L.PAIR_OK:
+            results.append(br.result(i))
+            errors.append(None)
+        else:
+            results.append(None)
+            errors.append(ErrEmptySeq if st == L.PAIR_EMPTY else ErrSeqTooLong if st == L.PAIR_TOO_LONG
+                          else WfaError("wfa: out of device memory for this pair"))
+    return results, errors
+
+
+def pack_pairs(blob, q_off, q_len, t_off, t_len, n_threads: int = 8):
+    """Host-side 2-bit packer (include/wfa_hip.h: wfahip_pack_pairs) -> (packed, q_woff, t_woff).  Raises WfaHipError
+    (ERR_UNSUPPORTED) when a byte outside ACGT is found: such input must use the byte entry."""
+    n = int(len(q_len))
+    blob = np.ascontiguousarray(blob, dtype=np.uint8)
+    q_off = np.ascontiguousarray(q_off, dtype=np.uint64)
+    t_off = np.ascontiguousarray(t_off, dtype=np.uint64)
+    q_len = np.ascontiguousarray(q_len, dtype=np.uint32)
+    t_len = np.ascontiguousarray(t_len, dtype=np.uint32)
+    words = int(((q_len.astype(np.uint64) + 15) // 16 + 1).sum() + ((t_len.astype(np.uint64) + 15) // 16 + 1).sum())
+    packed = np.zeros(max(words, 1), dtype=np.uint32)
+    q_woff = np.zeros(n, dtype=np.uint64)
+    t_woff = np.zeros(n, dtype=np.uint64)
+    n_words = C.c_uint64()
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    L.check(L.lib().wfahip_pack_pairs(vp(blob), vp(q_off), vp(q_len), vp(t_off), vp(t_len), n, n_threads, vp(packed),
+                                      vp(q_woff), vp(t_woff), C.byref(n_words)), "wfahip_pack_pairs")
+    assert int(n_words.value) == words
+    return packed, q_woff, t_woff
+
+
+class MultiAligner:
+    """One aligner over several GPUs (include/wfa_hip.h: wfahip_create_multi): AlignBatch cuts the batch into
+    contiguous shards, one per GPU, each aligned from its own host thread; results come back in pair order.  The
+    reference's model is one Aligner per goroutine (wfa.go:73-78); this is that, behind one call."""
+
+    def __init__(self, p: Penalties = None, opt: Options = None, devices: Optional[Sequence[int]] = None):
+        self.p = p or DefaultPenalties
+        self.opt = opt or DefaultOptions
+        self.ad: Optional[AdaptiveReductionOption] = None
+        self._m = C.c_void_p()
+        if devices is None:
+            L.check(L.lib().wfahip_create_multi(None, 0, C.byref(self._m)), "wfahip_create_multi")
+        else:
+            ids = (C.c_int * len(devices))(*devices)
+            L.check(L.lib().wfahip_create_multi(ids, len(devices), C.byref(self._m)), "wfahip_create_multi")
+
+    AdaptiveReduction = Aligner.AdaptiveReduction
+    _params = Aligner._params
+
+    def size(self) -> int:
+        return int(L.lib().wfahip_multi_size(self._m))
+
+    def set_option(self, key: str, value: int) -> None:
+        for i in range(self.size()):
+            L.check(L.lib().wfahip_set_option(L.lib().wfahip_multi_ctx(self._m, i), key.encode(), int(value)))
+
+    def align_arrays(self, blob, q_off, q_len, t_off, t_len) -> "BatchResult":
+        n = int(len(q_len))
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        q_off = np.ascontiguousarray(q_off, dtype=np.uint64)
+        t_off = np.ascontiguousarray(t_off, dtype=np.uint64)
+        q_len = np.ascontiguousarray(q_len, dtype=np.uint32)
+        t_len = np.ascontiguousarray(t_len, dtype=np.uint32)
+        res = L.Results()
+        prm = self._params()
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        L.check(L.lib().wfahip_align_batch_multi(self._m, C.byref(prm), vp(blob), blob.size, vp(q_off), vp(q_len),
+                                                 vp(t_off), vp(t_len), n, C.byref(res)), "wfahip_align_batch_multi")
+        return _take_results(res, n)
+
+    def AlignBatch(self, qs: Sequence[bytes], ts: Sequence[bytes]):
+        if len(qs) != len(ts):
+            raise ValueError("qs and ts differ in length")
+        if not qs:
+            return [], []
+        return _results_and_errors(self.align_arrays(*make_blob(qs, ts)))
+
+    def close(self):
+        if getattr(self, "_m", None):
+            L.lib().wfahip_destroy_multi(self._m)
+            self._m = None
 
     def __del__(self):
         try:

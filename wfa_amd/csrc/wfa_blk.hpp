@@ -570,7 +570,11 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : 4)) void
                     const uint32_t w  = (Msk << 7) | (dc << 5) | (ic << 3) | tg;
                     nM[p] = Msk, nI[p] = Isk, nD[p] = Dsk;
                     wd[p] = Msk ? w : 0u;
+#ifndef WFA_NO_CENSUS
                     cc[p] = tI + tD + umin2(Msk, 1u);
+#else
+                    cc[p] = 0u;
+#endif
                 }
             } else {
 #pragma unroll

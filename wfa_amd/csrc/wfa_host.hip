@@ -88,6 +88,11 @@ struct wfahip_ctx {
     hipEvent_t    evBtA = nullptr, evBtB = nullptr;
     bool          bt_pending = false;        // the first pass's backtrace kernel is still running on stream2
     DevBuf        in_blob, in_qoff, in_qlen, in_toff, in_tlen, out_rec, out_ops;  // host-entry staging
+    DevBuf        in_packed;                 // host entry with pre-packed input: the 2-bit words as uploaded (unpacked into in_blob on the device)
+    // wfahip_submit / wfahip_collect: pairs handed in one at a time, aligned as one batch
+    std::vector<uint8_t>  sub_blob;
+    std::vector<uint64_t> sub_qoff, sub_toff;
+    std::vector<uint32_t> sub_qlen, sub_tlen;
     // options (0 = automatic)
     int64_t       opt_arena_bytes_per_slot = 0;
     int64_t       opt_slots                = 0;
@@ -115,6 +120,11 @@ struct wfahip_ctx {
     int64_t       opt_overlap              = 0;  // 1: backtrace of chunk c on a second stream beside the forward kernel of chunk c+1 (measured: no gain)
     int64_t       opt_fail_pass            = 0;   // test aid (fault injection): the sub-wave pass of this kind reports WFAHIP_ERR_OOM
     int           force_mode               = -1;  // debug: start the ladder in this mode
+    // debug / parity aid (wfahip_debug_compact_arena): where the first chunk of the most recent first pass left its arena
+    const uint32_t *dbg_arena = nullptr;
+    const uint4    *dbg_meta  = nullptr;
+    uint64_t        dbg_words = 0, dbg_first = 0, dbg_n = 0;
+    uint32_t        dbg_fmt = 0, dbg_g = 1;
     wfahip_timing timing{};
     char          last_error[256] = {0};
 };
@@ -298,7 +308,7 @@ extern "C" void wfahip_destroy(wfahip_ctx *ctx) {
         if (ctx->pin_ev[i]) (void)hipEventDestroy(ctx->pin_ev[i]);
     }
     for (DevBuf *b : {&ctx->arena, &ctx->fin, &ctx->team_ctl, &ctx->arena2, &ctx->meta2, &ctx->doneq, &ctx->ctrl, &ctx->redo, &ctx->work, &ctx->meta, &ctx->in_blob, &ctx->in_qoff, &ctx->in_qlen,
-                      &ctx->in_toff, &ctx->in_tlen, &ctx->out_rec, &ctx->out_ops})
+                      &ctx->in_toff, &ctx->in_tlen, &ctx->out_rec, &ctx->out_ops, &ctx->in_packed})
         release(*b);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -395,6 +405,7 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
     if (rc != WFAHIP_OK) return rc;
     if (n_pairs > 0xFFFFFFF0ull) return WFAHIP_ERR_BAD_ARG;
     ctx->timing = wfahip_timing{};
+    ctx->dbg_arena = nullptr, ctx->dbg_n = 0;
     if (ctx->bt_pending) {  // a previous call failed half-way: let its backtrace kernel drain before buffers are reused
         (void)hipStreamSynchronize(ctx->stream2);
         ctx->bt_pending = false;
@@ -605,6 +616,9 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                 P.pair_meta   = static_cast<uint4 *>(meta_buf.p) + (uint64_t)buf * chunk;
                 P.chunk_first = (uint32_t)(first_pair + c0), P.chunk_n = (uint32_t)cn;
                 P.work        = list ? static_cast<const uint32_t *>(ctx->work.p) + c0 : nullptr;
+                if (!list && c == 0 && first_pair == 0)
+                    ctx->dbg_arena = P.arena, ctx->dbg_meta = P.pair_meta, ctx->dbg_words = words, ctx->dbg_first = first_pair,
+                    ctx->dbg_n = cn, ctx->dbg_fmt = P.compact_fmt, ctx->dbg_g = P.g;
                 uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)ctx->num_cus * waves_per_cu,
                                                             (cn + pairs_wave - 1) / pairs_wave);
                 const uint32_t n_bt = stream_bt ? (uint32_t)std::min<int64_t>(ctx->opt_bt_stream, grid / 4) : 0u;
@@ -917,8 +931,8 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
 #ifdef WFA_TEAM_STAMPS
             for (uint32_t t = 0; t < team_n; t++) {
                 const unsigned long long *a = reinterpret_cast<const unsigned long long *>(&tc[(size_t)t * TEAM_CTL_WORDS + 64]);
-                std::fprintf(stderr, "[team %u] us: P1 %.0f  barriers %.0f  P2 %.0f  P3 %.0f  tail(team) %.0f  solo steps %.0f\n", t,
-                             a[0] / 100.0, a[1] / 100.0, a[2] / 100.0, a[3] / 100.0, a[4] / 100.0, a[5] / 100.0);
+                std::fprintf(stderr, "[team %u] us: P1 %.0f  barriers %.0f  P2 %.0f  P3 %.0f  tail(team) %.0f  solo steps %.0f  end search %.0f  backtrace %.0f\n", t,
+                             a[0] / 100.0, a[1] / 100.0, a[2] / 100.0, a[3] / 100.0, a[4] / 100.0, a[5] / 100.0, a[6] / 100.0, a[7] / 100.0);
             }
 #endif
             for (uint32_t t = 0; t < team_n; t++)
@@ -1140,17 +1154,48 @@ int download(wfahip_ctx *ctx, void *dst, const void *src, size_t bytes, hipStrea
 
 }  // namespace
 
+// Pre-packed input (wfahip_align_batch_packed): 2-bit words -> the byte blob the kernels read, on the device.  One
+// thread per word: 16 bases = one 16-byte store.  Code -> letter is the inverse of the kernels' (c >> 1) & 3.
+__global__ __launch_bounds__(256) void wfa_unpack_kernel(const uint32_t *__restrict__ words, uint4 *__restrict__ bytes, uint64_t w0,
+                                                         uint64_t w1) {
+    const uint64_t i = w0 + (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= w1) return;
+    const uint32_t w = words[i];
+    uint32_t       o[4];
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) v |= ((0x47544341u >> (8u * ((w >> (2 * (4 * d + b))) & 3u))) & 0xFFu) << (8 * b);  // "ACTG"[code]
+        o[d] = v;
+    }
+    bytes[i] = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+// packed != nullptr: the sequences arrive 2-bit packed (word i of `packed` = bytes [16 i, 16 i + 16) of the blob the
+// offsets refer to); seq_blob is not read.
 static int align_batch_impl(wfahip_ctx *ctx, const wfahip_params *p, const uint8_t *seq_blob,
                             uint64_t blob_bytes, const uint64_t *q_off, const uint32_t *q_len,
                             const uint64_t *t_off, const uint32_t *t_len, uint64_t n_pairs,
-                            wfahip_results *out) {
+                            wfahip_results *out, const uint32_t *packed = nullptr) {
     if (!ctx || !out) return WFAHIP_ERR_BAD_ARG;
     results_zero(out);
     int rc = check_params(p);
     if (rc) return rc;
     if (n_pairs == 0) return WFAHIP_OK;
-    if (!q_off || !q_len || !t_off || !t_len || (!seq_blob && blob_bytes)) return WFAHIP_ERR_BAD_ARG;
+    if (!q_off || !q_len || !t_off || !t_len || (!seq_blob && !packed && blob_bytes)) return WFAHIP_ERR_BAD_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
+    // the bytes [lo, hi) of the blob -> in_blob on stream `s` (packed input: the words that hold them, then the unpack kernel)
+    const auto upload_range = [&](uint64_t lo, uint64_t hi, hipStream_t s) -> hipError_t {
+        if (hi <= lo) return hipSuccess;
+        if (!packed) return hipMemcpyAsync(static_cast<char *>(ctx->in_blob.p) + lo, seq_blob + lo, hi - lo, hipMemcpyHostToDevice, s);
+        const uint64_t w0 = lo / 16, w1 = (hi + 15) / 16;
+        hipError_t     e  = hipMemcpyAsync(static_cast<uint32_t *>(ctx->in_packed.p) + w0, packed + w0, (w1 - w0) * 4, hipMemcpyHostToDevice, s);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(wfa_unpack_kernel, dim3((uint32_t)((w1 - w0 + 255) / 256)), dim3(256), 0, s,
+                           static_cast<const uint32_t *>(ctx->in_packed.p), static_cast<uint4 *>(ctx->in_blob.p), w0, w1);
+        return hipGetLastError();
+    };
 
     uint32_t max_len = 1;
     uint64_t sum_len = 0;
@@ -1163,7 +1208,8 @@ static int align_batch_impl(wfahip_ctx *ctx, const wfahip_params *p, const uint8
     }
     hipStream_t st = ctx->stream;
     // device staging (+16 bytes so aligned dword loads at the tail stay inside the allocation)
-    if ((rc = ensure(ctx, ctx->in_blob, blob_bytes + 16))) return rc;
+    if ((rc = ensure(ctx, ctx->in_blob, blob_bytes + 32))) return rc;
+    if (packed && (rc = ensure(ctx, ctx->in_packed, (blob_bytes + 15) / 16 * 4 + 16))) return rc;
     if ((rc = ensure(ctx, ctx->in_qoff, n_pairs * 8))) return rc;
     if ((rc = ensure(ctx, ctx->in_toff, n_pairs * 8))) return rc;
     if ((rc = ensure(ctx, ctx->in_qlen, n_pairs * 4))) return rc;
@@ -1180,7 +1226,7 @@ static int align_batch_impl(wfahip_ctx *ctx, const wfahip_params *p, const uint8
     // Needs the blob ranges of consecutive slices to be disjoint enough (pairs laid out in order, the usual case).
     constexpr int     UP_SLICES = 4;
     uint64_t          sl_first[UP_SLICES + 1], sl_lo[UP_SLICES], sl_hi[UP_SLICES];
-    bool              sliced = n_pairs >= 200000 && blob_bytes >= (64u << 20) && !std::getenv("WFAHIP_NO_UPLOAD_OVERLAP");
+    bool              sliced = n_pairs >= 200000 && blob_bytes >= (packed ? (256u << 20) : (64u << 20)) && !std::getenv("WFAHIP_NO_UPLOAD_OVERLAP");
     if (sliced) {
         uint64_t covered = 0;
         for (int k = 0; k <= UP_SLICES; k++) sl_first[k] = n_pairs * k / UP_SLICES;
@@ -1206,7 +1252,7 @@ static int align_batch_impl(wfahip_ctx *ctx, const wfahip_params *p, const uint8
             ctx->ev_up.push_back(e);
         }
     }
-    if (blob_bytes && !sliced) HIP_TRY(hipMemcpyAsync(ctx->in_blob.p, seq_blob, blob_bytes, hipMemcpyHostToDevice, st));
+    if (blob_bytes && !sliced) HIP_TRY(upload_range(0, blob_bytes, st));
     HIP_TRY(hipMemcpyAsync(ctx->in_qoff.p, q_off, n_pairs * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(ctx->in_toff.p, t_off, n_pairs * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(ctx->in_qlen.p, q_len, n_pairs * 4, hipMemcpyHostToDevice, st));
@@ -1224,10 +1270,7 @@ static int align_batch_impl(wfahip_ctx *ctx, const wfahip_params *p, const uint8
             const auto upload_all = [&] {
                 if (hipSetDevice(ctx->device) != hipSuccess) up_err = 1;
                 for (int k = 0; k < UP_SLICES; k++) {
-                    if (!up_err && sl_hi[k] > sl_lo[k] &&
-                        hipMemcpyAsync(static_cast<char *>(ctx->in_blob.p) + sl_lo[k], seq_blob + sl_lo[k], sl_hi[k] - sl_lo[k],
-                                       hipMemcpyHostToDevice, ctx->stream_up) != hipSuccess)
-                        up_err = 1;
+                    if (!up_err && sl_hi[k] > sl_lo[k] && upload_range(sl_lo[k], sl_hi[k], ctx->stream_up) != hipSuccess) up_err = 1;
                     if (hipEventRecord(ctx->ev_up[k], ctx->stream_up) != hipSuccess) up_err = 1;
                     recorded = k + 1;
                 }
@@ -1515,6 +1558,146 @@ extern "C" int wfahip_align_batch(wfahip_ctx *ctx, const wfahip_params *p, const
                                   const uint64_t *t_off, const uint32_t *t_len, uint64_t n_pairs,
                                   wfahip_results *out) {
     WFAHIP_GUARD(align_batch_impl(ctx, p, seq_blob, blob_bytes, q_off, q_len, t_off, t_len, n_pairs, out))
+}
+
+// ---- pre-packed input (a quarter of the bytes cross PCIe)
+extern "C" int wfahip_align_batch_packed(wfahip_ctx *ctx, const wfahip_params *p, const uint32_t *packed, uint64_t n_words,
+                                         const uint64_t *q_woff, const uint32_t *q_len, const uint64_t *t_woff,
+                                         const uint32_t *t_len, uint64_t n_pairs, wfahip_results *out) {
+    if (!ctx || !out || (!packed && n_words)) return WFAHIP_ERR_BAD_ARG;
+    try {
+        std::vector<uint64_t> qo(n_pairs), to(n_pairs);  // byte offsets into the unpacked blob: 16 bases per word
+        for (uint64_t i = 0; i < n_pairs; i++) {
+            if (!q_woff || !t_woff) return WFAHIP_ERR_BAD_ARG;
+            qo[i] = q_woff[i] * 16, to[i] = t_woff[i] * 16;
+        }
+        static const uint32_t no_words[4] = {0, 0, 0, 0};
+        return align_batch_impl(ctx, p, nullptr, n_words * 16, qo.data(), q_len, to.data(), t_len, n_pairs, out, packed ? packed : no_words);
+    } catch (const std::bad_alloc &) {
+        return WFAHIP_ERR_OOM;
+    } catch (...) {
+        return WFAHIP_ERR_INTERNAL;
+    }
+}
+
+extern "C" uint64_t wfahip_packed_words(uint32_t len) { return ((uint64_t)len + 15) / 16 + 1; }  // (+1: the pad word the kernels' 16-base windows may read)
+
+// Host-side packer: n_pairs (query, target) byte sequences -> 2-bit words, every sequence at a word boundary, in pair
+// order (query then target).  Returns WFAHIP_ERR_UNSUPPORTED when a byte outside {A,C,G,T} is found (such a batch
+// must use the byte entry: the reference compares raw bytes, wfa.go:408-454).  packed must hold
+// sum(wfahip_packed_words(q_len[i]) + wfahip_packed_words(t_len[i])) words.
+static int pack_pairs_impl(const uint8_t *seq_blob, const uint64_t *q_off, const uint32_t *q_len, const uint64_t *t_off,
+                           const uint32_t *t_len, uint64_t n_pairs, int n_threads, uint32_t *packed, uint64_t *q_woff,
+                           uint64_t *t_woff, uint64_t *n_words) {
+    if (!q_off || !q_len || !t_off || !t_len || !packed || !q_woff || !t_woff || (!seq_blob && n_pairs)) return WFAHIP_ERR_BAD_ARG;
+    uint64_t pos = 0;
+    for (uint64_t i = 0; i < n_pairs; i++) {
+        q_woff[i] = pos, pos += wfahip_packed_words(q_len[i] <= WFAHIP_MAX_SEQ_LEN ? q_len[i] : 0);
+        t_woff[i] = pos, pos += wfahip_packed_words(t_len[i] <= WFAHIP_MAX_SEQ_LEN ? t_len[i] : 0);
+    }
+    if (n_words) *n_words = pos;
+    std::atomic<int> bad{0};
+    const auto       one = [&](const uint8_t *s, uint32_t len, uint32_t *dst) {
+        if (len > WFAHIP_MAX_SEQ_LEN) len = 0;  // (rejected per pair by the alignment itself)
+        uint32_t       b  = 0;
+        const uint32_t nw = (len + 15) / 16;
+        for (uint32_t w = 0; w < nw; w++) {
+            uint32_t       word = 0;
+            const uint32_t nb   = std::min<uint32_t>(16, len - 16 * w);
+            for (uint32_t k = 0; k < nb; k++) {
+                const uint8_t c = s[16 * w + k];
+                b |= (uint32_t)!((c == 'A') | (c == 'C') | (c == 'G') | (c == 'T'));
+                word |= ((uint32_t)(c >> 1) & 3u) << (2 * k);
+            }
+            dst[w] = word;
+        }
+        dst[nw] = 0;
+        if (b) bad = 1;
+    };
+    const auto range = [&](uint64_t a, uint64_t b) {
+        for (uint64_t i = a; i < b; i++) {
+            one(seq_blob + q_off[i], q_len[i], packed + q_woff[i]);
+            one(seq_blob + t_off[i], t_len[i], packed + t_woff[i]);
+        }
+    };
+    if (n_threads < 1) n_threads = 1;
+    if ((uint64_t)n_threads > n_pairs / 1024 + 1) n_threads = (int)(n_pairs / 1024 + 1);
+    std::vector<std::thread> th;
+    const uint64_t           per = (n_pairs + n_threads - 1) / n_threads;
+    for (int t = 0; t < n_threads; t++) {
+        const uint64_t a = std::min<uint64_t>(n_pairs, (uint64_t)t * per), b = std::min<uint64_t>(n_pairs, a + per);
+        bool inl = n_threads == 1;
+        if (!inl) {
+            try {
+                th.emplace_back(range, a, b);
+            } catch (...) {
+                inl = true;
+            }
+        }
+        if (inl) range(a, b);
+    }
+    for (auto &t : th) t.join();
+    return bad ? WFAHIP_ERR_UNSUPPORTED : WFAHIP_OK;
+}
+
+extern "C" int wfahip_pack_pairs(const uint8_t *seq_blob, const uint64_t *q_off, const uint32_t *q_len, const uint64_t *t_off,
+                                 const uint32_t *t_len, uint64_t n_pairs, int n_threads, uint32_t *packed, uint64_t *q_woff,
+                                 uint64_t *t_woff, uint64_t *n_words) {
+    WFAHIP_GUARD(pack_pairs_impl(seq_blob, q_off, q_len, t_off, t_len, n_pairs, n_threads, packed, q_woff, t_woff, n_words))
+}
+
+// ---- one pair at a time behind the batch: submit copies the pair, collect aligns everything submitted so far
+static int submit_impl(wfahip_ctx *ctx, const uint8_t *q, uint32_t n, const uint8_t *t, uint32_t m, uint64_t *ticket) {
+    if (!ctx || (!q && n) || (!t && m)) return WFAHIP_ERR_BAD_ARG;
+    const uint64_t pos  = ctx->sub_blob.size();
+    const uint64_t qcap = ((uint64_t)std::min<uint32_t>(n, WFAHIP_MAX_SEQ_LEN + 1u) + 15) & ~15ull;
+    const uint64_t tcap = ((uint64_t)std::min<uint32_t>(m, WFAHIP_MAX_SEQ_LEN + 1u) + 15) & ~15ull;
+    const bool     keep = n <= WFAHIP_MAX_SEQ_LEN && m <= WFAHIP_MAX_SEQ_LEN;  // (too long: rejected per pair, nothing to copy)
+    ctx->sub_blob.resize(pos + (keep ? qcap + tcap : 0));
+    if (keep && n) std::memcpy(ctx->sub_blob.data() + pos, q, n);
+    if (keep && m) std::memcpy(ctx->sub_blob.data() + pos + qcap, t, m);
+    if (ticket) *ticket = ctx->sub_qlen.size();
+    ctx->sub_qoff.push_back(pos), ctx->sub_toff.push_back(pos + qcap);
+    ctx->sub_qlen.push_back(n), ctx->sub_tlen.push_back(m);
+    return WFAHIP_OK;
+}
+
+extern "C" int wfahip_submit(wfahip_ctx *ctx, const uint8_t *q, uint32_t n, const uint8_t *t, uint32_t m, uint64_t *ticket) {
+    WFAHIP_GUARD(submit_impl(ctx, q, n, t, m, ticket))
+}
+
+extern "C" uint64_t wfahip_pending(const wfahip_ctx *ctx) { return ctx ? ctx->sub_qlen.size() : 0; }
+
+static int collect_impl(wfahip_ctx *ctx, const wfahip_params *p, wfahip_results *out) {
+    if (!ctx || !out) return WFAHIP_ERR_BAD_ARG;
+    const uint64_t n  = ctx->sub_qlen.size();
+    const int      rc = align_batch_impl(ctx, p, ctx->sub_blob.data(), ctx->sub_blob.size(), ctx->sub_qoff.data(), ctx->sub_qlen.data(),
+                                         ctx->sub_toff.data(), ctx->sub_tlen.data(), n, out);
+    if (rc == WFAHIP_OK) {  // (on failure the submissions stay: the caller may collect again, e.g. with other parameters)
+        ctx->sub_blob.clear(), ctx->sub_qoff.clear(), ctx->sub_toff.clear(), ctx->sub_qlen.clear(), ctx->sub_tlen.clear();
+    }
+    return rc;
+}
+
+extern "C" int wfahip_collect(wfahip_ctx *ctx, const wfahip_params *p, wfahip_results *out) { WFAHIP_GUARD(collect_impl(ctx, p, out)) }
+
+extern "C" int wfahip_debug_compact_arena(wfahip_ctx *ctx, uint64_t pair, uint32_t **words, uint64_t *n_words, uint32_t *fmt,
+                                          uint32_t *meta4) {
+    if (!ctx || !words || !n_words) return WFAHIP_ERR_BAD_ARG;
+    *words = nullptr, *n_words = 0;
+    if (!ctx->dbg_arena || pair < ctx->dbg_first || pair >= ctx->dbg_first + ctx->dbg_n) return WFAHIP_ERR_BAD_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    uint32_t *w = static_cast<uint32_t *>(std::malloc((size_t)ctx->dbg_words * 4));
+    if (!w) return WFAHIP_ERR_OOM;
+    const uint64_t slot = pair - ctx->dbg_first;
+    if (hipMemcpy(w, ctx->dbg_arena + slot * ctx->dbg_words, (size_t)ctx->dbg_words * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+        (meta4 && hipMemcpy(meta4, ctx->dbg_meta + slot, 16, hipMemcpyDeviceToHost) != hipSuccess)) {
+        std::free(w);
+        return WFAHIP_ERR_HIP;
+    }
+    *words = w, *n_words = ctx->dbg_words;
+    if (fmt) *fmt = ctx->dbg_fmt;
+    return WFAHIP_OK;
 }
 
 static int debug_wavefronts_impl(wfahip_ctx *ctx, const wfahip_params *p, const uint8_t *q, uint32_t n,

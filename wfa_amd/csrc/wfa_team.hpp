@@ -67,7 +67,7 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
     const int64_t  stripe = (int64_t)T * G;
 
 #ifdef WFA_TEAM_STAMPS
-    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memrealtime();
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memrealtime();
 #define TEAM_STAMP(i)                                                  \
     do {                                                               \
         const unsigned long long _t = __builtin_amdgcn_s_memrealtime(); \
@@ -480,6 +480,7 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
 #ifdef WFA_TEAM_STAMPS
         if (lead_wg && tid == 0)
             for (int i = 0; i < 6; i++) atomicAdd(reinterpret_cast<unsigned long long *>(ctl + 64) + i, tacc[i]), tacc[i] = 0;
+        tprev = __builtin_amdgcn_s_memrealtime();
 #endif
 
         // ---- a pair that ends in solo mode: wake the parked workgroups
@@ -557,6 +558,7 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
                 if (blo != 0xFFFFFFFFu) minS = bhi, lastK = (int)blo - 0x40000000;
             }
         }
+        TEAM_STAMP(6);  // wake-up, cell count, end-cell search
         if (!lead_wg) continue;  // backtrace: workgroup 0 (the others wait at the next pair's barrier)
 
         // ---- backtrace + result record: one lane
@@ -614,6 +616,10 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
                 rec[REC_CELLS_HI]    = 0u;
                 rec[REC_N_SCORES]    = s_final;
             }
+#ifdef WFA_TEAM_STAMPS
+            TEAM_STAMP(7);  // backtrace + result record
+            for (int i = 6; i < 8; i++) atomicAdd(reinterpret_cast<unsigned long long *>(ctl + 64) + i, tacc[i]), tacc[i] = 0;
+#endif
         }
     }
 }

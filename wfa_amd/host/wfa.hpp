@@ -146,13 +146,34 @@ class Aligner {
         return rs[0];
     }
 
-    // new: one device call for many pairs; results[i] / errors[i] per pair
+    // new: hand in one pair (copied), get its ticket; Collect aligns everything submitted so far as ONE batch and
+    // returns results[ticket] / errors[ticket].  Serves a per-pair loop like wfa-go/wfa-go.go:166-178 at batch speed.
+    uint64_t Submit(const std::string &q, const std::string &t) {
+        uint64_t ticket = 0;
+        if (ctx_)
+            wfahip_submit(ctx_, reinterpret_cast<const uint8_t *>(q.data()), (uint32_t)q.size(),
+                          reinterpret_cast<const uint8_t *>(t.data()), (uint32_t)t.size(), &ticket);
+        return ticket;
+    }
+    int Collect(std::vector<AlignmentResult> &results, std::vector<Error> &errors) {
+        const size_t n = ctx_ ? (size_t)wfahip_pending(ctx_) : 0;
+        results.assign(n, {});
+        errors.assign(n, Error::None);
+        if (!ctx_) return create_rc_;
+        const wfahip_params prm = params();
+        wfahip_results      out{};
+        const int           rc = wfahip_collect(ctx_, &prm, &out);
+        return unpack(rc, out, results, errors);
+    }
+
+    // new: one device call for many pairs; results[i] / errors[i] per pair.  With `multi` (a context set over several
+    // GPUs, wfahip_create_multi) the batch is sharded over them.
     int AlignBatch(const std::vector<std::string> &qs, const std::vector<std::string> &ts,
-                   std::vector<AlignmentResult> &results, std::vector<Error> &errors) {
+                   std::vector<AlignmentResult> &results, std::vector<Error> &errors, wfahip_multi *multi = nullptr) {
         const size_t n = qs.size();
         results.assign(n, {});
         errors.assign(n, Error::None);
-        if (!ctx_) {
+        if (!ctx_ && !multi) {
             errors.assign(n, Error::Device);
             return create_rc_;
         }
@@ -169,6 +190,17 @@ class Aligner {
             std::memcpy(blob.data() + q_off[i], qs[i].data(), qs[i].size());
             std::memcpy(blob.data() + t_off[i], ts[i].data(), ts[i].size());
         }
+        const wfahip_params prm = params();
+        wfahip_results      out{};
+        const int rc = multi ? wfahip_align_batch_multi(multi, &prm, blob.data(), blob.size(), q_off.data(), q_len.data(),
+                                                        t_off.data(), t_len.data(), n, &out)
+                             : wfahip_align_batch(ctx_, &prm, blob.data(), blob.size(), q_off.data(), q_len.data(),
+                                                  t_off.data(), t_len.data(), n, &out);
+        return unpack(rc, out, results, errors);
+    }
+
+  private:
+    wfahip_params params() const {
         wfahip_params prm{};
         prm.mismatch = p_.Mismatch, prm.gap_open = p_.GapOpen, prm.gap_ext = p_.GapExt;
         prm.global_alignment = opt_.GlobalAlignment ? 1 : 0;
@@ -176,9 +208,10 @@ class Aligner {
             prm.adaptive   = 1;
             prm.min_wf_len = ad_.MinWFLen, prm.max_dist_diff = ad_.MaxDistDiff, prm.cutoff_step = ad_.CutoffStep;
         }
-        wfahip_results out{};
-        const int rc = wfahip_align_batch(ctx_, &prm, blob.data(), blob.size(), q_off.data(), q_len.data(),
-                                          t_off.data(), t_len.data(), n, &out);
+        return prm;
+    }
+    static int unpack(int rc, wfahip_results &out, std::vector<AlignmentResult> &results, std::vector<Error> &errors) {
+        const size_t n = results.size();
         if (rc != 0) {
             errors.assign(n, Error::Device);
             return rc;
@@ -203,7 +236,6 @@ class Aligner {
         return 0;
     }
 
-  private:
     Penalties               p_;
     Options                 opt_;
     AdaptiveReductionOption ad_{};
