@@ -83,7 +83,7 @@ enum {
     WFAHIP_REC_STATUS = 0, WFAHIP_REC_SCORE, WFAHIP_REC_TBEGIN, WFAHIP_REC_TEND, WFAHIP_REC_QBEGIN,
     WFAHIP_REC_QEND, WFAHIP_REC_ALIGN_LEN, WFAHIP_REC_MATCHES, WFAHIP_REC_GAPS, WFAHIP_REC_GAP_REGIONS,
     WFAHIP_REC_OPS_LEN, WFAHIP_REC_OPS_OFF_LO, WFAHIP_REC_OPS_OFF_HI,
-    WFAHIP_REC_CELLS_LO, WFAHIP_REC_CELLS_HI, /* non-zero wavefront words stored (M+I+D) */
+    WFAHIP_REC_CELLS_LO, WFAHIP_REC_CELLS_HI, /* non-zero wavefront words stored (M+I+D); 0 unless option "census" is on */
     WFAHIP_REC_N_SCORES,
     WFAHIP_REC_WORDS = 16
 };
@@ -208,6 +208,11 @@ int  wfahip_last_timing(const wfahip_ctx *ctx, wfahip_timing *out);
  *   "blk_wide"  0|1        pairs whose band leaves the 64-diagonal window retry on the same kernel with a
  *                          wave per pair (256 diagonals) before the generic kernel takes them       default 1
  *   "arena_bytes_per_slot", "slots", "threads_per_pair"   generic kernel (one workgroup per pair)
+ *   "census"  0|1          count the wavefront words every pair stores (WFAHIP_REC_CELLS, timing.cells_stored: the roofline
+ *                          accounting of bench.py); instrumentation, 4 % of the forward pass on 1 kbp pairs.  The kernels for
+ *                          long / semi-global pairs always count                                                default 0
+ *   "learn"  0|1            long pairs (team kernel): start on the arena level by which 90 % of the long pairs of the
+ *                          previous call of the same kind had finished, instead of climbing from the smallest      default 1
  *   "team_min_len"         pairs at least this long use the team kernel (0 = never)              default 8192
  *   "team_wgs", "team_solo_max"   workgroups per team (0 = automatic), widest row done by one workgroup */
 int  wfahip_set_option(wfahip_ctx *ctx, const char *key, int64_t value);

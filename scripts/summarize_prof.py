@@ -26,11 +26,14 @@ for k in sorted(acc):
     print(k, "sum", acc[k], "dispatches", cnt[k])
 
 import json
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import bench
 pm = {}
 for k in sorted(acc):
     name, counter, grid = k
-    if counter in ("FETCH_SIZE", "WRITE_SIZE"):
-        pm.setdefault(name.strip(), {}).setdefault(grid, {})[counter + "_KB"] = acc[k] / cnt[k]
-with open(os.path.join(out, "pmc_hbm.json"), "w") as f:
-    json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KB per dispatch, keyed by kernel and grid size",
-               "kernels": pm}, f, indent=1)
+    key = counter + "_KB" if counter in ("FETCH_SIZE", "WRITE_SIZE") else counter
+    pm.setdefault(name.strip(), {}).setdefault(grid, {})[key] = acc[k] / cnt[k]
+with open(os.path.join(out, "pmc.json"), "w") as f:
+    json.dump({"note": "rocprofv3 --pmc passes (one counter group per pass), value per dispatch, keyed by kernel and grid size; "
+                       "FETCH_SIZE / WRITE_SIZE in KB",
+               "kernel_sources_sha": bench.kernel_sources_sha(), "kernels": pm}, f, indent=1)

@@ -262,11 +262,13 @@ def test_forward_kernel_variants(built, opts, kind):
         want = O.align_batch(_oracle_params(True, ad), *data, n_threads=8)
         ref = _aligner(True, ad)  # the census of stored wavefront cells must not depend on the kernel either
         ref.set_option("packed", 0)
+        ref.set_option("census", 1)
         ref.align_arrays(*data)
         want_cells = ref.last_timing().cells_stored
         ref.close()
         for small_arena in (False, True):
             al = _aligner(True, ad)
+            al.set_option("census", 1)
             for k, v in opts.items():
                 al.set_option(k, v)
             if small_arena:
@@ -336,6 +338,7 @@ def test_hand_over_does_not_depend_on_wave_mates(built):
     import wfa_amd as w
     data = w.generate_pairs(seed=108, n_pairs=300000, length=100, error_rate=0.06, n_threads=16)
     al = _aligner(True, (10, 50, 1))
+    al.set_option("census", 1)
     seen = set()
     for _ in range(4):
         al.align_arrays(*data)
@@ -673,6 +676,14 @@ def test_full_size_parity_c3(built):
         again = al.align_arrays(*data)
         assert_batch_equal(again, want, f"full size L={length}, serial schedule")
         assert al.last_timing().cells_stored == cells
+        al.set_option("tail_overlap", 1)
+        # the counting instance of the forward kernel (option census: off by default) gives the same records; its count
+        # is at most what the oracle ever set (wf-adaptive deletes some words afterwards) -- the exact count is checked
+        # pair by pair in test_blocked_kernel_arena_word_for_word
+        assert cells == 0
+        al.set_option("census", 1)
+        assert_batch_equal(al.align_arrays(*data), want, f"full size L={length}, census on")
+        assert 0 < al.last_timing().cells_stored <= int(want.cells.sum())
         al.close()
 
 
@@ -799,7 +810,8 @@ def _arena_slot(fmt, i, k):
 @pytest.mark.parametrize("length,err,pen,ad,fmt", [(1000, 0.05, (4, 6, 2), (10, 50, 1), 3), (400, 0.08, (4, 6, 2), (10, 50, 1), 3),
                                                    (300, 0.03, (2, 3, 1), None, 3), (600, 0.05, (8, 12, 4), (4, 10, 1), 3),
                                                    (150, 0.02, (4, 6, 2), None, 5), (120, 0.06, (4, 6, 2), (10, 50, 1), 5)])
-def test_blocked_kernel_arena_word_for_word(built, length, err, pen, ad, fmt):
+@pytest.mark.parametrize("census", [0, 1])
+def test_blocked_kernel_arena_word_for_word(built, length, err, pen, ad, fmt, census):
     """The dominant kernel's stored state, not only its results: every compact backtrace word wfa_blk_kernel leaves in
     HBM (M tag, I and D tag bits, pre-extension offset) against what the oracle's wavefronts imply -- visited by the
     backtrace or not.  Covers wf-adaptive pruning (deleted cells must not be there with a source role), ragged lengths
@@ -814,6 +826,7 @@ def test_blocked_kernel_arena_word_for_word(built, length, err, pen, ad, fmt):
     q_len = np.where(cut & (np.arange(n) % 2 == 0), np.maximum(1, q_len - rng.integers(1, 25, n)), q_len).astype(np.uint32)
     t_len = np.where(cut & (np.arange(n) % 2 == 1), np.maximum(1, t_len - rng.integers(1, 25, n)), t_len).astype(np.uint32)
     al = _aligner(True, ad, pen)
+    al.set_option("census", census)  # (two instances of the kernel: with and without the count of stored words)
     got = al.align_arrays(blob, q_off, q_len, t_off, t_len)
     assert al.last_timing().main_kernel_kind == (6 if fmt == 5 else 3)
     g = np.gcd.reduce([pen[0], pen[1] + pen[2], pen[2]])
@@ -828,8 +841,10 @@ def test_blocked_kernel_arena_word_for_word(built, length, err, pen, ad, fmt):
         t = bytes(blob[int(t_off[i]):int(t_off[i]) + int(t_len[i])])
         r = oa.align(q, t)
         assert meta[1] == r.score == int(got.score[i])
-        exp = _expected_compact_words(oa.dump(), *pen)
-        assert meta[3] == sum(r.cells), (i, meta, r.cells)  # the census: every stored M, I and D word
+        dump = oa.dump()
+        exp = _expected_compact_words(dump, *pen)
+        # the census: every M, I and D word the reference still holds after the alignment (wf-adaptive deletes some)
+        assert meta[3] == (sum(sum(1 for v in raw if v) for c in "MID" for (lo, hi, raw) in dump[c].values()) if census else 0), (i, meta)
         for (s, k), wv in exp.items():
             if s > r.score:
                 continue

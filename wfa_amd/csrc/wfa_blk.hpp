@@ -220,7 +220,10 @@ WFA_DEV void blk_push_not_ok(const KParams &P, uint32_t pidx) {
     blk_store_sc1(P.done_q + t, (pidx + 1u) | DONE_NOT_OK, 0u, 0u, 0u);
 }
 
-template <int G, int BATCH, bool STREAM = false, int PPT = 0>
+// CENSUS: count the wavefront words a pair stores (REC_CELLS: the roofline accounting of bench.py and the tests' cross-
+// check between kernels).  It is instrumentation, not part of the alignment, and costs 4 % of the forward pass
+// (23.3 vs 24.3 ms per 1e6 x 1 kbp pairs): off unless the context's option "census" asks for it.
+template <int G, int BATCH, bool STREAM = false, int PPT = 0, bool CENSUS = true>
 __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : 4)) void wfa_blk_kernel(const KParams P) {
     static_assert(!STREAM || (G == 16 && BATCH == 1), "streamed backtrace: 16 lanes per pair, unbatched refill");
     static_assert(PPT == 0 || (G == 8 && PPT == 4), "diagonals per lane can only be overridden for the 8-lane narrow instance");
@@ -570,11 +573,7 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : 4)) void
                     const uint32_t w  = (Msk << 7) | (dc << 5) | (ic << 3) | tg;
                     nM[p] = Msk, nI[p] = Isk, nD[p] = Dsk;
                     wd[p] = Msk ? w : 0u;
-#ifndef WFA_NO_CENSUS
-                    cc[p] = tI + tD + umin2(Msk, 1u);
-#else
-                    cc[p] = 0u;
-#endif
+                    cc[p] = CENSUS ? tI + tD + umin2(Msk, 1u) : 0u;
                 }
             } else {
 #pragma unroll
@@ -602,7 +601,7 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : 4)) void
                     const uint32_t w   = (o0 << 7) | (dc << 5) | (ic << 3) | tg;
                     nM[p] = kin ? Msk : 0u, nI[p] = kin ? Isk : 0u, nD[p] = kin ? Dsk : 0u;
                     wd[p] = (kin && Msk) ? w : 0u;
-                    cc[p] = kin ? tI + tD + umin2(Msk, 1u) : 0u;
+                    cc[p] = (CENSUS && kin) ? tI + tD + umin2(Msk, 1u) : 0u;
                 }
             }
             // seeds of initComponents (wfa.go:155-160): M[0][0] = 1/Match or M[x][0] = 1/Mismatch
@@ -611,7 +610,7 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : 4)) void
 #pragma unroll
                 for (int p = 0; p < PP; p++)
                     if (want && k0 + p == 0 && nM[p] == 0u)
-                        nM[p] = 1u, wd[p] = first_eq ? (uint32_t)TAG_MATCH : (uint32_t)TAG_MISMATCH, cc[p] = 1u;
+                        nM[p] = 1u, wd[p] = first_eq ? (uint32_t)TAG_MATCH : (uint32_t)TAG_MISMATCH, cc[p] = CENSUS ? 1u : 0u;
             }
             WFA_STAMP(1); WFA_MARK(1);  // next
 
@@ -824,7 +823,7 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : 4)) void
             // ------------------------------------------------------------ finish / next score
             bool fin = run && (term || no_room);
             if (__ballot(fin) != 0ull) {
-                int ctot = (int)cells;
+                int ctot = (CENSUS && P.census) ? (int)cells : 0;
                 int hf   = 0;  // extended offset of the end cell M[s][Ak]: where the backtrace starts
 #pragma unroll
                 for (int p = 0; p < PP; p++)

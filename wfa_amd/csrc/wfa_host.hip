@@ -119,6 +119,10 @@ struct wfahip_ctx {
     int64_t       opt_tail_overlap         = 1;  // 1: retry passes overlap the backtrace kernel of the first pass
     int64_t       opt_overlap              = 0;  // 1: backtrace of chunk c on a second stream beside the forward kernel of chunk c+1 (measured: no gain)
     int64_t       opt_fail_pass            = 0;   // test aid (fault injection): the sub-wave pass of this kind reports WFAHIP_ERR_OOM
+    int64_t       opt_census               = 0;   // 1: the sub-wave forward kernels count the wavefront words they store (REC_CELLS, timing.cells_stored)
+    int64_t       opt_learn                = 1;   // 1: long pairs start on the arena level the previous call of the same kind ended on
+    uint64_t      learn_key                = 0;   // workload class of the last call that used the team kernel
+    int           learn_level              = 0;   // ... and the level by which 90 % of its long pairs had finished
     int           force_mode               = -1;  // debug: start the ladder in this mode
     // debug / parity aid (wfahip_debug_compact_arena): where the first chunk of the most recent first pass left its arena
     const uint32_t *dbg_arena = nullptr;
@@ -192,7 +196,7 @@ hipError_t launch_generic(const KParams &P, const LaunchCfg &c, hipStream_t st) 
 
 struct Job {
     int                   mode;
-    int                   level;  // arena size = base * 8^level
+    int                   level;  // arena size = base * 8^min(level, 2) * 2^max(level - 2, 0)
     bool                  all;    // identity work list over all pairs
     std::vector<uint32_t> pairs;
     uint32_t              max_len = 0;  // length bound of these pairs (0 = the batch's)
@@ -216,8 +220,10 @@ int make_cfg(wfahip_ctx *ctx, uint32_t max_len, int mode, int level, uint64_t n_
     // semi-global rows are n+m-1 wide until wf-adaptive collapses the band (a few dozen scores): ~4x the words
     uint64_t base_words = std::max<uint64_t>(64 * 1024, (semi_global ? 384ull : 96ull) * max_len);
     if (ctx->opt_arena_bytes_per_slot > 0) base_words = std::max<uint64_t>(4096, ctx->opt_arena_bytes_per_slot / 4);
+    // the ladder: x8, x8, then x2 per level -- a slot of a long pair is tens of GB by then, and every doubling
+    // halves the number of pairs that can be in flight (level 3 of a 100 kbp semi-global pair: 21.6 GB)
     uint64_t words = base_words;
-    for (int i = 0; i < level; i++) words *= 8;
+    for (int i = 0; i < level; i++) words *= (i < 2 ? 8 : 2);
     words         = (words + 7) & ~7ull;  // directory entries are 32-byte aligned from the slot end
     c.arena_words = words;
 
@@ -372,6 +378,10 @@ static int set_option_impl(wfahip_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_team_solo_max = value;
     else if (k == "fail_pass")
         ctx->opt_fail_pass = value;
+    else if (k == "census")
+        ctx->opt_census = value;
+    else if (k == "learn")
+        ctx->opt_learn = value, ctx->learn_key = 0;
     else
         return WFAHIP_ERR_BAD_ARG;
     return WFAHIP_OK;
@@ -476,6 +486,7 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
     P.g                = gcd_u32(gcd_u32(P.x, P.oe), P.e);
     P.global_alignment = p->global_alignment ? 1 : 0;
     P.adaptive = p->adaptive ? 1 : 0, P.min_wf_len = p->min_wf_len, P.max_dist_diff = p->max_dist_diff;
+    P.census = ctx->opt_census ? 1u : 0u;
     P.rec = static_cast<uint32_t *>(d_rec);
     P.ops = static_cast<uint64_t *>(d_ops), P.ops_cap = ops_cap;
 
@@ -490,7 +501,7 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
     std::vector<uint32_t> no_memory;
     std::vector<uint32_t> h_len;   // max(q_len, t_len) per pair, only when the batch mixes short and long pairs
     uint32_t              sub_len_used = 0;
-    const int             max_level = 6;
+    const int             max_level = 12;
     bool                  first     = true;
 
     // ---- pass 1: sub-wave forward kernels + lane-per-pair backtrace kernel, chunk by chunk.
@@ -650,10 +661,14 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                     else
                         hipLaunchKernelGGL((wfa_blk_kernel<16, BLK_BATCH>), dim3(grid), dim3(64), lds_bytes, st, P);
                 }
-                else if (kind == 3 && stream_bt)
+                else if (kind == 3 && stream_bt && P.census)
                     hipLaunchKernelGGL((wfa_blk_kernel<16, 1, true>), dim3(grid), dim3(64), lds_bytes, st, P);
-                else if (kind == 3)
+                else if (kind == 3 && stream_bt)
+                    hipLaunchKernelGGL((wfa_blk_kernel<16, 1, true, 0, false>), dim3(grid), dim3(64), lds_bytes, st, P);
+                else if (kind == 3 && P.census)
                     hipLaunchKernelGGL((wfa_blk_kernel<16, 1>), dim3(grid), dim3(64), lds_bytes, st, P);
+                else if (kind == 3)
+                    hipLaunchKernelGGL((wfa_blk_kernel<16, 1, false, 0, false>), dim3(grid), dim3(64), lds_bytes, st, P);
                 else if (kind == 2)
                     hipLaunchKernelGGL((wfa_reg_kernel<2, 4, 1>), dim3(grid), dim3(64), lds_bytes, st, P);
                 else
@@ -833,9 +848,25 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             packed_done = true;
         }
     }
+    // Long pairs (team-kernel regime): the arena a pair needs is only known once it has been aligned -- a 100 kbp
+    // semi-global pair takes anything from 0.2 to 13 GB -- and climbing the ladder from the bottom costs a launch per
+    // level.  A context remembers, per workload class (mode, wf-adaptive, penalties, length bucket), the lowest level by
+    // which 90 % of the long pairs had finished, and starts the next call of that class there (the slots of the last
+    // levels are tens of GB: a few outliers must not size everybody's arena).
+    uint64_t  lkey = 0;
+    {
+        uint32_t lb = 0;
+        while ((2u << lb) <= max_len) lb++;
+        lkey = 1ull | ((uint64_t)lb << 1) | ((uint64_t)P.global_alignment << 8) | ((uint64_t)P.adaptive << 9) | ((uint64_t)(P.x & 0xFFF) << 12) |
+               ((uint64_t)(P.oe & 0xFFF) << 24) | ((uint64_t)(P.e & 0xFFF) << 36) | ((uint64_t)(P.max_dist_diff & 0xFFFF) << 48);
+    }
+    int      learned_now = -1;
+    uint64_t team_total = 0, team_done = 0;
     if (!packed_done) {
         Job j;
         j.mode = ctx->force_mode == 1 ? 1 : 0, j.level = 0, j.all = true;
+        if (ctx->opt_learn && !debug_single && ctx->learn_key == lkey && ctx->opt_team_min_len > 0 && max_len >= (uint64_t)ctx->opt_team_min_len)
+            j.level = ctx->learn_level;
         jobs.push_back(std::move(j));
     }
 
@@ -948,6 +979,11 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
         ctx->timing.n_launches++;
 
         const uint32_t n_redo = hctrl[1];
+        if (team_T > 0) {  // the lowest level by which 90 % of the long pairs of this call have finished
+            if (team_total == 0) team_total = n_work;
+            team_done += n_work - n_redo;
+            if (learned_now < 0 && 10 * team_done >= 9 * team_total) learned_now = job.level;
+        }
         if (n_redo) {
             ctx->timing.n_retried_pairs += n_redo;
             Job jb, ja;
@@ -962,6 +998,7 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
         }
         if (debug_single) break;
     }
+    if (learned_now >= 0) ctx->learn_key = lkey, ctx->learn_level = learned_now;
     if (ctx->bt_pending) HIP_TRY(hipStreamWaitEvent(st, ctx->evBtB, 0));
     HIP_TRY(hipEventRecord(ctx->ev1, st));
 
