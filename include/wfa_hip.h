@@ -229,8 +229,11 @@ void wfahip_free(void *p);
 
 /* Debug / parity aid: the compact backtrace arena of pair `pair` (an index of the most recent batch, inside its first
  * chunk) exactly as the first-pass sub-wave forward kernel left it in HBM, + the pair's meta words {status, final
- * score, end offset, cells}.  One word per diagonal and score: bits 0-2 M tag, 3-4 I tag (0 none, 1 open, 2 ext),
- * 5-6 D tag, 7-31 the pre-extension offset backTrace recomputes (wfa.go:766-817).  *fmt = layout: 1 = 64 words per
+ * score, end offset, cells}.  One word per diagonal and score: bit 0 the M cell took the insertion's offset, bit 1 it
+ * took the mismatch's (which wins ties, wfa.go:657-693; neither: the deletion's), bit 2 the D cell is a DeleteExt
+ * (else DeleteOpen), bit 3 the I cell is an InsertExt (else InsertOpen), bits 4-31 the pre-extension offset backTrace
+ * recomputes (wfa.go:766-817); a seed of initComponents has offset 0 and bit 0 = Match / bit 1 = Mismatch.  Whether a
+ * cell exists is not recorded (the walk only visits cells a stored decision names).  *fmt = layout: 1 = 64 words per
  * score index (score / gcd), diagonal k at slot k & 63; 3 = tiles of 8 score indices x 64 diagonals,
  * [(k & 63) / 4][index & 7][k & 3]; 4 = 256 words per index, slot k & 255; 5 = 32 words per index, slot k & 31.
  * Slots the kernel never wrote hold stale bytes.  Caller frees *words with wfahip_free. */
@@ -247,6 +250,15 @@ uint64_t wfahip_gen_stride(uint32_t length, double error_rate);
 int      wfahip_generate_pairs(uint64_t seed, uint64_t first_index, uint64_t n_pairs, uint32_t length,
                                double error_rate, int n_threads, uint8_t *blob, uint64_t *q_off,
                                uint32_t *q_len, uint64_t *t_off, uint32_t *t_len);
+
+/* The same dataset generated on the device: byte for byte what wfahip_generate_pairs writes
+ * into the sequences (padding bytes between sequences are not defined), with nothing crossing PCIe.  d_blob must hold
+ * n_pairs * wfahip_gen_stride(length, error_rate) + 16 bytes, the other arrays n_pairs entries; all device addresses
+ * on the context's GPU.  stream = hipStream_t (NULL = the context's own); returns when the data is there.
+ * WFAHIP_ERR_UNSUPPORTED when a pair's text does not fit the LDS it is edited in (length + edits > 160 KB). */
+int      wfahip_generate_pairs_device(wfahip_ctx *ctx, uint64_t seed, uint64_t first_index, uint64_t n_pairs, uint32_t length,
+                                      double error_rate, void *d_blob, void *d_q_off, void *d_q_len, void *d_t_off,
+                                      void *d_t_len, void *stream);
 
 #ifdef __cplusplus
 }

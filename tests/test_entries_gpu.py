@@ -103,3 +103,22 @@ def test_context_set_shards_and_merges_in_pair_order(built, devices):
     results, errors = m.AlignBatch(qs[:3], ts[:3])
     assert errors[0] is w.ErrEmptySeq and errors[1] is None
     m.close()
+
+
+@pytest.mark.parametrize("n,length,err,first", [(3000, 1000, 0.05, 0), (500, 150, 0.02, 12345), (4, 100_000, 0.10, 2), (64, 37, 0.3, 7)])
+def test_device_generator_writes_the_host_generator_s_dataset(built, n, length, err, first):
+    """the synthetic pairs generated in HBM are, byte for byte, the ones the host generator
+    makes (same seeded splitmix64 stream, same sequential edits) -- offsets, lengths and every sequence byte."""
+    import torch
+    import wfa_amd as w
+    host = w.generate_pairs(seed=11, n_pairs=n, length=length, error_rate=err, first_index=first, n_threads=8)
+    al = w.New()
+    dev = [t.cpu().numpy() for t in w.generate_pairs_device(al, 11, n, length, err, first_index=first)]
+    blob_h, q_off, q_len, t_off, t_len = host
+    assert np.array_equal(dev[1].view(np.uint64), q_off) and np.array_equal(dev[3].view(np.uint64), t_off)
+    assert np.array_equal(dev[2].view(np.uint32), q_len) and np.array_equal(dev[4].view(np.uint32), t_len)
+    for i in range(n):
+        for off, ln in ((q_off, q_len), (t_off, t_len)):
+            a, b = int(off[i]), int(off[i]) + int(ln[i])
+            assert np.array_equal(dev[0][a:b], blob_h[a:b]), i
+    al.close()

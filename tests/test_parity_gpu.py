@@ -773,8 +773,9 @@ def test_host_entry_slices_agree_with_the_plain_call(built):
 
 
 def _expected_compact_words(dump, x, o, e):
-    """{(s, k): compact word} from the oracle's final wavefronts: M tag, I / D tag codes, and the pre-extension offset
-    exactly as the reference's backTrace recomputes it from the UNBOUNDED sources (wfa.go:766-817)."""
+    """{(s, k): (word, mask)} from the oracle's final wavefronts, in the blocked kernels' encoding (wfa_device.hpp,
+    blk_word): which source the M cell took, whether the I / D cells are extensions, and the pre-extension offset exactly
+    as the reference's backTrace recomputes it from the UNBOUNDED sources (wfa.go:766-817)."""
     M, I, D = ({s: {lo + i: v for i, v in enumerate(raw) if v} for s, (lo, hi, raw) in dump[c].items()} for c in "MID")
 
     def get(C, s, k):  # Component.Get: 0 when the score underflows or nothing is stored (wfa_component.go:158-167)
@@ -797,7 +798,16 @@ def _expected_compact_words(dump, x, o, e):
                 off0 = max(isk, dsk, x0 + 1) if (isk or dsk or x0) else 0  # wfa.go:808-813 (else: fromItself)
             ic = I.get(s, {}).get(k, 0) & 7               # 0 / InsOpen 1 / InsExt 2
             dt = D.get(s, {}).get(k, 0) & 7               # 0 / DelOpen 3 / DelExt 4
-            out[(s, k)] = (off0 << 7) | ((dt - 2 if dt else 0) << 5) | (ic << 3) | tag
+            # (word, mask): the I / D bits only mean something where that cell exists
+            if off0 == 0:   # a seed of initComponents: Match / Mismatch in bits 0 / 1, offset field 0
+                out[(s, k)] = (1 if tag == 6 else 2, 0xFFFFFFF3)
+                continue
+            word = (off0 << 4) | ((ic == 2) << 3) | ((dt == 4) << 2) | ((tag == 5) << 1) | (tag in (1, 2))
+            mask = 0xFFFFFFF3 | (8 if ic else 0) | (4 if dt else 0)
+            if tag == 5:
+                mask &= ~1  # (the mismatch won: whether the insertion tied with it is not part of the decision)
+            assert tag in (1, 2, 3, 4, 5) and (tag not in (1, 2) or tag == ic) and (tag not in (3, 4) or tag == dt)
+            out[(s, k)] = (word, mask)
     return out
 
 
@@ -845,13 +855,13 @@ def test_blocked_kernel_arena_word_for_word(built, length, err, pen, ad, fmt, ce
         exp = _expected_compact_words(dump, *pen)
         # the census: every M, I and D word the reference still holds after the alignment (wf-adaptive deletes some)
         assert meta[3] == (sum(sum(1 for v in raw if v) for c in "MID" for (lo, hi, raw) in dump[c].values()) if census else 0), (i, meta)
-        for (s, k), wv in exp.items():
+        for (s, k), (wv, mask) in exp.items():
             if s > r.score:
                 continue
             have = int(words[_arena_slot(f, s // g, k)])
-            assert have == wv, (f"pair {i} score {s} diagonal {k}: arena {have:#x} = off {have >> 7} D{(have >> 5) & 3} "
-                                f"I{(have >> 3) & 3} tag {have & 7}, expected off {wv >> 7} D{(wv >> 5) & 3} I{(wv >> 3) & 3} tag {wv & 7}")
+            assert (have & mask) == (wv & mask), (f"pair {i} score {s} diagonal {k}: arena {have:#x} = off {have >> 4} bits {have & 15:04b}, "
+                                                 f"expected off {wv >> 4} bits {wv & 15:04b} (mask {mask & 15:04b})")
             checked += 1
         pairs += 1
-    assert pairs >= n * 3 // 4 and checked > 50 * pairs, (pairs, checked)
+    assert pairs >= n // 2 and checked > 50 * pairs, (pairs, checked)  # (the others were handed on: band or arena)
     al.close()

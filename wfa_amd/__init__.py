@@ -4,7 +4,7 @@ The package holds only what the hot path needs: csrc/ (HIP kernels + the C-ABI o
 lib/ (the built libwfahip.so) and aligner.py (host-side mirror of the reference's Go API over ctypes).
 """
 from .aligner import (  # noqa: F401
-    AdaptiveReductionOption, Aligner, AlignmentResult, MultiAligner, pack_pairs, BatchResult, DefaultAdaptiveOption, DefaultOptions,
+    AdaptiveReductionOption, Aligner, AlignmentResult, MultiAligner, pack_pairs, generate_pairs_device, BatchResult, DefaultAdaptiveOption, DefaultOptions,
     DefaultPenalties, ErrEmptySeq, ErrSeqTooLong, MaskLower32, MaxSeqLen, New, Op, OpD, OpH, OpI, OpM, OpX,
     Options, Penalties, RecycleAligner, RecycleAlignmentResult, RecycleAlignmentText, WfaError, generate_pairs,
     make_blob, plot_component, trimOps,

@@ -24,6 +24,7 @@ EXPORTS = [
     "wfahip_generate_pairs", "wfahip_packed_words", "wfahip_pack_pairs", "wfahip_align_batch_packed", "wfahip_submit",
     "wfahip_pending", "wfahip_collect", "wfahip_create_multi", "wfahip_destroy_multi", "wfahip_multi_size",
     "wfahip_multi_ctx", "wfahip_align_batch_multi", "wfahip_debug_compact_arena",
+    "wfahip_generate_pairs_device",
 ]
 
 
@@ -117,6 +118,8 @@ def lib():
         L.wfahip_debug_compact_arena.restype = C.c_int
         L.wfahip_debug_compact_arena.argtypes = [vp, u64, C.POINTER(C.POINTER(u32)), C.POINTER(u64), C.POINTER(u32),
                                                  C.POINTER(u32 * 4)]
+        L.wfahip_generate_pairs_device.restype = C.c_int
+        L.wfahip_generate_pairs_device.argtypes = [vp, u64, u64, u64, u32, C.c_double, vp, vp, vp, vp, vp, vp]
         _lib = L
     return _lib
 

@@ -586,3 +586,20 @@ def generate_pairs(seed: int, n_pairs: int, length: int, error_rate: float, firs
                                               vp(blob), vp(q_off), vp(q_len), vp(t_off), vp(t_len)),
                 "wfahip_generate_pairs")
     return blob, q_off, q_len, t_off, t_len
+
+
+def generate_pairs_device(ctx_owner: "Aligner", seed: int, n_pairs: int, length: int, error_rate: float, first_index: int = 0):
+    """The same dataset generated on the aligner's GPU (include/wfa_hip.h: wfahip_generate_pairs_device): returns torch
+    tensors (blob u8, q_off i64, q_len i32, t_off i64, t_len i32) resident in HBM; nothing crosses PCIe."""
+    import torch
+    dev = torch.device("cuda", torch.cuda.current_device())
+    stride = int(L.lib().wfahip_gen_stride(length, error_rate))
+    blob = torch.zeros(max(n_pairs * stride, 1) + 16, dtype=torch.uint8, device=dev)
+    q_off = torch.zeros(n_pairs, dtype=torch.int64, device=dev)
+    t_off = torch.zeros(n_pairs, dtype=torch.int64, device=dev)
+    q_len = torch.zeros(n_pairs, dtype=torch.int32, device=dev)
+    t_len = torch.zeros(n_pairs, dtype=torch.int32, device=dev)
+    L.check(L.lib().wfahip_generate_pairs_device(ctx_owner._ctx, seed, first_index, n_pairs, length, float(error_rate),
+                                                 blob.data_ptr(), q_off.data_ptr(), q_len.data_ptr(), t_off.data_ptr(),
+                                                 t_len.data_ptr(), None), "wfahip_generate_pairs_device")
+    return blob, q_off, q_len, t_off, t_len

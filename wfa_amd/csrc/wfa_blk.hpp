@@ -20,7 +20,8 @@
 // pre-extension offset (wfa.go:766-817) equals the offset just computed.  A sticky per-pair flag, set by the
 // first cell that hits an end, switches the wave to the exact code (bit-for-bit the rules of next_cell()).
 //
-// Output: one compact backtrace word per diagonal (compact_word()) in a directory-free arena layout (CompactView
+// Output: one backtrace word per diagonal (blk_word(): the pre-extension offset and the four decisions of next(), not
+// the reference's tag values) in a directory-free arena layout (CompactView
 // fmt 3: tiles of 8 scores x 64 diagonals; fmt 1 / 4: 64 / 256 words per score, diagonal k at slot k & (W-1); the
 // window base stays a multiple of PP so a lane's PP words are aligned 16-byte stores), and pair_meta for
 // wfa_backtrace_kernel.
@@ -192,6 +193,27 @@ WFA_DEV uint32_t ffbl_raw(uint32_t x) {  // index of the lowest set bit; 0xFFFFF
 
 WFA_DEV uint32_t umin2(uint32_t a, uint32_t b) { return a < b ? a : b; }
 WFA_DEV uint32_t umax3(uint32_t a, uint32_t b, uint32_t c) { return umax2(umax2(a, b), c); }
+
+// blk_word() of a cell computed without rejections, in eight instructions: four compares into scalar registers, then
+// four add-with-carry (w = 2 w + bit).  t = max(Isk, Dsk): the mismatch wins iff x1 >= t, else the insertion iff
+// Isk >= Dsk (bit 0 means nothing next to a set bit 1).  The compares stand three instructions before their consumers
+// (a scalar register written by a vector instruction may be read as an operand two wait states later).
+WFA_DEV uint32_t blk_word_asm(uint32_t Msk, uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t x1, uint32_t t, uint32_t Isk,
+                              uint32_t Dsk) {
+    uint32_t w = Msk;
+    asm("v_cmp_lt_u32_e64 s[40:41], %1, %2\n\t"
+        "v_cmp_lt_u32_e64 s[42:43], %3, %4\n\t"
+        "v_cmp_ge_u32_e64 s[44:45], %5, %6\n\t"
+        "v_cmp_ge_u32_e64 s[46:47], %7, %8\n\t"
+        "v_addc_co_u32_e64 %0, vcc, %0, %0, s[40:41]\n\t"
+        "v_addc_co_u32_e64 %0, vcc, %0, %0, s[42:43]\n\t"
+        "v_addc_co_u32_e64 %0, vcc, %0, %0, s[44:45]\n\t"
+        "v_addc_co_u32_e64 %0, vcc, %0, %0, s[46:47]"
+        : "+v"(w)
+        : "v"(a), "v"(b), "v"(c), "v"(d), "v"(x1), "v"(t), "v"(Isk), "v"(Dsk)
+        : "vcc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47");
+    return w;
+}
 
 constexpr int BK_BIG = 0x3FFFFFFF;
 #ifndef WFA_BLK8_WAVES
@@ -563,17 +585,20 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : 4)) void
                     const uint32_t a = p ? Mo[p - 1] : a_edge, b = p ? I[p - 1] : b_edge;
                     const uint32_t c = p < PP - 1 ? Mo[p + 1] : c_edge, d = p < PP - 1 ? D[p + 1] : d_edge;
                     const uint32_t x = Mx[p];
-                    const uint32_t mi = umax2(a, b), tI = umin2(mi, 1u), Isk = mi + tI;  // wfa.go:579-609
-                    const uint32_t Dsk = umax2(c, d), tD = umin2(Dsk, 1u);               // wfa.go:614-645
-                    const uint32_t x1  = x + umin2(x, 1u);
-                    const uint32_t Msk = umax3(Isk, Dsk, x1);                            // wfa.go:655
-                    const uint32_t ic = tI + (a < b ? 1u : 0u);  // 0 none, 1 InsOpen, 2 InsExt
-                    const uint32_t dc = tD + (c < d ? 1u : 0u);  // 0 none, 1 DelOpen, 2 DelExt
-                    const uint32_t tg = Msk == x1 ? (uint32_t)TAG_MISMATCH : (Msk == Isk ? ic : dc + 2u);  // wfa.go:657-693
-                    const uint32_t w  = (Msk << 7) | (dc << 5) | (ic << 3) | tg;
+                    const uint32_t mi = umax2(a, b), Isk = mi + (mi != 0u ? 1u : 0u);  // wfa.go:579-609
+                    const uint32_t Dsk = umax2(c, d);                                   // wfa.go:614-645
+                    const uint32_t x1  = x + (x != 0u ? 1u : 0u);
+                    const uint32_t Msk = umax3(Isk, Dsk, x1);                           // wfa.go:655
+                    // the four decisions of wfa.go:590-600,626-636,657-693, one bit each, shifted in under the offset
+                    // (blk_word(): what the backtrace needs of this diagonal and score; no rejections on this path,
+                    // so backTrace's recomputed pre-extension offset, wfa.go:766-817, is Msk itself)
                     nM[p] = Msk, nI[p] = Isk, nD[p] = Dsk;
-                    wd[p] = Msk ? w : 0u;
-                    cc[p] = CENSUS ? tI + tD + umin2(Msk, 1u) : 0u;
+#ifndef WFA_BLK_NO_ASM_BITS  // (hand-placed: 21.07 vs 21.77 ms per 1e6 x 1 kbp pairs against what hipcc makes of blk_word())
+                    wd[p] = blk_word_asm(Msk, a, b, c, d, x1, umax2(Isk, Dsk), Isk, Dsk);
+#else
+                    wd[p] = blk_word(Msk, a < b, c < d, Msk == x1, Msk == Isk);
+#endif
+                    cc[p] = CENSUS ? (mi != 0u ? 1u : 0u) + (Dsk != 0u ? 1u : 0u) + (Msk != 0u ? 1u : 0u) : 0u;
                 }
             } else {
 #pragma unroll
@@ -590,17 +615,17 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : 4)) void
                     const uint32_t Dsk = umax2(c, d), tD = umin2(Dsk, 1u);
                     const uint32_t x1  = x + umin2(x, 1u);
                     const uint32_t Msk = umax3(Isk, Dsk, x1);
-                    const uint32_t ic = tI + (a < b ? 1u : 0u);
-                    const uint32_t dc = tD + (c < d ? 1u : 0u);
-                    const uint32_t tg = Msk == x1 ? (uint32_t)TAG_MISMATCH : (Msk == Isk ? ic : dc + 2u);
+                    // wfa.go:657-693: the mismatch wins a tie when its source exists, then the insertion
+                    const bool fromX = x != 0u && Msk == x1;
+                    const bool fromI = !fromX && Msk == Isk;
                     // backTrace recomputes the pre-extension offset from the un-rejected sources (wfa.go:766-817)
                     const uint32_t mu = umax2(a0, b0), Iu = mu + umin2(mu, 1u), Du = umax2(c0, d0);
                     const uint32_t Xu = x0 + umin2(x0, 1u);
-                    const uint32_t o0 = tg == TAG_INS_EXT ? Iu : (tg == TAG_DEL_EXT ? Du : umax3(Iu, Du, Xu));
-                    const bool     kin = k >= -(n - 1) && k <= m - 1;  // wfa.go:562-563
-                    const uint32_t w   = (o0 << 7) | (dc << 5) | (ic << 3) | tg;
+                    const bool     iext = a < b, dext = c < d;
+                    const uint32_t o0   = (fromI && iext) ? Iu : ((!fromX && !fromI && dext) ? Du : umax3(Iu, Du, Xu));
+                    const bool     kin  = k >= -(n - 1) && k <= m - 1;  // wfa.go:562-563
                     nM[p] = kin ? Msk : 0u, nI[p] = kin ? Isk : 0u, nD[p] = kin ? Dsk : 0u;
-                    wd[p] = (kin && Msk) ? w : 0u;
+                    wd[p] = blk_word(o0, iext, dext, fromX, fromI);
                     cc[p] = (CENSUS && kin) ? tI + tD + umin2(Msk, 1u) : 0u;
                 }
             }
@@ -610,7 +635,7 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : 4)) void
 #pragma unroll
                 for (int p = 0; p < PP; p++)
                     if (want && k0 + p == 0 && nM[p] == 0u)
-                        nM[p] = 1u, wd[p] = first_eq ? (uint32_t)TAG_MATCH : (uint32_t)TAG_MISMATCH, cc[p] = CENSUS ? 1u : 0u;
+                        nM[p] = 1u, wd[p] = first_eq ? BLK_SEED_MATCH : BLK_SEED_MISMATCH, cc[p] = CENSUS ? 1u : 0u;
             }
             WFA_STAMP(1); WFA_MARK(1);  // next
 
@@ -620,12 +645,13 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : 4)) void
             for (int p = 0; p < PP; p++) {
                 const int      h    = (int)nM[p];
                 const int      rem  = lim[p] - h;  // bases left on this diagonal; <= 0: at / past an end (wfa.go:404)
-                const int      remc = h ? imin2(imax2(rem, 0), 16) : 0;
+                const uint32_t room = h ? (uint32_t)imax2(rem, 0) : 0u;  // (nothing for an absent cell)
                 const int      v    = h - (k0 + p);  // absent cells read a harmless word (LDS reads cannot fault)
                 const uint32_t xr   = SeqView<0>::win16(lq, v) ^ SeqView<0>::win16(lt, h);
-                const uint32_t cnt  = umin2(ffbl_raw(xr) >> 1, (uint32_t)remc);
-                nM[p] += cnt;
-                if (cnt == 16u && rem > 16) cmask |= 1u << p;  // the whole window matched and bases remain
+                // (v_ffbl_b32 of 0 is 0xFFFFFFFF: a window that matched completely runs to the end of the room)
+                const uint32_t run  = umin2(ffbl_raw(xr) >> 1, room);
+                nM[p] += umin2(run, 16u);
+                if (run > 16u) cmask |= 1u << p;  // the whole window matched and bases remain
             }
             // the few cells (normally the one on the alignment path) that matched a whole window: each lane takes its
             // candidates one at a time and keeps comparing 16-base windows until a mismatch or a sequence end
@@ -707,8 +733,7 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : 4)) void
                     const int  ix   = PP * j + p;
                     const bool keep = ix >= ilo && ix <= ihi;
                     nM[p] = keep ? nM[p] : 0u, nI[p] = keep ? nI[p] : 0u, nD[p] = keep ? nD[p] : 0u;
-                    wd[p] = keep ? wd[p] : 0u;
-                    csum += keep ? cc[p] : 0u;
+                    csum += keep ? cc[p] : 0u;  // (the words of deleted cells stay as they are: nothing ever reads them)
                 }
             } else {
                 // ------------------------------------------------------------ tight range of the M cells = M.Lo/M.Hi
@@ -771,7 +796,6 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : 4)) void
                             const int  ix   = PP * j + p;
                             const bool keep = ix >= ilo && ix <= ihi;
                             nM[p] = keep ? nM[p] : 0u, nI[p] = keep ? nI[p] : 0u, nD[p] = keep ? nD[p] : 0u;
-                            wd[p] = keep ? wd[p] : 0u;
                             csum += keep ? cc[p] : 0u;
                         }
                     }
@@ -784,10 +808,8 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : 4)) void
             const bool no_room = run && rows_left <= 0;
             const bool keepl   = anyM && ihi >= ilo && !no_room;
             cells += keepl ? csum : 0u;
-            uint32_t anyw = 0u;
-#pragma unroll
-            for (int p = 0; p < PP; p++) anyw |= wd[p];
-            if (keepl && anyw != 0u) {
+            // a lane stores its PP words when its diagonals meet the band (3/4 of the lanes do not: their lines stay untouched)
+            if (keepl && PP * j + PP - 1 >= ilo && PP * j <= ihi) {
                 if constexpr (TILED) {
                     // tile of 8 scores x 64 diagonals: [diagonal / 4][score & 7][diagonal & 3] (CompactView fmt 3)
                     uint32_t *const row = rowp + (((uint32_t)k0 & 63u) << 3);

@@ -203,7 +203,7 @@ WFA_DEV uint32_t off0_unrejected(uint32_t mo_km1, uint32_t ie_km1, uint32_t mo_k
     return tag == TAG_INS_EXT ? Iu : (tag == TAG_DEL_EXT ? Du : umax2(umax2(Iu, Du), Xu));
 }
 
-// Compact backtrace word (sub-wave pipeline only): everything backTrace needs from a diagonal of one score.
+// Compact backtrace word (wfa_reg_kernel / wfa_packed_kernel, CompactView fmt 0): everything backTrace needs from a diagonal of one score.
 //   bits 0-2  tag of the M cell (0 = no M cell)      bits 3-4  I cell: 0 none, 1 InsOpen, 2 InsExt
 //   bits 5-6  D cell: 0 none, 1 DelOpen, 2 DelExt     bits 7-31 off0 of the M cell (25 bits)
 // The walk never re-reads a cell's extended offset: it tracks h itself (wfa.go:851-853,886-909) and only
@@ -213,6 +213,37 @@ WFA_DEV uint32_t compact_word(uint32_t M, uint32_t I, uint32_t D, uint32_t off0)
     const uint32_t td = D ? (D & TAG_MASK) - 2u : 0u;
     const uint32_t wd = (M & TAG_MASK) | ((I & 3u) << 3) | (td << 5) | (off0 << 7);
     return M ? wd : 0u;
+}
+
+// Word of the BLOCKED kernels' arenas (wfa_blk_kernel; CompactView fmt 1, 3, 4, 5).  The forward pass is bound by the
+// number of vector instructions it issues, the walk by DRAM latency, so the word is what is cheapest to PRODUCE: the
+// pre-extension offset with the four comparison results of next() shifted in under it (one add-with-carry each),
+// not the reference's tag values -- the walk derives those:
+//   bit 0  fromI: the M cell took the insertion's offset (wfa.go:664,672: Msk == Isk, after the mismatch's tie)
+//   bit 1  fromX: the M cell took the mismatch's offset  (wfa.go:660,677,687: "mismatch is prefered")
+//   bit 2  dext:  the D cell is a DeleteExt (v1 < v2, wfa.go:626-636), else a DeleteOpen
+//   bit 3  iext:  the I cell is an InsertExt (v1 < v2, wfa.go:590-600), else an InsertOpen
+//   bits 4-31  off0 of the M cell; 0 marks a seed of initComponents (wfa.go:155-160): bit 0 = Match, bit 1 = Mismatch
+// Whether an I, D or M cell EXISTS is not recorded: the walk only ever steps to a cell that a stored decision
+// names as a source, and a source existed (after its own row's wf-adaptive) when the decision was taken.
+constexpr uint32_t BLK_SEED_MATCH = 1u, BLK_SEED_MISMATCH = 2u;
+WFA_DEV uint32_t blk_word(uint32_t off0, bool iext, bool dext, bool fromX, bool fromI) {
+    uint32_t w = off0;
+    w = w + w + (iext ? 1u : 0u);
+    w = w + w + (dext ? 1u : 0u);
+    w = w + w + (fromX ? 1u : 0u);
+    w = w + w + (fromI ? 1u : 0u);
+    return w;
+}
+// tag of the cell of component comp (0 = M, 1 = I, 2 = D) a blocked-kernel word describes; 0 for a word never written as zero
+WFA_DEV uint32_t blk_tag(uint32_t wd, int comp, uint32_t &off0) {
+    off0 = wd >> 4;
+    if (wd == 0u) return 0u;
+    const uint32_t ti = (wd & 8u) ? TAG_INS_EXT : TAG_INS_OPEN, td = (wd & 4u) ? TAG_DEL_EXT : TAG_DEL_OPEN;
+    if (comp == 1) return ti;
+    if (comp == 2) return td;
+    if (off0 == 0u) return (wd & 1u) ? TAG_MATCH : TAG_MISMATCH;  // a seed: the walk ends here (offset0 == 0, wfa.go:822-825)
+    return (wd & 2u) ? (uint32_t)TAG_MISMATCH : ((wd & 1u) ? ti : td);
 }
 
 // Seeds of initComponents (wfa.go:143-184) that belong to score s, as a raw word for diagonal k
@@ -449,6 +480,7 @@ struct CompactView {
     // tag of the cell of component comp (0 = M, 1 = I, 2 = D) at (s, k); 0 = absent
     WFA_DEV uint32_t tag(int comp, uint32_t s, int k, uint32_t &off0) const {
         const uint32_t wd = word(s, k);
+        if (fmt != 0u) return blk_tag(wd, comp, off0);  // the blocked kernels' word; fmt 0: compact_word()
         off0              = wd >> 7;
         if (comp == 0) return wd & TAG_MASK;
         if (comp == 1) {

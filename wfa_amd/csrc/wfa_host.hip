@@ -10,10 +10,12 @@
 #include "wfa_blk.hpp"
 #include "wfa_team.hpp"
 #include "wfa_finalize.hpp"
+#include "wfa_gen_dev.hpp"
 
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1734,6 +1736,29 @@ extern "C" int wfahip_debug_compact_arena(wfahip_ctx *ctx, uint64_t pair, uint32
     }
     *words = w, *n_words = ctx->dbg_words;
     if (fmt) *fmt = ctx->dbg_fmt;
+    return WFAHIP_OK;
+}
+
+// ---- the synthetic dataset generated where it is used (wfa_gen_dev.hpp): no host generation, no upload
+extern "C" int wfahip_generate_pairs_device(wfahip_ctx *ctx, uint64_t seed, uint64_t first_index, uint64_t n_pairs, uint32_t length,
+                                            double error_rate, void *d_blob, void *d_q_off, void *d_q_len, void *d_t_off, void *d_t_len,
+                                            void *stream) {
+    if (!ctx || !d_blob || !d_q_off || !d_q_len || !d_t_off || !d_t_len || length == 0 || error_rate < 0.0) return WFAHIP_ERR_BAD_ARG;
+    if (n_pairs == 0) return WFAHIP_OK;
+    if (n_pairs > 0x7FFFFFFFull) return WFAHIP_ERR_BAD_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const uint64_t stride = wfahip_gen_stride(length, error_rate);
+    const uint32_t edits  = (uint32_t)std::llround((double)length * error_rate);
+    const size_t   lds    = (size_t)length + edits + 16;
+    if (lds > LDS_MAX_BYTES) return WFAHIP_ERR_UNSUPPORTED;  // (the text of a pair is edited in LDS)
+    if (lds > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(wfa_gen_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+    hipLaunchKernelGGL(wfa_gen_kernel, dim3((uint32_t)n_pairs), dim3(GEN_THREADS), lds, st, seed, first_index, n_pairs, length, edits, stride,
+                       static_cast<uint8_t *>(d_blob), static_cast<uint64_t *>(d_q_off), static_cast<uint32_t *>(d_q_len),
+                       static_cast<uint64_t *>(d_t_off), static_cast<uint32_t *>(d_t_len));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
     return WFAHIP_OK;
 }
 
