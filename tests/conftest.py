@@ -14,6 +14,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _torch_hip_runtime_first(request):
+    """On a GPU box, bring up torch's HIP runtime before the library's (bench.py's order): torch ships its own runtime,
+    and tests that hold device buffers in torch tensors need it to have seen the GPUs first."""
+    if request.config.getoption("-m") and "not gpu" in request.config.getoption("-m"):
+        return
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.zeros(1, device="cuda:0")
+    except Exception:
+        pass
+
+
 def load_golden(name):
     with open(os.path.join(GOLDEN, name)) as f:
         return json.load(f)

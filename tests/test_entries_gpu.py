@@ -111,8 +111,9 @@ def test_device_generator_writes_the_host_generator_s_dataset(built, n, length, 
     makes (same seeded splitmix64 stream, same sequential edits) -- offsets, lengths and every sequence byte."""
     import torch
     import wfa_amd as w
+    torch.zeros(1, device="cuda:0")  # (torch's own HIP runtime has to come up before the library's: it holds the buffers)
     host = w.generate_pairs(seed=11, n_pairs=n, length=length, error_rate=err, first_index=first, n_threads=8)
-    al = w.New()
+    al = w.New(device=0)
     dev = [t.cpu().numpy() for t in w.generate_pairs_device(al, 11, n, length, err, first_index=first)]
     blob_h, q_off, q_len, t_off, t_len = host
     assert np.array_equal(dev[1].view(np.uint64), q_off) and np.array_equal(dev[3].view(np.uint64), t_off)

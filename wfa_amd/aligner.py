@@ -590,7 +590,9 @@ def generate_pairs(seed: int, n_pairs: int, length: int, error_rate: float, firs
 
 def generate_pairs_device(ctx_owner: "Aligner", seed: int, n_pairs: int, length: int, error_rate: float, first_index: int = 0):
     """The same dataset generated on the aligner's GPU (include/wfa_hip.h: wfahip_generate_pairs_device): returns torch
-    tensors (blob u8, q_off i64, q_len i32, t_off i64, t_len i32) resident in HBM; nothing crosses PCIe."""
+    tensors (blob u8, q_off i64, q_len i32, t_off i64, t_len i32) resident in HBM; nothing crosses PCIe.  (The buffers
+    are torch's: torch.cuda must have been initialised before the first aligner of the process was created -- torch
+    ships its own HIP runtime, and it does not find the GPUs once the library's runtime has come up first.)"""
     import torch
     dev = torch.device("cuda", torch.cuda.current_device())
     stride = int(L.lib().wfahip_gen_stride(length, error_rate))
