@@ -38,7 +38,7 @@ CONFIGS = {
     "c3": dict(pairs=1_000_000, length=1000, error=0.05, seed=3, semi_global=False, adaptive=True, total=0, cpu=150_000),
     "c2": dict(pairs=100_000, length=150, error=0.02, seed=2, semi_global=False, adaptive=False, total=0, cpu=100_000),
     "c4": dict(pairs=0, length=1000, error=0.05, seed=4, semi_global=False, adaptive=True, total=10_000_000, cpu=150_000),
-    "c5s": dict(pairs=8, length=100_000, error=0.10, seed=5, semi_global=True, adaptive=True, total=0, cpu=0),
+    "c5s": dict(pairs=8, length=100_000, error=0.10, seed=5, semi_global=True, adaptive=True, total=0, cpu=8),
 }
 
 
@@ -56,7 +56,7 @@ def parse_args(argv=None):
     ap.add_argument("--semi-global", action="store_true", default=None)
     ap.add_argument("--no-adaptive", action="store_true", default=None)
     ap.add_argument("--cpu-sample", type=int, default=None, help="pairs timed on host cores (0 = skip)")
-    ap.add_argument("--cpu-threads", type=int, default=1)
+    ap.add_argument("--cpu-threads", type=int, default=None, help="threads of the cpu_baseline leg (default 1; c5s: 8, one pair each)")
     ap.add_argument("--cpu-all-cores", type=int, default=1, help="1: also time the oracle on every host core (N = 1 only)")
     ap.add_argument("--host-entry", type=int, default=1, help="1: also time wfahip_align_batch (host blobs -> host results), N = 1 only")
     ap.add_argument("--latency", type=int, default=1, help="1: also time single-pair Align round trips, N = 1 only")
@@ -83,6 +83,8 @@ def parse_args(argv=None):
         args.no_adaptive = not c["adaptive"]
     if args.cpu_sample is None:
         args.cpu_sample = c["cpu"]
+    if args.cpu_threads is None:
+        args.cpu_threads = 8 if args.config == "c5s" else 1  # (a 100 kbp semi-global pair is minutes of one core)
     if args.steps is None:
         args.steps = {"c3": 200, "c2": 2000, "c4": 20, "c5s": 3}[args.config]
     if args.warmup is None:
