@@ -439,7 +439,7 @@ def extras(args, out, w, L, al, blob, q_off, q_len, t_off, t_len, rec, n):
         prm = al._params()
         vp = lambda a: a.ctypes.data_as(C.c_void_p)
         ts = []
-        reps = 1 if n * args.length >= 400_000_000 else 3
+        reps = 2 if n * args.length >= 400_000_000 else 3
         for i in range(reps + 1):
             res = L.Results()
             t1 = time.perf_counter()
@@ -452,6 +452,26 @@ def extras(args, out, w, L, al, blob, q_off, q_len, t_off, t_len, rec, n):
             L.lib().wfahip_results_free(C.byref(res))
             if i > 0:
                 ts.append(dt * 1e3)
+        # ... and from pre-packed 2-bit input (wfahip_align_batch_packed: a quarter of the bytes cross PCIe); the packing
+        # itself (wfahip_pack_pairs, host threads) is timed separately
+        if args.length <= 20000:
+            t1 = time.perf_counter()
+            packed, q_woff, t_woff = w.pack_pairs(blob, q_off, q_len, t_off, t_len, n_threads=min(32, os.cpu_count() or 8))
+            cfg["host_pack_ms"] = (time.perf_counter() - t1) * 1e3
+            tp = []
+            for i in range(reps + 1):
+                res = L.Results()
+                t1 = time.perf_counter()
+                L.check(L.lib().wfahip_align_batch_packed(al._ctx, C.byref(prm), vp(packed), packed.size, vp(q_woff), vp(q_len),
+                                                          vp(t_woff), vp(t_len), n, C.byref(res)), "wfahip_align_batch_packed")
+                dt = time.perf_counter() - t1
+                if i == reps:
+                    sc = np.ctypeslib.as_array(res.score, shape=(n,))
+                    cfg["host_to_host_packed_scores_match"] = bool(np.array_equal(sc, rec[:, L.REC_SCORE]))
+                L.lib().wfahip_results_free(C.byref(res))
+                if i > 0:
+                    tp.append(dt * 1e3)
+            cfg["host_to_host_packed_ms"] = min(tp)
         cfg["host_to_host_ms"] = min(ts)
         cfg["host_to_host_pairs_per_s"] = n / (min(ts) * 1e-3)
         cfg["host_to_host_note"] = ("wfahip_align_batch: pageable host blobs -> malloc'd host result arrays, "
