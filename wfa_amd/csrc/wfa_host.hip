@@ -90,6 +90,7 @@ struct wfahip_ctx {
     hipEvent_t    evBtA = nullptr, evBtB = nullptr;
     bool          bt_pending = false;        // the first pass's backtrace kernel is still running on stream2
     DevBuf        in_blob, in_qoff, in_qlen, in_toff, in_tlen, out_rec, out_ops;  // host-entry staging
+    DevBuf        in_small;                  // host entry, small batches: blob + offset / length arrays as one image
     DevBuf        in_packed;                 // host entry with pre-packed input: the 2-bit words as uploaded (unpacked into in_blob on the device)
     // wfahip_submit / wfahip_collect: pairs handed in one at a time, aligned as one batch
     std::vector<uint8_t>  sub_blob;
@@ -316,7 +317,7 @@ extern "C" void wfahip_destroy(wfahip_ctx *ctx) {
         if (ctx->pin_ev[i]) (void)hipEventDestroy(ctx->pin_ev[i]);
     }
     for (DevBuf *b : {&ctx->arena, &ctx->fin, &ctx->team_ctl, &ctx->arena2, &ctx->meta2, &ctx->doneq, &ctx->ctrl, &ctx->redo, &ctx->work, &ctx->meta, &ctx->in_blob, &ctx->in_qoff, &ctx->in_qlen,
-                      &ctx->in_toff, &ctx->in_tlen, &ctx->out_rec, &ctx->out_ops, &ctx->in_packed})
+                      &ctx->in_toff, &ctx->in_tlen, &ctx->out_rec, &ctx->out_ops, &ctx->in_packed, &ctx->in_small})
         release(*b);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -1291,11 +1292,31 @@ static int align_batch_impl(wfahip_ctx *ctx, const wfahip_params *p, const uint8
             ctx->ev_up.push_back(e);
         }
     }
-    if (blob_bytes && !sliced) HIP_TRY(upload_range(0, blob_bytes, st));
-    HIP_TRY(hipMemcpyAsync(ctx->in_qoff.p, q_off, n_pairs * 8, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(ctx->in_toff.p, t_off, n_pairs * 8, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(ctx->in_qlen.p, q_len, n_pairs * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(ctx->in_tlen.p, t_len, n_pairs * 4, hipMemcpyHostToDevice, st));
+    // Small batches (a caller that cannot batch: Align = a batch of one): every copy between pageable memory and the
+    // device is a staged transfer of 15-25 us, and a call makes 5 of them on the way in and 13 on the way out.  Here
+    // the inputs travel as ONE image through the context's pinned buffer and the result arrays come back as one.
+    const uint64_t small_img = ((blob_bytes + 15) & ~15ull) + 24 * n_pairs + 64;
+    const bool     small     = !sliced && !packed && n_pairs <= 4096 && small_img <= (4u << 20);
+    void *d_blob = ctx->in_blob.p, *d_qoff = ctx->in_qoff.p, *d_toff = ctx->in_toff.p, *d_qlen = ctx->in_qlen.p, *d_tlen = ctx->in_tlen.p;
+    if (small) {
+        if (!ctx->pin[0]) HIP_TRY(hipHostMalloc(&ctx->pin[0], PIN_CHUNK, hipHostMallocDefault));
+        if ((rc = ensure(ctx, ctx->in_small, small_img))) return rc;
+        char *const    img = static_cast<char *>(ctx->pin[0]);
+        const uint64_t o1 = (blob_bytes + 15) & ~15ull, o2 = o1 + 8 * n_pairs, o3 = o2 + 8 * n_pairs, o4 = o3 + 4 * n_pairs;
+        if (blob_bytes) std::memcpy(img, seq_blob, blob_bytes);
+        std::memcpy(img + o1, q_off, 8 * n_pairs), std::memcpy(img + o2, t_off, 8 * n_pairs);
+        std::memcpy(img + o3, q_len, 4 * n_pairs), std::memcpy(img + o4, t_len, 4 * n_pairs);
+        HIP_TRY(hipMemcpyAsync(ctx->in_small.p, img, o4 + 4 * n_pairs, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));  // (the pinned buffer is reused for the results)
+        char *const d = static_cast<char *>(ctx->in_small.p);
+        d_blob = d, d_qoff = d + o1, d_toff = d + o2, d_qlen = d + o3, d_tlen = d + o4;
+    } else {
+        if (blob_bytes && !sliced) HIP_TRY(upload_range(0, blob_bytes, st));
+        HIP_TRY(hipMemcpyAsync(ctx->in_qoff.p, q_off, n_pairs * 8, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(ctx->in_toff.p, t_off, n_pairs * 8, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(ctx->in_qlen.p, q_len, n_pairs * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(ctx->in_tlen.p, t_len, n_pairs * 4, hipMemcpyHostToDevice, st));
+    }
 
     if (dbg_t) HIP_TRY(hipStreamSynchronize(st));
     const auto t_dev = now();
@@ -1505,9 +1526,8 @@ static int align_batch_impl(wfahip_ctx *ctx, const wfahip_params *p, const uint8
                              ms_of(t_h2d, t_dev), ms_of(t_dev, now()));
             return WFAHIP_OK;
         }
-        rc = align_device(ctx, p, ctx->in_blob.p, blob_bytes, ctx->in_qoff.p, ctx->in_qlen.p, ctx->in_toff.p,
-                          ctx->in_tlen.p, n_pairs, max_len, ctx->out_rec.p, ctx->out_ops.p, ops_cap, &needed, st,
-                          false);
+        rc = align_device(ctx, p, d_blob, blob_bytes, d_qoff, d_qlen, d_toff, d_tlen, n_pairs, max_len, ctx->out_rec.p, ctx->out_ops.p,
+                          ops_cap, &needed, st, false);
         if (rc == WFAHIP_ERR_OOM && needed > ops_cap) {
             ops_cap = needed + 1024;
             continue;
@@ -1552,9 +1572,16 @@ static int align_batch_impl(wfahip_ctx *ctx, const wfahip_params *p, const uint8
     hipLaunchKernelGGL(fin_gather, dim3((uint32_t)((n + 3) / 4)), dim3(256), 0, st, F);
     HIP_TRY(hipGetLastError());
     unsigned long long totals[2] = {0, 0};
-    HIP_TRY(hipMemcpyAsync(ctx->hpin + HPIN_CTRL + CTRL_WORDS, F.totals, 16, hipMemcpyDeviceToHost, st));  // (pinned)
-    HIP_TRY(hipStreamSynchronize(st));
-    std::memcpy(totals, ctx->hpin + HPIN_CTRL + CTRL_WORDS, 16);
+    const bool         small_out = small && off <= PIN_CHUNK;  // every result array in ONE copy
+    if (small_out) {
+        HIP_TRY(hipMemcpyAsync(ctx->pin[0], fb, off, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        std::memcpy(totals, static_cast<char *>(ctx->pin[0]) + o_tot, 16);
+    } else {
+        HIP_TRY(hipMemcpyAsync(ctx->hpin + HPIN_CTRL + CTRL_WORDS, F.totals, 16, hipMemcpyDeviceToHost, st));  // (pinned)
+        HIP_TRY(hipStreamSynchronize(st));
+        std::memcpy(totals, ctx->hpin + HPIN_CTRL + CTRL_WORDS, 16);
+    }
     const auto t_unp = now();
 
     results_zero(out);
@@ -1580,9 +1607,16 @@ static int align_batch_impl(wfahip_ctx *ctx, const wfahip_params *p, const uint8
     }
     void *const       dsts[11] = {out->status, out->score, out->tbegin, out->tend, out->qbegin, out->qend,
                                   out->align_len, out->matches, out->gaps, out->gap_regions, out->ops_len};
-    for (int i = 0; i < 11 && rc == WFAHIP_OK; i++) rc = download(ctx, dsts[i], fb + o_f[i], 4ull * n, st);
-    if (rc == WFAHIP_OK) rc = download(ctx, out->ops_off, fb + o_ooff, 8ull * n, st);
-    if (rc == WFAHIP_OK) rc = download(ctx, out->ops, fb + o_ops, 8ull * totals[0], st);
+    if (small_out) {
+        const char *const img = static_cast<const char *>(ctx->pin[0]);
+        for (int i = 0; i < 11; i++) std::memcpy(dsts[i], img + o_f[i], 4ull * n);
+        std::memcpy(out->ops_off, img + o_ooff, 8ull * n);
+        if (totals[0]) std::memcpy(out->ops, img + o_ops, 8ull * totals[0]);
+    } else {
+        for (int i = 0; i < 11 && rc == WFAHIP_OK; i++) rc = download(ctx, dsts[i], fb + o_f[i], 4ull * n, st);
+        if (rc == WFAHIP_OK) rc = download(ctx, out->ops_off, fb + o_ooff, 8ull * n, st);
+        if (rc == WFAHIP_OK) rc = download(ctx, out->ops, fb + o_ops, 8ull * totals[0], st);
+    }
     const uint64_t cells = totals[1];
     if (dbg_t)
         std::fprintf(stderr, "[wfahip] host entry: H2D %.1f ms, device %.1f ms, finalize %.1f ms, download %.1f ms\n",
