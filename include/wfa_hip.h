@@ -38,7 +38,7 @@ enum {
     WFAHIP_ERR_BAD_ARG     = -2,
     WFAHIP_ERR_OOM         = -3,
     WFAHIP_ERR_HIP         = -4,
-    WFAHIP_ERR_UNSUPPORTED = -5, /* degenerate penalties (mismatch == 0 or gap_ext == 0) */
+    WFAHIP_ERR_UNSUPPORTED = -5, /* penalties the reference itself cannot align (mismatch == 0, gap_open + gap_ext == 0); non-ACGT input to the packer */
     WFAHIP_ERR_INTERNAL    = -6
 };
 

@@ -141,7 +141,9 @@ def test_synthetic_batches(built, length, err, n, glob, adaptive):
 # (6,4,2), (3,1,2): x == o+e; (2,4,2), (2,2,2): x == e; (4,2,2): o+e == 2e -- the shapes in which two of next()'s
 # sources come from the same earlier score
 @pytest.mark.parametrize("pen", [(4, 6, 2), (1, 1, 1), (2, 3, 1), (5, 0, 3), (3, 7, 2), (6, 5, 4), (2, 12, 1),
-                                 (6, 4, 2), (2, 4, 2), (4, 2, 2), (3, 1, 2), (2, 2, 2)])
+                                 (6, 4, 2), (2, 4, 2), (4, 2, 2), (3, 1, 2), (2, 2, 2),
+                                 # GapExt == 0: I[s-e] is the row being written, an insertion chains along it (wfa.go:580)
+                                 (4, 6, 0), (2, 3, 0), (3, 3, 0)])
 def test_other_penalties(built, pen):
     import wfa_amd as w
     from oracle import oracle as O
@@ -865,3 +867,16 @@ def test_blocked_kernel_arena_word_for_word(built, length, err, pen, ad, fmt, ce
         pairs += 1
     assert pairs >= n // 2 and checked > 50 * pairs, (pairs, checked)  # (the others were handed on: band or arena)
     al.close()
+
+
+def test_penalties_the_reference_cannot_align_are_refused(built):
+    """Mismatch == 0: the reference's own loop does not terminate when the first bases differ (DESIGN.md section 1);
+    GapOpen + GapExt == 0: M[s-o-e] is the row being written.  Both are refused with an error code, not aligned."""
+    import wfa_amd as w
+    from wfa_amd import _lib as L
+    for pen in ((0, 6, 2), (4, 0, 0)):
+        al = _aligner(True, None, pen)
+        with pytest.raises(L.WfaHipError) as ei:
+            al.Align(b"ACGT", b"CCGT")
+        assert ei.value.code == L.ERR_UNSUPPORTED
+        al.close()

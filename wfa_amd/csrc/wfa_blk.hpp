@@ -219,6 +219,10 @@ constexpr int BK_BIG = 0x3FFFFFFF;
 #ifndef WFA_BLK8_WAVES
 #define WFA_BLK8_WAVES 2
 #endif
+#ifndef WFA_BLK_WAVES
+#define WFA_BLK_WAVES 5  // waves per SIMD the main instance is compiled for: 96 VGPRs, ~30 spilled values in the window and refill code;
+                         // 20.2 ms per 1e6 x 1 kbp pairs against 20.9 at 4 waves (114 VGPRs, no spill): the issue rate of a SIMD grows with its waves
+#endif
 
 // BATCH > 1 (short reads: both sequences of a pair fit one staging pass of the group's own lanes): a group takes
 // BATCH consecutive queue entries at a time and stages all of them into its LDS slots, so the refill chain (queue
@@ -246,7 +250,7 @@ WFA_DEV void blk_push_not_ok(const KParams &P, uint32_t pidx) {
 // check between kernels).  It is instrumentation, not part of the alignment, and costs 4 % of the forward pass
 // (23.3 vs 24.3 ms per 1e6 x 1 kbp pairs): off unless the context's option "census" asks for it.
 template <int G, int BATCH, bool STREAM = false, int PPT = 0, bool CENSUS = true>
-__global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : 4)) void wfa_blk_kernel(const KParams P) {
+__global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16 && BATCH == 1 && !STREAM && !CENSUS ? WFA_BLK_WAVES : 4))) void wfa_blk_kernel(const KParams P) {
     static_assert(!STREAM || (G == 16 && BATCH == 1), "streamed backtrace: 16 lanes per pair, unbatched refill");
     static_assert(PPT == 0 || (G == 8 && PPT == 4), "diagonals per lane can only be overridden for the 8-lane narrow instance");
     constexpr int PP  = PPT ? PPT : (G == 64 ? 4 : 64 / G);  // diagonals per lane
@@ -289,8 +293,9 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : 4)) void
 
     // per-pair state (identical in the G lanes of a group)
     int        st = 0;  // 0 = needs a pair, 1 = running, 2 = queue exhausted
-    uint32_t   pidx = 0, pair = 0, si = 0, cells = 0;
-    int        n = 0, m = 0, Ak = 0, kb = 0, k0 = 0, rows_left = 0;
+    uint32_t   pidx = 0, si = 0, cells = 0;  // (pidx: the pair's index in the chunk = its arena slot; pair_of() is its id)
+    int        n = 0, m = 0, kb = 0, k0 = 0;
+    int        pend_h = 0;  // STREAM: end offset of the pair that waits to be pushed
     bool       slow = false, first_eq = false;
     bool       pend = false;  // STREAM: the pair just finished still has to be pushed (its score index, end offset and
                               // cell count wait in si, Ak and cells, which are dead until the next pair starts)
@@ -308,6 +313,8 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : 4)) void
 #pragma unroll
     for (int p = 0; p < PP; p++) I[p] = D[p] = 0u, lim[p] = 0, lmx[p] = 0;
 
+    const auto pair_of = [&](uint32_t idx) { return P.work ? P.work[idx] : P.chunk_first + idx; };
+    const int  rows_cap = (int)(cap / W);  // rows (score indices) a pair's arena slot holds
     const auto set_window = [&]() {
         k0 = kb + PP * j;
 #pragma unroll
@@ -460,13 +467,13 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : 4)) void
                         const uint32_t *const mw = gmeta + BM * bslot;
                         const uint32_t nq = mw[2], mt = mw[3];
                         if (nq != 0u) {
-                            pidx = mw[0], pair = mw[1];
+                            pidx = mw[0];
                             lq = gbase + bslot * 2 * SW, lt = lq + SW;
-                            n = (int)nq, m = (int)mt, Ak = m - n;
+                            n = (int)nq, m = (int)mt;
+                            const int Ak = m - n;
                             si = 0, cells = 0, slow = false;
                             kb   = -(W / 2) + PP * imax2(-(3 * W / 8) / PP, imin2((3 * W / 8) / PP, Ak / (2 * PP)));
                             rowp = P.arena + (uint64_t)pidx * cap;
-                            rows_left = (int)(cap / W);
                             first_eq = ((lq[0] ^ lt[0]) & 3u) == 0u;  // q[0] == t[0] (wfa.go:155)
                             set_window();
                             clear_rings();
@@ -495,7 +502,7 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : 4)) void
                     const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)r2, 1);
                     if (pend && j == 0)
                         blk_store_sc1(P.done_q + (t0 + (uint32_t)__builtin_popcount(pbits & ((1u << grp) - 1u))), pidx + 1u,
-                                      si * P.g, (uint32_t)Ak, cells);
+                                      si * P.g, (uint32_t)pend_h, cells);
                     pend = false;
                 } else {
                     if (lane == 0) base = atomicAdd(P.queue_head, (uint32_t)__builtin_popcount(gbits));
@@ -546,12 +553,12 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : 4)) void
                     if constexpr (STREAM) blk_push_not_ok(P, wi);
                 }  // (the group stays in state 0 and pulls another pair in the next round)
                 if (stage && !bad) {
-                    pidx = wi, pair = pr;
-                    n = (int)nq, m = (int)mt, Ak = m - n;
+                    pidx = wi;
+                    n = (int)nq, m = (int)mt;
+                    const int Ak = m - n;
                     si = 0, cells = 0, slow = false;
                     kb   = -(W / 2) + PP * imax2(-(3 * W / 8) / PP, imin2((3 * W / 8) / PP, Ak / (2 * PP)));  // k = 0 (the seed) inside, biased towards Ak
                     rowp = P.arena + (uint64_t)pidx * cap;
-                    rows_left = (int)(cap / W);
                     first_eq = ((lq[0] ^ lt[0]) & 3u) == 0u;  // q[0] == t[0] (wfa.go:155)
                     set_window();
                     clear_rings();
@@ -637,6 +644,34 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : 4)) void
                     if (want && k0 + p == 0 && nM[p] == 0u)
                         nM[p] = 1u, wd[p] = first_eq ? BLK_SEED_MATCH : BLK_SEED_MISMATCH, cc[p] = CENSUS ? 1u : 0u;
             }
+            // ------------------------------------------------------------ store the row's words
+            // Right away: the words are complete (they hold PRE-extension offsets), and their registers are free for the
+            // rest of the step.  A lane stores when one of its cells exists -- 3/4 of the lanes have none, their lines stay
+            // untouched; what wf-adaptive deletes below is stored too, nothing ever reads it.
+            const bool no_room = run && (int)si >= rows_cap;
+            {
+                uint32_t anyc = 0u;
+#pragma unroll
+                for (int p = 0; p < PP; p++) anyc |= nM[p];
+                if (run && !no_room && anyc != 0u) {
+                    if constexpr (TILED) {
+                        // tile of 8 scores x 64 diagonals: [diagonal / 4][score & 7][diagonal & 3] (CompactView fmt 3)
+                        uint32_t *const row = rowp + (((uint32_t)k0 & 63u) << 3);
+                        if constexpr (STREAM)
+                            blk_store_sc1(row, wd[0], wd[1], wd[2], wd[3]);
+                        else
+                            *reinterpret_cast<uint4 *>(row) = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+                        if constexpr (PP == 8) *reinterpret_cast<uint4 *>(row + 32) = make_uint4(wd[4], wd[5], wd[6], wd[7]);
+                    } else {
+                        uint32_t *const row = rowp + ((uint32_t)k0 & (uint32_t)(W - 1));
+                        if constexpr (STREAM)
+                            blk_store_sc1(row, wd[0], wd[1], wd[2], wd[3]);
+                        else
+                            *reinterpret_cast<uint4 *>(row) = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+                        if constexpr (PP == 8) *reinterpret_cast<uint4 *>(row + 4) = make_uint4(wd[4], wd[5], wd[6], wd[7]);
+                    }
+                }
+            }
             WFA_STAMP(1); WFA_MARK(1);  // next
 
             // ------------------------------------------------------------ WF_EXTEND (wfa.go:381-458), first 16 bases
@@ -689,7 +724,7 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : 4)) void
             if (hit_any) {
                 bool tl = false;
 #pragma unroll
-                for (int p = 0; p < PP; p++) tl |= (k0 + p == Ak && nz[p] && (int)nM[p] >= m);
+                for (int p = 0; p < PP; p++) tl |= (k0 + p == m - n && nz[p] && (int)nM[p] >= m);
                 const int r = Red::or1((hitl ? 1 : 0) | (tl ? 2 : 0));
                 ghit = (r & 1) != 0;
                 slow |= ghit;
@@ -803,37 +838,16 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : 4)) void
             }
             WFA_STAMP(3); WFA_MARK(3);  // ranges + wf-adaptive
 
-            // ------------------------------------------------------------ store the surviving band
+            // ------------------------------------------------------------ the row's census and position
             // (groups that are not running hold all-zero rings: every cell above is absent)
-            const bool no_room = run && rows_left <= 0;
-            const bool keepl   = anyM && ihi >= ilo && !no_room;
+            const bool keepl = anyM && ihi >= ilo && !no_room;
             cells += keepl ? csum : 0u;
-            // a lane stores its PP words when its diagonals meet the band (3/4 of the lanes do not: their lines stay untouched)
-            if (keepl && PP * j + PP - 1 >= ilo && PP * j <= ihi) {
-                if constexpr (TILED) {
-                    // tile of 8 scores x 64 diagonals: [diagonal / 4][score & 7][diagonal & 3] (CompactView fmt 3)
-                    uint32_t *const row = rowp + (((uint32_t)k0 & 63u) << 3);
-                    if constexpr (STREAM)
-                        blk_store_sc1(row, wd[0], wd[1], wd[2], wd[3]);
-                    else
-                        *reinterpret_cast<uint4 *>(row) = make_uint4(wd[0], wd[1], wd[2], wd[3]);
-                    if constexpr (PP == 8) *reinterpret_cast<uint4 *>(row + 32) = make_uint4(wd[4], wd[5], wd[6], wd[7]);
-                } else {
-                    uint32_t *const row = rowp + ((uint32_t)k0 & (uint32_t)(W - 1));
-                    if constexpr (STREAM)
-                        blk_store_sc1(row, wd[0], wd[1], wd[2], wd[3]);
-                    else
-                        *reinterpret_cast<uint4 *>(row) = make_uint4(wd[0], wd[1], wd[2], wd[3]);
-                    if constexpr (PP == 8) *reinterpret_cast<uint4 *>(row + 4) = make_uint4(wd[4], wd[5], wd[6], wd[7]);
-                }
-            }
             if constexpr (TILED) {
                 rowp += 4;
                 rowp += (((uint32_t)(uintptr_t)rowp & 0x70u) == 0u) ? 480 : 0;  // past the tile's 8th score: next tile
             } else {
                 rowp += W;
             }
-            rows_left -= 1;
             WFA_STAMP(4); WFA_MARK(4);  // stores
 
             // ------------------------------------------------------------ the new row enters the rings
@@ -849,12 +863,12 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : 4)) void
                 int hf   = 0;  // extended offset of the end cell M[s][Ak]: where the backtrace starts
 #pragma unroll
                 for (int p = 0; p < PP; p++)
-                    if (k0 + p == Ak) hf = (int)Mo[p];
+                    if (k0 + p == m - n) hf = (int)Mo[p];
                 Red::max_add(hf, ctot);
                 if (fin && j == 0) {
                     if (no_room) {
                         P.pair_meta[pidx] = make_uint4(ST_REDO_ARENA, 0u, 0u, 0u);
-                        push_redo(P, pair, ST_REDO_ARENA);
+                        push_redo(P, pair_of(pidx), ST_REDO_ARENA);
                         if constexpr (STREAM) blk_push_not_ok(P, pidx);
                     } else if constexpr (!STREAM) {
                         P.pair_meta[pidx] = make_uint4(ST_OK, si * P.g, (uint32_t)hf, (uint32_t)ctot);
@@ -863,7 +877,7 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : 4)) void
                 if (fin) {
                     if constexpr (STREAM) {
                         pend  = !no_room;  // pushed by the next refill; until then si / Ak / cells keep the entry's fields
-                        Ak    = hf;
+                        pend_h = hf;
                         cells = (uint32_t)ctot;
                     }
                     st = 0;
@@ -902,7 +916,7 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : 4)) void
                     if (__ballot(wide) != 0ull) {  // the band does not fit the window: hand the pair on
                         if (wide && j == 0) {
                             P.pair_meta[pidx] = make_uint4(ST_REDO_BAND, 0u, 0u, 0u);
-                            push_redo(P, pair, ST_REDO_BAND);
+                            push_redo(P, pair_of(pidx), ST_REDO_BAND);
                             if constexpr (STREAM) blk_push_not_ok(P, pidx);
                         }
                         if (wide) {

@@ -1,7 +1,7 @@
 // wfa_generic.hpp -- kernel A: the general wavefront-alignment kernel.
 //
 // One workgroup of 64*WAVES threads aligns one pair at a time (persistent: pairs are pulled from a
-// device queue).  Any penalties with mismatch > 0 and gap_ext > 0, any sequence length that fits the
+// device queue).  Any penalties with mismatch > 0 and gap_open + gap_ext > 0, any sequence length that fits the
 // slot's arena, global or semi-global, wf-adaptive on or off.  The M/I/D rows of finished scores
 // live in the slot's HBM arena (they are what the backtrace needs) and the sources of WF_NEXT are
 // read back from there (L2-resident: the slot wrote them a few scores ago).
@@ -98,16 +98,30 @@ __global__ __launch_bounds__(64 * WAVES) void wfa_generic_kernel(const KParams P
             // sources: M[s-x], M[s-o-e], I[s-e] / D[s-e]  (wfa.go:557-560; missing when diff > s)
             const DirEnt eX = (s >= x) ? load_ent(si - x / g) : none;
             const DirEnt eO = (s >= oe) ? load_ent(si - oe / g) : none;
-            const DirEnt eE = (s >= e) ? load_ent(si - e / g) : none;
+            // GapExt == 0 (e0): I[s-e] and D[s-e] are the rows of THIS score.  The reference reads them while it writes
+            // them, k ascending (wfa.go:572-580,614-615): I[s][k-1] is the cell of the previous iteration -- an
+            // insertion chains along the row at no cost -- and D[s][k+1] does not exist yet, so a deletion never extends.
+            const bool   e0 = e == 0u;
+            const DirEnt eE = (!e0 && s >= e) ? load_ent(si - e / g) : none;
             const bool   seeded = (s == 0u) || (s == x);
 
             int lo = INT32_MAX, hi = INT32_MIN;
             if (eX.w > 0) lo = imin2(lo, eX.lo - 1), hi = imax2(hi, eX.lo + eX.w);
             if (eO.w > 0) lo = imin2(lo, eO.lo - 1), hi = imax2(hi, eO.lo + eO.w);
             if (eE.w > 0) lo = imin2(lo, eE.lo - 1), hi = imax2(hi, eE.lo + eE.w);
+            if (e0) {
+                // KRange of a missing wavefront is (0, 0) (wfa_component.go:91-101), and here I[s] and D[s] always are
+                // when next(s) starts: diagonals -1 .. 1 belong to the range, and the chain of insertions may run
+                // through them even when every source lies to one side
+                const int xl = eX.w > 0 ? eX.lo : 0, xh = eX.w > 0 ? eX.lo + eX.w - 1 : 0;
+                const int ol = eO.w > 0 ? eO.lo : 0, oh = eO.w > 0 ? eO.lo + eO.w - 1 : 0;
+                lo = imin2(imin2(xl, ol), 0) - 1, hi = imax2(imax2(xh, oh), 0) + 1;
+            }
             lo = imax2(lo, -(n - 1));  // wfa.go:562-563
             hi = imin2(hi, m - 1);
             if (s == 0u) lo = INT32_MAX, hi = INT32_MIN;  // the reference never calls next(0)
+            // (GapExt == 0: the chain of insertions runs exactly over next()'s own range, not over the seeds' diagonals)
+            const int nx_lo = lo, nx_hi = hi;
             if (seeded) lo = imin2(lo, seed_lo), hi = imax2(hi, seed_hi);
 
             // room for 3 rows + this directory entry (+ ops scratch is checked later)
@@ -138,14 +152,28 @@ __global__ __launch_bounds__(64 * WAVES) void wfa_generic_kernel(const KParams P
                            : 0u;
             };
 
+            // ---- GapExt == 0: the I row is a serial scan along k (one lane; this is not a fast path)
+            if (e0 && s != 0u) {
+                if (tid == 0) {
+                    uint32_t prev = 0u;  // I[s][k-1]
+                    for (int64_t i = 0; i < W; i++) {
+                        const int k = lo + (int)i;
+                        Cell      c = {0u, 0u, 0u};
+                        if (k >= nx_lo && k <= nx_hi) c = next_cell(src(eO, 0, k - 1), prev, 0u, 0u, 0u, k, n, m);
+                        rowI[i] = prev = c.I;
+                    }
+                }
+                __syncthreads();
+            }
+
             // ---- P1: next + seeds + extend, store rows, partial reductions
             int mlo = INT32_MAX, mhi = INT32_MIN, term = 0, mind = INT32_MAX;
             for (int64_t i = tid; i < W; i += G) {
                 const int k = lo + (int)i;
                 Cell      c = {0u, 0u, 0u};
-                if (s != 0u)
-                    c = next_cell(src(eO, 0, k - 1), src(eE, 1, k - 1), src(eO, 0, k + 1), src(eE, 2, k + 1),
-                                  src(eX, 0, k), k, n, m);
+                if (s != 0u && (!e0 || (k >= nx_lo && k <= nx_hi)))
+                    c = next_cell(src(eO, 0, k - 1), e0 ? (i > 0 ? rowI[i - 1] : 0u) : src(eE, 1, k - 1), src(eO, 0, k + 1),
+                                  src(eE, 2, k + 1), src(eX, 0, k), k, n, m);
                 if (seeded && c.M == 0u) c.M = seed_word<MODE>(sv, k, s, x, glob);  // Set = last write wins (R2)
                 c.M = extend_word<MODE>(sv, c.M, k);
                 rowM[i] = c.M, rowI[i] = c.I, rowD[i] = c.D;

@@ -258,7 +258,7 @@ extern "C" const char *wfahip_strerror(int code) {
     case WFAHIP_ERR_BAD_ARG: return "bad argument";
     case WFAHIP_ERR_OOM: return "out of memory (device or ops buffer)";
     case WFAHIP_ERR_HIP: return "HIP runtime error";
-    case WFAHIP_ERR_UNSUPPORTED: return "unsupported penalties (mismatch and gap_ext must be > 0)";
+    case WFAHIP_ERR_UNSUPPORTED: return "unsupported penalties (mismatch and gap_open + gap_ext must be > 0) or input";
     case WFAHIP_ERR_INTERNAL: return "internal error";
     }
     return "unknown error";
@@ -402,7 +402,10 @@ extern "C" void wfahip_free(void *p) { std::free(p); }
 
 static int check_params(const wfahip_params *p) {
     if (!p) return WFAHIP_ERR_BAD_ARG;
-    if (p->mismatch == 0 || p->gap_ext == 0) return WFAHIP_ERR_UNSUPPORTED;
+    // Mismatch == 0: the reference's own loop does not terminate when the first bases differ (the seed is then a
+    // Mismatch cell at score 0 whose source M[s - 0][k] is itself).  GapOpen + GapExt == 0: M[s-o-e] is the row being
+    // written.  GapExt == 0 alone is aligned (by the generic kernel: the I row of a score becomes a serial scan).
+    if (p->mismatch == 0 || p->gap_open + p->gap_ext == 0) return WFAHIP_ERR_UNSUPPORTED;
     if (p->adaptive && p->min_wf_len == 0) return WFAHIP_ERR_BAD_ARG;  // AdaptiveReduction rejects it (wfa.go:134-137)
     return WFAHIP_OK;
 }
@@ -510,7 +513,7 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
     // ---- pass 1: sub-wave forward kernels + lane-per-pair backtrace kernel, chunk by chunk.
     //      kind 2 = register-window kernel (4 pairs per wave), kind 1 = LDS-ring packed kernel (2 pairs per wave).
     bool packed_done = false;
-    if (ctx->opt_packed && !debug_single && ctx->force_mode < 0 && P.global_alignment) {
+    if (ctx->opt_packed && !debug_single && ctx->force_mode < 0 && P.global_alignment && P.e != 0u) {
         const uint32_t dx = P.x / P.g, doe = P.oe / P.g, de = P.e / P.g;
         const uint32_t dm = std::max(dx, doe) + 1, di = de + 1;
         // Mixed lengths: the sub-wave kernels keep both sequences of a pair in a few KB of LDS.  When the longest
@@ -892,7 +895,7 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
         // It pays when one workgroup per pair cannot fill the GPU: few pairs, or arenas so large that only a few
         // fit (cfg.slots is the number of pairs the generic kernel could run at once).
         if (cr == 0 && !debug_single && ctx->opt_team_min_len > 0 && max_len >= (uint64_t)ctx->opt_team_min_len &&
-            (cfg.slots < (uint32_t)std::max(1, ctx->num_cus / 2) || ctx->opt_team_wgs > 0) &&
+            (cfg.slots < (uint32_t)std::max(1, ctx->num_cus / 2) || ctx->opt_team_wgs > 0) && P.e != 0u &&
             std::max(P.x, std::max(P.oe, P.e)) / P.g < (uint32_t)TEAM_RING) {
             const uint32_t cus = (uint32_t)std::max(1, ctx->num_cus);
             uint32_t t0 = (uint32_t)std::min<uint64_t>(cus, std::max<uint64_t>(2, (2ull * max_len + 8191) / 8192));
