@@ -219,6 +219,9 @@ constexpr int BK_BIG = 0x3FFFFFFF;
 #ifndef WFA_BLK8_WAVES
 #define WFA_BLK8_WAVES 2
 #endif
+#ifndef WFA_BLK_STREAM_WAVES5
+#define WFA_BLK_STREAM_WAVES5 0  // 1: the streaming instance is compiled for WFA_BLK_WAVES too (experiment)
+#endif
 #ifndef WFA_BLK_WAVES
 #define WFA_BLK_WAVES 5  // waves per SIMD the main instance is compiled for: 96 VGPRs, ~30 spilled values in the window and refill code;
                          // 20.2 ms per 1e6 x 1 kbp pairs against 20.9 at 4 waves (114 VGPRs, no spill): the issue rate of a SIMD grows with its waves
@@ -250,7 +253,7 @@ WFA_DEV void blk_push_not_ok(const KParams &P, uint32_t pidx) {
 // check between kernels).  It is instrumentation, not part of the alignment, and costs 4 % of the forward pass
 // (23.3 vs 24.3 ms per 1e6 x 1 kbp pairs): off unless the context's option "census" asks for it.
 template <int G, int BATCH, bool STREAM = false, int PPT = 0, bool CENSUS = true>
-__global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16 && BATCH == 1 && !STREAM && !CENSUS ? WFA_BLK_WAVES : 4))) void wfa_blk_kernel(const KParams P) {
+__global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16 && BATCH == 1 && !CENSUS && (!STREAM || WFA_BLK_STREAM_WAVES5) ? WFA_BLK_WAVES : 4))) void wfa_blk_kernel(const KParams P) {
     static_assert(!STREAM || (G == 16 && BATCH == 1), "streamed backtrace: 16 lanes per pair, unbatched refill");
     static_assert(PPT == 0 || (G == 8 && PPT == 4), "diagonals per lane can only be overridden for the 8-lane narrow instance");
     constexpr int PP  = PPT ? PPT : (G == 64 ? 4 : 64 / G);  // diagonals per lane

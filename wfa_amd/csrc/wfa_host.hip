@@ -105,8 +105,9 @@ struct wfahip_ctx {
     int64_t       opt_blk                  = 16; // blocked register-window kernel: lanes per pair (16 or 8), 0 = off
     int64_t       opt_bt_stream            = 96; // > 0: that many waves of the first pass's launch backtrace finished pairs while the others go on
     int64_t       opt_bt_stream_min        = 393216; // ... for chunks of at least this many pairs
-    int64_t       opt_bt_stream_single     = 0;      // 1: also when the pass is a single chunk (there the backtrace kernel already runs beside the
-                                                     // retry passes and, since its op stores are combined, costs less than the streaming: 25.35 vs 25.55 ms)
+    int64_t       opt_bt_stream_single     = 0;      // 1: stream the backtrace (off by default: the backtrace kernel of a single chunk runs beside the
+                                                     // retry passes, and on passes of several chunks the streaming instance's write-through stores cost
+                                                     // more than the kernel they save)
     int64_t       opt_bt_stream_wait_us    = 20000;  // a streaming wave gives up on a queue entry after this long
     int64_t       opt_blk_narrow           = 1;  // 1: reads under 200 bases start on the 8-lanes-per-pair instance (32-diagonal window, 8 pairs per wave)
     int64_t       opt_blk_wide             = 1;  // 1: pairs leaving the 64-diagonal window retry on the wave-per-pair blocked kernel (256 diagonals)
@@ -606,8 +607,11 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             if ((rc2 = ensure(ctx, meta_buf, chunk * 16 * n_buf))) return rc2;
             detach_bt = detach_bt && n_chunks == 1 && ctx->opt_tail_overlap != 0;
             // streamed backtrace: a few waves walk finished pairs while the forward kernel is still running
+            // (off unless asked for since round 2: with the forward pass at 20 ms per 1e6 pairs the write-through row
+            // stores of the streaming instance cost more than the backtrace kernel they save -- 3e6 x 1 kbp pairs in two
+            // chunks: 65.2 ms with a backtrace kernel per chunk, 70.5 ms streamed)
             const bool stream_bt = kind == 3 && !blk_batch && n_buf == 1 && ctx->opt_bt_stream > 0 && (int64_t)chunk >= ctx->opt_bt_stream_min &&
-                                   (n_chunks > 1 || ctx->opt_bt_stream_single != 0);
+                                   ctx->opt_bt_stream_single != 0;
             P.done_q = nullptr, P.done_ctl = nullptr, P.n_stream_wgs = 0;
             if (stream_bt) {
                 if ((rc2 = ensure(ctx, ctx->doneq, 256 + 16 * chunk))) return rc2;
