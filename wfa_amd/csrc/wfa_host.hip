@@ -123,6 +123,7 @@ struct wfahip_ctx {
     int64_t       opt_tail_overlap         = 1;  // 1: retry passes overlap the backtrace kernel of the first pass
     int64_t       opt_overlap              = 0;  // 1: backtrace of chunk c on a second stream beside the forward kernel of chunk c+1 (measured: no gain)
     int64_t       opt_fail_pass            = 0;   // test aid (fault injection): the sub-wave pass of this kind reports WFAHIP_ERR_OOM
+    int64_t       opt_narrow_long          = 0;   // experiment: reads of any length start on the 8-lanes-per-pair instance (32-diagonal windows)
     int64_t       opt_census               = 0;   // 1: the sub-wave forward kernels count the wavefront words they store (REC_CELLS, timing.cells_stored)
     int64_t       opt_learn                = 1;   // 1: long pairs start on the arena level the previous call of the same kind ended on
     uint64_t      learn_key                = 0;   // workload class of the last call that used the team kernel
@@ -382,6 +383,8 @@ static int set_option_impl(wfahip_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_team_solo_max = value;
     else if (k == "fail_pass")
         ctx->opt_fail_pass = value;
+    else if (k == "narrow_long")
+        ctx->opt_narrow_long = value;
     else if (k == "census")
         ctx->opt_census = value;
     else if (k == "learn")
@@ -573,9 +576,10 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             // short reads: the blocked kernel stages BLK_BATCH pairs per group at a time
             // (kind 6: eight pairs per wave, 32-diagonal window; only with the batched refill)
             const bool     blk_batch    = (kind == 3 || kind == 6) && seq_words <= 16 && ctx->opt_blk_batch != 0;
-            if (kind == 6 && !blk_batch) return WFAHIP_ERR_INTERNAL;
+            if (kind == 6 && !blk_batch && ctx->opt_narrow_long == 0) return WFAHIP_ERR_INTERNAL;
             if (ctx->opt_fail_pass == kind) return WFAHIP_ERR_OOM;  // (fault injection, tests only)
             const size_t   lds_bytes    = blk_batch ? (size_t)(kind == 6 ? 8 : 4) * BLK_BATCH * (2 * seq_words + 8) * 4 + 16
+                                          : kind == 6 ? (size_t)seq_words * 2 * 4 * 8 + 16
                                           : kind == 5 ? (size_t)seq_words * 2 * 4 + 16
                                                       : (kind >= 3 ? lds_d : (kind == 2 ? lds_c : lds_b));
             const uint32_t pairs_wave   = kind == 5 ? 1 : (kind == 4 || kind == 6 ? 8 : (kind >= 2 ? 4 : 2));
@@ -671,6 +675,8 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                     else
                         hipLaunchKernelGGL((wfa_blk_kernel<16, BLK_BATCH>), dim3(grid), dim3(64), lds_bytes, st, P);
                 }
+                else if (kind == 6)
+                    hipLaunchKernelGGL((wfa_blk_kernel<8, 1, false, 4>), dim3(grid), dim3(64), lds_bytes, st, P);
                 else if (kind == 3 && stream_bt && P.census)
                     hipLaunchKernelGGL((wfa_blk_kernel<16, 1, true>), dim3(grid), dim3(64), lds_bytes, st, P);
                 else if (kind == 3 && stream_bt)
@@ -713,8 +719,9 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             std::vector<uint64_t> redo1, redo2;
             // short reads (< 200 bases, batched refill): eight pairs per wave in 32-diagonal windows first; what outgrows
             // them retries on the 16-lane instance below
-            const bool narrow1 = can_d && ctx->opt_blk == 16 && ctx->opt_blk_narrow != 0 && ctx->opt_blk_batch != 0 && max_len < 200 &&
-                                 seq_words <= 16;
+            const bool narrow1 = can_d && ctx->opt_blk == 16 && ctx->opt_blk_narrow != 0 &&
+                                 ((ctx->opt_blk_batch != 0 && max_len < 200 && seq_words <= 16) ||
+                                  (ctx->opt_narrow_long != 0 && (size_t)seq_words * 2 * 4 * 8 + 16 <= 8 * 1024));
             const int  kind1   = narrow1 ? 6 : (can_d ? (ctx->opt_blk == 8 ? 4 : 3) : (can_c ? 2 : 1));
             // Pilot: on a large batch with wf-adaptive off the first 4 096 pairs go first.  When most of them leave the
             // 64-diagonal window the rest does not start there only to be handed on: it goes straight to the
