@@ -208,6 +208,10 @@ int  wfahip_last_timing(const wfahip_ctx *ctx, wfahip_timing *out);
  *   "blk_wide"  0|1        pairs whose band leaves the 64-diagonal window retry on the same kernel with a
  *                          wave per pair (256 diagonals) before the generic kernel takes them       default 1
  *   "arena_bytes_per_slot", "slots", "threads_per_pair"   generic kernel (one workgroup per pair)
+ *   "prepack"  0|1         the sequences of a chunk are 2-bit packed by a kernel of their own before the 16-lane forward
+ *                          kernel, whose refill then is one round of loads (forward pass -2 %, packing kernel +4 %)   default 0
+ *   "narrow_long"  0|1     reads of any length start on the 8-lanes-per-pair instance (experiment: the refills of the
+ *                          hand-over cost more than the narrow steps save)                                            default 0
  *   "census"  0|1          count the wavefront words every pair stores (WFAHIP_REC_CELLS, timing.cells_stored: the roofline
  *                          accounting of bench.py); instrumentation, 4 % of the forward pass on 1 kbp pairs.  The kernels for
  *                          long / semi-global pairs always count                                                default 0

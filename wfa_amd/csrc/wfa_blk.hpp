@@ -517,20 +517,35 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
                 if (want && !got) st = 2;
                 uint32_t pr = 0, nq = 0, mt = 0;
                 uint64_t qo = 0, to = 0;
+                uint32_t status = ST_PENDING;
+                const uint32_t *slot = nullptr;  // the pair's pre-packed slot
                 if (got) {
                     pr = P.work ? P.work[wi] : P.chunk_first + wi;
-                    nq = P.q_len[pr], mt = P.t_len[pr], qo = P.q_off[pr], to = P.t_off[pr];
+                    if (P.prepack) {
+                        // lengths, status and the packed words were prepared by wfa_prepack_kernel: one load round after the
+                        // queue atomic instead of two (lengths / offsets, then the bytes) and no packing arithmetic here
+                        slot = P.prepack + (uint64_t)wi * P.prepack_words;
+                        nq = slot[0], mt = slot[1], status = slot[2];
+                    } else {
+                        nq = P.q_len[pr], mt = P.t_len[pr], qo = P.q_off[pr], to = P.t_off[pr];
+                    }
                 }
-                uint32_t status = ST_PENDING;
-                if (nq == 0 || mt == 0)
-                    status = ST_EMPTY;  // wfa.go:204-206
-                else if (nq > 0x1FFFFFFFu || mt > 0x1FFFFFFFu)
-                    status = ST_TOO_LONG;  // wfa.go:207-209
-                else if (((nq > mt ? nq : mt) + 15u) / 16u + 1u > SW)
-                    status = ST_REDO_LDS;
+                if (!P.prepack) {
+                    if (nq == 0 || mt == 0)
+                        status = ST_EMPTY;  // wfa.go:204-206
+                    else if (nq > 0x1FFFFFFFu || mt > 0x1FFFFFFFu)
+                        status = ST_TOO_LONG;  // wfa.go:207-209
+                    else if (((nq > mt ? nq : mt) + 15u) / 16u + 1u > SW)
+                        status = ST_REDO_LDS;
+                }
                 const bool stage = got && status == ST_PENDING;
                 bool       bad   = false;
-                if (__ballot(stage && ((nq > mt ? nq : mt) + 15u) / 16u + 1u > (uint32_t)G) == 0ull) {
+                if (P.prepack) {
+                    if (stage) {  // every refilling group copies its own 2 SW words, all groups side by side
+                        uint32_t *const dst = const_cast<uint32_t *>(lq);
+                        for (uint32_t w = (uint32_t)j; w < 2u * SW; w += (uint32_t)G) dst[w] = slot[4u + w];
+                    }
+                } else if (__ballot(stage && ((nq > mt ? nq : mt) + 15u) / 16u + 1u > (uint32_t)G) == 0ull) {
                     if (stage) {
                         bad = stage_pack<G>(P.blob, qo, nq, const_cast<uint32_t *>(lq), j);
                         bad |= stage_pack<G>(P.blob, to, mt, const_cast<uint32_t *>(lt), j);
@@ -968,6 +983,33 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
         // backtrace of the pairs still in flight elsewhere.
         stream_backtrace(P);
     }
+}
+
+// The sequences of a chunk, 2-bit packed once, by the whole GPU, before the forward kernel starts (0.4 ms per 1e6 x 1 kbp
+// pairs: 2 GB read, 0.5 GB written).  One wave per pair.  The forward kernel's refill -- where a group's new pair stalls the
+// other pairs of its wave -- then is a queue atomic plus ONE round of loads and no arithmetic (it was a fifth of the wave time:
+// lengths and offsets, then the bytes, then ~100 vector instructions per 16 bases).
+__global__ __launch_bounds__(256) void wfa_prepack_kernel(const KParams P, uint32_t *out, uint32_t SW, uint32_t PW) {
+    const uint32_t wi = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (wi >= P.chunk_n) return;
+    const uint32_t pr = P.chunk_first + wi;
+    const uint32_t nq = P.q_len[pr], mt = P.t_len[pr];
+    uint32_t       status = ST_PENDING;
+    if (nq == 0 || mt == 0)
+        status = ST_EMPTY;  // wfa.go:204-206
+    else if (nq > 0x1FFFFFFFu || mt > 0x1FFFFFFFu)
+        status = ST_TOO_LONG;  // wfa.go:207-209
+    else if (((nq > mt ? nq : mt) + 15u) / 16u + 1u > SW)
+        status = ST_REDO_LDS;
+    uint32_t *const slot = out + (uint64_t)wi * PW;
+    bool            bad  = false;
+    if (status == ST_PENDING) {
+        const uint64_t qo = P.q_off[pr], to = P.t_off[pr];
+        for (uint32_t w = lane; w < SW; w += 64u) slot[4u + w] = stage_word(P.blob, qo, nq, w, bad);
+        for (uint32_t w = lane; w < SW; w += 64u) slot[4u + SW + w] = stage_word(P.blob, to, mt, w, bad);
+    }
+    if (__ballot(bad) != 0ull) status = ST_REDO_BYTES;  // a byte outside ACGT: the byte-compare path takes the pair
+    if (lane == 0u) slot[0] = nq, slot[1] = mt, slot[2] = status, slot[3] = 0u;
 }
 
 }  // namespace wfa

@@ -90,6 +90,10 @@ struct KParams {
     uint32_t  n_stream_wgs;  // the first workgroups of the launch only backtrace
     uint32_t  stream_wait;   // longest wait for a done_q entry, in ticks of the 100 MHz wall clock
     uint32_t  blk_batch_n;           // wfa_blk_kernel<.., BATCH > 1>: queue entries a group takes per refill (1 .. BATCH)
+    // pre-packed sequences of the chunk (wfa_prepack_kernel): slot i = {q_len, t_len, status, 0, q words [lds_seq_words],
+    // t words [lds_seq_words]} of pair chunk_first + i; nullptr: the forward kernel packs the bytes itself in its refill
+    const uint32_t *prepack;
+    uint32_t        prepack_words;   // words per slot
     uint32_t  census;                // sub-wave forward kernels: report the number of stored wavefront words (REC_CELLS), else 0
     uint32_t  compact_fmt;           // compact arena layout (CompactView): 0 = rows + directory; no directory: 1 = 64 words
                                      // per score, diagonal k at slot k & 63; 3 = tiles of 8 scores x 64 diagonals;

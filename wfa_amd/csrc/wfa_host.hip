@@ -90,6 +90,7 @@ struct wfahip_ctx {
     hipEvent_t    evBtA = nullptr, evBtB = nullptr;
     bool          bt_pending = false;        // the first pass's backtrace kernel is still running on stream2
     DevBuf        in_blob, in_qoff, in_qlen, in_toff, in_tlen, out_rec, out_ops;  // host-entry staging
+    DevBuf        prepack;                   // 2-bit packed sequences of the current chunk (wfa_prepack_kernel)
     DevBuf        in_small;                  // host entry, small batches: blob + offset / length arrays as one image
     DevBuf        in_packed;                 // host entry with pre-packed input: the 2-bit words as uploaded (unpacked into in_blob on the device)
     // wfahip_submit / wfahip_collect: pairs handed in one at a time, aligned as one batch
@@ -123,6 +124,8 @@ struct wfahip_ctx {
     int64_t       opt_tail_overlap         = 1;  // 1: retry passes overlap the backtrace kernel of the first pass
     int64_t       opt_overlap              = 0;  // 1: backtrace of chunk c on a second stream beside the forward kernel of chunk c+1 (measured: no gain)
     int64_t       opt_fail_pass            = 0;   // test aid (fault injection): the sub-wave pass of this kind reports WFAHIP_ERR_OOM
+    int64_t       opt_prepack              = 0;   // 1: a chunk's sequences are 2-bit packed by a kernel of their own before the 16-lane forward kernel
+                                                  // (measured: forward 19.96 -> 19.54 ms per 1e6 x 1 kbp pairs, but the packing kernel takes 0.9 ms: off)
     int64_t       opt_narrow_long          = 0;   // experiment: reads of any length start on the 8-lanes-per-pair instance (32-diagonal windows)
     int64_t       opt_census               = 0;   // 1: the sub-wave forward kernels count the wavefront words they store (REC_CELLS, timing.cells_stored)
     int64_t       opt_learn                = 1;   // 1: long pairs start on the arena level the previous call of the same kind ended on
@@ -319,7 +322,7 @@ extern "C" void wfahip_destroy(wfahip_ctx *ctx) {
         if (ctx->pin_ev[i]) (void)hipEventDestroy(ctx->pin_ev[i]);
     }
     for (DevBuf *b : {&ctx->arena, &ctx->fin, &ctx->team_ctl, &ctx->arena2, &ctx->meta2, &ctx->doneq, &ctx->ctrl, &ctx->redo, &ctx->work, &ctx->meta, &ctx->in_blob, &ctx->in_qoff, &ctx->in_qlen,
-                      &ctx->in_toff, &ctx->in_tlen, &ctx->out_rec, &ctx->out_ops, &ctx->in_packed, &ctx->in_small})
+                      &ctx->in_toff, &ctx->in_tlen, &ctx->out_rec, &ctx->out_ops, &ctx->in_packed, &ctx->in_small, &ctx->prepack})
         release(*b);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -383,6 +386,8 @@ static int set_option_impl(wfahip_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_team_solo_max = value;
     else if (k == "fail_pass")
         ctx->opt_fail_pass = value;
+    else if (k == "prepack")
+        ctx->opt_prepack = value;
     else if (k == "narrow_long")
         ctx->opt_narrow_long = value;
     else if (k == "census")
@@ -655,6 +660,16 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                     P.stream_wait  = (uint32_t)std::min<int64_t>(std::max<int64_t>(ctx->opt_bt_stream_wait_us, 0) * 100, 0x7FFFFFFF);
                     HIP_TRY(hipMemsetAsync(ctx->doneq.p, 0, 256 + 16 * cn, st));
                     HIP_TRY(hipMemsetAsync(P.pair_meta, 0xFF, 16 * cn, st));  // ST_PENDING: only pairs without a backtrace get a status
+                }
+                // the chunk's sequences 2-bit packed up front (unbatched 16-lane first pass over a range of pairs)
+                P.prepack = nullptr, P.prepack_words = 0;
+                if (kind == 3 && !blk_batch && !list && ctx->opt_prepack != 0) {
+                    const uint32_t pw = 4u + 2u * seq_words;
+                    if ((rc2 = ensure(ctx, ctx->prepack, (size_t)chunk * pw * 4))) return rc2;
+                    hipLaunchKernelGGL(wfa_prepack_kernel, dim3((uint32_t)((cn + 3) / 4)), dim3(256), 0, st, P,
+                                       static_cast<uint32_t *>(ctx->prepack.p), seq_words, pw);
+                    HIP_TRY(hipGetLastError());
+                    P.prepack = static_cast<const uint32_t *>(ctx->prepack.p), P.prepack_words = pw;
                 }
                 if (n_buf == 2 && c >= 2) HIP_TRY(hipStreamWaitEvent(st, ctx->evpool[4 * (c - 2) + 3], 0));  // buffer free
                 if (c > 0) HIP_TRY(hipMemsetAsync(d_ctrl, 0, 4, st));  // queue_head only (chunk 0: cleared with redo_count above)
