@@ -685,7 +685,9 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                     const uint64_t rounds = (share + BLK_BATCH - 1) / BLK_BATCH;
                     P.blk_batch_n = (uint32_t)std::min<uint64_t>(BLK_BATCH, std::max<uint64_t>(1, (share + rounds - 1) / std::max<uint64_t>(1, rounds)));
                     if (ctx->opt_blk_batch > 1) P.blk_batch_n = (uint32_t)std::min<int64_t>(BLK_BATCH, ctx->opt_blk_batch);
-                    if (kind == 6)
+                    if (kind == 6 && !P.census)
+                        hipLaunchKernelGGL((wfa_blk_kernel<8, BLK_BATCH, false, 4, false>), dim3(grid), dim3(64), lds_bytes, st, P);
+                    else if (kind == 6)
                         hipLaunchKernelGGL((wfa_blk_kernel<8, BLK_BATCH, false, 4>), dim3(grid), dim3(64), lds_bytes, st, P);
                     else
                         hipLaunchKernelGGL((wfa_blk_kernel<16, BLK_BATCH>), dim3(grid), dim3(64), lds_bytes, st, P);
