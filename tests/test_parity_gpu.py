@@ -880,3 +880,22 @@ def test_penalties_the_reference_cannot_align_are_refused(built):
             al.Align(b"ACGT", b"CCGT")
         assert ei.value.code == L.ERR_UNSUPPORTED
         al.close()
+
+
+@pytest.mark.parametrize("opts", [{}, {"prepack": 1}, {"overlap": 1}, {"narrow_long": 1}])
+def test_several_chunks_and_optional_paths(built, opts):
+    """A pass cut into several chunks (each chunk's arenas are reused by the next: the default for batches that do not fit
+    35 % of HBM, forced here with chunk_pairs), and the optional paths kept behind options: the pre-packing kernel, the
+    double-buffered chunks, the 8-lanes-per-pair first pass for long reads."""
+    import wfa_amd as w
+    from oracle import oracle as O
+    data = w.generate_pairs(seed=61, n_pairs=5000, length=600, error_rate=0.05, n_threads=8)
+    want = O.align_batch(_oracle_params(True, (10, 50, 1)), *data, n_threads=8)
+    al = _aligner(True, (10, 50, 1))
+    al.set_option("chunk_pairs", 1200)
+    for k, v in opts.items():
+        al.set_option(k, v)
+    for rep in range(2):
+        assert_batch_equal(al.align_arrays(*data), want, f"chunks opts={opts} rep={rep}")
+    assert al.last_timing().n_main_launches == 5
+    al.close()
