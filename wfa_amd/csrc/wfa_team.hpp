@@ -34,7 +34,7 @@ namespace wfa {
 constexpr int TEAM_THREADS   = 1024;
 constexpr int TEAM_RING      = 64;   // directory entries every workgroup keeps in LDS (sources reach back < 64 scores)
 constexpr int TEAM_CTL_WORDS = 128;  // per team, in global memory: [0] barrier count [1] abort [2] work index
-                                     // [3] cells [4] command [5] score [6..7] arena top [8..9] end-cell key (u64) [10] end flags
+                                     // [3] - [4] command [5] score [6..7] arena top [8..9] end-cell key (u64) [10] end flags [12..13] stored cells (u64)
                                      // [16 + 16*set ..] three reduction sets [64..] diagnostic stamps
 constexpr uint32_t TEAM_SPIN_LIMIT = 1u << 24;
 #ifndef WFA_TEAM_U
@@ -121,7 +121,8 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
         if (b == 0 && tid == 0) {
             const uint32_t w0 = atomicAdd(P.queue_head, 1u);
             __hip_atomic_store(&ctl[2], w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&ctl[3], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ctl[12], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // [12..13]: stored cells (64-bit: a
+            __hip_atomic_store(&ctl[13], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // 100 kbp semi-global pair stores > 2^32 / 1.3)
             __hip_atomic_store(&ctl[4], (uint32_t)TEAM_CMD_NONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&ctl[8], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&ctl[9], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -497,7 +498,7 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
         __syncthreads();
         atomicAdd(reinterpret_cast<unsigned int *>(&red[10]), (unsigned int)(my_cells & 0xFFFFFFFFull));
         __syncthreads();
-        if (tid == 0) atomicAdd(&ctl[3], (uint32_t)red[10]);
+        if (tid == 0) atomicAdd(reinterpret_cast<unsigned long long *>(ctl + 12), (unsigned long long)(uint32_t)red[10]);
         team_barrier(true);  // every row, the directory and the cell count are visible to workgroup 0
         if (aborted) return;
 
@@ -612,8 +613,8 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
                 rec[REC_OPS_LEN]     = L;
                 rec[REC_OPS_OFF_LO]  = (uint32_t)off;
                 rec[REC_OPS_OFF_HI]  = (uint32_t)(off >> 32);
-                rec[REC_CELLS_LO]    = __hip_atomic_load(&ctl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                rec[REC_CELLS_HI]    = 0u;
+                rec[REC_CELLS_LO]    = __hip_atomic_load(&ctl[12], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                rec[REC_CELLS_HI]    = __hip_atomic_load(&ctl[13], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 rec[REC_N_SCORES]    = s_final;
             }
 #ifdef WFA_TEAM_STAMPS
