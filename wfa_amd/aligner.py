@@ -601,6 +601,7 @@ def generate_pairs_device(ctx_owner: "Aligner", seed: int, n_pairs: int, length:
     t_off = torch.zeros(n_pairs, dtype=torch.int64, device=dev)
     q_len = torch.zeros(n_pairs, dtype=torch.int32, device=dev)
     t_len = torch.zeros(n_pairs, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize(dev)  # (the fills run on torch's stream, the generator on the library's: not ordered otherwise)
     L.check(L.lib().wfahip_generate_pairs_device(ctx_owner._ctx, seed, first_index, n_pairs, length, float(error_rate),
                                                  blob.data_ptr(), q_off.data_ptr(), q_len.data_ptr(), t_off.data_ptr(),
                                                  t_len.data_ptr(), None), "wfahip_generate_pairs_device")

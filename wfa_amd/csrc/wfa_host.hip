@@ -1089,6 +1089,16 @@ std::vector<ResBlock> g_res_cache;
 size_t                g_res_cached_bytes = 0;
 constexpr size_t      RES_CACHE_MIN = 1u << 20, RES_CACHE_MAX_BYTES = 4ull << 30, RES_CACHE_MAX_BLOCKS = 32;
 
+// Blocks that come back from the cache are page-locked (hipHostRegister, once per block): the result download then
+// goes straight into them at link rate -- through pinned staging plus copy-out threads 0.8 GB of results took 36 ms of
+// a 44 ms call.  They stay registered while they circulate between wfahip_results_free and the next call.
+std::vector<ResBlock> g_res_pinned;  // (guarded by g_res_mu)
+bool res_is_pinned(const void *p, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_res_mu);
+    for (const ResBlock &b : g_res_pinned)
+        if (p >= b.p && static_cast<const char *>(p) + bytes <= static_cast<const char *>(b.p) + b.bytes) return true;
+    return false;
+}
 void *res_alloc(size_t bytes) {
     if (bytes >= RES_CACHE_MIN) {
         std::lock_guard<std::mutex> lk(g_res_mu);
@@ -1099,8 +1109,16 @@ void *res_alloc(size_t bytes) {
                 best = i;
         if (best != g_res_cache.size()) {
             void *p = g_res_cache[best].p;
-            g_res_cached_bytes -= g_res_cache[best].bytes;
+            const size_t cap = g_res_cache[best].bytes;
+            g_res_cached_bytes -= cap;
             g_res_cache.erase(g_res_cache.begin() + (long)best);
+            bool pinned = false;
+            for (const ResBlock &b : g_res_pinned) pinned = pinned || b.p == p;
+            if (!pinned && !std::getenv("WFAHIP_NO_PINNED_RESULTS") &&
+                hipHostRegister(p, cap, hipHostRegisterPortable) == hipSuccess)
+                g_res_pinned.push_back({p, cap});
+            else if (!pinned)
+                (void)hipGetLastError();
             return p;
         }
     }
@@ -1116,6 +1134,15 @@ void res_release(void *p) {
             g_res_cached_bytes += bytes;
             return;
         }
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_res_mu);
+        for (size_t i = 0; i < g_res_pinned.size(); i++)
+            if (g_res_pinned[i].p == p) {
+                (void)hipHostUnregister(p);
+                g_res_pinned.erase(g_res_pinned.begin() + (long)i);
+                break;
+            }
     }
     std::free(p);
 }
@@ -1183,6 +1210,11 @@ constexpr size_t PIN_CHUNK = 32u << 20;
 // malloc'd result arrays are what limits a plain hipMemcpy here).
 int download(wfahip_ctx *ctx, void *dst, const void *src, size_t bytes, hipStream_t st) {
     if (bytes == 0) return WFAHIP_OK;
+    if (res_is_pinned(dst, bytes)) {  // a recycled, page-locked result block: one copy at link rate
+        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        return WFAHIP_OK;
+    }
     for (int i = 0; i < 2; i++) {
         if (!ctx->pin[i]) HIP_TRY(hipHostMalloc(&ctx->pin[i], PIN_CHUNK, hipHostMallocDefault));
         if (!ctx->pin_ev[i]) HIP_TRY(hipEventCreateWithFlags(&ctx->pin_ev[i], hipEventDisableTiming));
@@ -1243,6 +1275,11 @@ __global__ __launch_bounds__(256) void wfa_unpack_kernel(const uint32_t *__restr
     bytes[i] = make_uint4(o[0], o[1], o[2], o[3]);
 }
 
+__global__ __launch_bounds__(256) void wfa_scale_offsets_kernel(uint64_t *q_off, uint64_t *t_off, uint64_t n) {  // words -> bytes
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) q_off[i] *= 16, t_off[i] *= 16;
+}
+
 // packed != nullptr: the sequences arrive 2-bit packed (word i of `packed` = bytes [16 i, 16 i + 16) of the blob the
 // offsets refer to); seq_blob is not read.
 static int align_batch_impl(wfahip_ctx *ctx, const wfahip_params *p, const uint8_t *seq_blob,
@@ -1250,6 +1287,9 @@ static int align_batch_impl(wfahip_ctx *ctx, const wfahip_params *p, const uint8
                             const uint64_t *t_off, const uint32_t *t_len, uint64_t n_pairs,
                             wfahip_results *out, const uint32_t *packed = nullptr) {
     if (!ctx || !out) return WFAHIP_ERR_BAD_ARG;
+    // (pre-packed input: q_off / t_off arrive in WORDS of 16 bases; they are uploaded as they are and scaled to byte
+    // offsets on the device -- a second pair of host arrays would cost more in page faults than the alignment of a slice)
+    const uint64_t osc = packed ? 16 : 1;
     results_zero(out);
     int rc = check_params(p);
     if (rc) return rc;
@@ -1272,7 +1312,7 @@ static int align_batch_impl(wfahip_ctx *ctx, const wfahip_params *p, const uint8
     uint64_t sum_len = 0;
     for (uint64_t i = 0; i < n_pairs; i++) {
         if (q_len[i] <= WFAHIP_MAX_SEQ_LEN && t_len[i] <= WFAHIP_MAX_SEQ_LEN && q_len[i] && t_len[i]) {
-            if (q_off[i] + q_len[i] > blob_bytes || t_off[i] + t_len[i] > blob_bytes) return WFAHIP_ERR_BAD_ARG;
+            if (q_off[i] * osc + q_len[i] > blob_bytes || t_off[i] * osc + t_len[i] > blob_bytes) return WFAHIP_ERR_BAD_ARG;
             max_len = std::max(max_len, std::max(q_len[i], t_len[i]));
             sum_len += (uint64_t)q_len[i] + t_len[i];
         }
@@ -1305,8 +1345,8 @@ static int align_batch_impl(wfahip_ctx *ctx, const wfahip_params *p, const uint8
             uint64_t lo = blob_bytes, hi = 0;
             for (uint64_t i = sl_first[k]; i < sl_first[k + 1]; i++) {
                 if (!(q_len[i] <= WFAHIP_MAX_SEQ_LEN && t_len[i] <= WFAHIP_MAX_SEQ_LEN && q_len[i] && t_len[i])) continue;
-                lo = std::min(lo, std::min(q_off[i], t_off[i]));
-                hi = std::max(hi, std::max(q_off[i] + q_len[i], t_off[i] + t_len[i]));
+                lo = std::min(lo, std::min(q_off[i], t_off[i]) * osc);
+                hi = std::max(hi, std::max(q_off[i] * osc + q_len[i], t_off[i] * osc + t_len[i]));
             }
             if (hi <= lo) lo = hi = 0;
             lo &= ~15ull;  // (whole aligned dwords of the first sequence; the tail padding of in_blob covers the end)
@@ -1347,6 +1387,11 @@ static int align_batch_impl(wfahip_ctx *ctx, const wfahip_params *p, const uint8
         HIP_TRY(hipMemcpyAsync(ctx->in_toff.p, t_off, n_pairs * 8, hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(ctx->in_qlen.p, q_len, n_pairs * 4, hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(ctx->in_tlen.p, t_len, n_pairs * 4, hipMemcpyHostToDevice, st));
+        if (packed) {
+            hipLaunchKernelGGL(wfa_scale_offsets_kernel, dim3((uint32_t)((n_pairs + 255) / 256)), dim3(256), 0, st,
+                               static_cast<uint64_t *>(ctx->in_qoff.p), static_cast<uint64_t *>(ctx->in_toff.p), n_pairs);
+            HIP_TRY(hipGetLastError());
+        }
     }
 
     if (dbg_t) HIP_TRY(hipStreamSynchronize(st));
@@ -1670,13 +1715,9 @@ extern "C" int wfahip_align_batch_packed(wfahip_ctx *ctx, const wfahip_params *p
                                          const uint32_t *t_len, uint64_t n_pairs, wfahip_results *out) {
     if (!ctx || !out || (!packed && n_words)) return WFAHIP_ERR_BAD_ARG;
     try {
-        std::vector<uint64_t> qo(n_pairs), to(n_pairs);  // byte offsets into the unpacked blob: 16 bases per word
-        for (uint64_t i = 0; i < n_pairs; i++) {
-            if (!q_woff || !t_woff) return WFAHIP_ERR_BAD_ARG;
-            qo[i] = q_woff[i] * 16, to[i] = t_woff[i] * 16;
-        }
+        if (n_pairs && (!q_woff || !t_woff)) return WFAHIP_ERR_BAD_ARG;
         static const uint32_t no_words[4] = {0, 0, 0, 0};
-        return align_batch_impl(ctx, p, nullptr, n_words * 16, qo.data(), q_len, to.data(), t_len, n_pairs, out, packed ? packed : no_words);
+        return align_batch_impl(ctx, p, nullptr, n_words * 16, q_woff, q_len, t_woff, t_len, n_pairs, out, packed ? packed : no_words);
     } catch (const std::bad_alloc &) {
         return WFAHIP_ERR_OOM;
     } catch (...) {
