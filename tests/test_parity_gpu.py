@@ -709,6 +709,7 @@ def test_device_entry_with_an_unaligned_ops_buffer(built):
     cap = int(want.ops_len.astype(np.int64).sum()) * 4 + 16 * n
     d_ops_all = torch.zeros(cap + 8, dtype=torch.int64, device=dev)
     d_rec = torch.zeros((n, L.REC_WORDS), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize(dev)  # (torch's fills are on its stream, the calls below on the context's own)
     for shift in (0, 1, 3):  # ops buffer 64-byte aligned / 8 bytes off / 24 bytes off
         d_ops = d_ops_all[shift:shift + cap]
         needed = C.c_uint64()
