@@ -1,0 +1,85 @@
+"""CPU: the C oracle (oracle/wfa_oracle.c) against a second restatement of the reference written independently in plain
+Python (oracle/pyref.py: dictionaries instead of zig-zag slices, written from the Go sources).  Every result field, and
+for a subset every stored M / I / D word with each wavefront's Lo / Hi -- which pins reduce() (wf-adaptive), the part of
+the path the reference's own published vectors barely exercise -- over thousands of small random pairs: the usual
+penalties, the shapes where two of next()'s sources share a score, GapExt == 0, global and semi-global, wf-adaptive off
+and at several settings."""
+import random
+
+import pytest
+
+
+def _pair(rng, max_len, alphabet=b"ACGT"):
+    n = rng.randint(1, max_len)
+    q = bytes(rng.choice(alphabet) for _ in range(n))
+    mode = rng.random()
+    if mode < 0.15:  # unrelated
+        t = bytes(rng.choice(alphabet) for _ in range(rng.randint(1, max_len)))
+    else:
+        t = bytearray(q)
+        for _ in range(int(len(t) * rng.uniform(0, 0.3)) + rng.randint(0, 2)):
+            kind, pos = rng.randint(0, 2), rng.randint(0, max(0, len(t) - 1))
+            if kind == 0 and t:
+                t[pos] = rng.choice(alphabet)
+            elif kind == 1:
+                t.insert(pos, rng.choice(alphabet))
+            elif len(t) > 1:
+                del t[pos]
+        if rng.random() < 0.2:  # overhangs (semi-global shapes)
+            t = bytes(rng.choice(alphabet) for _ in range(rng.randint(0, 12))) + bytes(t) + \
+                bytes(rng.choice(alphabet) for _ in range(rng.randint(0, 12)))
+        t = bytes(t) or b"A"
+    return q, t
+
+
+PENALTIES = [(4, 6, 2), (2, 3, 1), (1, 1, 1), (5, 0, 3), (3, 7, 2), (6, 4, 2), (2, 4, 2), (4, 2, 2), (2, 2, 2), (4, 6, 0), (3, 3, 0)]
+ADAPTIVE = [None, (10, 50, 1), (4, 5, 1), (1, 1, 1), (6, 20, 1)]
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_c_oracle_agrees_with_the_python_restatement(built, seed):
+    from oracle import oracle as O
+    from oracle import pyref as P
+    rng = random.Random(1000 + seed)
+    n_checked = n_dumped = 0
+    for _ in range(45):
+        pen = rng.choice(PENALTIES)
+        glob = rng.random() < 0.6
+        ad = rng.choice(ADAPTIVE)
+        co = O.Aligner(O.make_params(*pen, global_alignment=glob, adaptive=ad))
+        py = P.Aligner(*pen, global_alignment=glob, adaptive=ad)
+        for _ in range(6):
+            q, t = _pair(rng, 90 if glob else 60, b"ACGT" if rng.random() < 0.8 else b"ACGTN")
+            a, b = co.align(q, t), py.align(q, t)
+            assert a.key() == b.key(), (pen, glob, ad, q, t)
+            n_checked += 1
+            if n_checked % 3 == 0:  # internal state: every stored word and every wavefront's Lo / Hi
+                dump = co.dump()
+                for name, comp in (("M", py.M), ("I", py.I), ("D", py.D)):
+                    for s, wf in comp.wf.items():
+                        have = dump[name].get(s)
+                        words = {k: r for k, r in wf.raw.items() if r and wf.lo <= k <= wf.hi}
+                        if have is None:
+                            assert not words, (name, s, pen, glob, ad, q, t)
+                            continue
+                        lo, hi, raw = have
+                        assert {lo + i: r for i, r in enumerate(raw) if r} == words, (name, s, pen, glob, ad, q, t)
+                        if words:  # (an emptied wavefront's Lo / Hi are whatever Delete left: compared when it holds cells)
+                            assert (lo, hi) == (wf.lo, wf.hi), (name, s, (lo, hi), (wf.lo, wf.hi), pen, glob, ad, q, t)
+                    assert set(dump[name]) <= set(comp.wf) | {s for s, (lo, hi, raw) in dump[name].items() if not any(raw)}
+                n_dumped += 1
+        co.close()
+    assert n_checked == 270 and n_dumped == 90
+
+
+def test_python_restatement_on_the_published_vectors(known_answers):
+    """The second restatement is pinned on the same published vectors as the C oracle (README outputs, wfa_test.go:94)."""
+    from oracle import pyref as P
+    for ka in known_answers["vectors"]:
+        r = P.Aligner(4, 6, 2, global_alignment=ka["mode"] == "global", adaptive=tuple(ka["adaptive"])).align(
+            ka["q"].encode(), ka["t"].encode())
+        if ka.get("cigar_exact", True):
+            assert r.cigar == ka["cigar"], ka["id"]
+        for f in ("score", "qbegin", "qend", "tbegin", "tend", "align_len", "matches", "gaps", "gap_regions"):
+            if f in ka:
+                assert getattr(r, f) == ka[f], (ka["id"], f)
