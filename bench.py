@@ -86,7 +86,7 @@ def parse_args(argv=None):
     if args.cpu_threads is None:
         args.cpu_threads = 8 if args.config == "c5s" else 1  # (a 100 kbp semi-global pair is minutes of one core)
     if args.steps is None:
-        args.steps = {"c3": 200, "c2": 2000, "c4": 20, "c5s": 3}[args.config]
+        args.steps = {"c3": 250, "c2": 10000, "c4": 25, "c5s": 4}[args.config]  # (timed regions of ~5 s; c5s ~3 s)
     if args.warmup is None:
         args.warmup = 1 if args.config == "c5s" else 3
     return args
