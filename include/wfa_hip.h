@@ -218,7 +218,8 @@ int  wfahip_last_timing(const wfahip_ctx *ctx, wfahip_timing *out);
  *   "learn"  0|1            long pairs (team kernel): start on the arena level by which 90 % of the long pairs of the
  *                          previous call of the same kind had finished, instead of climbing from the smallest      default 1
  *   "team_min_len"         pairs at least this long use the team kernel (0 = never)              default 8192
- *   "team_wgs", "team_solo_max"   workgroups per team (0 = automatic), widest row done by one workgroup */
+ *   "team_wgs", "team_solo_max"   workgroups per team (0 = automatic), widest row done by one workgroup
+ *   "team_wave"                   1 (default): rows of at most 64 diagonals are stepped by one wave out of an LDS ring */
 int  wfahip_set_option(wfahip_ctx *ctx, const char *key, int64_t value);
 
 /* Debug / parity aid: align ONE pair and return every stored wavefront row.  rows[] receives

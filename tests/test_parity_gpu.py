@@ -584,6 +584,57 @@ def test_config5_sample(built):
     al.close()
 
 
+@pytest.mark.parametrize("penalties", [(4, 6, 2), (2, 3, 1), (6, 4, 2), (2, 4, 2), (1, 1, 1), (5, 20, 3), (3, 40, 1)])
+def test_team_kernel_wave_mode(built, penalties):
+    """The team kernel's wave mode (rows of <= 64 diagonals stepped by one wave out of an LDS ring of the last rows;
+    backtrace by a wave over an LDS window of the directory) against the oracle: ring depths 2..64 rows
+    (farthest source 1..41 scores back), bands that grow past 64 diagonals and shrink again (adaptive off: wave ->
+    solo -> wave), global and semi-global; the same batch with wave mode off must store the same number of cells."""
+    import wfa_amd as w
+    from oracle import oracle as O
+    a = w.generate_pairs(seed=21, n_pairs=24, length=600, error_rate=0.08)
+    b = w.generate_pairs(seed=22, n_pairs=4, length=4000, error_rate=0.12)
+    for data in (a, b):
+        for glob, ad in ((True, (10, 50, 1)), (False, (10, 50, 1)), (True, None), (False, (4, 5, 1))):
+            want = O.align_batch(_oracle_params(glob, ad, penalties), *data, n_threads=8)
+            cells = []
+            for wave in (1, 0):
+                al = _aligner(glob, ad, penalties)
+                for k, v in (("packed", 0), ("team_min_len", 1), ("team_wgs", 3), ("team_solo_max", 4096), ("team_wave", wave)):
+                    al.set_option(k, v)
+                got = al.align_arrays(*data)
+                assert_batch_equal(got, want, f"wave={wave} pen={penalties} glob={glob} ad={ad}")
+                cells.append(al.last_timing().cells_stored)
+                al.close()
+            assert cells[0] == cells[1]
+
+
+@pytest.mark.parametrize("penalties", [(4, 6, 2), (5, 20, 3), (2, 3, 1)])
+def test_team_kernel_wavefronts_word_for_word(built, penalties):
+    """Every stored M / I / D word of the team kernel -- team, solo and wave mode, and the switches between them --
+    against the oracle's final wavefronts (the dump entry runs the team kernel when `team_wgs` is set)."""
+    import wfa_amd as w
+    from oracle import oracle as O
+    blob, qo, ql, to, tl = w.generate_pairs(seed=31, n_pairs=3, length=900, error_rate=0.1)
+    for glob, ad in ((True, (10, 50, 1)), (False, (10, 50, 1)), (False, (4, 5, 1)), (True, None)):
+        oa = O.Aligner(_oracle_params(glob, ad, penalties))
+        for wave, solo_max in ((1, 4096), (1, 100), (0, 4096)):
+            al = _aligner(glob, ad, penalties)
+            for k, v in (("packed", 0), ("team_min_len", 1), ("team_wgs", 3), ("team_solo_max", solo_max), ("team_wave", wave)):
+                al.set_option(k, v)
+            for i in range(len(ql)):
+                q, t = bytes(blob[qo[i]:qo[i] + ql[i]]), bytes(blob[to[i]:to[i] + tl[i]])
+                r = oa.align(q, t)
+                want = {c: {sc: {lo + j: v for j, v in enumerate(raw) if v} for sc, (lo, hi, raw) in d.items()}
+                        for c, d in oa.dump().items()}
+                wf, res = al.debug_wavefronts(q, t)
+                assert res.Score == r.score
+                for c in "MID":
+                    assert wf[c] == {sc: row for sc, row in want[c].items() if row}, (penalties, glob, ad, wave, solo_max, i, c)
+            al.close()
+        oa.close()
+
+
 @pytest.mark.timeout(1500)
 def test_config5_full_length_pair(built):
     """BASELINE configs[4] at its stated length: 100 kbp pairs @10 %, semi-global + wf-adaptive 10/50/1 (seed 5, the

@@ -304,6 +304,7 @@ struct ArenaView {
     uint32_t        n_ent;  // directory entries written (scores 0, g, .., (n_ent-1)*g)
 
     WFA_DEV DirEnt ent(uint32_t idx) const { return load_dir(A + cap - (uint64_t)DIR_WORDS * (idx + 1)); }
+    WFA_DEV void   prepare(uint32_t, int) const {}  // (ArenaViewWave: loads the directory window of a backtrace step)
     // Component.GetRaw (wfa_component.go:150-155 + wfa_wavefront.go:163-169); s may have wrapped
     // below zero (uint32), which lands beyond the directory like the reference's len check.
     WFA_DEV uint32_t get_raw(int comp, uint32_t s, int k) const {
@@ -313,6 +314,86 @@ struct ArenaView {
         DirEnt e = ent(idx);
         if (e.w <= 0 || k < e.lo || k >= e.lo + e.w) return 0u;
         return A[e.base + (uint64_t)comp * e.stride + (uint32_t)(k - e.lo)];
+    }
+};
+
+// The same view for a whole wave walking the backtrace together (every lane executes the same steps on the same
+// values): the directory entries of a 64-score window live in LDS, loaded by the 64 lanes at once, so a step
+// costs the round trip of its cells only.  back_trace() calls prepare() once per step: the window then holds the
+// entries of the scores s - dmax*g .. s, all a step can look at, and the lookups themselves carry no refill code.
+// On a refill every lane also touches the cells of ITS entry that the walk can reach while the window lasts (the
+// walk changes diagonal by at most one per entry it descends): the misses of ~20 steps are taken together, in
+// one round trip, instead of one after the other.
+struct ArenaViewWave {
+    const uint32_t *A;
+    uint64_t        cap;
+    uint32_t        g, n_ent;
+    DirEnt         *win;      // LDS, 64 entries, slot = index & 63
+    uint32_t        dmax;     // farthest source of a step, in entries (< 64)
+    int             g_shift;  // log2(g) when g is a power of two (no division per lookup), else -1
+    mutable uint32_t win_lo, win_hi;  // entries [win_lo, win_hi] are loaded; win_lo > win_hi: none
+
+    WFA_DEV void init(const uint32_t *A_, uint64_t cap_, uint32_t g_, uint32_t n_ent_, DirEnt *lds_win, uint32_t dmax_) {
+        A = A_, cap = cap_, g = g_, n_ent = n_ent_, win = lds_win, dmax = dmax_;
+        g_shift = (g & (g - 1u)) == 0u ? (int)__builtin_ctz(g) : -1;
+        win_lo = 1u, win_hi = 0u;
+    }
+    WFA_DEV bool split(uint32_t s, uint32_t &idx) const {  // s = idx * g ?
+        if (g_shift >= 0) {
+            idx = s >> g_shift;
+            return (s & (g - 1u)) == 0u;
+        }
+        idx = s / g;
+        return s % g == 0u;
+    }
+    WFA_DEV void refill(uint32_t top, int k) const {
+        const uint32_t hi = top < n_ent ? top : n_ent - 1u;
+        const uint32_t lo = hi >= 63u ? hi - 63u : 0u;
+        const uint32_t j  = lo + (uint32_t)(threadIdx.x & 63);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (j <= hi) {
+            const DirEnt d = load_dir(A + cap - (uint64_t)DIR_WORDS * (j + 1));
+            win[j & 63u]   = d;
+            if (d.w > 0) {
+                const int reach = 66;
+                const int k0 = k - reach > d.lo ? k - reach : d.lo, k1 = k + reach < d.lo + d.w - 1 ? k + reach : d.lo + d.w - 1;
+                uint32_t  acc = 0;
+                for (int c = 0; c < 3; c++) {
+                    const uint32_t *row = A + d.base + (uint64_t)c * d.stride - d.lo;  // indexed by diagonal
+                    for (int kk = k0; kk <= k1; kk += 32) acc ^= row[kk];
+                    if (k1 >= k0) acc ^= row[k1];
+                }
+                asm volatile("" ::"v"(acc));  // the loads are wanted for the lines they bring in
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        win_lo = lo, win_hi = hi;
+    }
+    WFA_DEV void prepare(uint32_t s, int k) const {  // wave-uniform
+        uint32_t idx;
+        (void)split(s, idx);
+        if (n_ent == 0u) return;
+        if (idx >= n_ent) idx = n_ent - 1u;
+        const uint32_t need_lo = idx >= dmax ? idx - dmax : 0u;
+        if (need_lo < win_lo || idx > win_hi) refill(idx, k);
+    }
+    // No early return and no branch around the cell load: the five lookups of a backtrace step then have their loads
+    // in flight together (a lookup that finds nothing reads word 0 of the arena and drops it).
+    WFA_DEV uint32_t get_raw(int comp, uint32_t s, int k) const {
+        uint32_t idx;
+        bool     ok = split(s, idx);
+        ok          = ok && idx < n_ent;
+        DirEnt e;
+        if (ok && (idx < win_lo || idx > win_hi))  // (not reached: prepare() has loaded what a step reads)
+            e = load_dir(A + cap - (uint64_t)DIR_WORDS * (idx + 1));
+        else
+            e = win[idx & 63u];
+        ok = ok && e.w > 0 && k >= e.lo && k < e.lo + e.w;
+        const uint64_t off = ok ? e.base + (uint64_t)comp * e.stride + (uint32_t)(k - e.lo) : 0ull;
+        const uint32_t v   = A[off];
+        return ok ? v : 0u;
     }
 };
 
@@ -563,8 +644,12 @@ WFA_DEV void backtrace_start(const ArenaView &av, int n, int m, uint32_t s, uint
 
 // backTrace (wfa.go:703-983), one lane.  Source lookups are plain Gets with NO bounds rejection,
 // exactly as the reference recomputes the pre-extension offset.
-template <class Writer>
-WFA_DEV void back_trace(const ArenaView &av, int lenQ, int lenT, uint32_t s, int Ak, bool semiGlobal,
+//
+// The cell read at the end of a step (wfa.go:915-920) is always one of the source cells the step has just read
+// (M[s-x][k], M[s-o-e][k-+1], I/D[s-e][k-+1]), so it is taken from those registers: one memory round trip per
+// step instead of two.  View: ArenaView, or ArenaViewWave when a whole wave walks together.
+template <class View, class Writer>
+WFA_DEV void back_trace(const View &av, int lenQ, int lenT, uint32_t s, int Ak, bool semiGlobal,
                         uint32_t px, uint32_t po, uint32_t pe, Writer &ow, TraceOut &out) {
     out.score  = s;
     out.tbegin = out.tend = out.qbegin = out.qend = 0;
@@ -578,7 +663,9 @@ WFA_DEV void back_trace(const ArenaView &av, int lenQ, int lenT, uint32_t s, int
     bool     previousFromM = true, firstMatch = true;
     int      nMatches;
     int      M0 = 0;  // component to read the next tag from: 0 = M, 1 = I, 2 = D
+    uint32_t nxMis = 0, nxOpenI = 0, nxOpenD = 0, nxExt = 0;  // the source cells of this step, by the move that reaches them
 
+    av.prepare(s, k);
     offset  = av.get_raw(0, s, k);  // wfa.go:738
     wfaType = offset & TAG_MASK;
     h       = (int)(offset >> TAG_BITS);
@@ -590,6 +677,7 @@ WFA_DEV void back_trace(const ArenaView &av, int lenQ, int lenT, uint32_t s, int
         ow.add('H', (uint32_t)lenQ - (uint32_t)v);
 
     while (v > 0 && h > 0) {  // wfa.go:753
+        av.prepare(s, k);
         sMismatch = s - px;
         sGapOpen  = s - po - pe;
         sGapExt   = s - pe;
@@ -602,7 +690,8 @@ WFA_DEV void back_trace(const ArenaView &av, int lenQ, int lenT, uint32_t s, int
             } else {
                 offset0 = 0;
             }
-            M0 = 1;
+            nxExt = r2;
+            M0    = 1;
         } else if (wfaType == TAG_DEL_EXT) {  // wfa.go:778-788
             uint32_t r1 = av.get_raw(0, sGapOpen, k + 1), r2 = av.get_raw(2, sGapExt, k + 1);
             if (r1 != 0 || r2 != 0) {
@@ -611,11 +700,13 @@ WFA_DEV void back_trace(const ArenaView &av, int lenQ, int lenT, uint32_t s, int
             } else {
                 offset0 = 0;
             }
-            M0 = 2;
+            nxExt = r2;
+            M0    = 2;
         } else {  // wfa.go:789-817
             uint32_t r1 = av.get_raw(0, sGapOpen, k - 1), r2 = av.get_raw(1, sGapExt, k - 1);
             uint32_t r3 = av.get_raw(0, sGapOpen, k + 1), r4 = av.get_raw(2, sGapExt, k + 1);
             uint32_t r5 = av.get_raw(0, sMismatch, k);
+            nxMis = r5, nxOpenI = r1, nxOpenD = r3;
             v1 = r1 >> TAG_BITS, v2 = r2 >> TAG_BITS;
             if (r1 != 0 || r2 != 0) {
                 fromMI = true;
@@ -640,7 +731,7 @@ WFA_DEV void back_trace(const ArenaView &av, int lenQ, int lenT, uint32_t s, int
             }
             M0 = 0;
         }
-        (void)fromM;
+        (void)fromM, (void)M0;
         if (fromItself) break;    // wfa.go:818-821
         if (offset0 == 0) break;  // wfa.go:822-825
         h0 = (int)offset0;
@@ -672,17 +763,16 @@ WFA_DEV void back_trace(const ArenaView &av, int lenQ, int lenT, uint32_t s, int
         previousFromM = true;  // wfa.go:885-909
         bool stop     = false;
         switch (wfaType) {
-        case TAG_MISMATCH: s = sMismatch; h--; break;
-        case TAG_INS_OPEN: s = sGapOpen; k--; h--; break;
-        case TAG_INS_EXT: s = sGapExt; k--; h--; previousFromM = false; break;
-        case TAG_DEL_OPEN: s = sGapOpen; k++; break;
-        case TAG_DEL_EXT: s = sGapExt; k++; previousFromM = false; break;
+        case TAG_MISMATCH: s = sMismatch; h--; offset = nxMis; break;
+        case TAG_INS_OPEN: s = sGapOpen; k--; h--; offset = nxOpenI; break;
+        case TAG_INS_EXT: s = sGapExt; k--; h--; previousFromM = false; offset = nxExt; break;
+        case TAG_DEL_OPEN: s = sGapOpen; k++; offset = nxOpenD; break;
+        case TAG_DEL_EXT: s = sGapExt; k++; previousFromM = false; offset = nxExt; break;
         default: stop = true; break;
         }
         if (stop) break;
         v = h - k;
-
-        offset = av.get_raw(M0, s, k);  // wfa.go:915-920
+        // wfa.go:915-920: offset = component M0 at (s, k) -- the source cell read above
         if (offset == 0) break;
         wfaType = offset & TAG_MASK;
     }

@@ -120,6 +120,7 @@ struct wfahip_ctx {
                                                     // per pair) in the generic ladder; 0 = never
     int64_t       opt_team_wgs             = 0;     // workgroups per team, 0 = automatic
     int64_t       opt_team_solo_max        = TEAM_SOLO_MAX;  // rows up to this width are done by one workgroup
+    int64_t       opt_team_wave            = 1;              // rows up to 64 diagonals are done by one wave (LDS ring)
     int64_t       opt_pilot                = 1;  // 1: a 4 096-pair pilot decides whether a large batch uses the sub-wave kernels
     int64_t       opt_tail_overlap         = 1;  // 1: retry passes overlap the backtrace kernel of the first pass
     int64_t       opt_overlap              = 0;  // 1: backtrace of chunk c on a second stream beside the forward kernel of chunk c+1 (measured: no gain)
@@ -384,6 +385,8 @@ static int set_option_impl(wfahip_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_team_wgs = value;
     else if (k == "team_solo_max")
         ctx->opt_team_solo_max = value;
+    else if (k == "team_wave")
+        ctx->opt_team_wave = value;
     else if (k == "fail_pass")
         ctx->opt_fail_pass = value;
     else if (k == "prepack")
@@ -919,10 +922,10 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
         }
         if (debug_single) cfg.slots = 1;
         // Wide wavefronts: a team of workgroups per pair (wfa_team_kernel) instead of one workgroup per pair.
-        uint32_t team_T = 0, team_n = 0;
+        uint32_t team_T = 0, team_n = 0, team_wave_rows = 0;
         // It pays when one workgroup per pair cannot fill the GPU: few pairs, or arenas so large that only a few
         // fit (cfg.slots is the number of pairs the generic kernel could run at once).
-        if (cr == 0 && !debug_single && ctx->opt_team_min_len > 0 && max_len >= (uint64_t)ctx->opt_team_min_len &&
+        if (cr == 0 && (!debug_single || ctx->opt_team_wgs > 0) && ctx->opt_team_min_len > 0 && max_len >= (uint64_t)ctx->opt_team_min_len &&
             (cfg.slots < (uint32_t)std::max(1, ctx->num_cus / 2) || ctx->opt_team_wgs > 0) && P.e != 0u &&
             std::max(P.x, std::max(P.oe, P.e)) / P.g < (uint32_t)TEAM_RING) {
             const uint32_t cus = (uint32_t)std::max(1, ctx->num_cus);
@@ -939,6 +942,17 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             cfg.lds_seq_words = (cfg.lds_seq_words + 1u) & ~1u;
             cfg.lds_bytes     = (2ull * cfg.lds_seq_words + 16 + TEAM_RING * (sizeof(DirEnt) / 4)) * 4ull;
             if (cfg.lds_bytes > LDS_MAX_BYTES) team_T = 0;  // (cannot happen: make_cfg already bounded the sequences)
+            // wave mode: an LDS ring of the last rows (a power of two above the farthest source), if it fits
+            team_wave_rows = 0;
+            if (ctx->opt_team_wave) {
+                uint32_t rows = 2;
+                while (rows <= std::max(P.x, std::max(P.oe, P.e)) / P.g) rows *= 2;
+                const size_t ring_bytes = (size_t)rows * 3 * 64 * 4;
+                if (rows <= (uint32_t)TEAM_RING && cfg.lds_bytes + ring_bytes <= LDS_MAX_BYTES) {
+                    team_wave_rows = rows;
+                    cfg.lds_bytes += ring_bytes;
+                }
+            }
         }
         if (cr == 2 || job.level > max_level) {
             if (job.all) {
@@ -981,7 +995,8 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)cfg.lds_bytes));
             hipLaunchKernelGGL(kfn, dim3(team_n * team_T), dim3(TEAM_THREADS), cfg.lds_bytes, st, P,
-                               static_cast<uint32_t *>(ctx->team_ctl.p), team_T, (uint32_t)std::max<int64_t>(0, ctx->opt_team_solo_max));
+                               static_cast<uint32_t *>(ctx->team_ctl.p), team_T, (uint32_t)std::max<int64_t>(0, ctx->opt_team_solo_max),
+                               team_wave_rows);
             HIP_TRY(hipGetLastError());
         } else {
             HIP_TRY(launch_generic(P, cfg, st));
@@ -996,8 +1011,9 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
 #ifdef WFA_TEAM_STAMPS
             for (uint32_t t = 0; t < team_n; t++) {
                 const unsigned long long *a = reinterpret_cast<const unsigned long long *>(&tc[(size_t)t * TEAM_CTL_WORDS + 64]);
-                std::fprintf(stderr, "[team %u] us: P1 %.0f  barriers %.0f  P2 %.0f  P3 %.0f  tail(team) %.0f  solo steps %.0f  end search %.0f  backtrace %.0f\n", t,
-                             a[0] / 100.0, a[1] / 100.0, a[2] / 100.0, a[3] / 100.0, a[4] / 100.0, a[5] / 100.0, a[6] / 100.0, a[7] / 100.0);
+                std::fprintf(stderr, "[team %u] us: P1 %.0f  barriers %.0f  P2 %.0f  P3 %.0f  tail(team) %.0f  solo steps %.0f  end search %.0f  backtrace %.0f  wave mode %.0f | steps: wave %llu solo %llu team %llu\n", t,
+                             a[0] / 100.0, a[1] / 100.0, a[2] / 100.0, a[3] / 100.0, a[4] / 100.0, a[5] / 100.0, a[6] / 100.0, a[7] / 100.0,
+                             a[8] / 100.0, a[9], a[10], a[11]);
             }
 #endif
             for (uint32_t t = 0; t < team_n; t++)

@@ -24,6 +24,13 @@
 // barrier (agent-scope release before the arrive, acquire after the spin).  After wf-adaptive has collapsed the
 // band of a semi-global pair the rest of the alignment runs solo at the generic kernel's speed.
 //
+// Rows of at most 64 diagonals -- what is left of a semi-global pair once wf-adaptive has collapsed its band:
+// ~3e4 of the 3.3e4 score steps of a 100 kbp pair -- run in WAVE mode: wave 0 of workgroup 0 alone, one diagonal
+// per lane, the last `wave_rows` rows of M, I and D in an LDS ring (slot = diagonal & 63: every source of a row of
+// <= 64 diagonals lies inside the row's own range), the ranges and the wf-adaptive ends from ballots (lanes are
+// ordered by diagonal), no barrier of any kind; rows and directory entries still go to the arena for the
+// backtrace.  0.6 us per step against 5 us in solo mode.
+//
 // A barrier that does not complete within the spin bound raises the team's abort flag and every workgroup leaves
 // (the host reports an internal error instead of hanging the device).
 #pragma once
@@ -45,18 +52,20 @@ constexpr uint32_t TEAM_SOLO_MAX   = 4096;  // default: rows up to this width ar
 enum : uint32_t { TEAM_CMD_NONE = 0, TEAM_CMD_RESUME = 1, TEAM_CMD_DONE = 2 };  // ctl[4]; ctl[5] = score, ctl[6..7] = top
 
 struct TeamRed {  // one reduction set (global memory, 16 words)
-    int mlo, mhi, term, mind, first_ok, last_ok, anyfail, lead, hitmin, pad[7];
+    int mlo, mhi, term, mind, first_ok, last_ok, anyfail, lead, hitmin, maxd, pad[6];
 };
 
 template <int MODE>
 __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P, uint32_t *team_ctl, uint32_t T,
-                                                                uint32_t solo_max) {
+                                                                uint32_t solo_max, uint32_t wave_rows) {
     constexpr int G = TEAM_THREADS;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t *const lq   = lds;
     uint32_t *const lt   = lds + P.lds_seq_words;
     int *const      red  = reinterpret_cast<int *>(lds + 2 * (MODE == 0 ? P.lds_seq_words : 0));  // 16 ints
     DirEnt *const   ring = reinterpret_cast<DirEnt *>(red + 16);                                   // TEAM_RING entries
+    // wave mode: the last wave_rows (a power of two, 0 = wave mode off) rows, [row][component][diagonal & 63]
+    uint32_t *const wring = reinterpret_cast<uint32_t *>(ring + TEAM_RING);
 
     const int      tid = threadIdx.x, lane = tid & 63;
     const uint32_t team = blockIdx.x / T, b = blockIdx.x % T;
@@ -67,7 +76,7 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
     const int64_t  stripe = (int64_t)T * G;
 
 #ifdef WFA_TEAM_STAMPS
-    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memrealtime();
+    unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memrealtime();
 #define TEAM_STAMP(i)                                                  \
     do {                                                               \
         const unsigned long long _t = __builtin_amdgcn_s_memrealtime(); \
@@ -111,9 +120,9 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
     auto tred = [&](uint32_t set) { return reinterpret_cast<TeamRed *>(ctl + 16 + 16 * set); };
     auto reset_set = [&](TeamRed *r) {  // memory-side stores: the other workgroups' atomics must see them
         uint32_t *const w = reinterpret_cast<uint32_t *>(r);
-        const int       v[9] = {INT32_MAX, INT32_MIN, 0, INT32_MAX, INT32_MAX, INT32_MIN, 0, INT32_MIN, INT32_MAX};
+        const int       v[10] = {INT32_MAX, INT32_MIN, 0, INT32_MAX, INT32_MAX, INT32_MIN, 0, INT32_MIN, INT32_MAX, INT32_MIN};
 #pragma unroll
-        for (int i = 0; i < 9; i++) __hip_atomic_store(w + i, (uint32_t)v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = 0; i < 10; i++) __hip_atomic_store(w + i, (uint32_t)v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
 
     for (;;) {
@@ -290,6 +299,167 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
                 teamed = true;
             }
 
+            // ---- wave mode (workgroup 0, solo): wave 0 steps alone while the rows stay within 64 diagonals
+            if (!teamed && wave_rows != 0u && W <= 64) {
+                if (tid < 64) {
+                    const uint32_t rmask = wave_rows - 1u;
+                    auto wrow = [&](uint32_t idx, int comp) { return wring + (((idx & rmask) * 3u + (uint32_t)comp) << 6); };
+                    // the rows the next steps can source: from the arena into the LDS ring (a row wider than 64
+                    // is never read here: a step that sources it is itself wider than 64 and leaves wave mode)
+                    for (uint32_t r = 1; r <= wave_rows && r <= si; r++) {
+                        const DirEnt d = ring[(si - r) % TEAM_RING];
+                        if (d.w > 0 && d.w <= 64 && lane < d.w) {
+                            const uint32_t sl = (uint32_t)(d.lo + lane) & 63u;
+#pragma unroll
+                            for (int c = 0; c < 3; c++) wrow(si - r, c)[sl] = A[d.base + (uint64_t)c * d.stride + (uint32_t)lane];
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    // Everything that is the same in every lane is kept in scalar registers (readfirstlane): the
+                    // score, the arena top, the ranges of the source rows -- the loop control is scalar code.
+                    auto rfl = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+                    const int2 *const ring_lw = reinterpret_cast<const int2 *>(ring);  // entry i: [4 i + 1] = {lo, w}
+                    uint32_t wflags = 0;  // 1: done, 2: overflow, 4: the row at s is wider than 64 (back to solo mode)
+                    uint32_t su = rfl(s), sj = rfl(s / g);
+                    uint64_t utop = (uint64_t)rfl((uint32_t)top) | ((uint64_t)rfl((uint32_t)(top >> 32)) << 32);
+                    const uint32_t dx = x / g, doe = oe / g, de = e / g;
+                    for (;; su += g, sj++) {
+                        int xlo = 0, xw = 0, olo = 0, ow_ = 0, elo = 0, ew = 0;
+                        if (su >= x) {
+                            const int2 v = ring_lw[((sj - dx) % TEAM_RING) * 4u + 1u];
+                            xlo = (int)rfl((uint32_t)v.x), xw = (int)rfl((uint32_t)v.y);
+                        }
+                        if (su >= oe) {
+                            const int2 v = ring_lw[((sj - doe) % TEAM_RING) * 4u + 1u];
+                            olo = (int)rfl((uint32_t)v.x), ow_ = (int)rfl((uint32_t)v.y);
+                        }
+                        if (su >= e) {
+                            const int2 v = ring_lw[((sj - de) % TEAM_RING) * 4u + 1u];
+                            elo = (int)rfl((uint32_t)v.x), ew = (int)rfl((uint32_t)v.y);
+                        }
+                        const bool wseed = (su == 0u) || (su == x);
+                        int wlo = INT32_MAX, whi = INT32_MIN;
+                        if (xw > 0) wlo = imin2(wlo, xlo - 1), whi = imax2(whi, xlo + xw);
+                        if (ow_ > 0) wlo = imin2(wlo, olo - 1), whi = imax2(whi, olo + ow_);
+                        if (ew > 0) wlo = imin2(wlo, elo - 1), whi = imax2(whi, elo + ew);
+                        wlo = imax2(wlo, -(n - 1));
+                        whi = imin2(whi, m - 1);
+                        if (su == 0u) wlo = INT32_MAX, whi = INT32_MIN;
+                        if (wseed) wlo = imin2(wlo, seed_lo), whi = imax2(whi, seed_hi);
+                        const int64_t WW = (whi >= wlo) ? ((int64_t)whi - wlo + 1) : 0;
+                        if (utop + 3ull * (uint64_t)WW + (uint64_t)DIR_WORDS * (sj + 2) > cap) {
+                            wflags = 2u;
+                            break;
+                        }
+                        if (WW > 64) {
+                            wflags = 4u;
+                            break;
+                        }
+                        if (WW == 0) {
+                            put_ent(sj, 0ull, 0, 0, 0u);
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            continue;
+                        }
+                        const uint64_t wbase = utop;
+                        const int      k     = wlo + lane;
+                        const bool     on    = lane < (int)WW;
+                        const uint32_t sl    = (uint32_t)k & 63u;
+                        auto wsrc = [&](int dlo, int dw, uint32_t idx, int comp, int kk) -> uint32_t {
+                            return (kk >= dlo && kk < dlo + dw) ? wrow(idx, comp)[(uint32_t)kk & 63u] : 0u;  // (dw <= 0: never)
+                        };
+                        Cell c = {0u, 0u, 0u};
+                        if (on) {
+                            if (su != 0u) {
+                                const uint32_t sa = wsrc(olo, ow_, sj - doe, 0, k - 1), sb = wsrc(elo, ew, sj - de, 1, k - 1);
+                                const uint32_t sc2 = wsrc(olo, ow_, sj - doe, 0, k + 1), sd = wsrc(elo, ew, sj - de, 2, k + 1);
+                                const uint32_t sx = wsrc(xlo, xw, sj - dx, 0, k);
+                                c = next_cell(sa, sb, sc2, sd, sx, k, n, m);
+                            }
+                            if (wseed && c.M == 0u) c.M = seed_word<MODE>(sv, k, su, x, glob);
+                            c.M = extend_word<MODE>(sv, c.M, k);
+                            uint32_t *const rowM = A + wbase + lane;
+                            rowM[0] = c.M, rowM[WW] = c.I, rowM[2 * WW] = c.D;
+                            wrow(sj, 0)[sl] = c.M, wrow(sj, 1)[sl] = c.I, wrow(sj, 2)[sl] = c.D;
+                            my_cells += (c.M != 0u) + (c.I != 0u) + (c.D != 0u);
+                        }
+                        utop += 3ull * (uint64_t)WW;
+                        // lanes are ordered by diagonal: first / last lane of a ballot = lowest / highest diagonal
+                        const unsigned long long bM = __ballot(c.M != 0u);
+                        if (bM == 0ull) {  // no M cell: nothing to reduce, the entry is empty (mlo > mhi)
+                            put_ent(sj, 0ull, 0, 0, 0u);
+                        } else {
+                            const int  wmlo = wlo + (int)__builtin_ctzll(bM), wmhi = wlo + 63 - (int)__builtin_clzll(bM);
+                            const int  dd   = reduce_dist(c.M, k, n, m);
+                            const bool hit  = c.M != 0u && k == Ak && (int)(c.M >> TAG_BITS) >= m;
+                            if (__ballot(hit) != 0ull) {
+                                put_ent(sj, wbase, wlo, (int)WW, (uint32_t)WW);
+                                wflags = 1u;
+                                break;
+                            }
+                            int wnlo = wmlo, wnhi = wmhi;
+                            const unsigned long long bV = __ballot(dd >= 0);
+                            if (P.adaptive && (wmhi - wmlo + 1) >= (int)P.min_wf_len && bV != 0ull) {
+                                const int wmind = wave_min(dd >= 0 ? dd : INT32_MAX);
+                                const int maxdiff = (int)P.max_dist_diff;
+                                const unsigned long long bFail = __ballot(dd >= 0 && dd - wmind > maxdiff);
+                                const unsigned long long bOk   = bV & ~bFail;
+                                if (bFail != 0ull) {
+                                    // (bOk is never empty: the cell at the minimum distance passes)
+                                    const int first_ok = wlo + (int)__builtin_ctzll(bOk), last_ok = wlo + 63 - (int)__builtin_clzll(bOk);
+                                    const unsigned long long bEnd = bM & ~bV;  // present cells at / past a sequence end
+                                    const int hitmin = bEnd != 0ull ? wlo + (int)__builtin_ctzll(bEnd) : INT32_MAX;
+                                    if (hitmin >= first_ok) {
+                                        wnlo = first_ok, wnhi = last_ok;
+                                    } else {
+                                        // _lo: one past the last valid entry before the first non-failing one
+                                        const unsigned long long below = bV & ((1ull << (first_ok - wlo)) - 1ull);
+                                        wnlo = below != 0ull ? wlo + 63 - (int)__builtin_clzll(below) + 1 : wmlo;
+                                        wnhi = last_ok;
+                                    }
+                                    if (on && (k < wnlo || k > wnhi)) my_cells -= (c.M != 0u) + (c.I != 0u) + (c.D != 0u);
+                                }
+                            }
+                            if (wnhi >= wnlo)
+                                put_ent(sj, wbase + (uint64_t)(wnlo - wlo), wnlo, wnhi - wnlo + 1, (uint32_t)WW);
+                            else
+                                put_ent(sj, 0ull, 0, 0, 0u);
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+#ifdef WFA_TEAM_STAMPS
+                        tacc[9]++;
+#endif
+                    }
+                    // su: the score the loop stopped at (done: the final score; overflow / wide: the score to redo);
+                    // every score below it has its directory entry
+                    s = su, top = utop, n_ent = (wflags == 1u) ? sj + 1u : sj;
+                    if (wflags == 1u) s_final = su;
+                    if (tid == 0) {
+                        unsigned int *const ur = reinterpret_cast<unsigned int *>(red);
+                        ur[0] = s, ur[1] = (uint32_t)top, ur[2] = (uint32_t)(top >> 32), ur[3] = n_ent, ur[4] = wflags, ur[5] = s_final;
+                    }
+                }
+                __syncthreads();
+                {
+                    const unsigned int *const ur = reinterpret_cast<const unsigned int *>(red);
+                    s = ur[0], top = (uint64_t)ur[1] | ((uint64_t)ur[2] << 32), n_ent = ur[3];
+                    const uint32_t wf = ur[4];
+                    if (wf & 1u) done = true, s_final = ur[5];
+                    if (wf & 2u) overflow = true;
+                }
+                __syncthreads();
+                TEAM_STAMP(8);
+                if (done || overflow) break;
+                // the row at s is wider than 64: redo the loop head for it in solo (or team) mode.  The loop heads of
+                // the scores stepped here did not run: the reduction set of score s is still the one of s - 3g
+                // (nobody else is using the sets: the other workgroups are parked)
+                if (tid == 0) reset_set(tred((s / g) % 3u));
+                s -= g;
+                continue;
+            }
+
             if (W == 0) {
                 put_ent(si, 0ull, 0, 0, 0u);
                 n_ent = si + 1;
@@ -300,7 +470,7 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
             uint32_t *const rowM = A + base, *const rowI = rowM + W, *const rowD = rowI + W;
             if (tid == 0) {
                 red[0] = INT32_MAX, red[1] = INT32_MIN, red[2] = 0, red[3] = INT32_MAX;
-                red[4] = INT32_MAX, red[5] = INT32_MIN, red[6] = 0, red[7] = INT32_MIN, red[11] = INT32_MAX;
+                red[4] = INT32_MAX, red[5] = INT32_MIN, red[6] = 0, red[7] = INT32_MIN, red[11] = INT32_MAX, red[12] = INT32_MIN;
             }
             __syncthreads();
             const int64_t i0 = teamed ? (int64_t)b * G + tid : tid, istep = teamed ? stripe : G;
@@ -312,7 +482,7 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
             };
 
             // ---- P1: next + seeds + extend, store rows, partial reductions
-            int mlo = INT32_MAX, mhi = INT32_MIN, term = 0, mind = INT32_MAX;
+            int mlo = INT32_MAX, mhi = INT32_MIN, term = 0, mind = INT32_MAX, maxd = INT32_MIN;
             // TEAM_U cells of a thread are in flight together (their source loads overlap: in team mode every load
             // is a memory-side round trip), and the thread's first TEAM_U cells of the row stay in registers for
             // the wf-adaptive passes below (kM = M word, kF = number of non-zero I / D words).
@@ -348,29 +518,29 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
                         mlo = imin2(mlo, k), mhi = imax2(mhi, k);
                         if (k == Ak && (int)(c.M >> TAG_BITS) >= m) term = 1;  // wfa.go:235-239
                         const int d = reduce_dist(c.M, k, n, m);
-                        if (d >= 0) mind = imin2(mind, d);
+                        if (d >= 0) mind = imin2(mind, d), maxd = imax2(maxd, d);
                     }
                 }
             }
             // the thread's j-th cell of this row: from registers for j < TEAM_U, else from the arena
             const int64_t i_rest = i0 + TEAM_U * istep;
-            mlo = wave_min(mlo), mhi = wave_max(mhi), mind = wave_min(mind);
+            mlo = wave_min(mlo), mhi = wave_max(mhi), mind = wave_min(mind), maxd = wave_max(maxd);
             term = __ballot(term) != 0ull;
             if (lane == 0) {
-                atomicMin(&red[0], mlo), atomicMax(&red[1], mhi), atomicMin(&red[3], mind);
+                atomicMin(&red[0], mlo), atomicMax(&red[1], mhi), atomicMin(&red[3], mind), atomicMax(&red[12], maxd);
                 if (term) red[2] = 1;
             }
             __syncthreads();
             if (teamed) {
-                team_min(&tr->mlo, 0), team_max(&tr->mhi, 1), team_or(&tr->term, 2), team_min(&tr->mind, 3);
+                team_min(&tr->mlo, 0), team_max(&tr->mhi, 1), team_or(&tr->term, 2), team_min(&tr->mind, 3), team_max(&tr->maxd, 12);
                 TEAM_STAMP(0);
                 team_barrier(false);  // B1: the rows of this score are visible to the whole team
                 TEAM_STAMP(1);
                 if (aborted) return;
-                team_get(&tr->mlo, 0), team_get(&tr->mhi, 1), team_get(&tr->term, 2), team_get(&tr->mind, 3);
+                team_get(&tr->mlo, 0), team_get(&tr->mhi, 1), team_get(&tr->term, 2), team_get(&tr->mind, 3), team_get(&tr->maxd, 12);
                 __syncthreads();
             }
-            mlo = red[0], mhi = red[1], term = red[2], mind = red[3];
+            mlo = red[0], mhi = red[1], term = red[2], mind = red[3], maxd = red[12];
             top += 3ull * (uint64_t)W;
             n_ent = si + 1;
             if (term) {
@@ -384,7 +554,66 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
             int nlo = mlo, nhi = mhi;  // surviving band: I and D only hold cells where M does
             if (P.adaptive && mhi >= mlo && (mhi - mlo + 1) >= (int)P.min_wf_len && mind != INT32_MAX) {
                 const int maxdiff = (int)P.max_dist_diff;
+                // Team mode: the ends of the surviving band without a second team barrier.  Some cell fails the
+                // distance test exactly when the LARGEST distance of the row does (reduced with the minimum before
+                // B1); if none fails the row keeps its range.  Otherwise only the two ends of the row move
+                // (wfa.go:496-524), and everything the rule looks at -- the first / last cell that passes, a present
+                // cell at a sequence end below the first one, the last valid cell before it -- lies between the end of
+                // the row and that first / last passing cell: every workgroup scans the first and the last
+                // TEAM_THREADS / 2 cells of the row itself (visible since B1) and arrives at the same band.  When a
+                // passing cell is not within that window (the band collapses by more than 512 diagonals in one step)
+                // the full passes below run, with their barriers.
+                bool windowed = false;
+                if (teamed && maxd - mind <= maxdiff) {
+                    windowed = true;  // nothing fails
+                } else if (teamed) {
+                    constexpr int HALF = TEAM_THREADS / 2;
+                    const bool    low = tid < HALF;
+                    const int64_t iw  = low ? (int64_t)tid : W - 1 - (int64_t)(tid - HALF);
+                    const bool    in  = iw >= 0 && iw < W;
+                    const int     kw  = lo + (int)iw;
+                    const uint32_t mw = in ? ldw(rowM + iw) : 0u;
+                    const int     dw  = reduce_dist(mw, kw, n, m);
+                    const bool    okw = dw >= 0 && dw - mind <= maxdiff;
+                    int f_ok = okw ? kw : INT32_MAX, l_ok = okw ? kw : INT32_MIN, hmin = (dw < 0 && mw != 0u) ? kw : INT32_MAX;
+                    f_ok = wave_min(f_ok), l_ok = wave_max(l_ok), hmin = wave_min(hmin);
+                    if (lane == 0) atomicMin(&red[4], f_ok), atomicMax(&red[5], l_ok), atomicMin(&red[11], hmin);
+                    __syncthreads();
+                    const int first_ok = red[4], last_ok = red[5], hitmin = red[11];
+                    const bool whole = W <= (int64_t)TEAM_THREADS;  // the two windows cover the row
+                    if (first_ok != INT32_MAX && (whole || (first_ok < lo + HALF && last_ok > lo + (int)W - 1 - HALF))) {
+                        windowed = true;
+                        if (hitmin >= first_ok) {
+                            nlo = first_ok, nhi = last_ok;
+                        } else {
+                            // _lo: one past the last valid entry before the first non-failing one (wfa.go:503-516)
+                            int lead = (in && kw < first_ok && dw >= 0) ? kw : INT32_MIN;
+                            lead = wave_max(lead);
+                            if (lane == 0) atomicMax(&red[7], lead);
+                            __syncthreads();
+                            lead = red[7];
+                            nlo  = (lead != INT32_MIN) ? lead + 1 : mlo;
+                            nhi  = last_ok;
+                        }
+#pragma unroll
+                        for (int u = 0; u < TEAM_U; u++) {
+                            const int k = lo + (int)(i0 + u * istep);
+                            if (i0 + u * istep < W && (k < nlo || k > nhi)) my_cells -= (kM[u] != 0u) + kF[u];
+                        }
+                        for (int64_t i = i_rest; i < W; i += istep) {
+                            const int k = lo + (int)i;
+                            if (k < nlo || k > nhi)
+                                my_cells -= (ldw(rowM + i) != 0u) + (ldw(rowI + i) != 0u) + (ldw(rowD + i) != 0u);
+                        }
+                    } else {
+                        __syncthreads();
+                        if (tid == 0) red[4] = INT32_MAX, red[5] = INT32_MIN, red[11] = INT32_MAX;
+                        __syncthreads();
+                    }
+                    TEAM_STAMP(2);
+                }
                 int       first_ok = INT32_MAX, last_ok = INT32_MIN, anyfail = 0, hitmin = INT32_MAX;
+                if (!windowed) {
                 auto p2cell = [&](uint32_t mw, int k) {
                     const int d = reduce_dist(mw, k, n, m);
                     if (d >= 0) {
@@ -470,6 +699,7 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
                             my_cells -= (ldw(rowM + i) != 0u) + (ldw(rowI + i) != 0u) + (ldw(rowD + i) != 0u);
                     }
                 }
+                }  // !windowed
             }
             if (nhi >= nlo)
                 put_ent(si, base + (uint64_t)(nlo - lo), nlo, nhi - nlo + 1, (uint32_t)W);
@@ -477,10 +707,14 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
                 put_ent(si, 0ull, 0, 0, 0u);
             __syncthreads();
             TEAM_STAMP(teamed ? 4 : 5);
+#ifdef WFA_TEAM_STAMPS
+            tacc[teamed ? 11 : 10]++;
+#endif
         }
 #ifdef WFA_TEAM_STAMPS
         if (lead_wg && tid == 0)
-            for (int i = 0; i < 6; i++) atomicAdd(reinterpret_cast<unsigned long long *>(ctl + 64) + i, tacc[i]), tacc[i] = 0;
+            for (int i = 0; i < 12; i++)
+                if (i < 6 || i >= 8) atomicAdd(reinterpret_cast<unsigned long long *>(ctl + 64) + i, tacc[i]), tacc[i] = 0;
         tprev = __builtin_amdgcn_s_memrealtime();
 #endif
 
@@ -562,10 +796,12 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
         TEAM_STAMP(6);  // wake-up, cell count, end-cell search
         if (!lead_wg) continue;  // backtrace: workgroup 0 (the others wait at the next pair's barrier)
 
-        // ---- backtrace + result record: one lane
-        if (tid == 0) {
-            ArenaView av;
-            av.A = A, av.cap = cap, av.g = g, av.n_ent = n_ent;
+        // ---- backtrace: wave 0 walks together (same steps, same values in every lane; the directory entries of the
+        // scores around the walk sit in LDS -- the ring is free now -- and are loaded 64 at a time); result record: one lane
+        __syncthreads();
+        if (tid < 64) {
+            ArenaViewWave av;
+            av.init(A, cap, g, n_ent, ring, (uint32_t)imax2((int)x, imax2((int)oe, (int)e)) / g);
             uint64_t  scratch0 = (top + 1ull) & ~1ull;
             uint64_t  dir_lo   = cap - (uint64_t)DIR_WORDS * (uint64_t)n_ent;
             uint64_t  room     = dir_lo > scratch0 ? (dir_lo - scratch0) / 2ull : 0ull;
@@ -574,24 +810,36 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
             TraceOut to;
             back_trace(av, n, m, minS, lastK, !glob, x, P.o, e, ow, to);
             if (ow.overflow) {
-                rec[REC_STATUS] = ST_REDO_ARENA;
-                push_redo(P, pair, ST_REDO_ARENA);
+                if (tid == 0) {
+                    rec[REC_STATUS] = ST_REDO_ARENA;
+                    push_redo(P, pair, ST_REDO_ARENA);
+                }
             } else {
-                // process() (wfa_cigar.go:136-214): the forward list is the scratch list reversed
-                const uint32_t L   = ow.n;
-                const uint64_t off = atomicAdd(P.ops_cursor, (unsigned long long)L);
-                uint32_t begin = 0, end = 0;
-                bool     seenM = false;
-                for (uint32_t i = 0; i < L; i++) {
+                // process() (wfa_cigar.go:136-214): the forward list is the scratch list reversed; the 64 lanes copy
+                // and count together (the ops of a 100 kbp pair: 1.7e4 dependent round trips for one lane)
+                const uint32_t L = ow.n;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the list was written by this wave)
+                uint32_t off_lo = 0, off_hi = 0;
+                if (tid == 0) {
+                    const uint64_t o = atomicAdd(P.ops_cursor, (unsigned long long)L);
+                    off_lo = (uint32_t)o, off_hi = (uint32_t)(o >> 32);
+                }
+                const uint64_t off = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)off_lo) |
+                                     ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)off_hi) << 32);
+                int firstM = INT32_MAX, lastM = INT32_MIN;
+                for (uint32_t i = (uint32_t)lane; i < L; i += 64u) {
                     const uint64_t op = ow.buf[L - 1 - i];
-                    if ((uint32_t)(op >> 32) == 'M') {
-                        if (!seenM) begin = i, seenM = true;
-                        end = i;
-                    }
+                    if ((uint32_t)(op >> 32) == 'M') firstM = imin2(firstM, (int)i), lastM = imax2(lastM, (int)i);
                     if (off + i < P.ops_cap) P.ops[off + i] = op;
                 }
+                firstM = wave_min(firstM), lastM = wave_max(lastM);
+                const uint32_t begin = firstM != INT32_MAX ? (uint32_t)firstM : 0u, end = firstM != INT32_MAX ? (uint32_t)lastM : 0u;
+                unsigned int *const acc = reinterpret_cast<unsigned int *>(red);
+                if (tid == 0) acc[0] = acc[1] = acc[2] = acc[3] = 0u;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
                 uint32_t alen = 0, matches = 0, gaps = 0, regions = 0;
-                for (uint32_t i = begin; i <= end && i < L; i++) {
+                for (uint32_t i = begin + (uint32_t)lane; i <= end && i < L; i += 64u) {
                     const uint64_t op  = ow.buf[L - 1 - i];
                     const uint32_t cnt = (uint32_t)op, o = (uint32_t)(op >> 32);
                     alen += cnt;
@@ -600,6 +848,11 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
                     else if (o == 'I' || o == 'D')
                         gaps += cnt, regions++;
                 }
+                atomicAdd(&acc[0], alen), atomicAdd(&acc[1], matches), atomicAdd(&acc[2], gaps), atomicAdd(&acc[3], regions);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                alen = acc[0], matches = acc[1], gaps = acc[2], regions = acc[3];
+                if (tid == 0) {
                 rec[REC_STATUS]      = ST_OK;
                 rec[REC_SCORE]       = to.score;
                 rec[REC_TBEGIN]      = (uint32_t)to.tbegin;
@@ -616,10 +869,13 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
                 rec[REC_CELLS_LO]    = __hip_atomic_load(&ctl[12], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 rec[REC_CELLS_HI]    = __hip_atomic_load(&ctl[13], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 rec[REC_N_SCORES]    = s_final;
+                if (P.debug_info) P.debug_info[0] = n_ent, P.debug_info[1] = s_final;  // (wfahip_debug_wavefronts)
+                }
             }
 #ifdef WFA_TEAM_STAMPS
             TEAM_STAMP(7);  // backtrace + result record
-            for (int i = 6; i < 8; i++) atomicAdd(reinterpret_cast<unsigned long long *>(ctl + 64) + i, tacc[i]), tacc[i] = 0;
+            if (tid == 0)
+                for (int i = 6; i < 8; i++) atomicAdd(reinterpret_cast<unsigned long long *>(ctl + 64) + i, tacc[i]), tacc[i] = 0;
 #endif
         }
     }
