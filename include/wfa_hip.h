@@ -219,7 +219,9 @@ int  wfahip_last_timing(const wfahip_ctx *ctx, wfahip_timing *out);
  *                          previous call of the same kind had finished, instead of climbing from the smallest      default 1
  *   "team_min_len"         pairs at least this long use the team kernel (0 = never)              default 8192
  *   "team_wgs", "team_solo_max"   workgroups per team (0 = automatic), widest row done by one workgroup
- *   "team_wave"                   1 (default): rows of at most 64 diagonals are stepped by one wave out of an LDS ring */
+ *   "team_wave"                   1 (default): rows of at most 64 diagonals are stepped by one wave out of an LDS ring
+ *   "team_strict"                 1: every team barrier carries an agent-scope release (L2 write-back); default 0 -- the
+ *                                 barriers order write-through stores against loads a round trip later (wfa_team.hpp) */
 int  wfahip_set_option(wfahip_ctx *ctx, const char *key, int64_t value);
 
 /* Debug / parity aid: align ONE pair and return every stored wavefront row.  rows[] receives

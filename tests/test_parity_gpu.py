@@ -598,15 +598,16 @@ def test_team_kernel_wave_mode(built, penalties):
         for glob, ad in ((True, (10, 50, 1)), (False, (10, 50, 1)), (True, None), (False, (4, 5, 1))):
             want = O.align_batch(_oracle_params(glob, ad, penalties), *data, n_threads=8)
             cells = []
-            for wave in (1, 0):
+            for wave, strict in ((1, 0), (0, 0)) + (((1, 1),) if penalties == (4, 6, 2) else ()):
                 al = _aligner(glob, ad, penalties)
-                for k, v in (("packed", 0), ("team_min_len", 1), ("team_wgs", 3), ("team_solo_max", 4096), ("team_wave", wave)):
+                for k, v in (("packed", 0), ("team_min_len", 1), ("team_wgs", 3), ("team_solo_max", 4096), ("team_wave", wave),
+                             ("team_strict", strict)):  # strict: an agent-scope release in every team barrier
                     al.set_option(k, v)
                 got = al.align_arrays(*data)
-                assert_batch_equal(got, want, f"wave={wave} pen={penalties} glob={glob} ad={ad}")
+                assert_batch_equal(got, want, f"wave={wave} strict={strict} pen={penalties} glob={glob} ad={ad}")
                 cells.append(al.last_timing().cells_stored)
                 al.close()
-            assert cells[0] == cells[1]
+            assert len(set(cells)) == 1
 
 
 @pytest.mark.parametrize("penalties", [(4, 6, 2), (5, 20, 3), (2, 3, 1)])

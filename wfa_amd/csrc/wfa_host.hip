@@ -121,6 +121,7 @@ struct wfahip_ctx {
     int64_t       opt_team_wgs             = 0;     // workgroups per team, 0 = automatic
     int64_t       opt_team_solo_max        = TEAM_SOLO_MAX;  // rows up to this width are done by one workgroup
     int64_t       opt_team_wave            = 1;              // rows up to 64 diagonals are done by one wave (LDS ring)
+    int64_t       opt_team_strict          = 0;              // agent-scope release in every team barrier
     int64_t       opt_pilot                = 1;  // 1: a 4 096-pair pilot decides whether a large batch uses the sub-wave kernels
     int64_t       opt_tail_overlap         = 1;  // 1: retry passes overlap the backtrace kernel of the first pass
     int64_t       opt_overlap              = 0;  // 1: backtrace of chunk c on a second stream beside the forward kernel of chunk c+1 (measured: no gain)
@@ -387,6 +388,8 @@ static int set_option_impl(wfahip_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_team_solo_max = value;
     else if (k == "team_wave")
         ctx->opt_team_wave = value;
+    else if (k == "team_strict")
+        ctx->opt_team_strict = value;
     else if (k == "fail_pass")
         ctx->opt_fail_pass = value;
     else if (k == "prepack")
@@ -996,7 +999,7 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                                             (int)cfg.lds_bytes));
             hipLaunchKernelGGL(kfn, dim3(team_n * team_T), dim3(TEAM_THREADS), cfg.lds_bytes, st, P,
                                static_cast<uint32_t *>(ctx->team_ctl.p), team_T, (uint32_t)std::max<int64_t>(0, ctx->opt_team_solo_max),
-                               team_wave_rows);
+                               team_wave_rows, (uint32_t)(ctx->opt_team_strict != 0));
             HIP_TRY(hipGetLastError());
         } else {
             HIP_TRY(launch_generic(P, cfg, st));

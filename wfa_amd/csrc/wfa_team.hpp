@@ -16,6 +16,12 @@
 // the memory side, not by the XCD's L2), so the per-step barriers need no cache write-back or invalidate: they are
 // __syncthreads (drains every wave's stores) -> one lane: atomic arrive, bounded spin on the counter with
 // agent-scope loads -> __syncthreads.  Rows written before a barrier are read by other workgroups only after it.
+// What this leans on: a write-through store whose vmcnt has returned is at the memory side before a load that is
+// issued at least one further memory-side round trip after the barrier was seen complete (every cross-workgroup
+// read here comes after the read-back of the team reductions).  Measured on MI355X: a load issued STRAIGHT after
+// the barrier can overtake the last arriver's write-through (a 0.25 us delay already hides it).  Option
+// `team_strict` adds an agent-scope release (L2 write-back + wait) to every barrier for the architectural
+// guarantee: +3 us per score step (0.63 -> 0.72 s on the configs[4] sample).
 //
 // Narrow rows do not pay for barriers: when a row is at most TEAM_SOLO_MAX diagonals wide the team switches to
 // SOLO mode -- workgroup 0 runs the steps alone with plain (L2-cached) accesses and __syncthreads only, the others
@@ -57,7 +63,7 @@ struct TeamRed {  // one reduction set (global memory, 16 words)
 
 template <int MODE>
 __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P, uint32_t *team_ctl, uint32_t T,
-                                                                uint32_t solo_max, uint32_t wave_rows) {
+                                                                uint32_t solo_max, uint32_t wave_rows, uint32_t strict) {
     constexpr int G = TEAM_THREADS;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t *const lq   = lds;
@@ -94,12 +100,16 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
         __syncthreads();
         if (tid == 0) {
             bar_target += T;
-            if (fenced) __threadfence();
+            if (fenced)
+                __threadfence();
+            else if (strict)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // option team_strict, see the header comment
             bool bad = false;
-            // the last workgroup to arrive sees the full count in the value its own atomic returns
-            if (atomicAdd(&ctl[0], 1u) + 1u < bar_target) {
+            // the last workgroup to arrive sees the full count in the value its own atomic returns.  The count runs
+            // over all the pairs of a launch: compared modulo 2^32.
+            if ((int32_t)(atomicAdd(&ctl[0], 1u) + 1u - bar_target) < 0) {
                 uint32_t spins = 0;
-                while (__hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < bar_target) {
+                while ((int32_t)(__hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - bar_target) < 0) {
                     if ((++spins & 1023u) == 0u &&
                         (spins > TEAM_SPIN_LIMIT || __hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
                         atomicExch(&ctl[1], 1u);
@@ -572,6 +582,9 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
                     const int64_t iw  = low ? (int64_t)tid : W - 1 - (int64_t)(tid - HALF);
                     const bool    in  = iw >= 0 && iw < W;
                     const int     kw  = lo + (int)iw;
+                    // (this load comes a full round trip to the memory side -- the team results above -- after the barrier
+                    // was seen complete; issued straight after the barrier it can overtake the write-through of the last
+                    // workgroup's stores: measured)
                     const uint32_t mw = in ? ldw(rowM + iw) : 0u;
                     const int     dw  = reduce_dist(mw, kw, n, m);
                     const bool    okw = dw >= 0 && dw - mind <= maxdiff;
