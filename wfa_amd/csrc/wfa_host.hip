@@ -206,7 +206,7 @@ hipError_t launch_generic(const KParams &P, const LaunchCfg &c, hipStream_t st) 
 
 struct Job {
     int                   mode;
-    int                   level;  // arena size = base * 8^min(level, 2) * 2^max(level - 2, 0)
+    int                   level;  // arena size: make_cfg's ladder (x8, x8, x2 .., then one slot fewer per level)
     bool                  all;    // identity work list over all pairs
     std::vector<uint32_t> pairs;
     uint32_t              max_len = 0;  // length bound of these pairs (0 = the batch's)
@@ -232,9 +232,23 @@ int make_cfg(wfahip_ctx *ctx, uint32_t max_len, int mode, int level, uint64_t n_
     if (ctx->opt_arena_bytes_per_slot > 0) base_words = std::max<uint64_t>(4096, ctx->opt_arena_bytes_per_slot / 4);
     // the ladder: x8, x8, then x2 per level -- a slot of a long pair is tens of GB by then, and every doubling
     // halves the number of pairs that can be in flight (level 3 of a 100 kbp semi-global pair: 21.6 GB)
-    uint64_t words = base_words;
-    for (int i = 0; i < level; i++) words *= (i < 2 ? 8 : 2);
-    words         = (words + 7) & ~7ull;  // directory entries are 32-byte aligned from the slot end
+    // Once at most four slots fit the budget (tens of GB per pair), a level is "one slot fewer", and a slot takes
+    // its whole share of the budget: 4 x 43 GB, 3 x 57, 2 x 86, 1 x 172 on a 288 GB device instead of 4 x 39, 2 x 79,
+    // 1 x 157 -- every slot dropped is a team of workgroups less in flight.
+    const uint64_t budget_words = (uint64_t)((double)ctx->total_mem * 0.6) / 4ull;
+    uint64_t       words        = base_words;
+    auto snap = [&](uint64_t w) {
+        const uint64_t fit = w ? budget_words / w : 0;
+        return (fit >= 1 && fit <= 4 && ctx->opt_arena_bytes_per_slot <= 0) ? budget_words / fit : w;  // (not an explicit size)
+    };
+    for (int i = 0; i < level; i++) {
+        const uint64_t fit = budget_words / words;
+        if (fit >= 2 && fit <= 4)
+            words = budget_words / (fit - 1);
+        else
+            words *= (i < 2 ? 8 : 2);
+    }
+    words         = snap(words) & ~7ull;  // directory entries are 32-byte aligned from the slot end
     c.arena_words = words;
 
     // resident workgroups per CU: 32 wave slots, LDS, and keep <= 8 blocks of >=256 threads
@@ -244,7 +258,7 @@ int make_cfg(wfahip_ctx *ctx, uint32_t max_len, int mode, int level, uint64_t n_
     uint64_t slots  = (uint64_t)ctx->num_cus * per_cu;
     if (ctx->opt_slots > 0) slots = (uint64_t)ctx->opt_slots;
     // arena budget: at most ~60 % of device memory
-    uint64_t budget = (uint64_t)((double)ctx->total_mem * 0.6);
+    uint64_t budget = budget_words * 4ull;
     uint64_t fit    = budget / (words * 4ull);
     if (fit == 0) return 2;  // even one slot does not fit
     slots   = std::min<uint64_t>(slots, fit);
