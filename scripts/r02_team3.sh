@@ -18,4 +18,4 @@ for spec in sys.argv[2:] or ["team_wgs=0"]:
         t0 = time.time(); r = al.align_arrays(*data); print(spec, "wall", time.time() - t0, al.last_timing(), flush=True)
     al.close()
 PY
-cd $REPO; grep -B4 "wall 0\.[0-9]" $OUT/stamps.txt | cut -c1-300 | grep -v "^--" | awk 'NR%5!=0 || 1' | tail -40
+cd $REPO; grep "band ends\|wall 0" $OUT/stamps.txt | tail -10 | cut -c1-260

@@ -1031,6 +1031,9 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                 std::fprintf(stderr, "[team %u] us: P1 %.0f  barriers %.0f  P2 %.0f  P3 %.0f  tail(team) %.0f  solo steps %.0f  end search %.0f  backtrace %.0f  wave mode %.0f | steps: wave %llu solo %llu team %llu\n", t,
                              a[0] / 100.0, a[1] / 100.0, a[2] / 100.0, a[3] / 100.0, a[4] / 100.0, a[5] / 100.0, a[6] / 100.0, a[7] / 100.0,
                              a[8] / 100.0, a[9], a[10], a[11]);
+                std::fprintf(stderr, "[team %u] band ends: nothing fails %llu, both within 64 cells %llu, within the 512-cell windows %llu, full passes %llu; mean trim low %.1f high %.1f\n",
+                             t, a[12], a[13], a[14], a[15], (double)a[16] / (double)std::max<unsigned long long>(1, a[13] + a[14]),
+                             (double)a[17] / (double)std::max<unsigned long long>(1, a[13] + a[14]));
             }
 #endif
             for (uint32_t t = 0; t < team_n; t++)

@@ -58,7 +58,7 @@ constexpr uint32_t TEAM_SOLO_MAX   = 4096;  // default: rows up to this width ar
 enum : uint32_t { TEAM_CMD_NONE = 0, TEAM_CMD_RESUME = 1, TEAM_CMD_DONE = 2 };  // ctl[4]; ctl[5] = score, ctl[6..7] = top
 
 struct TeamRed {  // one reduction set (global memory, 16 words)
-    int mlo, mhi, term, mind, first_ok, last_ok, anyfail, lead, hitmin, maxd, pad[6];
+    int mlo, mhi, term, mind, first_ok, last_ok, anyfail, lead, hitmin, maxd, fvm, lvm, pad[4];
 };
 
 template <int MODE>
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
     const int64_t  stripe = (int64_t)T * G;
 
 #ifdef WFA_TEAM_STAMPS
-    unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memrealtime();
+    unsigned long long tacc[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memrealtime();
 #define TEAM_STAMP(i)                                                  \
     do {                                                               \
         const unsigned long long _t = __builtin_amdgcn_s_memrealtime(); \
@@ -130,9 +130,9 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
     auto tred = [&](uint32_t set) { return reinterpret_cast<TeamRed *>(ctl + 16 + 16 * set); };
     auto reset_set = [&](TeamRed *r) {  // memory-side stores: the other workgroups' atomics must see them
         uint32_t *const w = reinterpret_cast<uint32_t *>(r);
-        const int       v[10] = {INT32_MAX, INT32_MIN, 0, INT32_MAX, INT32_MAX, INT32_MIN, 0, INT32_MIN, INT32_MAX, INT32_MIN};
+        const int v[12] = {INT32_MAX, INT32_MIN, 0, INT32_MAX, INT32_MAX, INT32_MIN, 0, INT32_MIN, INT32_MAX, INT32_MIN, INT32_MAX, INT32_MIN};
 #pragma unroll
-        for (int i = 0; i < 10; i++) __hip_atomic_store(w + i, (uint32_t)v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = 0; i < 12; i++) __hip_atomic_store(w + i, (uint32_t)v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
 
     for (;;) {
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
             uint32_t *const rowM = A + base, *const rowI = rowM + W, *const rowD = rowI + W;
             if (tid == 0) {
                 red[0] = INT32_MAX, red[1] = INT32_MIN, red[2] = 0, red[3] = INT32_MAX;
-                red[4] = INT32_MAX, red[5] = INT32_MIN, red[6] = 0, red[7] = INT32_MIN, red[11] = INT32_MAX, red[12] = INT32_MIN;
+                red[4] = INT32_MAX, red[5] = INT32_MIN, red[6] = 0, red[7] = INT32_MIN, red[11] = INT32_MAX, red[12] = INT32_MIN, red[13] = INT32_MAX, red[14] = INT32_MIN;
             }
             __syncthreads();
             const int64_t i0 = teamed ? (int64_t)b * G + tid : tid, istep = teamed ? stripe : G;
@@ -493,6 +493,7 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
 
             // ---- P1: next + seeds + extend, store rows, partial reductions
             int mlo = INT32_MAX, mhi = INT32_MIN, term = 0, mind = INT32_MAX, maxd = INT32_MIN;
+            int fvm = INT32_MAX, lvm = INT32_MIN;  // first / last diagonal whose M cell lies inside both sequences (d >= 0)
             // TEAM_U cells of a thread are in flight together (their source loads overlap: in team mode every load
             // is a memory-side round trip), and the thread's first TEAM_U cells of the row stay in registers for
             // the wf-adaptive passes below (kM = M word, kF = number of non-zero I / D words).
@@ -528,29 +529,33 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
                         mlo = imin2(mlo, k), mhi = imax2(mhi, k);
                         if (k == Ak && (int)(c.M >> TAG_BITS) >= m) term = 1;  // wfa.go:235-239
                         const int d = reduce_dist(c.M, k, n, m);
-                        if (d >= 0) mind = imin2(mind, d), maxd = imax2(maxd, d);
+                        if (d >= 0) mind = imin2(mind, d), maxd = imax2(maxd, d), fvm = imin2(fvm, k), lvm = imax2(lvm, k);
                     }
                 }
             }
             // the thread's j-th cell of this row: from registers for j < TEAM_U, else from the arena
             const int64_t i_rest = i0 + TEAM_U * istep;
             mlo = wave_min(mlo), mhi = wave_max(mhi), mind = wave_min(mind), maxd = wave_max(maxd);
+            fvm = wave_min(fvm), lvm = wave_max(lvm);
             term = __ballot(term) != 0ull;
             if (lane == 0) {
                 atomicMin(&red[0], mlo), atomicMax(&red[1], mhi), atomicMin(&red[3], mind), atomicMax(&red[12], maxd);
+                atomicMin(&red[13], fvm), atomicMax(&red[14], lvm);
                 if (term) red[2] = 1;
             }
             __syncthreads();
             if (teamed) {
                 team_min(&tr->mlo, 0), team_max(&tr->mhi, 1), team_or(&tr->term, 2), team_min(&tr->mind, 3), team_max(&tr->maxd, 12);
+                team_min(&tr->fvm, 13), team_max(&tr->lvm, 14);
                 TEAM_STAMP(0);
                 team_barrier(false);  // B1: the rows of this score are visible to the whole team
                 TEAM_STAMP(1);
                 if (aborted) return;
                 team_get(&tr->mlo, 0), team_get(&tr->mhi, 1), team_get(&tr->term, 2), team_get(&tr->mind, 3), team_get(&tr->maxd, 12);
+                team_get(&tr->fvm, 13), team_get(&tr->lvm, 14);
                 __syncthreads();
             }
-            mlo = red[0], mhi = red[1], term = red[2], mind = red[3], maxd = red[12];
+            mlo = red[0], mhi = red[1], term = red[2], mind = red[3], maxd = red[12], fvm = red[13], lvm = red[14];
             top += 3ull * (uint64_t)W;
             n_ent = si + 1;
             if (term) {
@@ -576,12 +581,18 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
                 bool windowed = false;
                 if (teamed && maxd - mind <= maxdiff) {
                     windowed = true;  // nothing fails
+#ifdef WFA_TEAM_STAMPS
+                    tacc[12]++;
+#endif
                 } else if (teamed) {
+                    // (windows: from the first cell inside both sequences upwards, from the last one downwards -- the
+                    // stretches of cells that sit at a sequence end, thousands of diagonals in a semi-global row, hold no
+                    // passing cell and no valid one; a present cell below fvm is by definition one of them)
                     constexpr int HALF = TEAM_THREADS / 2;
                     const bool    low = tid < HALF;
-                    const int64_t iw  = low ? (int64_t)tid : W - 1 - (int64_t)(tid - HALF);
-                    const bool    in  = iw >= 0 && iw < W;
-                    const int     kw  = lo + (int)iw;
+                    const int     kw  = low ? fvm + tid : lvm - (tid - HALF);
+                    const int64_t iw  = (int64_t)kw - lo;
+                    const bool    in  = kw >= fvm && kw <= lvm;  // (fvm <= lvm: mind exists)
                     // (this load comes a full round trip to the memory side -- the team results above -- after the barrier
                     // was seen complete; issued straight after the barrier it can overtake the write-through of the last
                     // workgroup's stores: measured)
@@ -592,10 +603,15 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
                     f_ok = wave_min(f_ok), l_ok = wave_max(l_ok), hmin = wave_min(hmin);
                     if (lane == 0) atomicMin(&red[4], f_ok), atomicMax(&red[5], l_ok), atomicMin(&red[11], hmin);
                     __syncthreads();
-                    const int first_ok = red[4], last_ok = red[5], hitmin = red[11];
-                    const bool whole = W <= (int64_t)TEAM_THREADS;  // the two windows cover the row
-                    if (first_ok != INT32_MAX && (whole || (first_ok < lo + HALF && last_ok > lo + (int)W - 1 - HALF))) {
+                    const int first_ok = red[4], last_ok = red[5];
+                    const int hitmin   = mlo < fvm ? mlo : red[11];
+                    const bool whole = (int64_t)lvm - fvm < (int64_t)TEAM_THREADS;  // the two windows cover every valid cell
+                    if (first_ok != INT32_MAX && (whole || (first_ok < fvm + HALF && last_ok > lvm - HALF))) {
                         windowed = true;
+#ifdef WFA_TEAM_STAMPS
+                        tacc[(first_ok - fvm < 64 && lvm - last_ok < 64) ? 13 : 14]++;
+                        tacc[16] += (unsigned long long)(first_ok - fvm), tacc[17] += (unsigned long long)(lvm - last_ok);
+#endif
                         if (hitmin >= first_ok) {
                             nlo = first_ok, nhi = last_ok;
                         } else {
@@ -619,6 +635,9 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
                                 my_cells -= (ldw(rowM + i) != 0u) + (ldw(rowI + i) != 0u) + (ldw(rowD + i) != 0u);
                         }
                     } else {
+#ifdef WFA_TEAM_STAMPS
+                        tacc[15]++;
+#endif
                         __syncthreads();
                         if (tid == 0) red[4] = INT32_MAX, red[5] = INT32_MIN, red[11] = INT32_MAX;
                         __syncthreads();
@@ -726,7 +745,7 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
         }
 #ifdef WFA_TEAM_STAMPS
         if (lead_wg && tid == 0)
-            for (int i = 0; i < 12; i++)
+            for (int i = 0; i < 20; i++)
                 if (i < 6 || i >= 8) atomicAdd(reinterpret_cast<unsigned long long *>(ctl + 64) + i, tacc[i]), tacc[i] = 0;
         tprev = __builtin_amdgcn_s_memrealtime();
 #endif
