@@ -18,4 +18,4 @@ for spec in sys.argv[2:] or ["team_wgs=0"]:
         t0 = time.time(); r = al.align_arrays(*data); print(spec, "wall", time.time() - t0, al.last_timing(), flush=True)
     al.close()
 PY
-cd $REPO; grep "band ends\|wall 0" $OUT/stamps.txt | tail -10 | cut -c1-260
+cd $REPO; grep "band ends\|wall 0\|inside P1\|us: P1" $OUT/stamps.txt | tail -10 | cut -c1-260

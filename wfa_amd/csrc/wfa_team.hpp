@@ -82,7 +82,7 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
     const int64_t  stripe = (int64_t)T * G;
 
 #ifdef WFA_TEAM_STAMPS
-    unsigned long long tacc[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memrealtime();
+    unsigned long long tacc[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memrealtime();
 #define TEAM_STAMP(i)                                                  \
     do {                                                               \
         const unsigned long long _t = __builtin_amdgcn_s_memrealtime(); \
@@ -240,9 +240,19 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
             // the set of the next score was last used three scores ago; every workgroup is past that score
             if (lead_wg && tid == 0) reset_set(tred((si + 1u) % 3u));
             // sources: M[s-x], M[s-o-e], I[s-e] / D[s-e]  (wfa.go:557-560; missing when diff > s)
-            const DirEnt eX = (s >= x) ? ring[(si - x / g) % TEAM_RING] : none;
-            const DirEnt eO = (s >= oe) ? ring[(si - oe / g) % TEAM_RING] : none;
-            const DirEnt eE = (s >= e) ? ring[(si - e / g) % TEAM_RING] : none;
+            // (the entries are the same in every lane: into scalar registers, so that the row addresses and range tests
+            // of the five source loads of a cell are scalar operands instead of 64-bit vector arithmetic)
+            auto uni = [](DirEnt d) {
+                auto r = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+                DirEnt u;
+                u.base   = (uint64_t)r((uint32_t)d.base) | ((uint64_t)r((uint32_t)(d.base >> 32)) << 32);
+                u.lo     = (int)r((uint32_t)d.lo), u.w = (int)r((uint32_t)d.w), u.stride = r(d.stride);
+                u.pad[0] = u.pad[1] = u.pad[2] = 0u;
+                return u;
+            };
+            const DirEnt eX = uni((s >= x) ? ring[(si - x / g) % TEAM_RING] : none);
+            const DirEnt eO = uni((s >= oe) ? ring[(si - oe / g) % TEAM_RING] : none);
+            const DirEnt eE = uni((s >= e) ? ring[(si - e / g) % TEAM_RING] : none);
             const bool   seeded = (s == 0u) || (s == x);
 
             int lo = INT32_MAX, hi = INT32_MIN;
@@ -476,7 +486,8 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
                 __syncthreads();
                 continue;
             }
-            const uint64_t base = top;
+            const uint64_t base = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)top) |
+                                  ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(top >> 32)) << 32);
             uint32_t *const rowM = A + base, *const rowI = rowM + W, *const rowD = rowI + W;
             if (tid == 0) {
                 red[0] = INT32_MAX, red[1] = INT32_MIN, red[2] = 0, red[3] = INT32_MAX;
@@ -533,6 +544,9 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
                     }
                 }
             }
+#ifdef WFA_TEAM_STAMPS
+            if (teamed) TEAM_STAMP(18);  // loads, next, extend, stores issued (this wave)
+#endif
             // the thread's j-th cell of this row: from registers for j < TEAM_U, else from the arena
             const int64_t i_rest = i0 + TEAM_U * istep;
             mlo = wave_min(mlo), mhi = wave_max(mhi), mind = wave_min(mind), maxd = wave_max(maxd);
@@ -543,7 +557,13 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
                 atomicMin(&red[13], fvm), atomicMax(&red[14], lvm);
                 if (term) red[2] = 1;
             }
+#ifdef WFA_TEAM_STAMPS
+            if (teamed) TEAM_STAMP(19);  // wave reductions
+#endif
             __syncthreads();
+#ifdef WFA_TEAM_STAMPS
+            if (teamed) TEAM_STAMP(20);  // the other waves of the workgroup
+#endif
             if (teamed) {
                 team_min(&tr->mlo, 0), team_max(&tr->mhi, 1), team_or(&tr->term, 2), team_min(&tr->mind, 3), team_max(&tr->maxd, 12);
                 team_min(&tr->fvm, 13), team_max(&tr->lvm, 14);
@@ -745,7 +765,7 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
         }
 #ifdef WFA_TEAM_STAMPS
         if (lead_wg && tid == 0)
-            for (int i = 0; i < 20; i++)
+            for (int i = 0; i < 24; i++)
                 if (i < 6 || i >= 8) atomicAdd(reinterpret_cast<unsigned long long *>(ctl + 64) + i, tacc[i]), tacc[i] = 0;
         tprev = __builtin_amdgcn_s_memrealtime();
 #endif
