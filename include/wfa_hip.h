@@ -220,8 +220,10 @@ int  wfahip_last_timing(const wfahip_ctx *ctx, wfahip_timing *out);
  *   "team_min_len"         pairs at least this long use the team kernel (0 = never)              default 8192
  *   "team_wgs", "team_solo_max"   workgroups per team (0 = automatic), widest row done by one workgroup
  *   "team_wave"                   1 (default): rows of at most 64 diagonals are stepped by one wave out of an LDS ring
- *   "team_strict"                 1: every team barrier carries an agent-scope release (L2 write-back); default 0 -- the
- *                                 barriers order write-through stores against loads a round trip later (wfa_team.hpp) */
+ *   "team_strict"                 1 (default): every team barrier carries an agent-scope release (L2 write-back + wait).
+ *                                 0: no release -- 10 % faster on 100 kbp pairs and NOT safe: a row word can be read before
+ *                                 its write-through has landed (measured; wfa_team.hpp)
+ *   "arena_poison"                tests: fill the arena with a pattern before every launch of the long-pair kernels */
 int  wfahip_set_option(wfahip_ctx *ctx, const char *key, int64_t value);
 
 /* Debug / parity aid: align ONE pair and return every stored wavefront row.  rows[] receives

@@ -598,16 +598,37 @@ def test_team_kernel_wave_mode(built, penalties):
         for glob, ad in ((True, (10, 50, 1)), (False, (10, 50, 1)), (True, None), (False, (4, 5, 1))):
             want = O.align_batch(_oracle_params(glob, ad, penalties), *data, n_threads=8)
             cells = []
-            for wave, strict in ((1, 0), (0, 0)) + (((1, 1),) if penalties == (4, 6, 2) else ()):
+            for wave, strict in ((1, 1), (0, 1)):
                 al = _aligner(glob, ad, penalties)
                 for k, v in (("packed", 0), ("team_min_len", 1), ("team_wgs", 3), ("team_solo_max", 4096), ("team_wave", wave),
-                             ("team_strict", strict)):  # strict: an agent-scope release in every team barrier
+                             ("team_strict", strict), ("arena_poison", 1)):  # (poison: a stale arena word cannot pass)
                     al.set_option(k, v)
                 got = al.align_arrays(*data)
                 assert_batch_equal(got, want, f"wave={wave} strict={strict} pen={penalties} glob={glob} ad={ad}")
                 cells.append(al.last_timing().cells_stored)
                 al.close()
             assert len(set(cells)) == 1
+
+
+def test_team_kernel_sees_no_stale_arena_words(built):
+    """Rows written by one workgroup of a team are read by the others after a barrier; a read that overtakes the
+    write returns what an EARLIER launch left at that address -- the right value when the same batch is run twice,
+    which is how such a race hides.  Two different batches alternate through one aligner (each launch finds the other
+    batch's rows in the arena), then once more over an arena filled with a pattern: every result equals the
+    oracle's."""
+    import wfa_amd as w
+    from oracle import oracle as O
+    batches = [w.generate_pairs(seed=sd, n_pairs=4, length=20000, error_rate=0.10) for sd in (5, 6)]
+    wants = [O.align_batch(_oracle_params(False), *b, n_threads=4) for b in batches]
+    al = _aligner(False, (10, 50, 1))
+    al.set_option("team_min_len", 1)
+    for rnd in range(3):
+        for i in (0, 1):
+            assert_batch_equal(al.align_arrays(*batches[i]), wants[i], f"round {rnd} batch {i}")
+    al.set_option("arena_poison", 1)
+    for i in (0, 1):
+        assert_batch_equal(al.align_arrays(*batches[i]), wants[i], f"poisoned arena, batch {i}")
+    al.close()
 
 
 @pytest.mark.parametrize("penalties", [(4, 6, 2), (5, 20, 3), (2, 3, 1)])
@@ -645,6 +666,7 @@ def test_config5_full_length_pair(built):
     from oracle import oracle as O
     data = w.generate_pairs(seed=5, n_pairs=2, length=100_000, error_rate=0.10)
     al = _aligner(False, (10, 50, 1))
+    al.set_option("arena_poison", 1)  # no word an earlier launch left in the arena may be read
     got = al.align_arrays(*data)
     want = O.align_batch(_oracle_params(False), *data, n_threads=2)
     assert_batch_equal(got, want, "C5 full length")

@@ -332,9 +332,10 @@ struct ArenaViewWave {
     uint32_t        dmax;     // farthest source of a step, in entries (< 64)
     int             g_shift;  // log2(g) when g is a power of two (no division per lookup), else -1
     mutable uint32_t win_lo, win_hi;  // entries [win_lo, win_hi] are loaded; win_lo > win_hi: none
+    mutable bool     missed;          // a lookup fell outside the window
 
     WFA_DEV void init(const uint32_t *A_, uint64_t cap_, uint32_t g_, uint32_t n_ent_, DirEnt *lds_win, uint32_t dmax_) {
-        A = A_, cap = cap_, g = g_, n_ent = n_ent_, win = lds_win, dmax = dmax_;
+        A = A_, cap = cap_, g = g_, n_ent = n_ent_, win = lds_win, dmax = dmax_, missed = false;
         g_shift = (g & (g - 1u)) == 0u ? (int)__builtin_ctz(g) : -1;
         win_lo = 1u, win_hi = 0u;
     }
@@ -385,11 +386,12 @@ struct ArenaViewWave {
         uint32_t idx;
         bool     ok = split(s, idx);
         ok          = ok && idx < n_ent;
-        DirEnt e;
-        if (ok && (idx < win_lo || idx > win_hi))  // (not reached: prepare() has loaded what a step reads)
-            e = load_dir(A + cap - (uint64_t)DIR_WORDS * (idx + 1));
-        else
-            e = win[idx & 63u];
+        // prepare() has loaded every entry a step reads.  No second path that reads the entry from memory: where the
+        // two meet the compiler has to wait for ALL outstanding loads, which puts the five cell loads of a step one
+        // after the other (3.3 -> 1.x us per step).  A lookup outside the window (cannot happen) poisons the walk
+        // instead: the caller fails the pair.
+        missed = missed || (ok && (idx < win_lo || idx > win_hi));
+        const DirEnt e = win[idx & 63u];
         ok = ok && e.w > 0 && k >= e.lo && k < e.lo + e.w;
         const uint64_t off = ok ? e.base + (uint64_t)comp * e.stride + (uint32_t)(k - e.lo) : 0ull;
         const uint32_t v   = A[off];

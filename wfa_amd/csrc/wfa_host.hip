@@ -121,7 +121,8 @@ struct wfahip_ctx {
     int64_t       opt_team_wgs             = 0;     // workgroups per team, 0 = automatic
     int64_t       opt_team_solo_max        = TEAM_SOLO_MAX;  // rows up to this width are done by one workgroup
     int64_t       opt_team_wave            = 1;              // rows up to 64 diagonals are done by one wave (LDS ring)
-    int64_t       opt_team_strict          = 0;              // agent-scope release in every team barrier
+    int64_t       opt_team_strict          = 1;              // agent-scope release in every team barrier (0: see wfa_team.hpp)
+    int64_t       opt_arena_poison         = 0;              // tests: fill the arena with a pattern before every long-pair launch
     int64_t       opt_pilot                = 1;  // 1: a 4 096-pair pilot decides whether a large batch uses the sub-wave kernels
     int64_t       opt_tail_overlap         = 1;  // 1: retry passes overlap the backtrace kernel of the first pass
     int64_t       opt_overlap              = 0;  // 1: backtrace of chunk c on a second stream beside the forward kernel of chunk c+1 (measured: no gain)
@@ -404,6 +405,8 @@ static int set_option_impl(wfahip_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_team_wave = value;
     else if (k == "team_strict")
         ctx->opt_team_strict = value;
+    else if (k == "arena_poison")
+        ctx->opt_arena_poison = value;
     else if (k == "fail_pass")
         ctx->opt_fail_pass = value;
     else if (k == "prepack")
@@ -1003,6 +1006,10 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             P.work = static_cast<const uint32_t *>(ctx->work.p);
         }
         HIP_TRY(hipMemsetAsync(d_ctrl, 0, 8, st));  // queue_head, redo_count
+        // (tests: what an earlier launch left in the arena must never be read -- with the same batch run twice a stale
+        // read returns the right value and hides itself)
+        if (ctx->opt_arena_poison)
+            HIP_TRY(hipMemsetAsync(jarena.p, 0xA5, (size_t)cfg.arena_words * 4ull * cfg.slots, st));
         HIP_TRY(hipEventRecord(ctx->evA, st));
         if (team_T > 0) {
             if ((rc = ensure(ctx, ctx->team_ctl, (size_t)team_n * TEAM_CTL_WORDS * 4))) return rc;

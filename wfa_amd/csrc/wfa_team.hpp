@@ -16,12 +16,13 @@
 // the memory side, not by the XCD's L2), so the per-step barriers need no cache write-back or invalidate: they are
 // __syncthreads (drains every wave's stores) -> one lane: atomic arrive, bounded spin on the counter with
 // agent-scope loads -> __syncthreads.  Rows written before a barrier are read by other workgroups only after it.
-// What this leans on: a write-through store whose vmcnt has returned is at the memory side before a load that is
-// issued at least one further memory-side round trip after the barrier was seen complete (every cross-workgroup
-// read here comes after the read-back of the team reductions).  Measured on MI355X: a load issued STRAIGHT after
-// the barrier can overtake the last arriver's write-through (a 0.25 us delay already hides it).  Option
-// `team_strict` adds an agent-scope release (L2 write-back + wait) to every barrier for the architectural
-// guarantee: +3 us per score step (0.63 -> 0.72 s on the configs[4] sample).
+// A write-through store whose vmcnt has returned is NOT yet at the memory side: a load issued straight after the
+// barrier can overtake the last arriver's stores (measured on MI355X: a few stale words per 1e5 steps, none with a
+// 0.25 us delay; with the same batch run twice the stale word is the right one and the error hides itself -- the
+// tests poison the arena, option `arena_poison`).  So every barrier carries an agent-scope release (L2 write-back +
+// wait) before the arrive: +1.7 us per score step, 0.54 -> 0.59 s on the configs[4] sample.  `team_strict = 0` drops
+// it (every cross-workgroup read then comes one further memory-side round trip after the barrier: fast, and wrong
+// once in ~40 runs of that sample).
 //
 // Narrow rows do not pay for barriers: when a row is at most TEAM_SOLO_MAX diagonals wide the team switches to
 // SOLO mode -- workgroup 0 runs the steps alone with plain (L2-cached) accesses and __syncthreads only, the others
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
             if (fenced)
                 __threadfence();
             else if (strict)
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // option team_strict, see the header comment
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // (team_strict, the default: see the header comment)
             bool bad = false;
             // the last workgroup to arrive sees the full count in the value its own atomic returns.  The count runs
             // over all the pairs of a launch: compared modulo 2^32.
@@ -613,9 +614,7 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
                     const int     kw  = low ? fvm + tid : lvm - (tid - HALF);
                     const int64_t iw  = (int64_t)kw - lo;
                     const bool    in  = kw >= fvm && kw <= lvm;  // (fvm <= lvm: mind exists)
-                    // (this load comes a full round trip to the memory side -- the team results above -- after the barrier
-                    // was seen complete; issued straight after the barrier it can overtake the write-through of the last
-                    // workgroup's stores: measured)
+                    // (rows written by the other workgroups: visible since the release of B1, see the header comment)
                     const uint32_t mw = in ? ldw(rowM + iw) : 0u;
                     const int     dw  = reduce_dist(mw, kw, n, m);
                     const bool    okw = dw >= 0 && dw - mind <= maxdiff;
@@ -861,7 +860,7 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
             ow.init(reinterpret_cast<uint64_t *>(A + scratch0), (uint32_t)(room > 0xFFFFFFFFull ? 0xFFFFFFFFull : room));
             TraceOut to;
             back_trace(av, n, m, minS, lastK, !glob, x, P.o, e, ow, to);
-            if (ow.overflow) {
+            if (ow.overflow || av.missed) {  // (missed: see ArenaViewWave::get_raw -- the pair fails instead of a wrong CIGAR)
                 if (tid == 0) {
                     rec[REC_STATUS] = ST_REDO_ARENA;
                     push_redo(P, pair, ST_REDO_ARENA);
