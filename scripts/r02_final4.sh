@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round-2 closing run (2): the -m gpu suite, bench lines, rocprofv3 summaries with the final kernels.
+# Round-2 closing run (4): the -m gpu suite, bench lines, rocprofv3 summaries with the final kernels.
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=gpurun_out/r02_final3; mkdir -p $OUT
-timeout 1200 python -m pytest tests -m gpu -x -q --durations=5 > $OUT/pytest.log 2>&1; echo "pytest rc $?" >> $OUT/pytest.log; tail -9 $OUT/pytest.log
+OUT=gpurun_out/r02_final4; mkdir -p $OUT
+timeout 1800 python -m pytest tests -m gpu -x -q --durations=5 > $OUT/pytest.log 2>&1; echo "pytest rc $?" >> $OUT/pytest.log; tail -9 $OUT/pytest.log
 timeout 600 python bench.py > $OUT/bench_c3.json 2> $OUT/bench_c3.err
 timeout 600 python bench.py --config c2 > $OUT/bench_c2.json 2> $OUT/bench_c2.err
 timeout 900 python bench.py --config c5s --cpu-sample 0 > $OUT/bench_c5s.json 2> $OUT/bench_c5s.err
