@@ -223,7 +223,8 @@ int  wfahip_last_timing(const wfahip_ctx *ctx, wfahip_timing *out);
  *   "team_strict"                 1 (default): every team barrier carries an agent-scope release (L2 write-back + wait).
  *                                 0: no release -- 10 % faster on 100 kbp pairs and NOT safe: a row word can be read before
  *                                 its write-through has landed (measured; wfa_team.hpp)
- *   "arena_poison"                tests: fill the arena with a pattern before every launch of the long-pair kernels */
+ *   "arena_poison"                tests: fill the arena with a pattern before every forward launch (no kernel may read a word
+ *                                 it did not write in this launch) */
 int  wfahip_set_option(wfahip_ctx *ctx, const char *key, int64_t value);
 
 /* Debug / parity aid: align ONE pair and return every stored wavefront row.  rows[] receives

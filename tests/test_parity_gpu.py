@@ -610,6 +610,21 @@ def test_team_kernel_wave_mode(built, penalties):
             assert len(set(cells)) == 1
 
 
+def test_sub_wave_kernels_read_only_what_they_wrote(built):
+    """The blocked / register kernels zero nothing and skip the words nothing reads: over an arena filled with a
+    pattern before every forward launch (option arena_poison) every record and CIGAR equals the oracle's -- first
+    pass, the wider retry rungs and the short-read instance."""
+    import wfa_amd as w
+    from oracle import oracle as O
+    for length, err, glob, ad in ((1000, 0.05, True, (10, 50, 1)), (400, 0.12, True, None), (150, 0.02, True, None)):
+        data = w.generate_pairs(seed=17, n_pairs=3000, length=length, error_rate=err, n_threads=8)
+        want = O.align_batch(_oracle_params(glob, ad), *data, n_threads=8)
+        al = _aligner(glob, ad)
+        al.set_option("arena_poison", 1)
+        assert_batch_equal(al.align_arrays(*data), want, f"poisoned arena, {length} bp @{err}")
+        al.close()
+
+
 def test_team_kernel_sees_no_stale_arena_words(built):
     """Rows written by one workgroup of a team are read by the others after a barrier; a read that overtakes the
     write returns what an EARLIER launch left at that address -- the right value when the same batch is run twice,

@@ -234,8 +234,9 @@ constexpr int BK_BIG = 0x3FFFFFFF;
 //
 // STREAM: finished pairs are handed to wfa_backtrace_stream_kernel while this kernel is still running.  The arena
 // rows are stored write-through (sc1); a finished pair's done_q entry {index + 1, score, end offset, cells} is
-// stored -- one 16-byte write-through store -- in the following refill, right after the queue atomic has returned
-// (vmcnt = 0: every earlier store of the wave has been acknowledged), so it costs no wait of its own.
+// stored -- one 16-byte write-through store -- in the following refill, after an agent-scope release: the vmcnt of a
+// write-through store returns before the store is at the memory side (measured in the team kernel, DESIGN.md section
+// 6), so "every earlier store has been acknowledged" does not order the rows before the entry.
 typedef uint32_t blk_u32x4 __attribute__((ext_vector_type(4)));
 
 WFA_DEV void blk_store_sc1(void *p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
@@ -503,6 +504,7 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
                     if (lane < 2 && aval != 0u) r2 = atomicAdd(aptr, aval);
                     base              = (uint32_t)__builtin_amdgcn_readlane((int)r2, 0);
                     const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)r2, 1);
+                    if (pb != 0ull) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the rows before their entry
                     if (pend && j == 0)
                         blk_store_sc1(P.done_q + (t0 + (uint32_t)__builtin_popcount(pbits & ((1u << grp) - 1u))), pidx + 1u,
                                       si * P.g, (uint32_t)pend_h, cells);

@@ -696,6 +696,8 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                 }
                 if (n_buf == 2 && c >= 2) HIP_TRY(hipStreamWaitEvent(st, ctx->evpool[4 * (c - 2) + 3], 0));  // buffer free
                 if (c > 0) HIP_TRY(hipMemsetAsync(d_ctrl, 0, 4, st));  // queue_head only (chunk 0: cleared with redo_count above)
+                // (tests: the sub-wave kernels zero nothing -- no word the backtrace reads may be one they did not write)
+                if (ctx->opt_arena_poison) HIP_TRY(hipMemsetAsync(P.arena, 0xA5, (size_t)(words * 4ull * cn), st));
                 HIP_TRY(hipEventRecord(evFa, st));
                 if (kind == 5)
                     hipLaunchKernelGGL((wfa_blk_kernel<64, 1>), dim3(grid), dim3(64), lds_bytes, st, P);
