@@ -220,6 +220,7 @@ int  wfahip_last_timing(const wfahip_ctx *ctx, wfahip_timing *out);
  *   "team_min_len"         pairs at least this long use the team kernel (0 = never)              default 8192
  *   "team_wgs", "team_solo_max"   workgroups per team (0 = automatic), widest row done by one workgroup
  *   "team_wave"                   1 (default): rows of at most 64 diagonals are stepped by one wave out of an LDS ring
+ *                                 (team kernel and the one-workgroup-per-pair kernel: wfa_wave.hpp)
  *   "team_strict"                 1 (default): every team barrier carries an agent-scope release (L2 write-back + wait).
  *                                 0: no release -- 10 % faster on 100 kbp pairs and NOT safe: a row word can be read before
  *                                 its write-through has landed (measured; wfa_team.hpp)

@@ -672,6 +672,33 @@ def test_team_kernel_wavefronts_word_for_word(built, penalties):
         oa.close()
 
 
+@pytest.mark.parametrize("penalties", [(4, 6, 2), (5, 20, 3)])
+def test_generic_kernel_wavefronts_word_for_word(built, penalties):
+    """The one-workgroup-per-pair kernel, with its wave mode (rows of <= 64 diagonals stepped by one wave,
+    wfa_wave.hpp) and without: every stored M / I / D word against the oracle's final wavefronts -- global pairs run
+    in wave mode from the first score, semi-global ones enter it when the band collapses, wf-adaptive off leaves it
+    when the band outgrows 64 diagonals."""
+    import wfa_amd as w
+    from oracle import oracle as O
+    blob, qo, ql, to, tl = w.generate_pairs(seed=33, n_pairs=3, length=1200, error_rate=0.08)
+    for glob, ad in ((True, (10, 50, 1)), (False, (10, 50, 1)), (True, None), (False, (4, 5, 1))):
+        oa = O.Aligner(_oracle_params(glob, ad, penalties))
+        for wave in (1, 0):
+            al = _aligner(glob, ad, penalties)
+            al.set_option("team_wave", wave)
+            for i in range(len(ql)):
+                q, t = bytes(blob[qo[i]:qo[i] + ql[i]]), bytes(blob[to[i]:to[i] + tl[i]])
+                r = oa.align(q, t)
+                want = {c: {sc: {lo + j: v for j, v in enumerate(raw) if v} for sc, (lo, hi, raw) in d.items()}
+                        for c, d in oa.dump().items()}
+                wf, res = al.debug_wavefronts(q, t)
+                assert res.Score == r.score
+                for c in "MID":
+                    assert wf[c] == {sc: row for sc, row in want[c].items() if row}, (penalties, glob, ad, wave, i, c)
+            al.close()
+        oa.close()
+
+
 @pytest.mark.timeout(1500)
 def test_config5_full_length_pair(built):
     """BASELINE configs[4] at its stated length: 100 kbp pairs @10 %, semi-global + wf-adaptive 10/50/1 (seed 5, the

@@ -6,11 +6,16 @@
 // live in the slot's HBM arena (they are what the backtrace needs) and the sources of WF_NEXT are
 // read back from there (L2-resident: the slot wrote them a few scores ago).
 //
+// While the rows are at most 64 diagonals wide -- a long read under wf-adaptive, for all of its alignment -- the
+// steps are done by wave 0 alone out of LDS rings (wfa_wave.hpp: no workgroup barrier, no read-back from the arena;
+// 1.7 us per step against ~5); the workgroup-wide step below takes over when a row is wider.
+//
 // Per score s (a multiple of g = gcd(x, o+e, e); other scores cannot exist) the kernel runs the
 // reference's sequence  next(s) -> extend(s) -> termination test -> reduce(s)  (wfa.go:228-251)
 // fused per diagonal, so each cell is produced in registers and stored once.
 #pragma once
 #include "wfa_device.hpp"
+#include "wfa_wave.hpp"
 
 namespace wfa {
 
@@ -26,6 +31,9 @@ __global__ __launch_bounds__(64 * WAVES) void wfa_generic_kernel(const KParams P
     int *const      red = reinterpret_cast<int *>(lds + 2 * (MODE == 0 ? P.lds_seq_words : 0));
     // red[0]=mlo red[1]=mhi red[2]=term red[3]=minDist red[4]=first_ok red[5]=last_ok red[6]=anyfail
     // red[7]=lead  red[8]=pair broadcast  red[9]=bad  red[10..11] = cells count (lo, hi)
+    // wave mode (P.wave_rows != 0): directory entries of the last 64 scores, then the ring of the last rows
+    DirEnt *const   gring = reinterpret_cast<DirEnt *>(lds + ((2 * (MODE == 0 ? P.lds_seq_words : 0) + GEN_LDS_EXTRA_WORDS + 3u) & ~3u));
+    uint32_t *const wring = reinterpret_cast<uint32_t *>(gring + WAVE_DIR_RING);
 
     const int      tid  = threadIdx.x;
     const int      lane = tid & 63;
@@ -129,6 +137,32 @@ __global__ __launch_bounds__(64 * WAVES) void wfa_generic_kernel(const KParams P
             if (top + 3ull * (uint64_t)W + (uint64_t)DIR_WORDS * (si + 2) > cap) {
                 overflow = true;
                 break;
+            }
+            // ---- wave mode: wave 0 steps alone while the rows stay within 64 diagonals (wfa_wave.hpp)
+            if (!e0 && P.wave_rows != 0u && W <= 64) {
+                if (tid < 64) {
+                    if ((uint32_t)tid < si) gring[(si - 1u - (uint32_t)tid) % WAVE_DIR_RING] = load_ent(si - 1u - (uint32_t)tid);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    uint32_t ws = s;
+                    const uint32_t wflags =
+                        wave_mode_steps<MODE>(P, sv, A, cap, gring, wring, P.wave_rows, n, m, glob, ws, top, n_ent, s_final, my_cells, nullptr);
+                    if (tid == 0) {
+                        unsigned int *const ur = reinterpret_cast<unsigned int *>(red);
+                        ur[0] = ws, ur[1] = (uint32_t)top, ur[2] = (uint32_t)(top >> 32), ur[3] = n_ent, ur[4] = wflags, ur[5] = s_final;
+                    }
+                }
+                __syncthreads();
+                {
+                    const unsigned int *const ur = reinterpret_cast<const unsigned int *>(red);
+                    s = ur[0], top = (uint64_t)ur[1] | ((uint64_t)ur[2] << 32), n_ent = ur[3];
+                    if (ur[4] & WAVE_DONE) done = true, s_final = ur[5];
+                    if (ur[4] & WAVE_OVERFLOW) overflow = true;
+                }
+                __syncthreads();
+                if (done || overflow) break;
+                s -= g;  // the row at s is wider than 64: the workgroup-wide step
+                continue;
             }
             if (W == 0) {
                 if (tid == 0) store_dir(dir_ptr(si), 0ull, 0, 0, 0u);

@@ -1025,6 +1025,14 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                                team_wave_rows, (uint32_t)(ctx->opt_team_strict != 0));
             HIP_TRY(hipGetLastError());
         } else {
+            // wave mode of the generic kernel: directory ring + ring of the last rows in LDS, if they fit
+            P.wave_rows = 0;
+            if (ctx->opt_team_wave && P.e != 0u) {
+                uint32_t rows = 2;
+                while (rows <= std::max(P.x, std::max(P.oe, P.e)) / P.g) rows *= 2;
+                const size_t extra = 16 + (size_t)WAVE_DIR_RING * sizeof(DirEnt) + (size_t)rows * 3 * 64 * 4;
+                if (rows <= (uint32_t)WAVE_DIR_RING && cfg.lds_bytes + extra <= LDS_MAX_BYTES) P.wave_rows = rows, cfg.lds_bytes += extra;
+            }
             HIP_TRY(launch_generic(P, cfg, st));
         }
         HIP_TRY(hipEventRecord(ctx->evB, st));

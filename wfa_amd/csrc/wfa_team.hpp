@@ -42,11 +42,12 @@
 // (the host reports an internal error instead of hanging the device).
 #pragma once
 #include "wfa_device.hpp"
+#include "wfa_wave.hpp"
 
 namespace wfa {
 
 constexpr int TEAM_THREADS   = 1024;
-constexpr int TEAM_RING      = 64;   // directory entries every workgroup keeps in LDS (sources reach back < 64 scores)
+constexpr int TEAM_RING      = WAVE_DIR_RING;  // directory entries every workgroup keeps in LDS (sources reach back < 64 scores)
 constexpr int TEAM_CTL_WORDS = 128;  // per team, in global memory: [0] barrier count [1] abort [2] work index
                                      // [3] - [4] command [5] score [6..7] arena top [8..9] end-cell key (u64) [10] end flags [12..13] stored cells (u64)
                                      // [16 + 16*set ..] three reduction sets [64..] diagnostic stamps
@@ -323,140 +324,12 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
             // ---- wave mode (workgroup 0, solo): wave 0 steps alone while the rows stay within 64 diagonals
             if (!teamed && wave_rows != 0u && W <= 64) {
                 if (tid < 64) {
-                    const uint32_t rmask = wave_rows - 1u;
-                    auto wrow = [&](uint32_t idx, int comp) { return wring + (((idx & rmask) * 3u + (uint32_t)comp) << 6); };
-                    // the rows the next steps can source: from the arena into the LDS ring (a row wider than 64
-                    // is never read here: a step that sources it is itself wider than 64 and leaves wave mode)
-                    for (uint32_t r = 1; r <= wave_rows && r <= si; r++) {
-                        const DirEnt d = ring[(si - r) % TEAM_RING];
-                        if (d.w > 0 && d.w <= 64 && lane < d.w) {
-                            const uint32_t sl = (uint32_t)(d.lo + lane) & 63u;
-#pragma unroll
-                            for (int c = 0; c < 3; c++) wrow(si - r, c)[sl] = A[d.base + (uint64_t)c * d.stride + (uint32_t)lane];
-                        }
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    // Everything that is the same in every lane is kept in scalar registers (readfirstlane): the
-                    // score, the arena top, the ranges of the source rows -- the loop control is scalar code.
-                    auto rfl = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
-                    const int2 *const ring_lw = reinterpret_cast<const int2 *>(ring);  // entry i: [4 i + 1] = {lo, w}
-                    uint32_t wflags = 0;  // 1: done, 2: overflow, 4: the row at s is wider than 64 (back to solo mode)
-                    uint32_t su = rfl(s), sj = rfl(s / g);
-                    uint64_t utop = (uint64_t)rfl((uint32_t)top) | ((uint64_t)rfl((uint32_t)(top >> 32)) << 32);
-                    const uint32_t dx = x / g, doe = oe / g, de = e / g;
-                    for (;; su += g, sj++) {
-                        int xlo = 0, xw = 0, olo = 0, ow_ = 0, elo = 0, ew = 0;
-                        if (su >= x) {
-                            const int2 v = ring_lw[((sj - dx) % TEAM_RING) * 4u + 1u];
-                            xlo = (int)rfl((uint32_t)v.x), xw = (int)rfl((uint32_t)v.y);
-                        }
-                        if (su >= oe) {
-                            const int2 v = ring_lw[((sj - doe) % TEAM_RING) * 4u + 1u];
-                            olo = (int)rfl((uint32_t)v.x), ow_ = (int)rfl((uint32_t)v.y);
-                        }
-                        if (su >= e) {
-                            const int2 v = ring_lw[((sj - de) % TEAM_RING) * 4u + 1u];
-                            elo = (int)rfl((uint32_t)v.x), ew = (int)rfl((uint32_t)v.y);
-                        }
-                        const bool wseed = (su == 0u) || (su == x);
-                        int wlo = INT32_MAX, whi = INT32_MIN;
-                        if (xw > 0) wlo = imin2(wlo, xlo - 1), whi = imax2(whi, xlo + xw);
-                        if (ow_ > 0) wlo = imin2(wlo, olo - 1), whi = imax2(whi, olo + ow_);
-                        if (ew > 0) wlo = imin2(wlo, elo - 1), whi = imax2(whi, elo + ew);
-                        wlo = imax2(wlo, -(n - 1));
-                        whi = imin2(whi, m - 1);
-                        if (su == 0u) wlo = INT32_MAX, whi = INT32_MIN;
-                        if (wseed) wlo = imin2(wlo, seed_lo), whi = imax2(whi, seed_hi);
-                        const int64_t WW = (whi >= wlo) ? ((int64_t)whi - wlo + 1) : 0;
-                        if (utop + 3ull * (uint64_t)WW + (uint64_t)DIR_WORDS * (sj + 2) > cap) {
-                            wflags = 2u;
-                            break;
-                        }
-                        if (WW > 64) {
-                            wflags = 4u;
-                            break;
-                        }
-                        if (WW == 0) {
-                            put_ent(sj, 0ull, 0, 0, 0u);
-                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                            __builtin_amdgcn_wave_barrier();
-                            continue;
-                        }
-                        const uint64_t wbase = utop;
-                        const int      k     = wlo + lane;
-                        const bool     on    = lane < (int)WW;
-                        const uint32_t sl    = (uint32_t)k & 63u;
-                        auto wsrc = [&](int dlo, int dw, uint32_t idx, int comp, int kk) -> uint32_t {
-                            return (kk >= dlo && kk < dlo + dw) ? wrow(idx, comp)[(uint32_t)kk & 63u] : 0u;  // (dw <= 0: never)
-                        };
-                        Cell c = {0u, 0u, 0u};
-                        if (on) {
-                            if (su != 0u) {
-                                const uint32_t sa = wsrc(olo, ow_, sj - doe, 0, k - 1), sb = wsrc(elo, ew, sj - de, 1, k - 1);
-                                const uint32_t sc2 = wsrc(olo, ow_, sj - doe, 0, k + 1), sd = wsrc(elo, ew, sj - de, 2, k + 1);
-                                const uint32_t sx = wsrc(xlo, xw, sj - dx, 0, k);
-                                c = next_cell(sa, sb, sc2, sd, sx, k, n, m);
-                            }
-                            if (wseed && c.M == 0u) c.M = seed_word<MODE>(sv, k, su, x, glob);
-                            c.M = extend_word<MODE>(sv, c.M, k);
-                            uint32_t *const rowM = A + wbase + lane;
-                            rowM[0] = c.M, rowM[WW] = c.I, rowM[2 * WW] = c.D;
-                            wrow(sj, 0)[sl] = c.M, wrow(sj, 1)[sl] = c.I, wrow(sj, 2)[sl] = c.D;
-                            my_cells += (c.M != 0u) + (c.I != 0u) + (c.D != 0u);
-                        }
-                        utop += 3ull * (uint64_t)WW;
-                        // lanes are ordered by diagonal: first / last lane of a ballot = lowest / highest diagonal
-                        const unsigned long long bM = __ballot(c.M != 0u);
-                        if (bM == 0ull) {  // no M cell: nothing to reduce, the entry is empty (mlo > mhi)
-                            put_ent(sj, 0ull, 0, 0, 0u);
-                        } else {
-                            const int  wmlo = wlo + (int)__builtin_ctzll(bM), wmhi = wlo + 63 - (int)__builtin_clzll(bM);
-                            const int  dd   = reduce_dist(c.M, k, n, m);
-                            const bool hit  = c.M != 0u && k == Ak && (int)(c.M >> TAG_BITS) >= m;
-                            if (__ballot(hit) != 0ull) {
-                                put_ent(sj, wbase, wlo, (int)WW, (uint32_t)WW);
-                                wflags = 1u;
-                                break;
-                            }
-                            int wnlo = wmlo, wnhi = wmhi;
-                            const unsigned long long bV = __ballot(dd >= 0);
-                            if (P.adaptive && (wmhi - wmlo + 1) >= (int)P.min_wf_len && bV != 0ull) {
-                                const int wmind = wave_min(dd >= 0 ? dd : INT32_MAX);
-                                const int maxdiff = (int)P.max_dist_diff;
-                                const unsigned long long bFail = __ballot(dd >= 0 && dd - wmind > maxdiff);
-                                const unsigned long long bOk   = bV & ~bFail;
-                                if (bFail != 0ull) {
-                                    // (bOk is never empty: the cell at the minimum distance passes)
-                                    const int first_ok = wlo + (int)__builtin_ctzll(bOk), last_ok = wlo + 63 - (int)__builtin_clzll(bOk);
-                                    const unsigned long long bEnd = bM & ~bV;  // present cells at / past a sequence end
-                                    const int hitmin = bEnd != 0ull ? wlo + (int)__builtin_ctzll(bEnd) : INT32_MAX;
-                                    if (hitmin >= first_ok) {
-                                        wnlo = first_ok, wnhi = last_ok;
-                                    } else {
-                                        // _lo: one past the last valid entry before the first non-failing one
-                                        const unsigned long long below = bV & ((1ull << (first_ok - wlo)) - 1ull);
-                                        wnlo = below != 0ull ? wlo + 63 - (int)__builtin_clzll(below) + 1 : wmlo;
-                                        wnhi = last_ok;
-                                    }
-                                    if (on && (k < wnlo || k > wnhi)) my_cells -= (c.M != 0u) + (c.I != 0u) + (c.D != 0u);
-                                }
-                            }
-                            if (wnhi >= wnlo)
-                                put_ent(sj, wbase + (uint64_t)(wnlo - wlo), wnlo, wnhi - wnlo + 1, (uint32_t)WW);
-                            else
-                                put_ent(sj, 0ull, 0, 0, 0u);
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
+                    unsigned long long *wsteps = nullptr;
 #ifdef WFA_TEAM_STAMPS
-                        tacc[9]++;
+                    wsteps = &tacc[9];
 #endif
-                    }
-                    // su: the score the loop stopped at (done: the final score; overflow / wide: the score to redo);
-                    // every score below it has its directory entry
-                    s = su, top = utop, n_ent = (wflags == 1u) ? sj + 1u : sj;
-                    if (wflags == 1u) s_final = su;
+                    const uint32_t wflags = wave_mode_steps<MODE>(P, sv, A, cap, ring, wring, wave_rows, n, m, glob, s, top, n_ent,
+                                                                  s_final, my_cells, wsteps);
                     if (tid == 0) {
                         unsigned int *const ur = reinterpret_cast<unsigned int *>(red);
                         ur[0] = s, ur[1] = (uint32_t)top, ur[2] = (uint32_t)(top >> 32), ur[3] = n_ent, ur[4] = wflags, ur[5] = s_final;
@@ -467,8 +340,8 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
                     const unsigned int *const ur = reinterpret_cast<const unsigned int *>(red);
                     s = ur[0], top = (uint64_t)ur[1] | ((uint64_t)ur[2] << 32), n_ent = ur[3];
                     const uint32_t wf = ur[4];
-                    if (wf & 1u) done = true, s_final = ur[5];
-                    if (wf & 2u) overflow = true;
+                    if (wf & WAVE_DONE) done = true, s_final = ur[5];
+                    if (wf & WAVE_OVERFLOW) overflow = true;
                 }
                 __syncthreads();
                 TEAM_STAMP(8);
