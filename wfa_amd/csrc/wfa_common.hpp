@@ -95,6 +95,7 @@ struct KParams {
     const uint32_t *prepack;
     uint32_t        prepack_words;   // words per slot
     uint32_t  wave_rows;             // wfa_generic_kernel: rows of its wave mode's LDS ring (a power of two), 0 = wave mode off
+    uint32_t  wave_bt;               // wfa_generic_kernel: 1 = the LDS directory window exists (backtrace walked by a wave)
     uint32_t  census;                // sub-wave forward kernels: report the number of stored wavefront words (REC_CELLS), else 0
     uint32_t  compact_fmt;           // compact arena layout (CompactView): 0 = rows + directory; no directory: 1 = 64 words
                                      // per score, diagonal k at slot k & 63; 3 = tiles of 8 scores x 64 diagonals;

@@ -31,7 +31,8 @@ __global__ __launch_bounds__(64 * WAVES) void wfa_generic_kernel(const KParams P
     int *const      red = reinterpret_cast<int *>(lds + 2 * (MODE == 0 ? P.lds_seq_words : 0));
     // red[0]=mlo red[1]=mhi red[2]=term red[3]=minDist red[4]=first_ok red[5]=last_ok red[6]=anyfail
     // red[7]=lead  red[8]=pair broadcast  red[9]=bad  red[10..11] = cells count (lo, hi)
-    // wave mode (P.wave_rows != 0): directory entries of the last 64 scores, then the ring of the last rows
+    // P.wave_bt != 0: an LDS window of 64 directory entries (wave mode's ring, the backtrace's window);
+    // P.wave_rows != 0: behind it the ring of the last rows of wave mode
     DirEnt *const   gring = reinterpret_cast<DirEnt *>(lds + ((2 * (MODE == 0 ? P.lds_seq_words : 0) + GEN_LDS_EXTRA_WORDS + 3u) & ~3u));
     uint32_t *const wring = reinterpret_cast<uint32_t *>(gring + WAVE_DIR_RING);
 
@@ -346,7 +347,24 @@ __global__ __launch_bounds__(64 * WAVES) void wfa_generic_kernel(const KParams P
             }
         }
 
-        // ---- backtrace + result record: lane 0 of wave 0
+        // ---- backtrace + result record: wave 0 walks together over an LDS window of the directory (wfa_wave.hpp) ...
+        if (P.wave_bt != 0u) {
+            const uint32_t cells_lo = (uint32_t)red[10];  // (red[0..3] are the accumulators of the record's statistics)
+            __syncthreads();
+            if (tid < 64) {
+                if (!wave_backtrace_record(P, A, cap, n_ent, top, gring, reinterpret_cast<unsigned int *>(red), n, m, minS, lastK, glob, rec)) {
+                    if (tid == 0) {
+                        rec[REC_STATUS] = ST_REDO_ARENA;
+                        push_redo(P, pair, ST_REDO_ARENA);
+                    }
+                } else if (tid == 0) {
+                    rec[REC_CELLS_LO] = cells_lo, rec[REC_CELLS_HI] = 0u, rec[REC_N_SCORES] = s_final;
+                }
+                if (tid == 0 && P.debug_info) P.debug_info[0] = n_ent, P.debug_info[1] = s_final;
+            }
+            continue;
+        }
+        // ... or, without that window (it did not fit beside the sequences), lane 0 of wave 0
         if (tid == 0) {
             ArenaView av;
             av.A = A, av.cap = cap, av.g = g, av.n_ent = n_ent;

@@ -1026,12 +1026,16 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             HIP_TRY(hipGetLastError());
         } else {
             // wave mode of the generic kernel: directory ring + ring of the last rows in LDS, if they fit
-            P.wave_rows = 0;
-            if (ctx->opt_team_wave && P.e != 0u) {
-                uint32_t rows = 2;
-                while (rows <= std::max(P.x, std::max(P.oe, P.e)) / P.g) rows *= 2;
-                const size_t extra = 16 + (size_t)WAVE_DIR_RING * sizeof(DirEnt) + (size_t)rows * 3 * 64 * 4;
-                if (rows <= (uint32_t)WAVE_DIR_RING && cfg.lds_bytes + extra <= LDS_MAX_BYTES) P.wave_rows = rows, cfg.lds_bytes += extra;
+            P.wave_rows = 0, P.wave_bt = 0;
+            if (ctx->opt_team_wave && std::max(P.x, std::max(P.oe, P.e)) / P.g < (uint32_t)WAVE_DIR_RING) {
+                const size_t dir_bytes = 16 + (size_t)WAVE_DIR_RING * sizeof(DirEnt);
+                if (cfg.lds_bytes + dir_bytes <= LDS_MAX_BYTES) {
+                    P.wave_bt = 1, cfg.lds_bytes += dir_bytes;
+                    uint32_t rows = 2;
+                    while (rows <= std::max(P.x, std::max(P.oe, P.e)) / P.g) rows *= 2;
+                    const size_t ring_bytes = (size_t)rows * 3 * 64 * 4;
+                    if (P.e != 0u && cfg.lds_bytes + ring_bytes <= LDS_MAX_BYTES) P.wave_rows = rows, cfg.lds_bytes += ring_bytes;
+                }
             }
             HIP_TRY(launch_generic(P, cfg, st));
         }

@@ -724,76 +724,17 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
         // scores around the walk sit in LDS -- the ring is free now -- and are loaded 64 at a time); result record: one lane
         __syncthreads();
         if (tid < 64) {
-            ArenaViewWave av;
-            av.init(A, cap, g, n_ent, ring, (uint32_t)imax2((int)x, imax2((int)oe, (int)e)) / g);
-            uint64_t  scratch0 = (top + 1ull) & ~1ull;
-            uint64_t  dir_lo   = cap - (uint64_t)DIR_WORDS * (uint64_t)n_ent;
-            uint64_t  room     = dir_lo > scratch0 ? (dir_lo - scratch0) / 2ull : 0ull;
-            OpsWriter ow;
-            ow.init(reinterpret_cast<uint64_t *>(A + scratch0), (uint32_t)(room > 0xFFFFFFFFull ? 0xFFFFFFFFull : room));
-            TraceOut to;
-            back_trace(av, n, m, minS, lastK, !glob, x, P.o, e, ow, to);
-            if (ow.overflow || av.missed) {  // (missed: see ArenaViewWave::get_raw -- the pair fails instead of a wrong CIGAR)
+            if (!wave_backtrace_record(P, A, cap, n_ent, top, ring, reinterpret_cast<unsigned int *>(red), n, m, minS, lastK, glob, rec)) {
                 if (tid == 0) {
                     rec[REC_STATUS] = ST_REDO_ARENA;
                     push_redo(P, pair, ST_REDO_ARENA);
                 }
             } else {
-                // process() (wfa_cigar.go:136-214): the forward list is the scratch list reversed; the 64 lanes copy
-                // and count together (the ops of a 100 kbp pair: 1.7e4 dependent round trips for one lane)
-                const uint32_t L = ow.n;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the list was written by this wave)
-                uint32_t off_lo = 0, off_hi = 0;
                 if (tid == 0) {
-                    const uint64_t o = atomicAdd(P.ops_cursor, (unsigned long long)L);
-                    off_lo = (uint32_t)o, off_hi = (uint32_t)(o >> 32);
-                }
-                const uint64_t off = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)off_lo) |
-                                     ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)off_hi) << 32);
-                int firstM = INT32_MAX, lastM = INT32_MIN;
-                for (uint32_t i = (uint32_t)lane; i < L; i += 64u) {
-                    const uint64_t op = ow.buf[L - 1 - i];
-                    if ((uint32_t)(op >> 32) == 'M') firstM = imin2(firstM, (int)i), lastM = imax2(lastM, (int)i);
-                    if (off + i < P.ops_cap) P.ops[off + i] = op;
-                }
-                firstM = wave_min(firstM), lastM = wave_max(lastM);
-                const uint32_t begin = firstM != INT32_MAX ? (uint32_t)firstM : 0u, end = firstM != INT32_MAX ? (uint32_t)lastM : 0u;
-                unsigned int *const acc = reinterpret_cast<unsigned int *>(red);
-                if (tid == 0) acc[0] = acc[1] = acc[2] = acc[3] = 0u;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                uint32_t alen = 0, matches = 0, gaps = 0, regions = 0;
-                for (uint32_t i = begin + (uint32_t)lane; i <= end && i < L; i += 64u) {
-                    const uint64_t op  = ow.buf[L - 1 - i];
-                    const uint32_t cnt = (uint32_t)op, o = (uint32_t)(op >> 32);
-                    alen += cnt;
-                    if (o == 'M')
-                        matches += cnt;
-                    else if (o == 'I' || o == 'D')
-                        gaps += cnt, regions++;
-                }
-                atomicAdd(&acc[0], alen), atomicAdd(&acc[1], matches), atomicAdd(&acc[2], gaps), atomicAdd(&acc[3], regions);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                alen = acc[0], matches = acc[1], gaps = acc[2], regions = acc[3];
-                if (tid == 0) {
-                rec[REC_STATUS]      = ST_OK;
-                rec[REC_SCORE]       = to.score;
-                rec[REC_TBEGIN]      = (uint32_t)to.tbegin;
-                rec[REC_TEND]        = (uint32_t)to.tend;
-                rec[REC_QBEGIN]      = (uint32_t)to.qbegin;
-                rec[REC_QEND]        = (uint32_t)to.qend;
-                rec[REC_ALIGN_LEN]   = alen;
-                rec[REC_MATCHES]     = matches;
-                rec[REC_GAPS]        = gaps;
-                rec[REC_GAP_REGIONS] = regions;
-                rec[REC_OPS_LEN]     = L;
-                rec[REC_OPS_OFF_LO]  = (uint32_t)off;
-                rec[REC_OPS_OFF_HI]  = (uint32_t)(off >> 32);
-                rec[REC_CELLS_LO]    = __hip_atomic_load(&ctl[12], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                rec[REC_CELLS_HI]    = __hip_atomic_load(&ctl[13], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                rec[REC_N_SCORES]    = s_final;
-                if (P.debug_info) P.debug_info[0] = n_ent, P.debug_info[1] = s_final;  // (wfahip_debug_wavefronts)
+                    rec[REC_CELLS_LO] = __hip_atomic_load(&ctl[12], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    rec[REC_CELLS_HI] = __hip_atomic_load(&ctl[13], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    rec[REC_N_SCORES] = s_final;
+                    if (P.debug_info) P.debug_info[0] = n_ent, P.debug_info[1] = s_final;  // (wfahip_debug_wavefronts)
                 }
             }
 #ifdef WFA_TEAM_STAMPS

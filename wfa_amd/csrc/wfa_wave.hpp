@@ -173,4 +173,76 @@ WFA_DEV uint32_t wave_mode_steps(const KParams &P, const SeqView<MODE> &sv, uint
     return wflags;
 }
 
+// Backtrace of a finished pair by one wave walking together (same steps, same values in every lane; the directory
+// entries around the walk sit in the LDS window `win`, 64 entries, loaded 64 at a time), then process()
+// (wfa_cigar.go:136-214) by the 64 lanes: the forward list is the scratch list reversed, copied to P.ops, and the
+// statistics of the span first-M .. last-M.  Lane 0 writes the record except REC_CELLS_* and REC_N_SCORES.  Returns
+// false when the ops scratch between the rows and the directory was too small (the caller re-queues the pair).
+// `acc`: four LDS words.  Called by the 64 lanes of one wave, converged.
+WFA_DEV bool wave_backtrace_record(const KParams &P, uint32_t *const A, const uint64_t cap, const uint32_t n_ent, const uint64_t top,
+                                   DirEnt *const win, unsigned int *const acc, const int n, const int m, const uint32_t minS,
+                                   const int lastK, const bool glob, uint32_t *const rec) {
+    const uint32_t x = P.x, oe = P.oe, e = P.e, g = P.g;
+    const int      lane = (int)(threadIdx.x & 63u);
+    ArenaViewWave  av;
+    av.init(A, cap, g, n_ent, win, (uint32_t)imax2((int)x, imax2((int)oe, (int)e)) / g);
+    uint64_t  scratch0 = (top + 1ull) & ~1ull;
+    uint64_t  dir_lo   = cap - (uint64_t)DIR_WORDS * (uint64_t)n_ent;
+    uint64_t  room     = dir_lo > scratch0 ? (dir_lo - scratch0) / 2ull : 0ull;
+    OpsWriter ow;
+    ow.init(reinterpret_cast<uint64_t *>(A + scratch0), (uint32_t)(room > 0xFFFFFFFFull ? 0xFFFFFFFFull : room));
+    TraceOut to;
+    back_trace(av, n, m, minS, lastK, !glob, x, P.o, e, ow, to);
+    if (ow.overflow || av.missed) return false;  // (missed: see ArenaViewWave::get_raw -- the pair fails instead of a wrong CIGAR)
+    const uint32_t L = ow.n;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the list was written by this wave)
+    uint32_t off_lo = 0, off_hi = 0;
+    if (lane == 0) {
+        const uint64_t o = atomicAdd(P.ops_cursor, (unsigned long long)L);
+        off_lo = (uint32_t)o, off_hi = (uint32_t)(o >> 32);
+    }
+    const uint64_t off = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)off_lo) |
+                         ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)off_hi) << 32);
+    int firstM = INT32_MAX, lastM = INT32_MIN;
+    for (uint32_t i = (uint32_t)lane; i < L; i += 64u) {
+        const uint64_t op = ow.buf[L - 1 - i];
+        if ((uint32_t)(op >> 32) == 'M') firstM = imin2(firstM, (int)i), lastM = imax2(lastM, (int)i);
+        if (off + i < P.ops_cap) P.ops[off + i] = op;
+    }
+    firstM = wave_min(firstM), lastM = wave_max(lastM);
+    const uint32_t begin = firstM != INT32_MAX ? (uint32_t)firstM : 0u, end = firstM != INT32_MAX ? (uint32_t)lastM : 0u;
+    if (lane == 0) acc[0] = acc[1] = acc[2] = acc[3] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint32_t alen = 0, matches = 0, gaps = 0, regions = 0;
+    for (uint32_t i = begin + (uint32_t)lane; i <= end && i < L; i += 64u) {
+        const uint64_t op  = ow.buf[L - 1 - i];
+        const uint32_t cnt = (uint32_t)op, o = (uint32_t)(op >> 32);
+        alen += cnt;
+        if (o == 'M')
+            matches += cnt;
+        else if (o == 'I' || o == 'D')
+            gaps += cnt, regions++;
+    }
+    atomicAdd(&acc[0], alen), atomicAdd(&acc[1], matches), atomicAdd(&acc[2], gaps), atomicAdd(&acc[3], regions);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        rec[REC_STATUS]      = ST_OK;
+        rec[REC_SCORE]       = to.score;
+        rec[REC_TBEGIN]      = (uint32_t)to.tbegin;
+        rec[REC_TEND]        = (uint32_t)to.tend;
+        rec[REC_QBEGIN]      = (uint32_t)to.qbegin;
+        rec[REC_QEND]        = (uint32_t)to.qend;
+        rec[REC_ALIGN_LEN]   = acc[0];
+        rec[REC_MATCHES]     = acc[1];
+        rec[REC_GAPS]        = acc[2];
+        rec[REC_GAP_REGIONS] = acc[3];
+        rec[REC_OPS_LEN]     = L;
+        rec[REC_OPS_OFF_LO]  = (uint32_t)off;
+        rec[REC_OPS_OFF_HI]  = (uint32_t)(off >> 32);
+    }
+    return true;
+}
+
 }  // namespace wfa
