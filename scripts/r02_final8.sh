@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round-2 closing run (7): final sources -- the -m gpu suite, streamed-path tests, bench lines, rocprofv3 summaries.
+# Round-2 closing run (8): final sources -- the -m gpu suite, streamed-path tests, bench lines, rocprofv3 summaries.
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=gpurun_out/r02_final7; mkdir -p $OUT
+OUT=gpurun_out/r02_final8; mkdir -p $OUT
 timeout 1800 python -m pytest tests -m gpu -x -q --durations=5 > $OUT/pytest.log 2>&1; echo "pytest rc $?" >> $OUT/pytest.log; tail -9 $OUT/pytest.log
 WFA_TEST_OPTS=bt_stream_min=1,bt_stream_single=1 timeout 900 python -m pytest tests/test_parity_gpu.py -m gpu -x -q -k "parity_c3 or fuzz or other_penalties or chunks or mixed" > $OUT/pytest_stream.log 2>&1; echo "streamed backtrace forced: pytest rc $?" | tee -a $OUT/pytest_stream.log; tail -3 $OUT/pytest_stream.log
 timeout 600 python bench.py > $OUT/bench_c3.json 2> $OUT/bench_c3.err

@@ -145,12 +145,14 @@ __global__ __launch_bounds__(64 * WAVES) void wfa_generic_kernel(const KParams P
                     if ((uint32_t)tid < si) gring[(si - 1u - (uint32_t)tid) % WAVE_DIR_RING] = load_ent(si - 1u - (uint32_t)tid);
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
-                    uint32_t ws = s;
+                    uint32_t ws = s, wn = n_ent, wfin = s_final;
+                    uint64_t wtop = top, wcells = 0;
                     const uint32_t wflags =
-                        wave_mode_steps<MODE>(P, sv, A, cap, gring, wring, P.wave_rows, n, m, glob, ws, top, n_ent, s_final, my_cells, nullptr);
+                        wave_mode_steps<MODE>(P, sv, A, cap, gring, wring, P.wave_rows, n, m, glob, ws, wtop, wn, wfin, wcells, nullptr);
+                    my_cells += wcells;
                     if (tid == 0) {
                         unsigned int *const ur = reinterpret_cast<unsigned int *>(red);
-                        ur[0] = ws, ur[1] = (uint32_t)top, ur[2] = (uint32_t)(top >> 32), ur[3] = n_ent, ur[4] = wflags, ur[5] = s_final;
+                        ur[0] = ws, ur[1] = (uint32_t)wtop, ur[2] = (uint32_t)(wtop >> 32), ur[3] = wn, ur[4] = wflags, ur[5] = wfin;
                     }
                 }
                 __syncthreads();

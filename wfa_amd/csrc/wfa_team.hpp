@@ -328,11 +328,15 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
 #ifdef WFA_TEAM_STAMPS
                     wsteps = &tacc[9];
 #endif
-                    const uint32_t wflags = wave_mode_steps<MODE>(P, sv, A, cap, ring, wring, wave_rows, n, m, glob, s, top, n_ent,
-                                                                  s_final, my_cells, wsteps);
+                    // (locals: the loop's own variables stay out of the callee's references)
+                    uint32_t ws = s, wn = n_ent, wfin = s_final;
+                    uint64_t wtop = top, wcells = 0;
+                    const uint32_t wflags =
+                        wave_mode_steps<MODE>(P, sv, A, cap, ring, wring, wave_rows, n, m, glob, ws, wtop, wn, wfin, wcells, wsteps);
+                    my_cells += wcells;
                     if (tid == 0) {
                         unsigned int *const ur = reinterpret_cast<unsigned int *>(red);
-                        ur[0] = s, ur[1] = (uint32_t)top, ur[2] = (uint32_t)(top >> 32), ur[3] = n_ent, ur[4] = wflags, ur[5] = s_final;
+                        ur[0] = ws, ur[1] = (uint32_t)wtop, ur[2] = (uint32_t)(wtop >> 32), ur[3] = wn, ur[4] = wflags, ur[5] = wfin;
                     }
                 }
                 __syncthreads();
