@@ -39,7 +39,16 @@ CONFIGS = {
     "c2": dict(pairs=100_000, length=150, error=0.02, seed=2, semi_global=False, adaptive=False, total=0, cpu=100_000),
     "c4": dict(pairs=0, length=1000, error=0.05, seed=4, semi_global=False, adaptive=True, total=10_000_000, cpu=150_000),
     "c5s": dict(pairs=8, length=100_000, error=0.10, seed=5, semi_global=True, adaptive=True, total=0, cpu=8),
+    # the reference's own published grid beyond the headline row (README.md:326-345 = benchmark.tsv:4-19: wfa-go -N -i,
+    # global, wf-adaptive 10/50/1, 1e5 x 1 kbp and 500 x 50 kbp at 5 / 10 / 20 % error; 1 kbp @5 % is c3 at 1e6 pairs)
+    "k10": dict(pairs=100_000, length=1000, error=0.10, seed=10, semi_global=False, adaptive=True, total=0, cpu=60_000),
+    "k20": dict(pairs=100_000, length=1000, error=0.20, seed=20, semi_global=False, adaptive=True, total=0, cpu=25_000),
+    "l5": dict(pairs=500, length=50_000, error=0.05, seed=55, semi_global=False, adaptive=True, total=0, cpu=500),
+    "l10": dict(pairs=500, length=50_000, error=0.10, seed=510, semi_global=False, adaptive=True, total=0, cpu=300),
+    "l20": dict(pairs=500, length=50_000, error=0.20, seed=520, semi_global=False, adaptive=True, total=0, cpu=120),
 }
+# steps of the default run: timed regions of a few seconds
+DEFAULT_STEPS = {"c3": 250, "c2": 10000, "c4": 25, "c5s": 4, "k10": 400, "k20": 150, "l5": 150, "l10": 60, "l20": 25}
 
 
 def parse_args(argv=None):
@@ -65,6 +74,12 @@ def parse_args(argv=None):
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl")
     ap.add_argument("--dry", action="store_true", help="no kernels, CPU tensors: exercises the multi-rank control flow only")
     ap.add_argument("--master-port", type=int, default=0)
+    ap.add_argument("--share-gpus", action="store_true",
+                    help="N ranks on fewer GPUs (rank r uses GPU r mod device_count): every rank runs the real kernels on "
+                         "its own shard, the record gather goes over gloo through host copies (two RCCL ranks cannot share "
+                         "a device).  For exercising the sharded path on a 1-GPU box; not a scaling measurement")
+    ap.add_argument("--dump-records", default=None,
+                    help="rank 0 writes the records gathered in the last timed step (all ranks, pair order) to this .npy file")
     args = ap.parse_args(argv)
     c = CONFIGS[args.config]
     if args.pairs is None:
@@ -86,7 +101,7 @@ def parse_args(argv=None):
     if args.cpu_threads is None:
         args.cpu_threads = 8 if args.config == "c5s" else 1  # (a 100 kbp semi-global pair is minutes of one core)
     if args.steps is None:
-        args.steps = {"c3": 250, "c2": 10000, "c4": 25, "c5s": 4}[args.config]  # (timed regions of ~5 s; c5s ~3 s)
+        args.steps = DEFAULT_STEPS[args.config]  # (timed regions of ~5 s; c5s ~3 s)
     if args.warmup is None:
         args.warmup = 1 if args.config == "c5s" else 3
     return args
@@ -129,18 +144,26 @@ def run_rank(args):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dry = args.dry
+    share = bool(args.share_gpus) and not dry
     if dry:
         dev = torch.device("cpu")
+        dev_index = 0
     else:
-        dev = torch.device(f"cuda:{local_rank}")
+        # (device_count() does not initialise the GPU on this image; --share-gpus: rank r on GPU r mod device_count)
+        dev_index = local_rank % max(1, torch.cuda.device_count()) if share else local_rank
+        dev = torch.device(f"cuda:{dev_index}")
+    backend = "gloo" if (dry or share or args.backend == "gloo") else "nccl"
+    # tensors handed to collectives: HBM for RCCL, host copies for gloo (--share-gpus: the records are staged through
+    # the host, because two RCCL ranks cannot sit on one device)
+    cdev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl" and not dry:
+        if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
     if not dry:
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(dev_index)
 
     import __graft_entry__ as entry
     if rank == 0:  # one rank builds (a no-op when the in-tree library is current), the others wait for it
@@ -182,7 +205,7 @@ def run_rank(args):
         d_toff = torch.from_numpy(t_off.view(np.int64)).to(dev)
         d_qlen = torch.from_numpy(q_len.view(np.int32)).to(dev)
         d_tlen = torch.from_numpy(t_len.view(np.int32)).to(dev)
-        al = w.New(w.DefaultPenalties, w.Options(GlobalAlignment=not args.semi_global), device=local_rank)
+        al = w.New(w.DefaultPenalties, w.Options(GlobalAlignment=not args.semi_global), device=dev_index)
         if not args.no_adaptive:
             assert al.AdaptiveReduction(w.DefaultAdaptiveOption) is None
         for kv in args.opt:
@@ -219,7 +242,11 @@ def run_rank(args):
                 pending[0].wait()
             rec_out = d_rec if args.gather_ops else d_rec[:, :L.REC_OPS_OFF_LO]
             gather_bytes[0] = rec_out.shape[0] * rec_out.shape[1] * 4 + (8 * n_ops if args.gather_ops else 0)
-            pending[0] = gather_results_async(rec_out, d_ops, n_ops, dst=0, with_ops=args.gather_ops)
+            ops_out = d_ops
+            if cdev != dev:  # gloo beside real kernels: stage through the host (the D2H copy waits for the kernels)
+                rec_out = rec_out.to(cdev)
+                ops_out = d_ops[:n_ops].to(cdev) if args.gather_ops else d_ops[:0].to(cdev)
+            pending[0] = gather_results_async(rec_out, ops_out, n_ops, dst=0, with_ops=args.gather_ops)
         return n_ops
 
     last_gather = [None]
@@ -253,7 +280,7 @@ def run_rank(args):
     drain()  # the last gather completes inside the timed region
     sync_all()
     elapsed = time.perf_counter() - t0
-    tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     elapsed = float(tt.item())
@@ -264,11 +291,15 @@ def run_rank(args):
         sync_all()
         t1 = time.perf_counter()
         rec_out = d_rec if args.gather_ops else d_rec[:, :L.REC_OPS_OFF_LO]
-        gather_results_async(rec_out, d_ops, n_ops, dst=0, with_ops=args.gather_ops).wait()
+        ops_out = d_ops
+        if cdev != dev:
+            rec_out = rec_out.to(cdev)
+            ops_out = d_ops[:n_ops].to(cdev) if args.gather_ops else d_ops[:0].to(cdev)
+        gather_results_async(rec_out, ops_out, n_ops, dst=0, with_ops=args.gather_ops).wait()
         sync_all()
         gather_ms = (time.perf_counter() - t1) * 1e3
         # per-rank pair counts as the collective saw them
-        cnt = torch.tensor([n], dtype=torch.int64, device=dev)
+        cnt = torch.tensor([n], dtype=torch.int64, device=cdev)
         cnts = [torch.empty_like(cnt) for _ in range(world)]
         dist.all_gather(cnts, cnt)
         pairs_per_rank = [int(c.item()) for c in cnts]
@@ -280,8 +311,12 @@ def run_rank(args):
             if dry:  # the records of every rank arrived, in rank order, untouched
                 scores = torch.cat([r[:, L.REC_SCORE] for r in recs]).cpu()
                 gathered_ok = gathered_ok and bool(torch.equal(scores, torch.arange(n_all, dtype=torch.int32)))
+            if args.dump_records:  # (tests: the gathered records of ALL shards against the oracle, in pair order)
+                np.save(args.dump_records, torch.cat([r for r in recs]).cpu().numpy())
     else:
         pairs_per_rank, n_seen, gathered_ok = [n], 1, None
+        if args.dump_records and rank == 0:
+            np.save(args.dump_records, d_rec[:, :L.REC_OPS_OFF_LO].cpu().numpy())
 
     # ---- accounting for the roofline (algorithmic bytes): one more pass, untimed, with the forward
     # kernel's count of stored wavefront words switched on (instrumentation: off in the timed steps, where it would
@@ -321,7 +356,9 @@ def run_rank(args):
                            f"wf-adaptive {'off' if args.no_adaptive else '10/50/1'}, seed {args.seed}",
                "config": args.config, "pairs_per_gpu": n, "pairs_per_rank": pairs_per_rank, "total_pairs_per_step": n_all,
                "length": args.length, "error_rate": args.error,
-               "parallelism": f"pair-sharded x{world}", "ranks_seen_by_collective": n_seen, "backend": "none (1 GPU)" if world == 1 else args.backend,
+               "parallelism": f"pair-sharded x{world}", "ranks_seen_by_collective": n_seen, "backend": "none (1 GPU)" if world == 1 else backend,
+               "gpus_shared": (f"{world} ranks on {torch.cuda.device_count()} GPU(s): sharded path exercised, NOT a scaling measurement"
+                               if share and world > 1 else None),
                "status_ok": int(ok.sum()), "setup_steps": setup_steps,
                "gather": "none (1 GPU)" if world == 1 else ("records + CIGAR ops" if args.gather_ops else "records"),
                "gather_bytes_per_rank_step": gather_bytes[0] if world > 1 else 0, "gather_ms_standalone": gather_ms,
@@ -334,7 +371,9 @@ def run_rank(args):
                "timed_region_s": elapsed}
         if dry:
             cfg["dry"] = True
-        out = {"metric": METRIC, "value": value, "unit": "pairs/s", "n_gpus": n_seen, "steps": args.steps, "warmup": args.warmup,
+        metric = METRIC if args.config in ("c3", "c4") else (
+            f"aligned pairs/sec (and Gcells/s) on {n} synthetic {args.length} bp pairs @{args.error:.0%} error")
+        out = {"metric": metric, "value": value, "unit": "pairs/s", "n_gpus": n_seen, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
                "vs_baseline": None, "dtype": "u32", "data": "synthetic", "config": cfg}
         if not dry:
