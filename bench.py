@@ -191,7 +191,9 @@ def run_rank(args):
                                                         n_threads=min(32, os.cpu_count() or 8))
     max_len = int(max(q_len.max(), t_len.max())) if n else 1
     sum_len = int(q_len.astype(np.int64).sum() + t_len.astype(np.int64).sum())
-    ops_cap = sum_len // 4 + 8 * n + 1024
+    # (the backtrace reserves score / min(x, e) * 2 + 8 op slots per pair before it knows the CIGAR: ~2.5 x error rate x
+    # the pair's bases at 4/6/2)
+    ops_cap = int(sum_len * max(0.25, 3.0 * args.error)) + 8 * n + 1024
     if args.semi_global or args.length >= 20000:
         ops_cap = sum_len + 2 * n + 1024
     d_rec = torch.zeros((max(n, 1), L.REC_WORDS), dtype=torch.int32, device=dev)[:n]
@@ -337,7 +339,7 @@ def run_rank(args):
     achieved = alg_bytes / (main_k_ms * 1e-3) / 1e9 if main_k_ms > 0 else 0.0  # GB/s over the dominant kernel's launches of one step
 
     KNAMES = ["wfa_generic_kernel<1, 0>", "wfa_packed_kernel", "wfa_reg_kernel<2, 4, 1>", "wfa_blk_kernel<16",
-              "wfa_blk_kernel<8", "wfa_blk_kernel<64", "wfa_blk_kernel<8, 8, false, 4", "wfa_team_kernel"]
+              "wfa_blk_kernel<8", "wfa_blk_kernel<64", "wfa_blk_kernel<8, 8, false, 4", "wfa_team_kernel", "wfa_duo_kernel"]
     kname = KNAMES[min(int(timing.main_kernel_kind), len(KNAMES) - 1)]
 
     out = None

@@ -246,7 +246,10 @@ func (algn *Aligner) unpack(rc C.int, out *C.wfahip_results, n int) ([]*Alignmen
 // the last Collect as ONE batch.  A per-pair loop like the reference's CLI (wfa-go/wfa-go.go:166-178) keeps its shape --
 // Submit where it called Align, one Collect at the end -- and runs at batch throughput instead of one device round
 // trip per pair.
-func (algn *Aligner) Submit(q, t []byte) uint64 {
+//
+// The error is non-nil when the pair could not be queued (context gone after RecycleAligner, out of host memory): the
+// ticket is then meaningless and nothing was added, so the tickets of later pairs still line up with Collect.
+func (algn *Aligner) Submit(q, t []byte) (uint64, error) {
 	var ticket C.uint64_t
 	var qp, tp *C.uint8_t
 	if len(q) > 0 {
@@ -255,10 +258,13 @@ func (algn *Aligner) Submit(q, t []byte) uint64 {
 	if len(t) > 0 {
 		tp = (*C.uint8_t)(unsafe.Pointer(&t[0]))
 	}
-	C.wfahip_submit(algn.ctx, qp, C.uint32_t(len(q)), tp, C.uint32_t(len(t)), &ticket)
+	rc := C.wfahip_submit(algn.ctx, qp, C.uint32_t(len(q)), tp, C.uint32_t(len(t)), &ticket)
 	runtime.KeepAlive(q)
 	runtime.KeepAlive(t)
-	return uint64(ticket)
+	if rc != 0 {
+		return 0, fmt.Errorf("wfa: %s", C.GoString(C.wfahip_strerror(rc)))
+	}
+	return uint64(ticket), nil
 }
 
 // Collect returns results[ticket], errs[ticket] for every pair submitted since the last Collect.
@@ -278,6 +284,9 @@ func (algn *Aligner) Wavefronts(q, t []byte) (map[byte]map[uint32]map[int]uint32
 	var rows *C.wfahip_row
 	var words *C.uint32_t
 	var nRows, nWords C.uint64_t
+	if len(q) == 0 || len(t) == 0 {
+		return nil, ErrEmptySeq
+	}
 	p := algn.params()
 	rc := C.wfahip_debug_wavefronts(algn.ctx, &p, (*C.uint8_t)(unsafe.Pointer(&q[0])), C.uint32_t(len(q)),
 		(*C.uint8_t)(unsafe.Pointer(&t[0])), C.uint32_t(len(t)), &rows, &nRows, &words, &nWords, nil)

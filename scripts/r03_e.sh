@@ -1,0 +1,11 @@
+#!/bin/bash
+cd ${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=gpurun_out/r03_e; mkdir -p $OUT
+timeout 900 python -m pytest tests/test_parity_gpu.py -m gpu -x -q -k "duo or (forward_kernel_variants and (opts7 or opts8)) or several_chunks" > $OUT/pytest_duo.log 2>&1; echo "pytest rc $?" >> $OUT/pytest_duo.log; tail -5 $OUT/pytest_duo.log
+for d in 1; do
+  WFAHIP_DEBUG_TIMING=1 timeout 300 python bench.py --steps 20 --warmup 2 --cpu-sample 0 --host-entry 0 --latency 0 --opt duo=$d > $OUT/bench_duo$d.json 2> $OUT/bench_duo$d.err
+  python3 -c "
+import json; d=json.load(open('$OUT/bench_duo$d.json')); c=d['config']; print('duo=$d', 'value', round(d['value'],1), 'ms', round(d['ms_per_step'],3), 'fwd', round(c['main_kernel_ms'],3), 'allk', round(c['kernel_ms_per_step'],3), 'launches', c['launches_per_step'], 'retried', c['retried_pairs'], 'ok', c['status_ok'])" || tail -5 $OUT/bench_duo$d.err
+  tail -3 $OUT/bench_duo$d.err
+done
+WFA_OPTS=duo=1,blk_wide=0 timeout 600 bash scripts/stamps.sh 100000 > $OUT/stamps_duo.txt 2>&1; tail -8 $OUT/stamps_duo.txt

@@ -17,6 +17,9 @@ err = float(sys.argv[3]) if len(sys.argv) > 3 else 0.05
 data = w.generate_pairs(3, n, length, err, n_threads=32)
 al = w.New()
 if length >= 500: al.AdaptiveReduction(w.DefaultAdaptiveOption)
+import os
+for kv in filter(None, os.environ.get("WFA_OPTS", "").split(",")):  # e.g. WFA_OPTS=duo=1,blk_wide=0
+    k, v = kv.split("="); al.set_option(k, int(v))
 r = al.align_arrays(*data); r = al.align_arrays(*data)
 print(al.last_timing())
 PY

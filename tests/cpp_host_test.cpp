@@ -103,7 +103,10 @@ int main() {
             CHECK(em[i] == ew[i] && gm[i].Ops == want[i].Ops && gm[i].Score == want[i].Score && gm[i].TEnd == want[i].TEnd);
         }
         // per-pair submissions collected as one batch
-        for (size_t i = 0; i < 200; i++) CHECK(one->Submit(qs[i], ts[i]) == i);
+        for (size_t i = 0; i < 200; i++) {
+            uint64_t tk = ~0ull;
+            CHECK(one->Submit(qs[i], ts[i], &tk) && tk == i);
+        }
         std::vector<wfa::AlignmentResult> gs;
         std::vector<wfa::Error>           es2;
         CHECK(one->Collect(gs, es2) == 0 && gs.size() == 200);

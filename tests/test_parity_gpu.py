@@ -228,7 +228,8 @@ def test_unaligned_blob_offsets(built):
 
 @pytest.mark.parametrize("opts,kind", [({"blk": 16}, 3), ({"blk": 16, "bt_stream_min": 1, "bt_stream_single": 1}, 3),
                                        ({"blk": 16, "bt_stream_min": 1, "bt_stream_single": 1, "bt_stream": 4}, 3), ({"blk": 8}, 4),
-                                       ({"blk": 0}, 2), ({"blk": 0, "reg": 0}, 1), ({"packed": 0}, 0)])
+                                       ({"blk": 0}, 2), ({"blk": 0, "reg": 0}, 1), ({"packed": 0}, 0), ({"blk": 16, "duo": 1}, 8),
+                                       ({"blk": 16, "duo": 0}, 3)])
 def test_forward_kernel_variants(built, opts, kind):
     """Every forward kernel (blocked register-window with 16 / 8 lanes per pair, strided register-window, LDS-ring
     packed, generic; the blocked kernel also with the streamed backtrace forced on for this small batch) on one
@@ -940,7 +941,8 @@ def _arena_slot(fmt, i, k):
                                                    (300, 0.03, (2, 3, 1), None, 3), (600, 0.05, (8, 12, 4), (4, 10, 1), 3),
                                                    (150, 0.02, (4, 6, 2), None, 5), (120, 0.06, (4, 6, 2), (10, 50, 1), 5)])
 @pytest.mark.parametrize("census", [0, 1])
-def test_blocked_kernel_arena_word_for_word(built, length, err, pen, ad, fmt, census):
+@pytest.mark.parametrize("duo", [0, 1])
+def test_blocked_kernel_arena_word_for_word(built, length, err, pen, ad, fmt, census, duo):
     """The dominant kernel's stored state, not only its results: every compact backtrace word wfa_blk_kernel leaves in
     HBM (M tag, I and D tag bits, pre-extension offset) against what the oracle's wavefronts imply -- visited by the
     backtrace or not.  Covers wf-adaptive pruning (deleted cells must not be there with a source role), ragged lengths
@@ -956,8 +958,11 @@ def test_blocked_kernel_arena_word_for_word(built, length, err, pen, ad, fmt, ce
     t_len = np.where(cut & (np.arange(n) % 2 == 1), np.maximum(1, t_len - rng.integers(1, 25, n)), t_len).astype(np.uint32)
     al = _aligner(True, ad, pen)
     al.set_option("census", census)  # (two instances of the kernel: with and without the count of stored words)
+    if fmt == 5 and duo:
+        pytest.skip("short reads stay on the batched 8-lane instance")
+    al.set_option("duo", duo)  # wfa_duo_kernel (8 or 16 lanes per pair) writes the same arena as wfa_blk_kernel<16,1>
     got = al.align_arrays(blob, q_off, q_len, t_off, t_len)
-    assert al.last_timing().main_kernel_kind == (6 if fmt == 5 else 3)
+    assert al.last_timing().main_kernel_kind == (6 if fmt == 5 else (8 if duo else 3))
     g = np.gcd.reduce([pen[0], pen[1] + pen[2], pen[2]])
     oa = O.Aligner(O.make_params(*pen, global_alignment=True, adaptive=ad))
     checked = pairs = 0
@@ -999,7 +1004,7 @@ def test_penalties_the_reference_cannot_align_are_refused(built):
         al.close()
 
 
-@pytest.mark.parametrize("opts", [{}, {"prepack": 1}, {"overlap": 1}, {"narrow_long": 1}])
+@pytest.mark.parametrize("opts", [{}, {"prepack": 1}, {"overlap": 1}, {"narrow_long": 1}, {"duo": 1}, {"duo": 0}])
 def test_several_chunks_and_optional_paths(built, opts):
     """A pass cut into several chunks (each chunk's arenas are reused by the next: the default for batches that do not fit
     35 % of HBM, forced here with chunk_pairs), and the optional paths kept behind options: the pre-packing kernel, the
@@ -1016,3 +1021,65 @@ def test_several_chunks_and_optional_paths(built, opts):
         assert_batch_equal(al.align_arrays(*data), want, f"chunks opts={opts} rep={rep}")
     assert al.last_timing().n_main_launches == 5
     al.close()
+
+
+@pytest.mark.parametrize("length,err,n,ad", [(1000, 0.05, 60000, (10, 50, 1)), (1000, 0.05, 777, (10, 50, 1)), (700, 0.08, 20000, (10, 50, 1)),
+                                             (1000, 0.03, 20000, None), (400, 0.10, 20000, (10, 50, 1)), (1500, 0.04, 9000, (20, 100, 1)),
+                                             (1000, 0.05, 3, (10, 50, 1))])
+def test_duo_kernel_batches(built, length, err, n, ad):
+    """wfa_duo_kernel (a pair runs on 8 or 16 lanes and changes between the two; pairs are parked in LDS and resumed;
+    every wave prefetches its next pair) on batches large enough that every wave widens, narrows, parks and resumes many
+    times, plus tiny ones (fewer pairs than halves of one wave).  Twice through the same aligner over a poisoned arena
+    (the kernel zeroes nothing), every field and every CIGAR op against the oracle."""
+    import wfa_amd as w
+    from oracle import oracle as O
+    data = w.generate_pairs(seed=900 + length + n % 97, n_pairs=n, length=length, error_rate=err, n_threads=8)
+    want = O.align_batch(_oracle_params(True, ad), *data, n_threads=max(8, (os.cpu_count() or 8) // 2))
+    al = _aligner(True, ad)
+    al.set_option("duo", 1)
+    al.set_option("arena_poison", 1)
+    for rep in range(2):
+        got = al.align_arrays(*data)
+        assert al.last_timing().main_kernel_kind == 8
+        assert_batch_equal(got, want, f"duo L={length} err={err} n={n} ad={ad} rep={rep}")
+    al.close()
+
+
+def test_duo_kernel_ragged_lengths(built):
+    """Unequal lengths (windows that start off-centre and follow the band), overhangs that end at sequence ends (the exact
+    WF_NEXT), bands that outgrow a whole row (handed on), 15 % error pairs between easy ones, a small arena."""
+    import wfa_amd as w
+    from oracle import oracle as O
+    rng = np.random.default_rng(4242)
+    qs, ts = [], []
+    for i in range(6000):
+        L = int(rng.integers(250, 1400))
+        q = rng.integers(0, 4, L)
+        t = list(q)
+        for _ in range(int(L * (0.15 if i % 9 == 0 else 0.05))):
+            kind_e, pos = int(rng.integers(0, 3)), int(rng.integers(0, max(1, len(t))))
+            if kind_e == 0 and t:
+                t[pos] = int(rng.integers(0, 4))
+            elif kind_e == 1:
+                t.insert(pos, int(rng.integers(0, 4)))
+            elif t:
+                del t[pos]
+        if i % 7 == 0:
+            extra = list(rng.integers(0, 4, int(rng.integers(1, 120))))
+            t = (extra + t) if i % 2 else (t + extra)
+        if i % 11 == 0:
+            q = q[int(rng.integers(0, 100)):]
+        qs.append(bytes(b"ACGT"[c] for c in q))
+        ts.append(bytes(b"ACGT"[c] for c in t))
+    data = w.make_blob(qs, ts)
+    for ad in ((10, 50, 1), None):
+        want = O.align_batch(_oracle_params(True, ad), *data, n_threads=max(8, (os.cpu_count() or 8) // 2))
+        for small in (False, True):
+            al = _aligner(True, ad)
+            al.set_option("duo", 1)
+            if small:
+                al.set_option("packed_arena_bytes", 24 * 1024)
+            got = al.align_arrays(*data)
+            assert al.last_timing().main_kernel_kind == 8
+            assert_batch_equal(got, want, f"duo ragged ad={ad} small={small}")
+            al.close()

@@ -987,14 +987,44 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
     }
 }
 
-// The sequences of a chunk, 2-bit packed once, by the whole GPU, before the forward kernel starts (0.4 ms per 1e6 x 1 kbp
-// pairs: 2 GB read, 0.5 GB written).  One wave per pair.  The forward kernel's refill -- where a group's new pair stalls the
-// other pairs of its wave -- then is a queue atomic plus ONE round of loads and no arithmetic (it was a fifth of the wave time:
-// lengths and offsets, then the bytes, then ~100 vector instructions per 16 bases).
+// The sequences of a chunk, 2-bit packed once, by the whole GPU, before the forward kernel starts: 2 GB read, 0.5 GB
+// written per 1e6 x 1 kbp pairs.  One workgroup per pair, one thread per packed word (16 bases): four or five aligned
+// dword loads, a funnel shift, and per dword ten integer instructions -- the 2-bit codes are (byte >> 1) & 3, gathered
+// with two shift-or steps; a byte outside ACGT shows when the code's canonical letter (one v_perm_b32 through "ACTG")
+// differs from the byte.  (Round 2's version ran stage_word(), ~100 instructions per word, and was bound by them:
+// 0.89 ms; the forward kernels' own refill still uses stage_word.)  slot = {n, m, status, 0, q words [SW], t words [SW]}.
+WFA_DEV uint32_t prepack_word(const uint8_t *blob, uint64_t off, uint32_t len, uint32_t jw, bool &bad) {
+    const uint32_t nw = (len + 15u) >> 4;
+    if (jw >= nw) return 0u;
+    const uintptr_t a  = (uintptr_t)(blob + off) + 16ull * jw;
+    const uint32_t *p  = (const uint32_t *)(a & ~(uintptr_t)3);
+    const uint32_t  sh = (uint32_t)(a & 3) * 8u;
+    const uint32_t  nb = (len - 16u * jw) < 16u ? (len - 16u * jw) : 16u;
+    const uint32_t  nd = ((uint32_t)(a & 3) + nb + 3u) >> 2;  // dwords that hold valid bytes: 1..5
+    uint32_t        d[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) d[i] = ((uint32_t)i < nd) ? p[i] : 0u;
+    uint32_t word = 0u;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        uint32_t w = __funnelshift_r(d[i], d[i + 1], sh);
+        if (nb < 16u) {  // the last word of a sequence: bytes past its end count as 'A' (code 0)
+            const uint32_t mb = nb > 4u * i ? (nb - 4u * i < 4u ? nb - 4u * i : 4u) : 0u;
+            const uint32_t km = mb >= 4u ? 0xFFFFFFFFu : ((1u << (8u * mb)) - 1u);
+            w = (w & km) | (0x41414141u & ~km);
+        }
+        const uint32_t x = (w >> 1) & 0x03030303u;
+        bad |= __builtin_amdgcn_perm(0u, 0x47544341u, x) != w;  // code -> 'A' 'C' 'T' 'G'
+        uint32_t y = x | (x >> 6);
+        y          = (y & 0xFu) | ((y >> 12) & 0xF0u);
+        word |= y << (8 * i);
+    }
+    return word;
+}
+
 __global__ __launch_bounds__(256) void wfa_prepack_kernel(const KParams P, uint32_t *out, uint32_t SW, uint32_t PW) {
-    const uint32_t wi = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
-    if (wi >= P.chunk_n) return;
-    const uint32_t pr = P.chunk_first + wi;
+    const uint32_t wi = blockIdx.x, w = threadIdx.x;
+    const uint32_t pr = P.work ? P.work[wi] : P.chunk_first + wi;
     const uint32_t nq = P.q_len[pr], mt = P.t_len[pr];
     uint32_t       status = ST_PENDING;
     if (nq == 0 || mt == 0)
@@ -1007,11 +1037,13 @@ __global__ __launch_bounds__(256) void wfa_prepack_kernel(const KParams P, uint3
     bool            bad  = false;
     if (status == ST_PENDING) {
         const uint64_t qo = P.q_off[pr], to = P.t_off[pr];
-        for (uint32_t w = lane; w < SW; w += 64u) slot[4u + w] = stage_word(P.blob, qo, nq, w, bad);
-        for (uint32_t w = lane; w < SW; w += 64u) slot[4u + SW + w] = stage_word(P.blob, to, mt, w, bad);
+        for (uint32_t v = w; v < 2u * SW; v += blockDim.x) {
+            const bool isq = v < SW;
+            slot[4u + v]   = prepack_word(P.blob, isq ? qo : to, isq ? nq : mt, isq ? v : v - SW, bad);
+        }
     }
-    if (__ballot(bad) != 0ull) status = ST_REDO_BYTES;  // a byte outside ACGT: the byte-compare path takes the pair
-    if (lane == 0u) slot[0] = nq, slot[1] = mt, slot[2] = status, slot[3] = 0u;
+    if (__syncthreads_or(bad ? 1 : 0)) status = ST_REDO_BYTES;  // a byte outside ACGT: the byte-compare path takes the pair
+    if (w == 0u) slot[0] = nq, slot[1] = mt, slot[2] = status, slot[3] = 0u;
 }
 
 }  // namespace wfa

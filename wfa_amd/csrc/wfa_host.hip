@@ -8,6 +8,7 @@
 #include "wfa_packed.hpp"
 #include "wfa_reg.hpp"
 #include "wfa_blk.hpp"
+#include "wfa_duo.hpp"
 #include "wfa_team.hpp"
 #include "wfa_finalize.hpp"
 #include "wfa_gen_dev.hpp"
@@ -130,10 +131,13 @@ struct wfahip_ctx {
     int64_t       opt_prepack              = 0;   // 1: a chunk's sequences are 2-bit packed by a kernel of their own before the 16-lane forward kernel
                                                   // (measured: forward 19.96 -> 19.54 ms per 1e6 x 1 kbp pairs, but the packing kernel takes 0.9 ms: off)
     int64_t       opt_narrow_long          = 0;   // experiment: reads of any length start on the 8-lanes-per-pair instance (32-diagonal windows)
+    int64_t       opt_duo                  = 0;   // 1: reads of 240+ bases start on wfa_duo_kernel (8 or 16 lanes per pair, changing while the pair runs)
     int64_t       opt_census               = 0;   // 1: the sub-wave forward kernels count the wavefront words they store (REC_CELLS, timing.cells_stored)
     int64_t       opt_learn                = 1;   // 1: long pairs start on the arena level the previous call of the same kind ended on
     uint64_t      learn_key                = 0;   // workload class of the last call that used the team kernel
     int           learn_level              = 0;   // ... and the level by which 90 % of its long pairs had finished
+    uint32_t      learn_calls              = 0;   // calls of that class since the level was learned (every 4th one probes one level lower)
+    int64_t       opt_mem_limit            = 0;   // tests: pretend the device has this many bytes (arena budgets follow)
     int           force_mode               = -1;  // debug: start the ladder in this mode
     // debug / parity aid (wfahip_debug_compact_arena): where the first chunk of the most recent first pass left its arena
     const uint32_t *dbg_arena = nullptr;
@@ -152,6 +156,9 @@ int ensure(wfahip_ctx *ctx, DevBuf &b, size_t bytes) {
         HIP_TRY(hipFree(b.p));
         b.p = nullptr, b.bytes = 0;
     }
+    // (wfahip_debug_compact_arena keeps pointers into the first pass's arena and meta buffers: a later retry or ladder
+    // pass that re-allocates either of them ends that snapshot instead of leaving it dangling)
+    if (&b == &ctx->arena || &b == &ctx->meta) ctx->dbg_arena = nullptr, ctx->dbg_meta = nullptr, ctx->dbg_n = 0;
     size_t want = std::max<size_t>(bytes, 256);
     HIP_TRY(hipMalloc(&b.p, want));
     b.bytes = want;
@@ -211,6 +218,7 @@ struct Job {
     bool                  all;    // identity work list over all pairs
     std::vector<uint32_t> pairs;
     uint32_t              max_len = 0;  // length bound of these pairs (0 = the batch's)
+    bool                  hint    = false;  // `level` came from an earlier call of the class (learn), not from a failed level below it
 };
 
 constexpr size_t LDS_MAX_BYTES = 160 * 1024;
@@ -415,8 +423,18 @@ static int set_option_impl(wfahip_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_narrow_long = value;
     else if (k == "census")
         ctx->opt_census = value;
+    else if (k == "duo")
+        ctx->opt_duo = value;
     else if (k == "learn")
         ctx->opt_learn = value, ctx->learn_key = 0;
+    else if (k == "mem_limit") {
+        ctx->opt_mem_limit = value;
+        hipDeviceProp_t prop;
+        if (value > 0)
+            ctx->total_mem = (size_t)value;
+        else if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess)
+            ctx->total_mem = prop.totalGlobalMem;
+    }
     else
         return WFAHIP_ERR_BAD_ARG;
     return WFAHIP_OK;
@@ -606,11 +624,15 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             const bool     blk_batch    = (kind == 3 || kind == 6) && seq_words <= 16 && ctx->opt_blk_batch != 0;
             if (kind == 6 && !blk_batch && ctx->opt_narrow_long == 0) return WFAHIP_ERR_INTERNAL;
             if (ctx->opt_fail_pass == kind) return WFAHIP_ERR_OOM;  // (fault injection, tests only)
-            const size_t   lds_bytes    = blk_batch ? (size_t)(kind == 6 ? 8 : 4) * BLK_BATCH * (2 * seq_words + 8) * 4 + 16
+            // kind 8 (wfa_duo_kernel): sequences come pre-packed, slot = 4 header words + 2 x (even) words per sequence
+            const uint32_t duo_sw       = (seq_words + 1u) & ~1u, duo_pw = 4u + 2u * duo_sw;
+            if (kind == 8 && (duo_pw > 256u || blk_batch)) return WFAHIP_ERR_INTERNAL;
+            const size_t   lds_bytes    = kind == 8 ? (size_t)duo_lds_words(duo_pw) * 4
+                                          : blk_batch ? (size_t)(kind == 6 ? 8 : 4) * BLK_BATCH * (2 * seq_words + 8) * 4 + 16
                                           : kind == 6 ? (size_t)seq_words * 2 * 4 * 8 + 16
                                           : kind == 5 ? (size_t)seq_words * 2 * 4 + 16
                                                       : (kind >= 3 ? lds_d : (kind == 2 ? lds_c : lds_b));
-            const uint32_t pairs_wave   = kind == 5 ? 1 : (kind == 4 || kind == 6 ? 8 : (kind >= 2 ? 4 : 2));
+            const uint32_t pairs_wave   = kind == 5 ? 1 : (kind == 4 || kind == 6 || kind == 8 ? 8 : (kind >= 2 ? 4 : 2));
             // blocked kernels: fixed-pitch arena, no directory.  64-diagonal window: 16 words per base = 250 scores at
             // 1 kbp; 256-diagonal window (kind 5, the retry rung): 128 words per base = 500 scores at 1 kbp
             const uint64_t words        = kind == 5   ? std::max<uint64_t>((words_dir * 16 + 511) & ~511ull, 8192)
@@ -619,7 +641,8 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             P.arena_words = words, P.compact_fmt = kind == 6 ? 5u : kind == 5 ? 4u : (kind >= 3 ? (WFA_BLK_TILED ? 3u : 1u) : 0u);
             const uint32_t waves_lds    = (uint32_t)std::min<size_t>(32, LDS_MAX_BYTES / lds_bytes);
             const bool     overlap      = ctx->opt_overlap != 0;
-            uint32_t       waves_per_cu = kind == 4 ? std::min<uint32_t>(waves_lds, 12)
+            uint32_t       waves_per_cu = kind == 8 ? std::min<uint32_t>(waves_lds, 4 * WFA_DUO_WAVES)
+                                          : kind == 4 ? std::min<uint32_t>(waves_lds, 12)
                                           : kind >= 2 ? std::min<uint32_t>(waves_lds, 20)
                                                       : (overlap ? std::min<uint32_t>(waves_lds, 24) : waves_lds);
             if (ctx->opt_packed_waves_per_cu > 0)
@@ -634,9 +657,14 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             if (ctx->opt_chunk_pairs > 0) chunk = std::min<uint64_t>(chunk, (uint64_t)ctx->opt_chunk_pairs);
             const uint64_t n_chunks = (count + chunk - 1) / chunk;
             const uint32_t n_buf    = (overlap && n_chunks > 1) ? 2 : 1;
-            int rc2 = ensure(ctx, arena_buf, (size_t)(words * 4ull * chunk * n_buf));
+            // (retry passes: how many pairs are handed on varies a little from call to call -- which pairs share a wave
+            // is a matter of timing -- so their buffers get a quarter of headroom instead of being re-allocated, tens
+            // of milliseconds for a few GB, whenever a call needs a few pairs more than the one before)
+            const uint64_t chunk_alloc = list ? chunk + chunk / 4 + 64 : chunk;
+            int rc2 = WFAHIP_OK;
+            if (arena_buf.bytes < (size_t)(words * 4ull * chunk * n_buf)) rc2 = ensure(ctx, arena_buf, (size_t)(words * 4ull * chunk_alloc * n_buf));
             if (rc2) return rc2;
-            if ((rc2 = ensure(ctx, meta_buf, chunk * 16 * n_buf))) return rc2;
+            if (meta_buf.bytes < chunk * 16 * n_buf && (rc2 = ensure(ctx, meta_buf, chunk_alloc * 16 * n_buf))) return rc2;
             detach_bt = detach_bt && n_chunks == 1 && ctx->opt_tail_overlap != 0;
             // streamed backtrace: a few waves walk finished pairs while the forward kernel is still running
             // (off unless asked for since round 2: with the forward pass at 20 ms per 1e6 pairs the write-through row
@@ -686,11 +714,12 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                 }
                 // the chunk's sequences 2-bit packed up front (unbatched 16-lane first pass over a range of pairs)
                 P.prepack = nullptr, P.prepack_words = 0;
-                if (kind == 3 && !blk_batch && !list && ctx->opt_prepack != 0) {
-                    const uint32_t pw = 4u + 2u * seq_words;
+                P.lds_seq_words = kind == 8 ? duo_sw : seq_words;
+                if ((kind == 3 && !blk_batch && !list && ctx->opt_prepack != 0) || kind == 8) {
+                    const uint32_t pw = 4u + 2u * P.lds_seq_words;
                     if ((rc2 = ensure(ctx, ctx->prepack, (size_t)chunk * pw * 4))) return rc2;
-                    hipLaunchKernelGGL(wfa_prepack_kernel, dim3((uint32_t)((cn + 3) / 4)), dim3(256), 0, st, P,
-                                       static_cast<uint32_t *>(ctx->prepack.p), seq_words, pw);
+                    hipLaunchKernelGGL(wfa_prepack_kernel, dim3((uint32_t)cn), dim3(std::min<uint32_t>(256u, (2u * P.lds_seq_words + 63u) & ~63u)), 0, st, P,
+                                       static_cast<uint32_t *>(ctx->prepack.p), P.lds_seq_words, pw);
                     HIP_TRY(hipGetLastError());
                     P.prepack = static_cast<const uint32_t *>(ctx->prepack.p), P.prepack_words = pw;
                 }
@@ -699,7 +728,11 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                 // (tests: the sub-wave kernels zero nothing -- no word the backtrace reads may be one they did not write)
                 if (ctx->opt_arena_poison) HIP_TRY(hipMemsetAsync(P.arena, 0xA5, (size_t)(words * 4ull * cn), st));
                 HIP_TRY(hipEventRecord(evFa, st));
-                if (kind == 5)
+                if (kind == 8 && P.census)
+                    hipLaunchKernelGGL((wfa_duo_kernel<true>), dim3(grid), dim3(64), lds_bytes, st, P);
+                else if (kind == 8)
+                    hipLaunchKernelGGL((wfa_duo_kernel<false>), dim3(grid), dim3(64), lds_bytes, st, P);
+                else if (kind == 5)
                     hipLaunchKernelGGL((wfa_blk_kernel<64, 1>), dim3(grid), dim3(64), lds_bytes, st, P);
                 else if (kind == 4)
                     hipLaunchKernelGGL((wfa_blk_kernel<8, 1>), dim3(grid), dim3(64), lds_bytes, st, P);
@@ -754,6 +787,7 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                 ctx->timing.n_launches += 2;
             }
             P.work = nullptr;
+            P.lds_seq_words = seq_words;
             return WFAHIP_OK;
         };
 
@@ -764,7 +798,10 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             const bool narrow1 = can_d && ctx->opt_blk == 16 && ctx->opt_blk_narrow != 0 &&
                                  ((ctx->opt_blk_batch != 0 && max_len < 200 && seq_words <= 16) ||
                                   (ctx->opt_narrow_long != 0 && (size_t)seq_words * 2 * 4 * 8 + 16 <= 8 * 1024));
-            const int  kind1   = narrow1 ? 6 : (can_d ? (ctx->opt_blk == 8 ? 4 : 3) : (can_c ? 2 : 1));
+            // reads of 240+ bases: the variable-lanes kernel (its slots hold at most 126 packed words per sequence)
+            const bool duo1    = can_d && ctx->opt_blk == 16 && !narrow1 && ctx->opt_duo != 0 && seq_words > 16 &&
+                                 4u + 2u * ((seq_words + 1u) & ~1u) <= 256u;
+            const int  kind1   = duo1 ? 8 : narrow1 ? 6 : (can_d ? (ctx->opt_blk == 8 ? 4 : 3) : (can_c ? 2 : 1));
             // Pilot: on a large batch with wf-adaptive off the first 4 096 pairs go first.  When most of them leave the
             // 64-diagonal window the rest does not start there only to be handed on: it goes straight to the
             // wave-per-pair kernel (256 diagonals) if that one takes most of the pilot's leftovers, else to the
@@ -832,12 +869,14 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             // once, backtrace included) than through another forward + backtrace pass; beyond that the LDS-ring
             // kernel's throughput wins.
             const uint64_t resident_generic = (uint64_t)ctx->num_cus * 32;
-            if (kind1 == 6) {  // band / arena failures of the 32-diagonal instance -> the 64-diagonal one
+            if (kind1 == 6 || kind1 == 8) {  // band / arena failures of the 32-diagonal instance -> the 64-diagonal one; pairs the
+                                             // variable-lanes kernel handed on (no park record free, or a band wider than a
+                                             // row) -> a 64-diagonal window of their own
                 std::vector<uint32_t> lst;
                 std::vector<uint64_t> keep, r2;
                 for (uint64_t e : redo1) {
                     const uint32_t stw = (uint32_t)(e >> 32);
-                    if (stw == ST_REDO_BAND || stw == ST_REDO_ARENA) lst.push_back((uint32_t)e);
+                    if (stw == ST_REDO_BAND || (stw == ST_REDO_ARENA && kind1 == 6)) lst.push_back((uint32_t)e);
                     else keep.push_back(e);
                 }
                 if (!lst.empty()) {
@@ -924,8 +963,15 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
     if (!packed_done) {
         Job j;
         j.mode = ctx->force_mode == 1 ? 1 : 0, j.level = 0, j.all = true;
-        if (ctx->opt_learn && !debug_single && ctx->learn_key == lkey && ctx->opt_team_min_len > 0 && max_len >= (uint64_t)ctx->opt_team_min_len)
+        // The learned level is a HINT about speed, never about results: a call may start there, but (a) every fourth call of
+        // the class starts one level lower, so that one hard batch does not pin the class to large slots and few teams
+        // for ever (a start level can only be confirmed or raised by the call that uses it), and (b) a start level whose
+        // slot does not fit this call's lengths is stepped down below instead of failing the pairs.
+        if (ctx->opt_learn && !debug_single && ctx->learn_key == lkey && ctx->opt_team_min_len > 0 && max_len >= (uint64_t)ctx->opt_team_min_len) {
             j.level = ctx->learn_level;
+            if (j.level > 0 && (++ctx->learn_calls & 3u) == 0u) j.level -= 1;
+            j.hint = j.level > 0;
+        }
         jobs.push_back(std::move(j));
     }
 
@@ -941,6 +987,12 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
         if (cr == 1) {  // sequences do not fit LDS: byte path for the whole job
             job.mode = 1;
             cr       = make_cfg(ctx, max_len, 1, job.level, n_work, !P.global_alignment, cfg);
+        }
+        // a learned start level whose slot does not fit (the class buckets lengths by powers of two, slots scale with the
+        // length): climb down to the largest level that does, never straight to "no memory"
+        while (cr == 2 && job.hint && job.level > 0) {
+            job.level -= 1;
+            cr = make_cfg(ctx, max_len, job.mode, job.level, n_work, !P.global_alignment, cfg);
         }
         if (debug_single) cfg.slots = 1;
         // Wide wavefronts: a team of workgroups per pair (wfa_team_kernel) instead of one workgroup per pair.
@@ -1068,7 +1120,10 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, ctx->evA, ctx->evB));
         ctx->timing.kernel_ms += ms;
-        if (first) ctx->timing.main_kernel_ms = ms, ctx->timing.n_main_launches = 1, first = false;
+        if (first) {
+            ctx->timing.main_kernel_ms = ms, ctx->timing.n_main_launches = 1, first = false;
+            if (team_T > 0) ctx->timing.main_kernel_kind = 7;  // wfa_team_kernel (bench.py names the dominant kernel by this)
+        }
         ctx->timing.n_launches++;
 
         const uint32_t n_redo = hctrl[1];
@@ -1091,7 +1146,10 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
         }
         if (debug_single) break;
     }
-    if (learned_now >= 0) ctx->learn_key = lkey, ctx->learn_level = learned_now;
+    if (learned_now >= 0) {
+        if (ctx->learn_key != lkey || ctx->learn_level != learned_now) ctx->learn_calls = 0;
+        ctx->learn_key = lkey, ctx->learn_level = learned_now;
+    }
     if (ctx->bt_pending) HIP_TRY(hipStreamWaitEvent(st, ctx->evBtB, 0));
     HIP_TRY(hipEventRecord(ctx->ev1, st));
 
@@ -1138,8 +1196,10 @@ extern "C" int wfahip_align_batch_device(wfahip_ctx *ctx, const wfahip_params *p
 
 static void results_zero(wfahip_results *r) { std::memset(r, 0, sizeof *r); }
 
-// Result arrays are plain malloc blocks (a binding may free() them itself), but wfahip_results_free keeps the large
-// ones for the next call instead of returning them to the system: a fresh 0.7 GB ops array costs its download
+// Result arrays are malloc blocks OWNED BY THE LIBRARY: a binding must hand them back through wfahip_results_free and
+// never free() them itself -- blocks that circulate through the cache below are page-locked (hipHostRegister), and
+// freeing a registered block behind the runtime's back leaves a stale registration.  wfahip_results_free keeps the
+// large ones for the next call instead of returning them to the system: a fresh 0.7 GB ops array costs its download
 // twice over in first-touch page faults (the reference recycles its results the same way, wfa_cigar.go:92).
 namespace {
 struct ResBlock { void *p; size_t bytes; };
@@ -1371,7 +1431,10 @@ static int align_batch_impl(wfahip_ctx *ctx, const wfahip_params *p, const uint8
     uint64_t sum_len = 0;
     for (uint64_t i = 0; i < n_pairs; i++) {
         if (q_len[i] <= WFAHIP_MAX_SEQ_LEN && t_len[i] <= WFAHIP_MAX_SEQ_LEN && q_len[i] && t_len[i]) {
-            if (q_off[i] * osc + q_len[i] > blob_bytes || t_off[i] * osc + t_len[i] > blob_bytes) return WFAHIP_ERR_BAD_ARG;
+            // (written so that a hostile 64-bit offset cannot wrap the sum around)
+            if (q_off[i] > blob_bytes / osc || q_len[i] > blob_bytes - q_off[i] * osc || t_off[i] > blob_bytes / osc ||
+                t_len[i] > blob_bytes - t_off[i] * osc)
+                return WFAHIP_ERR_BAD_ARG;
             max_len = std::max(max_len, std::max(q_len[i], t_len[i]));
             sum_len += (uint64_t)q_len[i] + t_len[i];
         }

@@ -114,11 +114,16 @@ int align_multi_impl(wfahip_multi *m, const wfahip_params *p, const uint8_t *seq
         sh[k].first = at, sh[k].count = end - at;
         at = end;
     }
+    // Layout assumption: the pairs of a batch lie in the blob in pair order (make_blob, the generator, a cgo binding
+    // that appends pair after pair), so a shard's sequences span about its share of the blob and only blob[lo, hi) is
+    // uploaded to its GPU.  Batches that share sequences between pairs (one target against many queries) or store
+    // them out of order are still aligned correctly, but every GPU may then receive most of the blob.
     for (Shard &s : sh) {
         uint64_t lo = blob_bytes, hi = 0;
         for (uint64_t i = s.first; i < s.first + s.count; i++) {
             if (!valid_pair(q_len[i], t_len[i])) continue;
-            if (q_off[i] + q_len[i] > blob_bytes || t_off[i] + t_len[i] > blob_bytes) return WFAHIP_ERR_BAD_ARG;
+            if (q_off[i] > blob_bytes || q_len[i] > blob_bytes - q_off[i] || t_off[i] > blob_bytes || t_len[i] > blob_bytes - t_off[i])
+                return WFAHIP_ERR_BAD_ARG;  // (no sum that a hostile 64-bit offset could wrap)
             lo = std::min(lo, std::min(q_off[i], t_off[i]));
             hi = std::max(hi, std::max(q_off[i] + q_len[i], t_off[i] + t_len[i]));
         }

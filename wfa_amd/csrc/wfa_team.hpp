@@ -656,11 +656,17 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
             if (aborted) return;
         }
         // ---- count stored cells across the team
-        if (tid == 0) red[10] = 0;
+        // (64 bits all the way: workgroup 0 alone stores more than 2^32 words of a long pair in solo / wave mode)
+        if (tid == 0) red[10] = 0, red[11] = 0;
         __syncthreads();
-        atomicAdd(reinterpret_cast<unsigned int *>(&red[10]), (unsigned int)(my_cells & 0xFFFFFFFFull));
+        {
+            unsigned long long wsum = my_cells;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) wsum += __shfl_xor(wsum, o, 64);
+            if ((tid & 63) == 0) atomicAdd(reinterpret_cast<unsigned long long *>(&red[10]), wsum);
+        }
         __syncthreads();
-        if (tid == 0) atomicAdd(reinterpret_cast<unsigned long long *>(ctl + 12), (unsigned long long)(uint32_t)red[10]);
+        if (tid == 0) atomicAdd(reinterpret_cast<unsigned long long *>(ctl + 12), *reinterpret_cast<unsigned long long *>(&red[10]));
         team_barrier(true);  // every row, the directory and the cell count are visible to workgroup 0
         if (aborted) return;
 

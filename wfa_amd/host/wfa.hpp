@@ -148,12 +148,15 @@ class Aligner {
 
     // new: hand in one pair (copied), get its ticket; Collect aligns everything submitted so far as ONE batch and
     // returns results[ticket] / errors[ticket].  Serves a per-pair loop like wfa-go/wfa-go.go:166-178 at batch speed.
-    uint64_t Submit(const std::string &q, const std::string &t) {
-        uint64_t ticket = 0;
-        if (ctx_)
-            wfahip_submit(ctx_, reinterpret_cast<const uint8_t *>(q.data()), (uint32_t)q.size(),
-                          reinterpret_cast<const uint8_t *>(t.data()), (uint32_t)t.size(), &ticket);
-        return ticket;
+    // Returns false (and leaves *ticket alone) when the pair could not be queued -- no context, out of host memory --
+    // so that the tickets of later pairs still line up with Collect's results.
+    bool Submit(const std::string &q, const std::string &t, uint64_t *ticket) {
+        uint64_t tk = 0;
+        if (!ctx_ || wfahip_submit(ctx_, reinterpret_cast<const uint8_t *>(q.data()), (uint32_t)q.size(),
+                                   reinterpret_cast<const uint8_t *>(t.data()), (uint32_t)t.size(), &tk) != WFAHIP_OK)
+            return false;
+        if (ticket) *ticket = tk;
+        return true;
     }
     int Collect(std::vector<AlignmentResult> &results, std::vector<Error> &errors) {
         const size_t n = ctx_ ? (size_t)wfahip_pending(ctx_) : 0;
