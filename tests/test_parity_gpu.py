@@ -228,7 +228,7 @@ def test_unaligned_blob_offsets(built):
 
 @pytest.mark.parametrize("opts,kind", [({"blk": 16}, 3), ({"blk": 16, "bt_stream_min": 1, "bt_stream_single": 1}, 3),
                                        ({"blk": 16, "bt_stream_min": 1, "bt_stream_single": 1, "bt_stream": 4}, 3), ({"blk": 8}, 4),
-                                       ({"blk": 0}, 2), ({"blk": 0, "reg": 0}, 1), ({"packed": 0}, 0), ({"blk": 16, "duo": 1}, 8),
+                                       ({"blk": 0}, 2), ({"blk": 0, "reg": 0}, 1), ({"packed": 0}, 0), ({"blk": 16, "duo": 2}, 8),
                                        ({"blk": 16, "duo": 0}, 3)])
 def test_forward_kernel_variants(built, opts, kind):
     """Every forward kernel (blocked register-window with 16 / 8 lanes per pair, strided register-window, LDS-ring
@@ -785,10 +785,13 @@ def test_full_size_parity_c3(built):
         # streamed backtrace -- waves of the forward launch walk finished pairs while the others are still aligning;
         # the hand-over between them must hold every time
         al.set_option("bt_stream_single", 1)
+        al.set_option("duo", 0)  # (the streaming instance belongs to wfa_blk_kernel<16,1>; batches this large start on wfa_duo_kernel)
         for rep in range(3):
             assert_batch_equal(al.align_arrays(*data), want, f"full size L={length}, streamed, repeat {rep}")
             assert al.last_timing().cells_stored == cells
         al.set_option("bt_stream_single", 0)
+        assert_batch_equal(al.align_arrays(*data), want, f"full size L={length}, wfa_blk_kernel<16,1>")
+        al.set_option("duo", 1)
         # the retry passes run beside the first pass's backtrace kernel: same records and same cell census as the
         # serial schedule
         al.set_option("tail_overlap", 0)
@@ -960,7 +963,7 @@ def test_blocked_kernel_arena_word_for_word(built, length, err, pen, ad, fmt, ce
     al.set_option("census", census)  # (two instances of the kernel: with and without the count of stored words)
     if fmt == 5 and duo:
         pytest.skip("short reads stay on the batched 8-lane instance")
-    al.set_option("duo", duo)  # wfa_duo_kernel (8 or 16 lanes per pair) writes the same arena as wfa_blk_kernel<16,1>
+    al.set_option("duo", 2 * duo)  # wfa_duo_kernel (8 or 16 lanes per pair) writes the same arena as wfa_blk_kernel<16,1>
     got = al.align_arrays(blob, q_off, q_len, t_off, t_len)
     assert al.last_timing().main_kernel_kind == (6 if fmt == 5 else (8 if duo else 3))
     g = np.gcd.reduce([pen[0], pen[1] + pen[2], pen[2]])
@@ -1004,7 +1007,7 @@ def test_penalties_the_reference_cannot_align_are_refused(built):
         al.close()
 
 
-@pytest.mark.parametrize("opts", [{}, {"prepack": 1}, {"overlap": 1}, {"narrow_long": 1}, {"duo": 1}, {"duo": 0}])
+@pytest.mark.parametrize("opts", [{}, {"prepack": 1}, {"overlap": 1}, {"narrow_long": 1}, {"duo": 2}, {"duo": 0}])
 def test_several_chunks_and_optional_paths(built, opts):
     """A pass cut into several chunks (each chunk's arenas are reused by the next: the default for batches that do not fit
     35 % of HBM, forced here with chunk_pairs), and the optional paths kept behind options: the pre-packing kernel, the
@@ -1036,7 +1039,7 @@ def test_duo_kernel_batches(built, length, err, n, ad):
     data = w.generate_pairs(seed=900 + length + n % 97, n_pairs=n, length=length, error_rate=err, n_threads=8)
     want = O.align_batch(_oracle_params(True, ad), *data, n_threads=max(8, (os.cpu_count() or 8) // 2))
     al = _aligner(True, ad)
-    al.set_option("duo", 1)
+    al.set_option("duo", 2)
     al.set_option("arena_poison", 1)
     for rep in range(2):
         got = al.align_arrays(*data)
@@ -1076,10 +1079,45 @@ def test_duo_kernel_ragged_lengths(built):
         want = O.align_batch(_oracle_params(True, ad), *data, n_threads=max(8, (os.cpu_count() or 8) // 2))
         for small in (False, True):
             al = _aligner(True, ad)
-            al.set_option("duo", 1)
+            al.set_option("duo", 2)
             if small:
                 al.set_option("packed_arena_bytes", 24 * 1024)
             got = al.align_arrays(*data)
             assert al.last_timing().main_kernel_kind == 8
             assert_batch_equal(got, want, f"duo ragged ad={ad} small={small}")
             al.close()
+
+
+@pytest.mark.timeout(900)
+def test_learned_start_level_is_only_a_hint(built):
+    """The arena level a context learns for a class of long pairs (option learn, on by default) may speed a call up but
+    never changes its result: after a hard batch an easy one of the same class still aligns and -- every
+    fourth call -- probes a lower start level, so the class is not pinned to large slots for ever; and a batch of the
+    same class whose pairs are twice as long (slots scale with the length, the class buckets lengths by powers of two)
+    steps the start level down instead of reporting "no memory".  The device is made to look small (mem_limit) so that the
+    ladder reaches its one-slot-per-level region with 9-16 kbp pairs."""
+    import wfa_amd as w
+    from oracle import oracle as O
+    hard = w.generate_pairs(seed=71, n_pairs=4, length=9000, error_rate=0.12)
+    easy = w.generate_pairs(seed=72, n_pairs=4, length=8400, error_rate=0.01)
+    longer = w.generate_pairs(seed=73, n_pairs=3, length=15500, error_rate=0.10)
+    op = _oracle_params(False, (10, 50, 1))
+    want = {k: O.align_batch(op, *d, n_threads=8) for k, d in (("hard", hard), ("easy", easy), ("longer", longer))}
+    al = _aligner(False, (10, 50, 1))
+    al.set_option("mem_limit", 3 << 30)
+    assert_batch_equal(al.align_arrays(*hard), want["hard"], "hard, first call")
+    assert al.last_timing().reserved == 0  # nothing learned yet
+    assert_batch_equal(al.align_arrays(*hard), want["hard"], "hard, second call")
+    learned = al.last_timing().reserved
+    starts = []
+    for i in range(9):
+        assert_batch_equal(al.align_arrays(*easy), want["easy"], f"easy call {i} after the hard one")
+        starts.append(al.last_timing().reserved)
+    if learned > 0:
+        assert min(starts) < learned and starts[-1] < learned, (learned, starts)  # the hint decays
+    assert_batch_equal(al.align_arrays(*hard), want["hard"], "hard again")
+    assert_batch_equal(al.align_arrays(*hard), want["hard"], "hard again (start level learned)")
+    got = al.align_arrays(*longer)
+    assert (got.status == 0).all(), got.status  # never "no memory" straight from a learned start level
+    assert_batch_equal(got, want["longer"], "twice as long, same class")
+    al.close()

@@ -151,7 +151,10 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) void wfa_duo_kernel(const KParam
     uint32_t buf_free  = (1u << DUO_BUFS) - 1u;  // sequence buffers nobody owns
     uint32_t park_used = 0u;                     // park records in use
     // prefetch pipeline (stages overlap: one new pair per iteration in steady state, three iterations of latency)
-    bool     pf_tok_v = false, pf_ld_v = false, pf_staged = false, pf_dry = false;  // queue atomic in flight / slot loads in flight / a pair staged in LDS / queue exhausted
+    // (one word of flags, not four bools: hipcc merges the stores to two bools into one store through a selected address,
+    // which pins both in scratch memory -- two scratch loads per score step)
+    constexpr uint32_t PF_TOK = 1u, PF_LD = 2u, PF_STAGED = 4u, PF_DRY = 8u;  // queue atomic in flight / slot loads in flight / a pair staged in LDS / queue exhausted
+    uint32_t pf = 0u;
     uint32_t pf_tok = 0u, pf_ld_idx = 0u, pf_idx = 0u, pf_buf = 0u;
     uint4    pf_w = make_uint4(0u, 0u, 0u, 0u);  // (a slot is at most 256 words: one 16-byte load per lane)
 
@@ -200,27 +203,36 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) void wfa_duo_kernel(const KParam
         constexpr int ph  = decltype(ph_c)::value;
         constexpr int NEW = (ph + 3) & 3;  // ring slot of the newest row; M[ph] is the oldest (replaced by the next step)
         // ---------------------------------------------------------------- prefetch of the next pair, one stage per call
-        if (pf_ld_v && !pf_staged) {  // the words loaded an iteration ago go to a spare LDS buffer
+        // (wave-uniform by construction; said so explicitly, or hipcc keeps them in vector registers)
+        pf        = (uint32_t)__builtin_amdgcn_readfirstlane((int)pf);
+        park_used = (uint32_t)__builtin_amdgcn_readfirstlane((int)park_used);
+        buf_free  = (uint32_t)__builtin_amdgcn_readfirstlane((int)buf_free);
+        if ((pf & (PF_LD | PF_STAGED)) == PF_LD) {  // the words loaded an iteration ago go to a spare LDS buffer
             pf_buf = (uint32_t)__builtin_ctz(buf_free);
             buf_free &= buf_free - 1u;
             uint32_t *const dst = lds + pf_buf * PW;
             if ((uint32_t)lane * 4u < PW) *reinterpret_cast<uint4 *>(dst + lane * 4) = pf_w;
-            pf_idx = pf_ld_idx, pf_staged = true, pf_ld_v = false;
+            pf_idx = pf_ld_idx, pf = (pf | PF_STAGED) & ~PF_LD;
         }
-        if (pf_tok_v && !pf_ld_v) {  // the queue entry claimed an iteration ago: its slot's words into registers
+        if ((pf & (PF_TOK | PF_LD)) == PF_TOK) {  // the queue entry claimed an iteration ago: its slot's words into registers
+            // (the atomic below is inline assembly, so the compiler does not know a result is outstanding: it was issued a
+            // whole score step ago, and this wait also covers nothing the step would not have waited for by now)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_tok)::"memory");
             pf_ld_idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)pf_tok);
-            pf_tok_v  = false;
-            if (pf_ld_idx >= P.chunk_n) {
-                pf_dry = true;
-            } else {
+            const bool have = pf_ld_idx < P.chunk_n;
+            if (have) {
                 const uint32_t *const slot = P.prepack + (uint64_t)pf_ld_idx * PW;
                 if ((uint32_t)lane * 4u < PW) pf_w = *reinterpret_cast<const uint4 *>(slot + lane * 4);
-                pf_ld_v = true;
             }
+            pf = (pf & ~PF_TOK) | (have ? PF_LD : PF_DRY);
         }
-        if (!pf_tok_v && !pf_dry) {
-            if (lane == 0) pf_tok = atomicAdd(P.queue_head, 1u);
-            pf_tok_v = true;
+        if ((pf & (PF_TOK | PF_DRY)) == 0u) {
+            // One queue entry, by lane 0, result NOT awaited here.  (atomicAdd() would be turned into a wave-aggregated
+            // atomic followed at once by s_waitcnt + v_readfirstlane -- a memory round trip during which the wave's
+            // eight pairs stand still, every four steps.)
+            if (lane == 0)
+                asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=v"(pf_tok) : "v"(0u), "v"(1u), "s"(P.queue_head) : "memory");
+            pf |= PF_TOK;
         }
         // ---------------------------------------------------------------- does anything have to change?
         // (a loop: a parked pair that had asked to widen itself asks again as soon as it has resumed, before it steps)
@@ -238,7 +250,7 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) void wfa_duo_kernel(const KParam
         }
         const unsigned long long m_ev = __ballot(touch || narrowable);
         m_free = __ballot(st == 0);
-        if (!(m_ev != 0ull || (m_free != 0ull && (park_used != 0u || pf_staged)))) break;
+        if (!(m_ev != 0ull || (m_free != 0ull && (park_used != 0u || (pf & PF_STAGED) != 0u)))) break;
         WFA_EVT(1, 1);
         {
             // ------------------------------------------------------------ what each pair wants
@@ -380,7 +392,7 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) void wfa_duo_kernel(const KParam
             }
             // ------------------------------------------------------------ free halves: parked pairs first, then the staged pair
             m_free = __ballot(st == 0);
-            while (m_free != 0ull && (park_used != 0u || pf_staged)) {
+            while (m_free != 0ull && (park_used != 0u || (pf & PF_STAGED) != 0u)) {
                 const uint32_t oct  = (uint32_t)__builtin_ctzll(m_free) >> 3;  // wave-uniform
                 const bool     mine = ((uint32_t)lane >> 3) == oct;
                 if (park_used != 0u) {
@@ -410,8 +422,11 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) void wfa_duo_kernel(const KParam
                 }
                 // the staged pair: header {n, m, status, -} + packed words, in LDS buffer pf_buf
                 const uint32_t *const hb = lds + pf_buf * PW;
-                const uint32_t        nq = hb[0], mt = hb[1], status = hb[2];
-                pf_staged = false;
+                // (readfirstlane: an LDS load counts as divergent, and a branch on it would turn this wave-uniform loop and
+                // every scalar it updates -- the prefetch flags, the buffer masks -- into per-lane values)
+                const uint32_t nq = (uint32_t)__builtin_amdgcn_readfirstlane((int)hb[0]), mt = (uint32_t)__builtin_amdgcn_readfirstlane((int)hb[1]);
+                const uint32_t status = (uint32_t)__builtin_amdgcn_readfirstlane((int)hb[2]);
+                pf &= ~PF_STAGED;
                 if (status != ST_PENDING) {  // empty / too long / does not fit / a byte outside ACGT: no alignment here
                     if (lane == 0) {
                         P.pair_meta[pf_idx] = make_uint4(status, 0u, 0u, 0u);
@@ -439,7 +454,7 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) void wfa_duo_kernel(const KParam
         }
         }
         WFA_STAMP(1);  // restructuring
-        return m_free == ~0ull && park_used == 0u && pf_dry && !pf_ld_v && !pf_staged;
+        return m_free == ~0ull && park_used == 0u && (pf & (PF_DRY | PF_LD | PF_STAGED)) == PF_DRY;
     };
 
     // ================================================================ one score step of every running pair

@@ -131,7 +131,10 @@ struct wfahip_ctx {
     int64_t       opt_prepack              = 0;   // 1: a chunk's sequences are 2-bit packed by a kernel of their own before the 16-lane forward kernel
                                                   // (measured: forward 19.96 -> 19.54 ms per 1e6 x 1 kbp pairs, but the packing kernel takes 0.9 ms: off)
     int64_t       opt_narrow_long          = 0;   // experiment: reads of any length start on the 8-lanes-per-pair instance (32-diagonal windows)
-    int64_t       opt_duo                  = 0;   // 1: reads of 240+ bases start on wfa_duo_kernel (8 or 16 lanes per pair, changing while the pair runs)
+    int64_t       opt_duo                  = 1;   // reads of 240+ bases start on wfa_duo_kernel (8 or 16 lanes per pair, changing while the pair runs):
+                                                  // 0 never, 1 for batches of at least opt_duo_min_pairs (below that its start-up -- a wave takes one new pair
+                                                  // per step -- costs more than the fuller rows give: 1e5 pairs 2.6 vs 2.3 ms), 2 always
+    int64_t       opt_duo_min_pairs        = 200000;
     int64_t       opt_census               = 0;   // 1: the sub-wave forward kernels count the wavefront words they store (REC_CELLS, timing.cells_stored)
     int64_t       opt_learn                = 1;   // 1: long pairs start on the arena level the previous call of the same kind ended on
     uint64_t      learn_key                = 0;   // workload class of the last call that used the team kernel
@@ -425,6 +428,8 @@ static int set_option_impl(wfahip_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_census = value;
     else if (k == "duo")
         ctx->opt_duo = value;
+    else if (k == "duo_min_pairs")
+        ctx->opt_duo_min_pairs = value;
     else if (k == "learn")
         ctx->opt_learn = value, ctx->learn_key = 0;
     else if (k == "mem_limit") {
@@ -799,7 +804,8 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                                  ((ctx->opt_blk_batch != 0 && max_len < 200 && seq_words <= 16) ||
                                   (ctx->opt_narrow_long != 0 && (size_t)seq_words * 2 * 4 * 8 + 16 <= 8 * 1024));
             // reads of 240+ bases: the variable-lanes kernel (its slots hold at most 126 packed words per sequence)
-            const bool duo1    = can_d && ctx->opt_blk == 16 && !narrow1 && ctx->opt_duo != 0 && seq_words > 16 &&
+            const bool duo1    = can_d && ctx->opt_blk == 16 && !narrow1 && seq_words > 16 &&
+                                 (ctx->opt_duo >= 2 || (ctx->opt_duo == 1 && (int64_t)n_pairs >= ctx->opt_duo_min_pairs)) &&
                                  4u + 2u * ((seq_words + 1u) & ~1u) <= 256u;
             const int  kind1   = duo1 ? 8 : narrow1 ? 6 : (can_d ? (ctx->opt_blk == 8 ? 4 : 3) : (can_c ? 2 : 1));
             // Pilot: on a large batch with wf-adaptive off the first 4 096 pairs go first.  When most of them leave the
@@ -972,6 +978,7 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             if (j.level > 0 && (++ctx->learn_calls & 3u) == 0u) j.level -= 1;
             j.hint = j.level > 0;
         }
+        ctx->timing.reserved = (uint32_t)j.level;  // (start level of the long-pair ladder: tests of the learned hint read it)
         jobs.push_back(std::move(j));
     }
 
