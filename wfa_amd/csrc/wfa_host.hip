@@ -139,7 +139,12 @@ struct wfahip_ctx {
     int64_t       opt_learn                = 1;   // 1: long pairs start on the arena level the previous call of the same kind ended on
     uint64_t      learn_key                = 0;   // workload class of the last call that used the team kernel
     int           learn_level              = 0;   // ... and the level by which 90 % of its long pairs had finished
-    uint32_t      learn_calls              = 0;   // calls of that class since the level was learned (every 4th one probes one level lower)
+    uint32_t      learn_calls              = 0;
+    // rows per pair of the blocked kernels' arenas: the default holds scores up to half the read length (error rates up
+    // to ~8 % at 4/6/2); a class of batches whose pairs ran out of rows gets twice / four times / eight times as many
+    // from its next call on (the call that finds out re-runs those pairs on the same kernel with four times the rows)
+    uint64_t      rows_key                 = 0;
+    uint32_t      rows_scale               = 1;   // calls of that class since the level was learned (every 4th one probes one level lower)
     int64_t       opt_mem_limit            = 0;   // tests: pretend the device has this many bytes (arena budgets follow)
     int           force_mode               = -1;  // debug: start the ladder in this mode
     // debug / parity aid (wfahip_debug_compact_arena): where the first chunk of the most recent first pass left its arena
@@ -620,6 +625,15 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
         // one pass over `count` pairs (identity range when list == nullptr); returns the {pair,status} redo entries
         // detach_bt: (first pass, one chunk) the backtrace kernel goes to stream2 and is only waited for at the very
         // end of the call, so the retry passes -- which use the second arena -- run beside it.
+        // (workload class of the learned row count: length bucket, penalties, wf-adaptive)
+        uint64_t rkey = 0;
+        {
+            uint32_t lb = 0;
+            while ((2u << lb) <= max_len) lb++;
+            rkey = 1ull | ((uint64_t)lb << 1) | ((uint64_t)P.adaptive << 9) | ((uint64_t)(P.x & 0xFFF) << 12) | ((uint64_t)(P.oe & 0xFFF) << 24) |
+                   ((uint64_t)(P.e & 0xFFF) << 36) | ((uint64_t)(P.max_dist_diff & 0xFFFF) << 48);
+        }
+        uint64_t arena_mult = (ctx->rows_key == rkey && ctx->opt_packed_arena_bytes <= 0) ? ctx->rows_scale : 1;  // rows per pair, in units of the default
         auto forward_pass = [&](int kind, const std::vector<uint32_t> *list, uint64_t first_pair, uint64_t count,
                                 std::vector<uint64_t> &redo_out, bool detach_bt) -> int {
             DevBuf &arena_buf = ctx->bt_pending ? ctx->arena2 : ctx->arena;
@@ -640,8 +654,8 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             const uint32_t pairs_wave   = kind == 5 ? 1 : (kind == 4 || kind == 6 || kind == 8 ? 8 : (kind >= 2 ? 4 : 2));
             // blocked kernels: fixed-pitch arena, no directory.  64-diagonal window: 16 words per base = 250 scores at
             // 1 kbp; 256-diagonal window (kind 5, the retry rung): 128 words per base = 500 scores at 1 kbp
-            const uint64_t words        = kind == 5   ? std::max<uint64_t>((words_dir * 16 + 511) & ~511ull, 8192)
-                                          : kind >= 3 ? std::max<uint64_t>((words_dir * 2 + 511) & ~511ull, 2048)
+            const uint64_t words        = kind == 5   ? std::max<uint64_t>((words_dir * 16 * arena_mult + 511) & ~511ull, 8192)
+                                          : kind >= 3 ? std::max<uint64_t>((words_dir * 2 * arena_mult + 511) & ~511ull, 2048)
                                                       : words_dir;
             P.arena_words = words, P.compact_fmt = kind == 6 ? 5u : kind == 5 ? 4u : (kind >= 3 ? (WFA_BLK_TILED ? 3u : 1u) : 0u);
             const uint32_t waves_lds    = (uint32_t)std::min<size_t>(32, LDS_MAX_BYTES / lds_bytes);
@@ -899,6 +913,33 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             }
             redo1.insert(redo1.end(), redo_w.begin(), redo_w.end());
             redo_w.clear();
+            if (kind1 >= 3) {
+                // pairs that ran out of arena rows (a score above half the read length: error rates beyond ~8 %): the same
+                // 64-diagonal kernel with four times the rows; and the class starts with more rows next time
+                std::vector<uint32_t> lst;
+                std::vector<uint64_t> keep, r2;
+                for (uint64_t e : redo1) ((uint32_t)(e >> 32) == ST_REDO_ARENA ? (void)lst.push_back((uint32_t)e) : (void)keep.push_back(e));
+                if (lst.size() * 64 > n_pairs && ctx->opt_packed_arena_bytes <= 0) {
+                    const uint32_t nxt = (uint32_t)std::min<uint64_t>(8, arena_mult * 2);
+                    if (ctx->rows_key != rkey || ctx->rows_scale < nxt) ctx->rows_key = rkey, ctx->rows_scale = nxt;
+                }
+                if (!lst.empty() && arena_mult <= 8 && ctx->opt_packed_arena_bytes <= 0) {
+                    const uint64_t keep_mult = arena_mult;
+                    arena_mult *= 4;
+                    rc = forward_pass(kind1 == 5 ? 5 : 3, &lst, 0, lst.size(), r2, false);
+                    arena_mult = keep_mult;
+                    if (rc) return rc;
+                    ctx->timing.n_packed_pairs += (uint32_t)(lst.size() - r2.size());
+                    keep.insert(keep.end(), r2.begin(), r2.end());
+                    redo1.swap(keep);
+                    if (wide_ok) {  // (what outgrows the 64-diagonal window on the way)
+                        const int wv = wide_pass(redo1);
+                        if (wv < 0) return wv;
+                    }
+                }
+            }
+            redo1.insert(redo1.end(), redo_w.begin(), redo_w.end());
+            redo_w.clear();
             if (kind1 >= 2 && can_b && !wide_ok && redo1.size() > resident_generic) {
                 // second chance on the LDS-ring kernel (64-diagonal bands at any alignment) for band/arena misses
                 std::vector<uint32_t> lst;
@@ -966,6 +1007,9 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
     }
     int      learned_now = -1;
     uint64_t team_total = 0, team_done = 0;
+    // (tracked for every batch of long pairs that goes straight to this ladder -- team kernel or one workgroup per pair:
+    // 500 x 50 kbp global pairs at 20 % error all need the second level, 72 ms of a 172 ms call were spent finding that out)
+    const bool learn_track = !packed_done && ctx->opt_team_min_len > 0 && max_len >= (uint64_t)ctx->opt_team_min_len;
     if (!packed_done) {
         Job j;
         j.mode = ctx->force_mode == 1 ? 1 : 0, j.level = 0, j.all = true;
@@ -1134,7 +1178,7 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
         ctx->timing.n_launches++;
 
         const uint32_t n_redo = hctrl[1];
-        if (team_T > 0) {  // the lowest level by which 90 % of the long pairs of this call have finished
+        if (learn_track) {  // the lowest level by which 90 % of the long pairs of this call have finished
             if (team_total == 0) team_total = n_work;
             team_done += n_work - n_redo;
             if (learned_now < 0 && 10 * team_done >= 9 * team_total) learned_now = job.level;
