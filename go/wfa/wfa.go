@@ -65,6 +65,7 @@ type Aligner struct {
 	opt   *Options
 	ctx   *C.wfahip_ctx
 	multi *C.wfahip_multi // NewMulti: AlignBatch shards over several GPUs
+	oneOps []C.uint64_t   // Align's reusable CIGAR buffer (wfahip_align_pair)
 
 	// M, I, D: the reference exports its three components (wfa.go:86) for Plot and its test (wfa_test.go:154).
 	// On the GPU path the wavefronts live in HBM and are released per batch; Plot below fetches one pair's
@@ -149,8 +150,47 @@ func (algn *Aligner) AlignPointers(q, t *[]byte) (*AlignmentResult, error) {
 	if len(*q) > MaxSeqLen || len(*t) > MaxSeqLen {
 		return nil, ErrSeqTooLong
 	}
-	rs, errs := algn.AlignBatch([][]byte{*q}, [][]byte{*t})
-	return rs[0], errs[0]
+	if algn.multi != nil { // (a context set: the batch entry)
+		rs, errs := algn.AlignBatch([][]byte{*q}, [][]byte{*t})
+		return rs[0], errs[0]
+	}
+	// wfahip_align_pair: the record and the ops come back in two reusable buffers -- no offset arrays to build, no
+	// result arrays to take apart, and (for pairs shaped like the reference's defaults) two launches and no copy.
+	need := len(*q) + len(*t) + 2
+	if len(algn.oneOps) < need {
+		algn.oneOps = make([]C.uint64_t, 2*need+64)
+	}
+	var rec [C.WFAHIP_REC_WORDS]C.uint32_t
+	var nOps C.uint64_t
+	p := algn.params()
+	rc := C.wfahip_align_pair(algn.ctx, &p, (*C.uint8_t)(unsafe.Pointer(&(*q)[0])), C.uint32_t(len(*q)),
+		(*C.uint8_t)(unsafe.Pointer(&(*t)[0])), C.uint32_t(len(*t)), &rec[0], &algn.oneOps[0], C.uint64_t(len(algn.oneOps)), &nOps)
+	runtime.KeepAlive(q)
+	runtime.KeepAlive(t)
+	if rc != 0 {
+		return nil, fmt.Errorf("wfa: %s", C.GoString(C.wfahip_strerror(rc)))
+	}
+	switch rec[C.WFAHIP_REC_STATUS] {
+	case C.WFAHIP_PAIR_EMPTY:
+		return nil, ErrEmptySeq
+	case C.WFAHIP_PAIR_TOO_LONG:
+		return nil, ErrSeqTooLong
+	case C.WFAHIP_PAIR_OK:
+	default:
+		return nil, fmt.Errorf("wfa: not enough device memory for this pair")
+	}
+	r := NewAlignmentResult(algn.opt.GlobalAlignment)
+	r.proccessed = true // ops arrive reversed + merged (process(), wfa_cigar.go:136-214, ran on the device)
+	r.Ops = r.Ops[:0]
+	for i := 0; i < int(nOps); i++ {
+		r.Ops = append(r.Ops, uint64(algn.oneOps[i]))
+	}
+	r.Score = uint32(rec[C.WFAHIP_REC_SCORE])
+	r.TBegin, r.TEnd = int(int32(rec[C.WFAHIP_REC_TBEGIN])), int(int32(rec[C.WFAHIP_REC_TEND]))
+	r.QBegin, r.QEnd = int(int32(rec[C.WFAHIP_REC_QBEGIN])), int(int32(rec[C.WFAHIP_REC_QEND]))
+	r.AlignLen, r.Matches = uint32(rec[C.WFAHIP_REC_ALIGN_LEN]), uint32(rec[C.WFAHIP_REC_MATCHES])
+	r.Gaps, r.GapRegions = uint32(rec[C.WFAHIP_REC_GAPS]), uint32(rec[C.WFAHIP_REC_GAP_REGIONS])
+	return r, nil
 }
 
 // AlignBatch aligns qs[i] against ts[i] for every i in one device call (new: a GPU needs batches).

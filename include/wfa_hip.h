@@ -166,6 +166,18 @@ int  wfahip_align_batch_packed(wfahip_ctx *ctx, const wfahip_params *p, const ui
  * at once with the pair's ticket (0, 1, 2, ... since the last collect) -- and collects all results with ONE batch
  * alignment: out->...[ticket] is the result of that submission.  Same thread rule as every other call on a context. */
 int      wfahip_submit(wfahip_ctx *ctx, const uint8_t *q, uint32_t n, const uint8_t *t, uint32_t m, uint64_t *ticket);
+
+/* Aligner.Align (wfa.go:196) for ONE pair, without the batch plumbing: no offset arrays in, no malloc'd result arrays
+ * out.  rec receives the pair's record (WFAHIP_REC_WORDS u32: status, score, region, statistics, op count; OPS_OFF = 0),
+ * ops the CIGAR ops (op<<32 | n, forward order, merged; capacity ops_cap entries), *n_ops their number.  If ops_cap is
+ * too small the call returns WFAHIP_ERR_OOM with *n_ops = the capacity needed (at most n + m + 2).  Per-pair failures
+ * are statuses in rec[WFAHIP_REC_STATUS] (EMPTY / TOO_LONG), like the batch entry.  A pair whose shape allows it (global,
+ * penalties shaped like 4/6/2, lengths up to ~10 kbp) takes two kernel launches and no copy -- the kernels read the
+ * sequences from, and write the results to, a page-locked block mapped into the GPU's address space -- 3-4 x less time
+ * per call than wfahip_align_batch with n_pairs = 1; every other pair goes through that entry.  Same results either way.
+ * A caller that CAN batch should: a batch aligns ~50 million pairs a second, this call a few thousand. */
+int      wfahip_align_pair(wfahip_ctx *ctx, const wfahip_params *p, const uint8_t *q, uint32_t n, const uint8_t *t, uint32_t m,
+                           uint32_t *rec, uint64_t *ops, uint64_t ops_cap, uint64_t *n_ops);
 uint64_t wfahip_pending(const wfahip_ctx *ctx);
 int      wfahip_collect(wfahip_ctx *ctx, const wfahip_params *p, wfahip_results *out);
 

@@ -937,7 +937,7 @@ def _expected_compact_words(dump, x, o, e):
 def _arena_slot(fmt, i, k):
     if fmt == 3:
         return (i >> 3) * 512 + (((k & 63) >> 2) << 5) + ((i & 7) << 2) + (k & 3)
-    return i * {1: 64, 4: 256, 5: 32}[fmt] + (k & ({1: 63, 4: 255, 5: 31}[fmt]))
+    return i * {1: 64, 4: 256, 5: 32, 6: 128}[fmt] + (k & ({1: 63, 4: 255, 5: 31, 6: 127}[fmt]))
 
 
 @pytest.mark.parametrize("length,err,pen,ad,fmt", [(1000, 0.05, (4, 6, 2), (10, 50, 1), 3), (400, 0.08, (4, 6, 2), (10, 50, 1), 3),
@@ -1120,4 +1120,61 @@ def test_learned_start_level_is_only_a_hint(built):
     got = al.align_arrays(*longer)
     assert (got.status == 0).all(), got.status  # never "no memory" straight from a learned start level
     assert_batch_equal(got, want["longer"], "twice as long, same class")
+    al.close()
+
+
+@pytest.mark.parametrize("length,err,ad,n", [(1000, 0.20, (10, 50, 1), 3000), (1000, 0.10, (10, 50, 1), 6000), (600, 0.15, None, 3000),
+                                             (1200, 0.25, (10, 50, 1), 1500)])
+def test_mid_window_rung_and_learned_start(built, length, err, ad, n):
+    """Bands of 60-250 diagonals (1 kbp at 10-25 % error): the 64-diagonal first pass hands most pairs on, the 128-diagonal
+    instance (wfa_blk_kernel<32,1>, two pairs per wave) takes what fits, the 256-diagonal one the rest; pairs that run
+    out of arena rows (scores above half the read length) are re-run with four times the rows.  From its second call
+    on a context starts such a class on the window that took the pairs, with the rows they needed -- the results are the
+    same on every call, every field and every CIGAR op against the oracle."""
+    import wfa_amd as w
+    from oracle import oracle as O
+    data = w.generate_pairs(seed=int(err * 100) + length, n_pairs=n, length=length, error_rate=err, n_threads=8)
+    want = O.align_batch(_oracle_params(True, ad), *data, n_threads=max(8, (os.cpu_count() or 8) // 2))
+    al = _aligner(True, ad)
+    kinds = []
+    for rep in range(4):
+        assert_batch_equal(al.align_arrays(*data), want, f"L={length} err={err} ad={ad} call {rep}")
+        kinds.append(al.last_timing().main_kernel_kind)
+    al.set_option("blk_mid", 0)  # without the 128-diagonal rung
+    assert_batch_equal(al.align_arrays(*data), want, f"L={length} err={err} ad={ad} blk_mid=0")
+    al.close()
+    if ad is not None and err >= 0.2:
+        assert kinds[0] == 3 and kinds[-1] in (9, 5), kinds  # the class moved to a wider window
+
+
+def test_mid_window_arena_word_for_word(built):
+    """The 128-diagonal instance's stored words (plain rows of 128, CompactView fmt 6) against the oracle's wavefronts."""
+    import wfa_amd as w
+    from oracle import oracle as O
+    n, pen, ad = 96, (4, 6, 2), (10, 50, 1)
+    blob, q_off, q_len, t_off, t_len = w.generate_pairs(seed=2020, n_pairs=n, length=800, error_rate=0.2)
+    al = _aligner(True, ad, pen)
+    al.align_arrays(blob, q_off, q_len, t_off, t_len)  # first call: the class learns its window (and its rows)
+    al.align_arrays(blob, q_off, q_len, t_off, t_len)
+    got = al.align_arrays(blob, q_off, q_len, t_off, t_len)
+    assert al.last_timing().main_kernel_kind == 9
+    oa = O.Aligner(O.make_params(*pen, global_alignment=True, adaptive=ad))
+    checked = pairs = 0
+    for i in range(n):
+        words, f, meta = al.debug_compact_arena(i)
+        assert f == 6
+        if meta[0] != 0:
+            continue
+        q = bytes(blob[int(q_off[i]):int(q_off[i]) + int(q_len[i])])
+        t = bytes(blob[int(t_off[i]):int(t_off[i]) + int(t_len[i])])
+        r = oa.align(q, t)
+        assert meta[1] == r.score == int(got.score[i])
+        for (s, k), (wv, mask) in _expected_compact_words(oa.dump(), *pen).items():
+            if s > r.score:
+                continue
+            have = int(words[_arena_slot(f, s // 2, k)])
+            assert (have & mask) == (wv & mask), (i, s, k, hex(have), hex(wv))
+            checked += 1
+        pairs += 1
+    assert pairs >= n // 2 and checked > 50 * pairs, (pairs, checked)
     al.close()

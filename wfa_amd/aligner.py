@@ -181,6 +181,7 @@ class Aligner:
         self.opt = opt
         self.ad: Optional[AdaptiveReductionOption] = None
         self._ctx = C.c_void_p()
+        self._one = None  # Align's reusable record / ops buffers
         L.check(L.lib().wfahip_create(device, C.byref(self._ctx)), "wfahip_create")
 
     # -- reference API ---------------------------------------------------------------------------
@@ -197,10 +198,20 @@ class Aligner:
             raise ErrEmptySeq
         if len(q) > MaxSeqLen or len(t) > MaxSeqLen:
             raise ErrSeqTooLong
-        results, errors = self.AlignBatch([q], [t])
-        if errors[0] is not None:
-            raise errors[0]
-        return results[0]
+        # wfahip_align_pair: record + ops into two reusable buffers (no arrays to build, none to take apart)
+        if self._one is None or len(self._one[1]) < len(q) + len(t) + 2:
+            self._one = ((C.c_uint32 * L.REC_WORDS)(), (C.c_uint64 * (2 * (len(q) + len(t)) + 64))(), C.c_uint64())
+        rec, ops, n_ops = self._one
+        prm = self._params()
+        L.check(L.lib().wfahip_align_pair(self._ctx, C.byref(prm), q, len(q), t, len(t), rec, ops, len(ops), C.byref(n_ops)),
+                "wfahip_align_pair")
+        if rec[L.REC_STATUS] != L.PAIR_OK:
+            raise ErrSeqTooLong if rec[L.REC_STATUS] == L.PAIR_TOO_LONG else (
+                ErrEmptySeq if rec[L.REC_STATUS] == L.PAIR_EMPTY else WfaError("pair could not be aligned (out of device memory)"))
+        i32 = lambda v: v - (1 << 32) if v >= (1 << 31) else v
+        return AlignmentResult(Ops=ops[:n_ops.value], Score=rec[L.REC_SCORE], TBegin=i32(rec[L.REC_TBEGIN]), TEnd=i32(rec[L.REC_TEND]),
+                               QBegin=i32(rec[L.REC_QBEGIN]), QEnd=i32(rec[L.REC_QEND]), AlignLen=rec[L.REC_ALIGN_LEN],
+                               Matches=rec[L.REC_MATCHES], Gaps=rec[L.REC_GAPS], GapRegions=rec[L.REC_GAP_REGIONS])
 
     AlignPointers = Align  # wfa.go:201 (pointer arguments have no Python analogue)
 

@@ -99,6 +99,24 @@ struct BlkOps<64> {
     static WFA_DEV uint32_t shl(uint32_t x, int j) { return up1(x, j); }
 };
 
+// G = 32: two pairs per wave, a 128-diagonal window each (round 3: the rung between the 64- and the 256-diagonal
+// windows -- 1 kbp pairs at 10-20 % error have bands of 60-110 diagonals).  Wave-wide shifts like G = 64, zeros
+// forced at the boundary between the two halves of the wave.
+template <>
+struct BlkOps<32> {
+    static WFA_DEV uint32_t dn1(uint32_t x, int j) {
+        const uint32_t r = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xf, 0xf, true);  // wave_shr:1
+        return j == 0 ? 0u : r;
+    }
+    static WFA_DEV uint32_t up1(uint32_t x, int j) {
+        const uint32_t r = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x130, 0xf, 0xf, true);  // wave_shl:1
+        return j == 31 ? 0u : r;
+    }
+    static constexpr int SHIFT_D = 4;
+    static WFA_DEV uint32_t shr(uint32_t x, int j) { return dn1(x, j); }
+    static WFA_DEV uint32_t shl(uint32_t x, int j) { return up1(x, j); }
+};
+
 // Butterfly reductions inside a group, written as DPP-fused VOP2 instructions (one instruction per stage and
 // value).  hipcc lowers the same butterfly from __builtin_amdgcn_update_dpp to mov + mov_dpp + op per stage.
 // A DPP operand may be read two wait states after the VALU instruction that wrote it: the partner value's
@@ -185,6 +203,33 @@ struct BlkRed<64> {
     }
 };
 
+// 32 lanes: the two row results of each half of the wave are combined through readlane + scalar ops and handed back
+// to the half they belong to.
+template <>
+struct BlkRed<32> {
+    static WFA_DEV int rl(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+    static WFA_DEV int pick(int lo, int hi) { return (threadIdx.x & 32u) ? hi : lo; }
+    static WFA_DEV int mn2(int v) { return pick(imin2(rl(v, 0), rl(v, 16)), imin2(rl(v, 32), rl(v, 48))); }
+    static WFA_DEV int mx2(int v) { return pick(imax2(rl(v, 0), rl(v, 16)), imax2(rl(v, 32), rl(v, 48))); }
+    static WFA_DEV void min_max(int &a, int &b) {
+        BlkRed<16>::min_max(a, b);
+        a = mn2(a), b = mx2(b);
+    }
+    static WFA_DEV void min_max_min(int &a, int &b, int &c) {
+        BlkRed<16>::min_max_min(a, b, c);
+        a = mn2(a), b = mx2(b), c = mn2(c);
+    }
+    static WFA_DEV void max_add(int &a, int &b) {
+        BlkRed<16>::max_add(a, b);
+        a = mx2(a), b = pick(rl(b, 0) + rl(b, 16), rl(b, 32) + rl(b, 48));
+    }
+    static WFA_DEV int max1(int a) { return mx2(BlkRed<16>::max1(a)); }
+    static WFA_DEV int or1(int a) {
+        a = BlkRed<16>::or1(a);
+        return pick(rl(a, 0) | rl(a, 16), rl(a, 32) | rl(a, 48));
+    }
+};
+
 WFA_DEV uint32_t ffbl_raw(uint32_t x) {  // index of the lowest set bit; 0xFFFFFFFF for x == 0
     uint32_t r;
     asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x));
@@ -257,12 +302,12 @@ template <int G, int BATCH, bool STREAM = false, int PPT = 0, bool CENSUS = true
 __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16 && BATCH == 1 && !CENSUS && (!STREAM || WFA_BLK_STREAM_WAVES5) ? WFA_BLK_WAVES : 4))) void wfa_blk_kernel(const KParams P) {
     static_assert(!STREAM || (G == 16 && BATCH == 1), "streamed backtrace: 16 lanes per pair, unbatched refill");
     static_assert(PPT == 0 || (G == 8 && PPT == 4), "diagonals per lane can only be overridden for the 8-lane narrow instance");
-    constexpr int PP  = PPT ? PPT : (G == 64 ? 4 : 64 / G);  // diagonals per lane
+    constexpr int PP  = PPT ? PPT : (G >= 32 ? 4 : 64 / G);  // diagonals per lane
     constexpr int NG  = 64 / G;                // pairs per wave
 #ifdef WFA_BLK_W
     constexpr int W = WFA_BLK_W;  // experiment: pretend the window is narrower
 #else
-    constexpr int W   = G * PP;   // window width in diagonals: 64 (G = 16, 8) or 256 (G = 64); also the arena's row pitch
+    constexpr int W   = G * PP;   // window width in diagonals: 64 (G = 16, 8), 128 (G = 32) or 256 (G = 64); also the arena's row pitch
 #endif
     constexpr bool TILED = WFA_BLK_TILED != 0 && W == 64;  // arena layout: CompactView fmt 3 (else fmt 1 / 4: plain rows)
     using Ops         = typename std::conditional<(G == 8 && PP == 4), BlkOps8n, BlkOps<G>>::type;

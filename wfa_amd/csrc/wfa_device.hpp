@@ -555,6 +555,7 @@ struct CompactView {
         if (fmt == 1u) return ld(64ull * idx + ((uint32_t)k & 63u));
         if (fmt == 4u) return ld(256ull * idx + ((uint32_t)k & 255u));
         if (fmt == 5u) return ld(32ull * idx + ((uint32_t)k & 31u));
+        if (fmt == 6u) return ld(128ull * idx + ((uint32_t)k & 127u));
         const uint4 e = *reinterpret_cast<const uint4 *>(A + cap - 4ull * (idx + 1));
         const int   lo = (int)e.y, w = (int)e.z;
         if (w <= 0 || k < lo || k >= lo + w) return 0u;

@@ -93,6 +93,9 @@ struct wfahip_ctx {
     DevBuf        in_blob, in_qoff, in_qlen, in_toff, in_tlen, out_rec, out_ops;  // host-entry staging
     DevBuf        prepack;                   // 2-bit packed sequences of the current chunk (wfa_prepack_kernel)
     DevBuf        in_small;                  // host entry, small batches: blob + offset / length arrays as one image
+    char         *one_pin    = nullptr;      // wfahip_align_pair: mapped pinned block (input image, record, ops) the kernels read and write directly
+    char         *one_dev    = nullptr;      // ... its device address
+    int64_t       opt_pair_fast            = 1;   // 1: wfahip_align_pair uses its two-launch path when the pair allows it
     DevBuf        in_packed;                 // host entry with pre-packed input: the 2-bit words as uploaded (unpacked into in_blob on the device)
     // wfahip_submit / wfahip_collect: pairs handed in one at a time, aligned as one batch
     std::vector<uint8_t>  sub_blob;
@@ -144,7 +147,13 @@ struct wfahip_ctx {
     // to ~8 % at 4/6/2); a class of batches whose pairs ran out of rows gets twice / four times / eight times as many
     // from its next call on (the call that finds out re-runs those pairs on the same kernel with four times the rows)
     uint64_t      rows_key                 = 0;
-    uint32_t      rows_scale               = 1;   // calls of that class since the level was learned (every 4th one probes one level lower)
+    uint32_t      rows_scale               = 1;
+    // ... and the window such a class starts on: 0 = the 64-diagonal first pass, 9 = wfa_blk_kernel<32,1> (128 diagonals),
+    // 5 = wfa_blk_kernel<64,1> (256), learned when most pairs of a call were handed on because of their band
+    uint64_t      band_key                 = 0;
+    int           band_kind                = 0;
+    uint32_t      band_calls               = 0;   // (every eighth call of the class starts on the 64-diagonal pass again: data changes)
+    int64_t       opt_blk_mid              = 1;   // 1: band failures of the 64-diagonal kernels try the 128-diagonal instance before the 256-diagonal one   // calls of that class since the level was learned (every 4th one probes one level lower)
     int64_t       opt_mem_limit            = 0;   // tests: pretend the device has this many bytes (arena budgets follow)
     int           force_mode               = -1;  // debug: start the ladder in this mode
     // debug / parity aid (wfahip_debug_compact_arena): where the first chunk of the most recent first pass left its arena
@@ -347,6 +356,7 @@ extern "C" void wfahip_destroy(wfahip_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->hpin) (void)hipHostFree(ctx->hpin);
+    if (ctx->one_pin) (void)hipHostFree(ctx->one_pin);
     if (ctx->stream_up) (void)hipStreamDestroy(ctx->stream_up);
     if (ctx->stream_dn) (void)hipStreamDestroy(ctx->stream_dn);
     for (hipEvent_t e : ctx->ev_up) (void)hipEventDestroy(e);
@@ -435,6 +445,10 @@ static int set_option_impl(wfahip_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_duo = value;
     else if (k == "duo_min_pairs")
         ctx->opt_duo_min_pairs = value;
+    else if (k == "blk_mid")
+        ctx->opt_blk_mid = value;
+    else if (k == "pair_fast")
+        ctx->opt_pair_fast = value;
     else if (k == "learn")
         ctx->opt_learn = value, ctx->learn_key = 0;
     else if (k == "mem_limit") {
@@ -647,17 +661,19 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             const uint32_t duo_sw       = (seq_words + 1u) & ~1u, duo_pw = 4u + 2u * duo_sw;
             if (kind == 8 && (duo_pw > 256u || blk_batch)) return WFAHIP_ERR_INTERNAL;
             const size_t   lds_bytes    = kind == 8 ? (size_t)duo_lds_words(duo_pw) * 4
+                                          : kind == 9 ? (size_t)seq_words * 2 * 4 * 2 + 16
                                           : blk_batch ? (size_t)(kind == 6 ? 8 : 4) * BLK_BATCH * (2 * seq_words + 8) * 4 + 16
                                           : kind == 6 ? (size_t)seq_words * 2 * 4 * 8 + 16
                                           : kind == 5 ? (size_t)seq_words * 2 * 4 + 16
                                                       : (kind >= 3 ? lds_d : (kind == 2 ? lds_c : lds_b));
-            const uint32_t pairs_wave   = kind == 5 ? 1 : (kind == 4 || kind == 6 || kind == 8 ? 8 : (kind >= 2 ? 4 : 2));
+            const uint32_t pairs_wave   = kind == 5 ? 1 : kind == 9 ? 2 : (kind == 4 || kind == 6 || kind == 8 ? 8 : (kind >= 2 ? 4 : 2));
             // blocked kernels: fixed-pitch arena, no directory.  64-diagonal window: 16 words per base = 250 scores at
             // 1 kbp; 256-diagonal window (kind 5, the retry rung): 128 words per base = 500 scores at 1 kbp
             const uint64_t words        = kind == 5   ? std::max<uint64_t>((words_dir * 16 * arena_mult + 511) & ~511ull, 8192)
+                                          : kind == 9 ? std::max<uint64_t>((words_dir * 4 * arena_mult + 511) & ~511ull, 4096)
                                           : kind >= 3 ? std::max<uint64_t>((words_dir * 2 * arena_mult + 511) & ~511ull, 2048)
                                                       : words_dir;
-            P.arena_words = words, P.compact_fmt = kind == 6 ? 5u : kind == 5 ? 4u : (kind >= 3 ? (WFA_BLK_TILED ? 3u : 1u) : 0u);
+            P.arena_words = words, P.compact_fmt = kind == 6 ? 5u : kind == 5 ? 4u : kind == 9 ? 6u : (kind >= 3 ? (WFA_BLK_TILED ? 3u : 1u) : 0u);
             const uint32_t waves_lds    = (uint32_t)std::min<size_t>(32, LDS_MAX_BYTES / lds_bytes);
             const bool     overlap      = ctx->opt_overlap != 0;
             uint32_t       waves_per_cu = kind == 8 ? std::min<uint32_t>(waves_lds, 4 * WFA_DUO_WAVES)
@@ -753,6 +769,8 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                     hipLaunchKernelGGL((wfa_duo_kernel<false>), dim3(grid), dim3(64), lds_bytes, st, P);
                 else if (kind == 5)
                     hipLaunchKernelGGL((wfa_blk_kernel<64, 1>), dim3(grid), dim3(64), lds_bytes, st, P);
+                else if (kind == 9)
+                    hipLaunchKernelGGL((wfa_blk_kernel<32, 1>), dim3(grid), dim3(64), lds_bytes, st, P);
                 else if (kind == 4)
                     hipLaunchKernelGGL((wfa_blk_kernel<8, 1>), dim3(grid), dim3(64), lds_bytes, st, P);
                 else if (blk_batch) {
@@ -831,7 +849,10 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             int      kind_rest  = kind1;
             const bool wide_ok  = kind1 >= 3 && ctx->opt_blk_wide != 0;
             std::vector<uint64_t> redo_w;  // handed on by the 256-diagonal kernel, or not eligible for it
-            const auto wide_pass = [&](std::vector<uint64_t> &from) -> int {  // band failures of `from` -> kind 5; the rest -> redo_w
+            // band failures of `from` -> kind 9 (128 diagonals, two pairs per wave; unless `from` comes from there), its band
+            // failures -> kind 5 (256 diagonals, a wave per pair); everything else -> redo_w
+            uint64_t mid_in = 0, mid_fail = 0;  // what the 128-diagonal instance was given / handed on (learned routing below)
+            const auto wide_pass = [&](std::vector<uint64_t> &from, bool from_mid = false) -> int {
                 std::vector<uint32_t> lst;
                 for (uint64_t e : from) {
                     if ((uint32_t)(e >> 32) == ST_REDO_BAND) lst.push_back((uint32_t)e);
@@ -839,12 +860,27 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                 }
                 from.clear();
                 if (lst.empty()) return 0;
+                const size_t n_in = lst.size();
                 std::vector<uint64_t> r2;
+                if (!from_mid && ctx->opt_blk_mid != 0) {
+                    const int rcm = forward_pass(9, &lst, 0, lst.size(), r2, false);
+                    if (rcm) return rcm;
+                    ctx->timing.n_packed_pairs += (uint32_t)(lst.size() - r2.size());
+                    mid_in += lst.size();
+                    lst.clear();
+                    for (uint64_t e : r2) {
+                        if ((uint32_t)(e >> 32) == ST_REDO_BAND) lst.push_back((uint32_t)e);
+                        else redo_w.push_back(e);
+                    }
+                    mid_fail += lst.size();
+                    r2.clear();
+                    if (lst.empty()) return 1;
+                }
                 const int rcw = forward_pass(5, &lst, 0, lst.size(), r2, false);
                 if (rcw) return rcw;  // WFAHIP_ERR_* (negative): the whole call fails, no pair is silently dropped
                 ctx->timing.n_packed_pairs += (uint32_t)(lst.size() - r2.size());
                 redo_w.insert(redo_w.end(), r2.begin(), r2.end());
-                return r2.size() * 2 > lst.size() ? 2 : 1;  // 2: the wide kernel does not take most of them either
+                return r2.size() * 2 > n_in ? 2 : 1;  // 2: the wide kernels do not take most of them either
             };
             uint64_t n_first_fail = 0;  // pairs the first-pass kernel(s) handed on
             if (n_pairs >= 65536 && !P.adaptive && max_len >= 200 && ctx->opt_pilot != 0) {  // (the pilot costs one extra pass, ~0.1 ms)
@@ -859,11 +895,25 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                     else skip_rest = true;
                 }
             }
+            // a class of batches whose pairs were mostly handed on for their band the last time starts on the window that
+            // took them (1 kbp at 20 % error: every pair needs ~100 diagonals)
+            if (wide_ok && done_pairs == 0 && ctx->band_key == rkey && ctx->band_kind != 0 && (kind1 == 3 || kind1 == 8) &&
+                (ctx->band_kind == 5 || ctx->opt_blk_mid != 0) && (++ctx->band_calls & 7u) != 0u)
+                kind_rest = ctx->band_kind;
             if (!skip_rest) {
                 std::vector<uint64_t> more;
                 if ((rc = forward_pass(kind_rest, nullptr, done_pairs, n_pairs - done_pairs, more, true))) return rc;
                 n_first_fail += more.size();
-                (kind_rest == 5 ? redo_w : redo1).insert((kind_rest == 5 ? redo_w : redo1).end(), more.begin(), more.end());
+                uint64_t n_band = 0;
+                for (uint64_t e : more) n_band += (uint32_t)(e >> 32) == ST_REDO_BAND;
+                if (kind_rest == 9) {
+                    mid_in += n_pairs - done_pairs, mid_fail += n_band;
+                    if ((rc = wide_pass(more, true)) < 0) return rc;  // -> the 256-diagonal instance
+                } else {
+                    (kind_rest == 5 ? redo_w : redo1).insert((kind_rest == 5 ? redo_w : redo1).end(), more.begin(), more.end());
+                }
+                if ((kind_rest == 3 || kind_rest == 8) && P.adaptive && n_band * 2 > n_pairs - done_pairs) ctx->band_key = rkey, ctx->band_kind = 9;
+                else if ((kind_rest == 3 || kind_rest == 8) && ctx->band_key == rkey) ctx->band_kind = 0;
                 done_pairs = n_pairs;
             }
             if (std::getenv("WFAHIP_DEBUG_TIMING") && P.done_ctl) {
@@ -926,7 +976,7 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                 if (!lst.empty() && arena_mult <= 8 && ctx->opt_packed_arena_bytes <= 0) {
                     const uint64_t keep_mult = arena_mult;
                     arena_mult *= 4;
-                    rc = forward_pass(kind1 == 5 ? 5 : 3, &lst, 0, lst.size(), r2, false);
+                    rc = forward_pass((kind_rest == 5 || kind_rest == 9) ? kind_rest : 3, &lst, 0, lst.size(), r2, false);
                     arena_mult = keep_mult;
                     if (rc) return rc;
                     ctx->timing.n_packed_pairs += (uint32_t)(lst.size() - r2.size());
@@ -989,6 +1039,7 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                 P.debug_info = nullptr;
             }
 #endif
+            if (ctx->band_key == rkey && ctx->band_kind == 9 && mid_in > 0 && mid_fail * 2 > mid_in) ctx->band_kind = 5;
             first       = false;
             packed_done = true;
         }
@@ -1962,6 +2013,137 @@ extern "C" int wfahip_pack_pairs(const uint8_t *seq_blob, const uint64_t *q_off,
                                  const uint32_t *t_len, uint64_t n_pairs, int n_threads, uint32_t *packed, uint64_t *q_woff,
                                  uint64_t *t_woff, uint64_t *n_words) {
     WFAHIP_GUARD(pack_pairs_impl(seq_blob, q_off, q_len, t_off, t_len, n_pairs, n_threads, packed, q_woff, t_woff, n_words))
+}
+
+// ---- Align (wfa.go:196) for ONE pair without the batch plumbing.
+// A caller that cannot batch pays per call, not per base: through wfahip_align_batch a 1 kbp pair took 0.45-0.75 ms, of
+// which the kernels were a fifth -- five launches, a dozen staged copies, thirteen result arrays.  Here the pair is
+// written into a page-locked block that is mapped into the GPU's address space; the forward kernel reads the two
+// sequences from there (2 KB over PCIe, inside its refill), the backtrace kernel writes the record and the CIGAR ops
+// back into it, and the host waits for the stream once: one memset of the control words, two launches, no copy.
+// Taken by global alignments with penalties shaped 2 : 4 : 1 (4/6/2, the default) whose sequences fit the blocked
+// kernel's LDS budget and whose worst-case CIGAR fits the block; everything else -- and a pair the blocked kernel hands
+// on (band wider than 64 diagonals, a byte outside ACGT, arena rows) -- goes through wfahip_align_batch: same results.
+namespace {
+constexpr size_t ONE_PIN_BYTES = 1u << 20, ONE_IMG_MAX = 64u << 10, ONE_REC_OFF = ONE_IMG_MAX, ONE_OPS_OFF = ONE_IMG_MAX + 256;
+}
+
+static int align_pair_impl(wfahip_ctx *ctx, const wfahip_params *p, const uint8_t *q, uint32_t n, const uint8_t *t, uint32_t m,
+                           uint32_t *rec_out, uint64_t *ops_out, uint64_t ops_cap, uint64_t *n_ops) {
+    if (!ctx || !p || !rec_out || !n_ops || (!ops_out && ops_cap)) return WFAHIP_ERR_BAD_ARG;
+    int rc = check_params(p);
+    if (rc != WFAHIP_OK) return rc;
+    std::memset(rec_out, 0, REC_WORDS * 4);
+    *n_ops = 0;
+    if (n == 0 || m == 0) {
+        rec_out[REC_STATUS] = ST_EMPTY;  // wfa.go:204-206
+        return WFAHIP_OK;
+    }
+    if (n > WFAHIP_MAX_SEQ_LEN || m > WFAHIP_MAX_SEQ_LEN) {
+        rec_out[REC_STATUS] = ST_TOO_LONG;  // wfa.go:207-209
+        return WFAHIP_OK;
+    }
+    if (!q || !t) return WFAHIP_ERR_BAD_ARG;
+    const uint32_t max_len = std::max(n, m), min_len = std::min(n, m);
+    const uint32_t g = gcd_u32(gcd_u32(p->mismatch, p->gap_open + p->gap_ext), p->gap_ext ? p->gap_ext : p->mismatch);
+    const uint32_t seq_words = (max_len + 15) / 16 + 1;
+    const uint64_t q_cap = ((uint64_t)n + 15) & ~15ull, img = q_cap + (((uint64_t)m + 15) & ~15ull) + 64;
+    // worst-case score of a global alignment under the reference's rules (first cell consumed as (mis)match):
+    // every shared base a mismatch, the overhang one gap, plus one more gap for the first-cell quirk
+    const uint64_t worst = (uint64_t)p->mismatch * min_len + 2ull * (p->gap_open + p->gap_ext) + (uint64_t)p->gap_ext * (max_len - min_len + 2);
+    const uint32_t min_xe = std::min(p->mismatch, p->gap_ext ? p->gap_ext : p->mismatch);
+    const uint64_t ops_bound = 2 * (worst / std::max(1u, min_xe)) + 64;
+    const bool fast = ctx->opt_pair_fast != 0 && ctx->opt_packed != 0 && ctx->opt_blk == 16 && ctx->force_mode < 0 && p->global_alignment &&
+                      p->gap_ext != 0 && p->mismatch / g == 2 && (p->gap_open + p->gap_ext) / g == 4 && p->gap_ext / g == 1 &&
+                      (size_t)seq_words * 2 * 4 * 4 + 16 <= 20 * 1024 && img <= ONE_IMG_MAX &&
+                      ONE_OPS_OFF + ops_bound * 8 <= ONE_PIN_BYTES;
+    if (fast) {
+        HIP_TRY(hipSetDevice(ctx->device));
+        if (ctx->bt_pending) {
+            (void)hipStreamSynchronize(ctx->stream2);
+            ctx->bt_pending = false;
+        }
+        if (!ctx->one_pin) {
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->one_pin), ONE_PIN_BYTES, hipHostMallocMapped));
+            HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&ctx->one_dev), ctx->one_pin, 0));
+        }
+        hipStream_t st = ctx->stream;
+        // arena: rows for the worst-case score (64 words per score index), capped: what does not fit retries the usual way
+        const uint64_t words = std::min<uint64_t>(((worst / g + 16) * 64 + 511) & ~511ull, std::max<uint64_t>(2048, (32ull * max_len + 511) & ~511ull));
+        if ((rc = ensure(ctx, ctx->ctrl, CTRL_WORDS * 4))) return rc;
+        if ((rc = ensure(ctx, ctx->redo, 64))) return rc;
+        if ((rc = ensure(ctx, ctx->meta, 64))) return rc;
+        if (ctx->arena.bytes < words * 4 && (rc = ensure(ctx, ctx->arena, words * 4))) return rc;
+        char *const h = ctx->one_pin;
+        std::memcpy(h, q, n);
+        std::memcpy(h + q_cap, t, m);
+        uint64_t *const offs = reinterpret_cast<uint64_t *>(h + img - 64);  // {q_off, t_off} {q_len, t_len}
+        offs[0] = 0, offs[1] = q_cap;
+        uint32_t *const lens = reinterpret_cast<uint32_t *>(offs + 2);
+        lens[0] = n, lens[1] = m;
+        uint32_t *const hrec = reinterpret_cast<uint32_t *>(h + ONE_REC_OFF);
+        hrec[REC_STATUS] = ST_PENDING;
+        uint32_t *const d_ctrl = static_cast<uint32_t *>(ctx->ctrl.p);
+        KParams P{};
+        char *const d = ctx->one_dev;
+        P.blob = reinterpret_cast<const uint8_t *>(d), P.blob_bytes = img - 64;
+        P.q_off = reinterpret_cast<const uint64_t *>(d + img - 64), P.t_off = P.q_off + 1;
+        P.q_len = reinterpret_cast<const uint32_t *>(d + img - 48), P.t_len = P.q_len + 1;
+        P.queue_head = d_ctrl + 0, P.redo_count = d_ctrl + 1, P.ops_cursor = reinterpret_cast<unsigned long long *>(d_ctrl + 2);
+        P.redo_list = static_cast<uint32_t *>(ctx->redo.p);
+        P.x = p->mismatch, P.o = p->gap_open, P.e = p->gap_ext, P.oe = p->gap_open + p->gap_ext, P.g = g;
+        P.global_alignment = 1, P.adaptive = p->adaptive ? 1 : 0, P.min_wf_len = p->min_wf_len, P.max_dist_diff = p->max_dist_diff;
+        P.rec = reinterpret_cast<uint32_t *>(d + ONE_REC_OFF);
+        P.ops = reinterpret_cast<uint64_t *>(d + ONE_OPS_OFF), P.ops_cap = (ONE_PIN_BYTES - ONE_OPS_OFF) / 8;
+        P.arena = static_cast<uint32_t *>(ctx->arena.p), P.arena_words = words, P.compact_fmt = WFA_BLK_TILED ? 3u : 1u;
+        P.pair_meta = static_cast<uint4 *>(ctx->meta.p);
+        P.dx = 2, P.doe = 4, P.de = 1, P.dm = 5, P.di = 2, P.min_xe = min_xe;
+        P.lds_seq_words = seq_words, P.chunk_first = 0, P.chunk_n = 1, P.n_work = 1;
+        HIP_TRY(hipMemsetAsync(d_ctrl, 0, CTRL_WORDS * 4, st));
+        hipLaunchKernelGGL((wfa_blk_kernel<16, 1, false, 0, false>), dim3(1), dim3(64), (size_t)seq_words * 2 * 4 * 4 + 16, st, P);
+        hipLaunchKernelGGL(wfa_backtrace_kernel, dim3(1), dim3(256), 0, st, P);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(st));
+        ctx->timing = wfahip_timing{};
+        ctx->timing.n_launches = 2, ctx->timing.main_kernel_kind = 3;
+        if (hrec[REC_STATUS] == ST_OK) {
+            const uint64_t off = (uint64_t)hrec[REC_OPS_OFF_LO] | ((uint64_t)hrec[REC_OPS_OFF_HI] << 32);
+            const uint32_t len = hrec[REC_OPS_LEN];
+            if (off + len <= P.ops_cap) {
+                *n_ops = len;
+                if (len > ops_cap) return WFAHIP_ERR_OOM;  // (*n_ops says how many the caller's buffer must hold)
+                std::memcpy(rec_out, hrec, REC_WORDS * 4);
+                rec_out[REC_OPS_OFF_LO] = rec_out[REC_OPS_OFF_HI] = 0;
+                std::memcpy(ops_out, reinterpret_cast<const uint64_t *>(h + ONE_OPS_OFF) + off, (size_t)len * 8);
+                return WFAHIP_OK;
+            }
+        }
+        // handed on (band / bytes / arena rows): the batch entry finishes it
+    }
+    const uint64_t qo = 0, to = ((uint64_t)n + 15) & ~15ull;
+    std::vector<uint8_t> blob(to + m);
+    std::memcpy(blob.data(), q, n);
+    std::memcpy(blob.data() + to, t, m);
+    wfahip_results res;
+    rc = wfahip_align_batch(ctx, p, blob.data(), blob.size(), &qo, &n, &to, &m, 1, &res);
+    if (rc != WFAHIP_OK) return rc;
+    rec_out[REC_STATUS] = (uint32_t)res.status[0];
+    if (res.status[0] == WFAHIP_PAIR_OK) {
+        rec_out[REC_SCORE] = res.score[0], rec_out[REC_TBEGIN] = (uint32_t)res.tbegin[0], rec_out[REC_TEND] = (uint32_t)res.tend[0];
+        rec_out[REC_QBEGIN] = (uint32_t)res.qbegin[0], rec_out[REC_QEND] = (uint32_t)res.qend[0];
+        rec_out[REC_ALIGN_LEN] = res.align_len[0], rec_out[REC_MATCHES] = res.matches[0], rec_out[REC_GAPS] = res.gaps[0];
+        rec_out[REC_GAP_REGIONS] = res.gap_regions[0], rec_out[REC_OPS_LEN] = res.ops_len[0];
+        *n_ops = res.ops_len[0];
+        if (res.ops_len[0] > ops_cap) rc = WFAHIP_ERR_OOM;
+        else std::memcpy(ops_out, res.ops + res.ops_off[0], (size_t)res.ops_len[0] * 8);
+    }
+    wfahip_results_free(&res);
+    return rc;
+}
+
+extern "C" int wfahip_align_pair(wfahip_ctx *ctx, const wfahip_params *p, const uint8_t *q, uint32_t n, const uint8_t *t, uint32_t m,
+                                 uint32_t *rec, uint64_t *ops, uint64_t ops_cap, uint64_t *n_ops) {
+    WFAHIP_GUARD(align_pair_impl(ctx, p, q, n, t, m, rec, ops, ops_cap, n_ops))
 }
 
 // ---- one pair at a time behind the batch: submit copies the pair, collect aligns everything submitted so far

@@ -141,9 +141,32 @@ class Aligner {
             if (err) *err = Error::EmptySeq;
             return {};
         }
-        AlignBatch({q}, {t}, rs, es);
-        if (err) *err = es[0];
-        return rs[0];
+        if (!ctx_) {
+            if (err) *err = Error::Device;
+            return {};
+        }
+        // wfahip_align_pair: record + ops into reusable buffers, two launches and no copy when the pair's shape allows it
+        (void)rs, (void)es;
+        uint32_t rec[WFAHIP_REC_WORDS];
+        uint64_t n_ops = 0;
+        if (one_ops_.size() < q.size() + t.size() + 2) one_ops_.resize(2 * (q.size() + t.size()) + 64);
+        const wfahip_params prm = params();
+        const int rc = wfahip_align_pair(ctx_, &prm, reinterpret_cast<const uint8_t *>(q.data()), (uint32_t)q.size(),
+                                         reinterpret_cast<const uint8_t *>(t.data()), (uint32_t)t.size(), rec, one_ops_.data(),
+                                         one_ops_.size(), &n_ops);
+        Error e = rc != WFAHIP_OK ? Error::Device
+                  : rec[WFAHIP_REC_STATUS] == WFAHIP_PAIR_OK       ? Error::None
+                  : rec[WFAHIP_REC_STATUS] == WFAHIP_PAIR_EMPTY    ? Error::EmptySeq
+                  : rec[WFAHIP_REC_STATUS] == WFAHIP_PAIR_TOO_LONG ? Error::SeqTooLong
+                                                                   : Error::NoMemory;
+        if (err) *err = e;
+        AlignmentResult r;
+        if (e != Error::None) return r;
+        r.Ops.assign(one_ops_.begin(), one_ops_.begin() + (long)n_ops);
+        r.Score = rec[WFAHIP_REC_SCORE], r.TBegin = (int)rec[WFAHIP_REC_TBEGIN], r.TEnd = (int)rec[WFAHIP_REC_TEND];
+        r.QBegin = (int)rec[WFAHIP_REC_QBEGIN], r.QEnd = (int)rec[WFAHIP_REC_QEND], r.AlignLen = rec[WFAHIP_REC_ALIGN_LEN];
+        r.Matches = rec[WFAHIP_REC_MATCHES], r.Gaps = rec[WFAHIP_REC_GAPS], r.GapRegions = rec[WFAHIP_REC_GAP_REGIONS];
+        return r;
     }
 
     // new: hand in one pair (copied), get its ticket; Collect aligns everything submitted so far as ONE batch and
@@ -244,6 +267,7 @@ class Aligner {
     AdaptiveReductionOption ad_{};
     bool                    has_ad_ = false;
     wfahip_ctx             *ctx_    = nullptr;
+    std::vector<uint64_t>   one_ops_;  // Align's reusable CIGAR buffer
     int                     create_rc_ = 0;
 };
 
