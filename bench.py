@@ -390,17 +390,22 @@ def run_rank(args):
                             "that step (HIP events on the launch stream); peak = 8 TB/s HBM3E spec; the forward kernel is "
                             "integer-VALU-issue bound, not HBM bound: see `secondary` (DESIGN.md section 5)"}
             if pm and pm.get("valu_insts") and main_k_ms > 0:
-                # second ceiling: vector-instruction issue.  1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction
-                # (MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles on a SIMD-32)
+                # second ceiling: vector-instruction issue.  `peak` is the guide's figure: 1024 SIMDs x 2.4 GHz / 2 cycles per
+                # wave64 instruction (MI355X_MICROARCH.md).  `attainable` is what a SIMD was MEASURED to issue for a stream that
+                # mixes the forms these kernels are made of (max / cmp / cndmask / DPP with adds) at the kernel's own occupancy,
+                # in nanoseconds per SIMD instruction so that no clock is assumed (profiles/r03_valu_issue_probe.txt, the
+                # calibrated probe: waves per SIMD asserted from HW_ID, ticks checked against s_memrealtime and HIP events):
+                # 1.333 ns at 4 waves per SIMD (wfa_duo_kernel), 1.079 ns at 5 (wfa_blk_kernel<16,1>), 1.080 ns at 8.
                 peak = 256 * 4 * 2.4e9 / 2 / 1e9
                 ach = pm["valu_insts"] / (main_k_ms * 1e-3) / 1e9
-                # what a SIMD sustains for THIS instruction mix at THIS occupancy (profiles/r02_valu_issue_probe.txt: max /
-                # cmp / cndmask / DPP / three-operand integer forms issue every 3.15-3.32 cycles at 4 waves per SIMD, and a
-                # stream that mixes them with 2-cycle forms runs at their rate): one instruction per 3.2 cycles
-                attainable = 256 * 4 * 2.4e9 / 3.2 / 1e9
+                waves = 4 if "duo" in kname else (5 if kname.startswith("wfa_blk_kernel<16") else 4)
+                ns_per = {4: 1.333, 5: 1.079, 8: 1.080}[waves]
+                attainable = 256 * 4 / ns_per
                 roof["secondary"] = {"bound": "valu-issue", "achieved": ach, "peak": peak, "unit": "G wave-instr/s",
                                      "frac": ach / peak, "valu_wave_insts_per_launch": pm["valu_insts"],
-                                     "attainable_at_4_waves_per_simd": attainable, "frac_of_attainable": ach / attainable,
+                                     "waves_per_simd": waves, "attainable_at_this_occupancy": attainable,
+                                     "frac_of_attainable": ach / attainable,
+                                     "attainable_source": "profiles/r03_valu_issue_probe.txt (mix_add_max row at this occupancy)",
                                      "source": pm["source"], "stale": pm["stale"]}
             out["roofline"] = roof
         if not dry and world == 1:

@@ -123,3 +123,60 @@ def test_device_generator_writes_the_host_generator_s_dataset(built, n, length, 
             a, b = int(off[i]), int(off[i]) + int(ln[i])
             assert np.array_equal(dev[0][a:b], blob_h[a:b]), i
     al.close()
+
+
+def test_align_pair_entry(built):
+    """wfahip_align_pair (Aligner.Align): the two-launch path through the mapped pinned block for pairs shaped like the
+    reference's defaults, the batch entry behind it for everything else -- semi-global, other penalties, bytes outside ACGT,
+    bands wider than 64 diagonals, long pairs -- every result against the oracle; a CIGAR buffer that is too small reports
+    the capacity it needs."""
+    import ctypes as C
+    import wfa_amd as w
+    from wfa_amd import _lib as L
+    from oracle import oracle as O
+    rng = np.random.default_rng(11)
+    cases = []
+    for length, err, n in ((1000, 0.05, 60), (150, 0.02, 60), (37, 0.1, 30), (1000, 0.25, 12), (5000, 0.03, 6), (12000, 0.02, 2)):
+        blob, q_off, q_len, t_off, t_len = w.generate_pairs(seed=length + 7, n_pairs=n, length=length, error_rate=err)
+        for i in range(n):
+            q = bytes(blob[int(q_off[i]):int(q_off[i]) + int(q_len[i])])
+            t = bytes(blob[int(t_off[i]):int(t_off[i]) + int(t_len[i])])
+            if i % 9 == 0:
+                q = q[int(rng.integers(0, max(1, len(q) // 3))):]  # overhangs: the exact WF_NEXT at sequence ends
+            if i % 13 == 0:
+                t = t.lower() if i % 2 else t[:len(t) // 2] + b"N" + t[len(t) // 2:]  # bytes outside ACGT: the byte-compare path
+            cases.append((q, t))
+    cases += [(b"ACCATACTCG", b"AGGATGCTCG"), (b"A", b"CA"), (b"C", b"C"), (b"ACTG", b"ACTGA")]
+    for glob, ad, pen in ((True, (10, 50, 1), (4, 6, 2)), (True, None, (4, 6, 2)), (False, (10, 50, 1), (4, 6, 2)), (True, (10, 50, 1), (2, 3, 1)),
+                          (True, None, (5, 3, 2))):
+        al = _aligner(glob, ad, pen)
+        oa = O.Aligner(_oracle_params(glob, ad, pen))
+        fast = 0
+        for q, t in cases:
+            r = al.Align(q, t)
+            fast += al.last_timing().n_launches == 2
+            want = oa.align(q, t)
+            assert (r.Score, r.CIGAR(False), r.QBegin, r.QEnd, r.TBegin, r.TEnd, r.AlignLen, r.Matches, r.Gaps, r.GapRegions) == \
+                   (want.score, want.cigar, want.qbegin, want.qend, want.tbegin, want.tend, want.align_len, want.matches, want.gaps,
+                    want.gap_regions), (glob, ad, pen, len(q), len(t))
+        if glob and pen in ((4, 6, 2), (2, 3, 1)):
+            # most pairs took the two-launch path (without wf-adaptive the 1 kbp pairs outgrow the 64-diagonal window)
+            assert fast > (len(cases) // 2 if ad else len(cases) // 3), fast
+        else:
+            assert fast == 0
+        # the same pairs with the fast path switched off: the batch entry alone
+        al.set_option("pair_fast", 0)
+        for q, t in cases[:40]:
+            r, want = al.Align(q, t), oa.align(q, t)
+            assert (r.Score, r.CIGAR(False)) == (want.score, want.cigar)
+        with pytest.raises(w.ErrEmptySeq.__class__):
+            al.Align(b"", b"ACGT")
+        al.close()
+    # a CIGAR buffer that is too small
+    al = _aligner(True, (10, 50, 1))
+    q, t = cases[0]
+    rec, ops, n_ops = (C.c_uint32 * 16)(), (C.c_uint64 * 4)(), C.c_uint64()
+    prm = al._params()
+    rc = L.lib().wfahip_align_pair(al._ctx, C.byref(prm), q, len(q), t, len(t), rec, ops, 4, C.byref(n_ops))
+    assert rc == L.ERR_OOM and n_ops.value == len(al.Align(q, t).Ops) > 4
+    al.close()
