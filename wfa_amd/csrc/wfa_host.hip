@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <functional>
 #include <malloc.h>
 #include <mutex>
 #include <new>
@@ -95,6 +96,11 @@ struct wfahip_ctx {
     DevBuf        in_small;                  // host entry, small batches: blob + offset / length arrays as one image
     char         *one_pin    = nullptr;      // wfahip_align_pair: mapped pinned block (input image, record, ops) the kernels read and write directly
     char         *one_dev    = nullptr;      // ... its device address
+    std::vector<uint64_t> pack_qw, pack_tw;  // ... and the word offsets of the sequences in it
+    uint32_t     *pack_pin   = nullptr;      // host entry: page-locked home of the 2-bit words it packs itself, slice by slice
+    size_t        pack_pin_bytes = 0;
+    int64_t       opt_autopack             = 1;   // 1: wfahip_align_batch 2-bit packs large pure-ACGT batches on host threads while earlier slices upload
+    DevBuf        one_ctl;                   // ... and its control words: queue head / redo count / ops cursor, then the done queue of the streamed backtrace
     int64_t       opt_pair_fast            = 1;   // 1: wfahip_align_pair uses its two-launch path when the pair allows it
     DevBuf        in_packed;                 // host entry with pre-packed input: the 2-bit words as uploaded (unpacked into in_blob on the device)
     // wfahip_submit / wfahip_collect: pairs handed in one at a time, aligned as one batch
@@ -357,6 +363,7 @@ extern "C" void wfahip_destroy(wfahip_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->hpin) (void)hipHostFree(ctx->hpin);
     if (ctx->one_pin) (void)hipHostFree(ctx->one_pin);
+    if (ctx->pack_pin) (void)hipHostFree(ctx->pack_pin);
     if (ctx->stream_up) (void)hipStreamDestroy(ctx->stream_up);
     if (ctx->stream_dn) (void)hipStreamDestroy(ctx->stream_dn);
     for (hipEvent_t e : ctx->ev_up) (void)hipEventDestroy(e);
@@ -365,7 +372,7 @@ extern "C" void wfahip_destroy(wfahip_ctx *ctx) {
         if (ctx->pin_ev[i]) (void)hipEventDestroy(ctx->pin_ev[i]);
     }
     for (DevBuf *b : {&ctx->arena, &ctx->fin, &ctx->team_ctl, &ctx->arena2, &ctx->meta2, &ctx->doneq, &ctx->ctrl, &ctx->redo, &ctx->work, &ctx->meta, &ctx->in_blob, &ctx->in_qoff, &ctx->in_qlen,
-                      &ctx->in_toff, &ctx->in_tlen, &ctx->out_rec, &ctx->out_ops, &ctx->in_packed, &ctx->in_small, &ctx->prepack})
+                      &ctx->in_toff, &ctx->in_tlen, &ctx->out_rec, &ctx->out_ops, &ctx->in_packed, &ctx->in_small, &ctx->prepack, &ctx->one_ctl})
         release(*b);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -449,6 +456,8 @@ static int set_option_impl(wfahip_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_blk_mid = value;
     else if (k == "pair_fast")
         ctx->opt_pair_fast = value;
+    else if (k == "autopack")
+        ctx->opt_autopack = value;
     else if (k == "learn")
         ctx->opt_learn = value, ctx->learn_key = 0;
     else if (k == "mem_limit") {
@@ -1506,7 +1515,10 @@ __global__ __launch_bounds__(256) void wfa_scale_offsets_kernel(uint64_t *q_off,
 static int align_batch_impl(wfahip_ctx *ctx, const wfahip_params *p, const uint8_t *seq_blob,
                             uint64_t blob_bytes, const uint64_t *q_off, const uint32_t *q_len,
                             const uint64_t *t_off, const uint32_t *t_len, uint64_t n_pairs,
-                            wfahip_results *out, const uint32_t *packed = nullptr) {
+                            wfahip_results *out, const uint32_t *packed = nullptr,
+                            const std::function<int(uint64_t, uint64_t)> *lazy_pack = nullptr) {
+    // (lazy_pack: `packed` is the library's own buffer and is only filled as the pipeline gets to a range of pairs --
+    // lazy_pack(first, last) packs pairs [first, last) and returns 0, or 2 when it meets a byte outside ACGT)
     if (!ctx || !out) return WFAHIP_ERR_BAD_ARG;
     // (pre-packed input: q_off / t_off arrive in WORDS of 16 bases; they are uploaded as they are and scaled to byte
     // offsets on the device -- a second pair of host arrays would cost more in page faults than the alignment of a slice)
@@ -1559,13 +1571,17 @@ static int align_batch_impl(wfahip_ctx *ctx, const wfahip_params *p, const uint8
     // Large batches: the pairs are aligned in a few slices, each as soon as the part of the blob it refers to has
     // arrived (an uploader thread feeds a copy stream), so most of the alignment time hides behind the upload.
     // Needs the blob ranges of consecutive slices to be disjoint enough (pairs laid out in order, the usual case).
-    constexpr int     UP_SLICES = 4;
+    constexpr int     UP_SLICES = 4;  // (at most; packed input -- a quarter of the bytes -- is cut into three: a slice costs ~2 ms of its own)
+    int               n_sl = (packed && !lazy_pack) ? 3 : UP_SLICES;
+    if (const char *e = std::getenv("WFAHIP_SLICES")) n_sl = std::max(1, std::min(UP_SLICES, std::atoi(e)));
     uint64_t          sl_first[UP_SLICES + 1], sl_lo[UP_SLICES], sl_hi[UP_SLICES];
     bool              sliced = n_pairs >= 200000 && blob_bytes >= (packed ? (256u << 20) : (64u << 20)) && !std::getenv("WFAHIP_NO_UPLOAD_OVERLAP");
     if (sliced) {
         uint64_t covered = 0;
-        for (int k = 0; k <= UP_SLICES; k++) sl_first[k] = n_pairs * k / UP_SLICES;
-        for (int k = 0; k < UP_SLICES && sliced; k++) {
+        for (int k = 0; k <= UP_SLICES; k++) sl_first[k] = k <= n_sl ? n_pairs * k / n_sl : n_pairs;
+        // (packing on the fly: nothing can be uploaded before the first slice is packed, so the first slice is a small one)
+        if (lazy_pack && n_sl == 4) sl_first[1] = n_pairs * 12 / 100, sl_first[2] = n_pairs * 40 / 100, sl_first[3] = n_pairs * 70 / 100;
+        for (int k = 0; k < n_sl && sliced; k++) {
             uint64_t lo = blob_bytes, hi = 0;
             for (uint64_t i = sl_first[k]; i < sl_first[k + 1]; i++) {
                 if (!(q_len[i] <= WFAHIP_MAX_SEQ_LEN && t_len[i] <= WFAHIP_MAX_SEQ_LEN && q_len[i] && t_len[i])) continue;
@@ -1593,6 +1609,10 @@ static int align_batch_impl(wfahip_ctx *ctx, const wfahip_params *p, const uint8
     const uint64_t small_img = ((blob_bytes + 15) & ~15ull) + 24 * n_pairs + 64;
     const bool     small     = !sliced && !packed && n_pairs <= 4096 && small_img <= (4u << 20);
     void *d_blob = ctx->in_blob.p, *d_qoff = ctx->in_qoff.p, *d_toff = ctx->in_toff.p, *d_qlen = ctx->in_qlen.p, *d_tlen = ctx->in_tlen.p;
+    if (lazy_pack && !sliced) {
+        const int e = (*lazy_pack)(0, n_pairs);
+        if (e) return e == 2 ? WFAHIP_ERR_UNSUPPORTED : WFAHIP_ERR_HIP;
+    }
     if (small) {
         if (!ctx->pin[0]) HIP_TRY(hipHostMalloc(&ctx->pin[0], PIN_CHUNK, hipHostMallocDefault));
         if ((rc = ensure(ctx, ctx->in_small, small_img))) return rc;
@@ -1629,7 +1649,12 @@ static int align_batch_impl(wfahip_ctx *ctx, const wfahip_params *p, const uint8
             std::atomic<int> recorded{0}, up_err{0};
             const auto upload_all = [&] {
                 if (hipSetDevice(ctx->device) != hipSuccess) up_err = 1;
-                for (int k = 0; k < UP_SLICES; k++) {
+                for (int k = 0; k < n_sl; k++) {
+                    // (host-side packing of slice k runs here, beside the upload of slice k-1 and the alignment of earlier ones)
+                    if (!up_err && lazy_pack) {
+                        const int e = (*lazy_pack)(sl_first[k], sl_first[k + 1]);
+                        if (e) up_err = e == 2 ? 2 : 1;
+                    }
                     if (!up_err && sl_hi[k] > sl_lo[k] && upload_range(sl_lo[k], sl_hi[k], ctx->stream_up) != hipSuccess) up_err = 1;
                     if (hipEventRecord(ctx->ev_up[k], ctx->stream_up) != hipSuccess) up_err = 1;
                     recorded = k + 1;
@@ -1685,7 +1710,7 @@ static int align_batch_impl(wfahip_ctx *ctx, const wfahip_params *p, const uint8
             std::atomic<int> dl_err{0};
             const auto dl_run = [&] {
                 if (hipSetDevice(ctx->device) != hipSuccess) dl_err = 1;
-                for (int k = 0; k < UP_SLICES; k++) {
+                for (int k = 0; k < n_sl; k++) {
                     while (dl_state[k].load() == 0) std::this_thread::yield();
                     if (dl_state[k].load() == 2 || dl_err) continue;
                     const DlTask t       = dl_tasks[k];
@@ -1715,10 +1740,10 @@ static int align_batch_impl(wfahip_ctx *ctx, const wfahip_params *p, const uint8
                 else if (dl_inline) dl_run();
             };
             if (!alloc_ok) rc = WFAHIP_ERR_OOM;
-            for (int k = 0; k < UP_SLICES && rc == WFAHIP_OK; k++) {
+            for (int k = 0; k < n_sl && rc == WFAHIP_OK; k++) {
                 while (recorded.load() <= k) std::this_thread::yield();  // (the event must have been recorded before the wait)
                 if (up_err) {
-                    rc = WFAHIP_ERR_HIP;
+                    rc = up_err == 2 ? WFAHIP_ERR_UNSUPPORTED : WFAHIP_ERR_HIP;  // (2: a byte outside ACGT -- the caller falls back to the byte path)
                     break;
                 }
                 if (hipStreamWaitEvent(st, ctx->ev_up[k], 0) != hipSuccess) {
@@ -1926,11 +1951,124 @@ static int align_batch_impl(wfahip_ctx *ctx, const wfahip_params *p, const uint8
     return rc;
 }
 
+// 16 bases -> one word, eight bytes at a time: the codes are (byte >> 1) & 3, gathered by three shift-or steps; a byte
+// outside ACGT shows as a difference between the byte and the canonical letter of its code (0x41 + 2 code, + 15 for T).
+namespace {
+inline uint32_t pack8(uint64_t w, uint64_t &bad) {
+    const uint64_t x = (w >> 1) & 0x0303030303030303ull;
+    const uint64_t t = (x >> 1) & ~x & 0x0101010101010101ull;  // code 2 = 'T'
+    bad |= (0x4141414141414141ull + 2 * x + 15 * t) ^ w;
+    uint64_t y = (x | (x >> 6)) & 0x000F000F000F000Full;
+    y          = (y | (y >> 12)) & 0x000000FF000000FFull;
+    return (uint32_t)((y | (y >> 24)) & 0xFFFFull);
+}
+// one sequence -> dst[0 .. (len + 15) / 16] (the last word is the zero pad word); returns true on a byte outside ACGT
+bool pack_seq_fast(const uint8_t *s, uint32_t len, uint32_t *dst) {
+    uint64_t       bad = 0;
+    const uint32_t nw = len / 16;
+    for (uint32_t w = 0; w < nw; w++) {
+        uint64_t a, b;
+        std::memcpy(&a, s + 16 * w, 8), std::memcpy(&b, s + 16 * w + 8, 8);
+        dst[w] = pack8(a, bad) | (pack8(b, bad) << 16);
+    }
+    const uint32_t rem = len - 16 * nw;
+    if (rem) {
+        uint8_t tail[16];
+        std::memset(tail, 'A', 16);
+        std::memcpy(tail, s + 16 * nw, rem);
+        uint64_t a, b;
+        std::memcpy(&a, tail, 8), std::memcpy(&b, tail + 8, 8);
+        dst[nw] = pack8(a, bad) | (pack8(b, bad) << 16);
+        dst[nw + 1] = 0;
+    } else {
+        dst[nw] = 0;
+    }
+    return bad != 0;
+}
+}  // namespace
+
+// wfahip_align_batch on a large batch: a quarter of the bytes cross PCIe.  The sequences are 2-bit packed by host threads,
+// a slice at a time, into a page-locked buffer of the context -- slice k is packed while slice k-1 uploads and earlier
+// slices are being aligned -- and expanded again on the device (wfa_unpack_kernel), where bandwidth is free.  A byte outside
+// ACGT anywhere (the reference compares raw bytes, wfa.go:408-454) ends the attempt and the batch takes the byte path.
+static int align_batch_autopack(wfahip_ctx *ctx, const wfahip_params *p, const uint8_t *seq_blob, uint64_t blob_bytes,
+                                const uint64_t *q_off, const uint32_t *q_len, const uint64_t *t_off, const uint32_t *t_len,
+                                uint64_t n_pairs, wfahip_results *out) {
+    if (!ctx || !out || !q_off || !q_len || !t_off || !t_len || !seq_blob) return WFAHIP_ERR_BAD_ARG;
+    std::vector<uint64_t> &q_woff = ctx->pack_qw, &t_woff = ctx->pack_tw;  // (kept between calls: fresh pages cost more than the sums)
+    q_woff.resize(n_pairs), t_woff.resize(n_pairs);
+    uint64_t pos = 0;
+    for (uint64_t i = 0; i < n_pairs; i++) {
+        const bool v = q_len[i] <= WFAHIP_MAX_SEQ_LEN && t_len[i] <= WFAHIP_MAX_SEQ_LEN;
+        if (v && (q_off[i] > blob_bytes || q_len[i] > blob_bytes - q_off[i] || t_off[i] > blob_bytes || t_len[i] > blob_bytes - t_off[i]))
+            return WFAHIP_ERR_BAD_ARG;
+        q_woff[i] = pos, pos += wfahip_packed_words(v ? q_len[i] : 0);
+        t_woff[i] = pos, pos += wfahip_packed_words(v ? t_len[i] : 0);
+    }
+    const size_t need = (size_t)(pos + 4) * 4;
+    if (ctx->pack_pin_bytes < need) {
+        HIP_TRY(hipSetDevice(ctx->device));
+        if (ctx->pack_pin) (void)hipHostFree(ctx->pack_pin);
+        ctx->pack_pin = nullptr, ctx->pack_pin_bytes = 0;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->pack_pin), need + need / 8, hipHostMallocDefault));
+        ctx->pack_pin_bytes = need + need / 8;
+    }
+    uint32_t *const packed = ctx->pack_pin;
+    unsigned n_thr = std::max(1u, std::min(64u, std::thread::hardware_concurrency() / 2));
+    if (const char *e = std::getenv("WFAHIP_PACK_THREADS")) n_thr = (unsigned)std::max(1, std::atoi(e));
+    const std::function<int(uint64_t, uint64_t)> lazy = [&](uint64_t first, uint64_t last) -> int {
+        std::atomic<int> bad{0};
+        const auto range = [&](uint64_t a, uint64_t b) {
+            bool bd = false;
+            for (uint64_t i = a; i < b; i++) {
+                if (!(q_len[i] <= WFAHIP_MAX_SEQ_LEN && t_len[i] <= WFAHIP_MAX_SEQ_LEN)) {
+                    packed[q_woff[i]] = 0, packed[t_woff[i]] = 0;
+                    continue;
+                }
+                bd |= pack_seq_fast(seq_blob + q_off[i], q_len[i], packed + q_woff[i]);
+                bd |= pack_seq_fast(seq_blob + t_off[i], t_len[i], packed + t_woff[i]);
+            }
+            if (bd) bad = 1;
+        };
+        const uint64_t cnt = last - first;
+        const unsigned nt  = (unsigned)std::min<uint64_t>(n_thr, cnt / 2048 + 1);
+        std::vector<std::thread> th;
+        const uint64_t per = (cnt + nt - 1) / nt;
+        for (unsigned t = 0; t < nt; t++) {
+            const uint64_t a = std::min<uint64_t>(last, first + (uint64_t)t * per), b = std::min<uint64_t>(last, a + per);
+            bool inl = nt == 1;
+            if (!inl) {
+                try {
+                    th.emplace_back(range, a, b);
+                } catch (...) {
+                    inl = true;
+                }
+            }
+            if (inl) range(a, b);
+        }
+        for (auto &t : th) t.join();
+        return bad ? 2 : 0;
+    };
+    return align_batch_impl(ctx, p, nullptr, pos * 16, q_woff.data(), q_len, t_woff.data(), t_len, n_pairs, out, packed, &lazy);
+}
+
+static int align_batch_entry(wfahip_ctx *ctx, const wfahip_params *p, const uint8_t *seq_blob, uint64_t blob_bytes,
+                             const uint64_t *q_off, const uint32_t *q_len, const uint64_t *t_off, const uint32_t *t_len,
+                             uint64_t n_pairs, wfahip_results *out) {
+    if (ctx && out && ctx->opt_autopack != 0 && seq_blob && n_pairs >= 200000 && blob_bytes >= (256u << 20) &&
+        !std::getenv("WFAHIP_NO_AUTOPACK") && !std::getenv("WFAHIP_NO_UPLOAD_OVERLAP")) {
+        const int rc = align_batch_autopack(ctx, p, seq_blob, blob_bytes, q_off, q_len, t_off, t_len, n_pairs, out);
+        if (rc != WFAHIP_ERR_UNSUPPORTED || check_params(p) != WFAHIP_OK) return rc;
+        // (a byte outside ACGT somewhere in the batch: the byte path takes all of it)
+    }
+    return align_batch_impl(ctx, p, seq_blob, blob_bytes, q_off, q_len, t_off, t_len, n_pairs, out);
+}
+
 extern "C" int wfahip_align_batch(wfahip_ctx *ctx, const wfahip_params *p, const uint8_t *seq_blob,
                                   uint64_t blob_bytes, const uint64_t *q_off, const uint32_t *q_len,
                                   const uint64_t *t_off, const uint32_t *t_len, uint64_t n_pairs,
                                   wfahip_results *out) {
-    WFAHIP_GUARD(align_batch_impl(ctx, p, seq_blob, blob_bytes, q_off, q_len, t_off, t_len, n_pairs, out))
+    WFAHIP_GUARD(align_batch_entry(ctx, p, seq_blob, blob_bytes, q_off, q_len, t_off, t_len, n_pairs, out))
 }
 
 // ---- pre-packed input (a quarter of the bytes cross PCIe)
@@ -1968,20 +2106,7 @@ static int pack_pairs_impl(const uint8_t *seq_blob, const uint64_t *q_off, const
     std::atomic<int> bad{0};
     const auto       one = [&](const uint8_t *s, uint32_t len, uint32_t *dst) {
         if (len > WFAHIP_MAX_SEQ_LEN) len = 0;  // (rejected per pair by the alignment itself)
-        uint32_t       b  = 0;
-        const uint32_t nw = (len + 15) / 16;
-        for (uint32_t w = 0; w < nw; w++) {
-            uint32_t       word = 0;
-            const uint32_t nb   = std::min<uint32_t>(16, len - 16 * w);
-            for (uint32_t k = 0; k < nb; k++) {
-                const uint8_t c = s[16 * w + k];
-                b |= (uint32_t)!((c == 'A') | (c == 'C') | (c == 'G') | (c == 'T'));
-                word |= ((uint32_t)(c >> 1) & 3u) << (2 * k);
-            }
-            dst[w] = word;
-        }
-        dst[nw] = 0;
-        if (b) bad = 1;
+        if (pack_seq_fast(s, len, dst)) bad = 1;  // (eight bytes at a time: round 2's byte loop packed 2 GB in 34 ms on 32 threads)
     };
     const auto range = [&](uint64_t a, uint64_t b) {
         for (uint64_t i = a; i < b; i++) {
@@ -2070,7 +2195,7 @@ static int align_pair_impl(wfahip_ctx *ctx, const wfahip_params *p, const uint8_
         hipStream_t st = ctx->stream;
         // arena: rows for the worst-case score (64 words per score index), capped: what does not fit retries the usual way
         const uint64_t words = std::min<uint64_t>(((worst / g + 16) * 64 + 511) & ~511ull, std::max<uint64_t>(2048, (32ull * max_len + 511) & ~511ull));
-        if ((rc = ensure(ctx, ctx->ctrl, CTRL_WORDS * 4))) return rc;
+        if ((rc = ensure(ctx, ctx->one_ctl, 1024))) return rc;
         if ((rc = ensure(ctx, ctx->redo, 64))) return rc;
         if ((rc = ensure(ctx, ctx->meta, 64))) return rc;
         if (ctx->arena.bytes < words * 4 && (rc = ensure(ctx, ctx->arena, words * 4))) return rc;
@@ -2083,7 +2208,7 @@ static int align_pair_impl(wfahip_ctx *ctx, const wfahip_params *p, const uint8_
         lens[0] = n, lens[1] = m;
         uint32_t *const hrec = reinterpret_cast<uint32_t *>(h + ONE_REC_OFF);
         hrec[REC_STATUS] = ST_PENDING;
-        uint32_t *const d_ctrl = static_cast<uint32_t *>(ctx->ctrl.p);
+        uint32_t *const d_ctrl = static_cast<uint32_t *>(ctx->one_ctl.p);
         KParams P{};
         char *const d = ctx->one_dev;
         P.blob = reinterpret_cast<const uint8_t *>(d), P.blob_bytes = img - 64;
@@ -2099,13 +2224,23 @@ static int align_pair_impl(wfahip_ctx *ctx, const wfahip_params *p, const uint8_
         P.pair_meta = static_cast<uint4 *>(ctx->meta.p);
         P.dx = 2, P.doe = 4, P.de = 1, P.dm = 5, P.di = 2, P.min_xe = min_xe;
         P.lds_seq_words = seq_words, P.chunk_first = 0, P.chunk_n = 1, P.n_work = 1;
-        HIP_TRY(hipMemsetAsync(d_ctrl, 0, CTRL_WORDS * 4, st));
-        hipLaunchKernelGGL((wfa_blk_kernel<16, 1, false, 0, false>), dim3(1), dim3(64), (size_t)seq_words * 2 * 4 * 4 + 16, st, P);
-        hipLaunchKernelGGL(wfa_backtrace_kernel, dim3(1), dim3(256), 0, st, P);
+        HIP_TRY(hipMemsetAsync(d_ctrl, 0, 1024, st));
+        if (ctx->opt_pair_fast == 2) {  // forward kernel, then the backtrace kernel (kept for comparison: 305 us per 1 kbp pair)
+            hipLaunchKernelGGL((wfa_blk_kernel<16, 1, false, 0, false>), dim3(1), dim3(64), (size_t)seq_words * 2 * 4 * 4 + 16, st, P);
+            hipLaunchKernelGGL(wfa_backtrace_kernel, dim3(1), dim3(256), 0, st, P);
+        } else {
+            // ONE launch: the streaming instance of the forward kernel -- the wave pushes its finished pair to the done
+            // queue and, once the pair queue is empty, walks it itself (stream_backtrace at the end of the kernel).  The
+            // walk's ~100 dependent arena reads then hit the L2 of the XCD that has just written those rows, instead of
+            // missing in the L2 of whichever XCD a second kernel lands on (~1.3 us each).
+            P.done_ctl = d_ctrl + 64, P.done_q = reinterpret_cast<uint4 *>(d_ctrl + 128), P.n_stream_wgs = 0;
+            P.stream_wait = 2000000;  // 20 ms of the 100 MHz clock
+            hipLaunchKernelGGL((wfa_blk_kernel<16, 1, true, 0, false>), dim3(1), dim3(64), (size_t)seq_words * 2 * 4 * 4 + 16, st, P);
+        }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(st));
         ctx->timing = wfahip_timing{};
-        ctx->timing.n_launches = 2, ctx->timing.main_kernel_kind = 3;
+        ctx->timing.n_launches = ctx->opt_pair_fast == 2 ? 2 : 1, ctx->timing.main_kernel_kind = 3;  // (the batch entry never makes fewer than two launches)
         if (hrec[REC_STATUS] == ST_OK) {
             const uint64_t off = (uint64_t)hrec[REC_OPS_OFF_LO] | ((uint64_t)hrec[REC_OPS_OFF_HI] << 32);
             const uint32_t len = hrec[REC_OPS_LEN];
