@@ -1028,7 +1028,8 @@ def test_several_chunks_and_optional_paths(built, opts):
 
 @pytest.mark.parametrize("length,err,n,ad", [(1000, 0.05, 60000, (10, 50, 1)), (1000, 0.05, 777, (10, 50, 1)), (700, 0.08, 20000, (10, 50, 1)),
                                              (1000, 0.03, 20000, None), (400, 0.10, 20000, (10, 50, 1)), (1500, 0.04, 9000, (20, 100, 1)),
-                                             (1000, 0.05, 3, (10, 50, 1))])
+                                             (1000, 0.05, 3, (10, 50, 1)), (150, 0.02, 100000, None), (100, 0.06, 30000, (10, 50, 1)),
+                                             (230, 0.03, 7, None), (60, 0.1, 50000, None)])
 def test_duo_kernel_batches(built, length, err, n, ad):
     """wfa_duo_kernel (a pair runs on 8 or 16 lanes and changes between the two; pairs are parked in LDS and resumed;
     every wave prefetches its next pair) on batches large enough that every wave widens, narrows, parks and resumes many
@@ -1040,6 +1041,7 @@ def test_duo_kernel_batches(built, length, err, n, ad):
     want = O.align_batch(_oracle_params(True, ad), *data, n_threads=max(8, (os.cpu_count() or 8) // 2))
     al = _aligner(True, ad)
     al.set_option("duo", 2)
+    al.set_option("duo_short", 2)  # (short reads: eight pairs per fetch)
     al.set_option("arena_poison", 1)
     for rep in range(2):
         got = al.align_arrays(*data)

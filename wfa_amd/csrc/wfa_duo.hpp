@@ -52,13 +52,21 @@ namespace wfa {
 #endif
 constexpr int DUO_PARK       = WFA_DUO_PARK;           // park records per wave
 constexpr int DUO_PARK_WORDS = 8 * 12 + 16;            // rings of 8 lanes, two 16-bit offsets per word (reads under 2 048 bases) + 16 scalars
-constexpr int DUO_BUFS       = 8 + 1 + DUO_PARK;       // sequence buffers per wave: running pairs, staging, parked pairs
+constexpr int DUO_BUFS       = 8 + 1 + DUO_PARK;       // sequence buffers per wave: running pairs, staging, parked pairs (one pair per fetch)
+constexpr int DUO_FETCH_MAX  = 8;                      // short reads: pairs per fetch (as many prepacked slots as one 16-byte load per lane covers)
 constexpr int DUO_WIDEN_AT   = WFA_DUO_WIDEN_AT;       // a narrow pair whose band spans more diagonals than this widens (a recentred band must fit 32 - 6)
 constexpr int DUO_NARROW_AT  = WFA_DUO_NARROW_AT;      // a wide pair whose band spans at most this many narrows
 constexpr int DUO_WIDE_MAX   = 56;                     // a wide pair whose band spans more is handed on
 
+// pairs one fetch brings in: the slots of consecutive queue entries are contiguous in the prepack buffer, and one
+// 16-byte load per lane covers 256 words -- eight slots of a 150-base pair, one of a 1 kbp pair
+__host__ __device__ inline uint32_t duo_fetch_pairs(uint32_t prepack_words) {
+    const uint32_t f = 256u / prepack_words;
+    return f < 1u ? 1u : (f > (uint32_t)DUO_FETCH_MAX ? (uint32_t)DUO_FETCH_MAX : f);
+}
+__host__ __device__ inline uint32_t duo_bufs(uint32_t prepack_words) { return 8u + duo_fetch_pairs(prepack_words) + (uint32_t)DUO_PARK; }
 __host__ __device__ inline uint32_t duo_lds_words(uint32_t prepack_words) {
-    return (uint32_t)DUO_BUFS * prepack_words + (uint32_t)DUO_PARK * DUO_PARK_WORDS;
+    return duo_bufs(prepack_words) * prepack_words + (uint32_t)DUO_PARK * DUO_PARK_WORDS;
 }
 
 // Group reductions: three butterfly stages inside the 8 lanes of a half row, and a fourth (row_mirror) whose result
@@ -115,7 +123,8 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) void wfa_duo_kernel(const KParam
     const bool hi_half = (lane & 8) != 0;
 
     const uint32_t  SW = P.lds_seq_words, PW = P.prepack_words;  // PW = 4 + 2 SW words per prepacked pair (a multiple of 4)
-    uint32_t *const park0 = lds + (uint32_t)DUO_BUFS * PW;
+    const uint32_t  FP = duo_fetch_pairs(PW), NBUF = duo_bufs(PW);  // pairs per fetch, sequence buffers of the wave
+    uint32_t *const park0 = lds + NBUF * PW;
     const uint64_t  cap      = P.arena_words;
     const int       mdd      = (int)P.max_dist_diff;
     const int       minwf    = (int)P.min_wf_len;
@@ -148,7 +157,7 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) void wfa_duo_kernel(const KParam
     for (int p = 0; p < PP; p++) I[p] = D[p] = 0u, lim[p] = 0, lmx[p] = 0;
 
     // ---- wave-uniform state
-    uint32_t buf_free  = (1u << DUO_BUFS) - 1u;  // sequence buffers nobody owns
+    uint32_t buf_free  = (1u << NBUF) - 1u;      // sequence buffers nobody owns
     uint32_t park_used = 0u;                     // park records in use
     // prefetch pipeline (stages overlap: one new pair per iteration in steady state, three iterations of latency)
     // (one word of flags, not four bools: hipcc merges the stores to two bools into one store through a selected address,
@@ -156,6 +165,7 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) void wfa_duo_kernel(const KParam
     constexpr uint32_t PF_TOK = 1u, PF_LD = 2u, PF_STAGED = 4u, PF_DRY = 8u;  // queue atomic in flight / slot loads in flight / a pair staged in LDS / queue exhausted
     uint32_t pf = 0u;
     uint32_t pf_tok = 0u, pf_ld_idx = 0u, pf_idx = 0u, pf_buf = 0u;
+    uint32_t st_mask = 0u;  // buffers of the staged pairs, lowest bit = next pair (queue entry pf_idx)
     uint4    pf_w = make_uint4(0u, 0u, 0u, 0u);  // (a slot is at most 256 words: one 16-byte load per lane)
 
 #ifdef WFA_STAMPS  // diagnostic build (scripts/stamps.sh): time per phase and event counts, summed over the waves
@@ -207,11 +217,23 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) void wfa_duo_kernel(const KParam
         pf        = (uint32_t)__builtin_amdgcn_readfirstlane((int)pf);
         park_used = (uint32_t)__builtin_amdgcn_readfirstlane((int)park_used);
         buf_free  = (uint32_t)__builtin_amdgcn_readfirstlane((int)buf_free);
-        if ((pf & (PF_LD | PF_STAGED)) == PF_LD) {  // the words loaded an iteration ago go to a spare LDS buffer
-            pf_buf = (uint32_t)__builtin_ctz(buf_free);
-            buf_free &= buf_free - 1u;
-            uint32_t *const dst = lds + pf_buf * PW;
-            if ((uint32_t)lane * 4u < PW) *reinterpret_cast<uint4 *>(dst + lane * 4) = pf_w;
+        st_mask   = (uint32_t)__builtin_amdgcn_readfirstlane((int)st_mask);
+        if ((pf & (PF_LD | PF_STAGED)) == PF_LD) {  // the words loaded an iteration ago go to spare LDS buffers, one per pair
+            const uint32_t cnt = umin2(FP, P.chunk_n - pf_ld_idx);  // pairs this fetch really holds
+            // the cnt lowest free buffers: slot s of the fetch goes to the s-th of them
+            st_mask = 0u;
+            {
+                uint32_t f = buf_free;
+                for (uint32_t c = 0; c < cnt; c++) st_mask |= f & (0u - f), f &= f - 1u;
+            }
+            buf_free &= ~st_mask;
+            const uint32_t w0 = (uint32_t)lane * 4u, slot = w0 / PW;  // (a slot is a whole number of 16-byte pieces)
+            if (slot < cnt) {
+                uint32_t f = st_mask;
+                for (uint32_t c = 0; c < slot; c++) f &= f - 1u;
+                const uint32_t b = (uint32_t)__builtin_ctz(f);
+                *reinterpret_cast<uint4 *>(lds + b * PW + (w0 - slot * PW)) = pf_w;
+            }
             pf_idx = pf_ld_idx, pf = (pf | PF_STAGED) & ~PF_LD;
         }
         if ((pf & (PF_TOK | PF_LD)) == PF_TOK) {  // the queue entry claimed an iteration ago: its slot's words into registers
@@ -222,7 +244,8 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) void wfa_duo_kernel(const KParam
             const bool have = pf_ld_idx < P.chunk_n;
             if (have) {
                 const uint32_t *const slot = P.prepack + (uint64_t)pf_ld_idx * PW;
-                if ((uint32_t)lane * 4u < PW) pf_w = *reinterpret_cast<const uint4 *>(slot + lane * 4);
+                const uint32_t cnt = umin2(FP, P.chunk_n - pf_ld_idx);
+                if ((uint32_t)lane * 4u < cnt * PW) pf_w = *reinterpret_cast<const uint4 *>(slot + lane * 4);
             }
             pf = (pf & ~PF_TOK) | (have ? PF_LD : PF_DRY);
         }
@@ -231,7 +254,7 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) void wfa_duo_kernel(const KParam
             // atomic followed at once by s_waitcnt + v_readfirstlane -- a memory round trip during which the wave's
             // eight pairs stand still, every four steps.)
             if (lane == 0)
-                asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=v"(pf_tok) : "v"(0u), "v"(1u), "s"(P.queue_head) : "memory");
+                asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=v"(pf_tok) : "v"(0u), "v"(FP), "s"(P.queue_head) : "memory");
             pf |= PF_TOK;
         }
         // ---------------------------------------------------------------- does anything have to change?
@@ -420,24 +443,28 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) void wfa_duo_kernel(const KParam
                     m_free &= ~(0xFFull << (8 * oct));
                     continue;
                 }
-                // the staged pair: header {n, m, status, -} + packed words, in LDS buffer pf_buf
+                // the next staged pair: header {n, m, status, -} + packed words, in the lowest buffer of st_mask
+                pf_buf   = (uint32_t)__builtin_ctz(st_mask);
+                st_mask &= st_mask - 1u;
+                const uint32_t this_idx = pf_idx;
+                pf_idx += 1u;
                 const uint32_t *const hb = lds + pf_buf * PW;
                 // (readfirstlane: an LDS load counts as divergent, and a branch on it would turn this wave-uniform loop and
                 // every scalar it updates -- the prefetch flags, the buffer masks -- into per-lane values)
                 const uint32_t nq = (uint32_t)__builtin_amdgcn_readfirstlane((int)hb[0]), mt = (uint32_t)__builtin_amdgcn_readfirstlane((int)hb[1]);
                 const uint32_t status = (uint32_t)__builtin_amdgcn_readfirstlane((int)hb[2]);
-                pf &= ~PF_STAGED;
+                if (st_mask == 0u) pf &= ~PF_STAGED;
                 if (status != ST_PENDING) {  // empty / too long / does not fit / a byte outside ACGT: no alignment here
                     if (lane == 0) {
-                        P.pair_meta[pf_idx] = make_uint4(status, 0u, 0u, 0u);
-                        if (status >= ST_REDO_BYTES) push_redo(P, pair_of(pf_idx), status);
+                        P.pair_meta[this_idx] = make_uint4(status, 0u, 0u, 0u);
+                        if (status >= ST_REDO_BYTES) push_redo(P, pair_of(this_idx), status);
                     }
                     buf_free |= 1u << pf_buf;
                     continue;  // (the half stays free; the next staged pair will take it)
                 }
                 WFA_EVT(5, 1);
                 if (mine) {
-                    pidx = pf_idx, sbuf = pf_buf;
+                    pidx = this_idx, sbuf = pf_buf;
                     n = (int)nq, m = (int)mt;
                     const int Ak = m - n;
                     si = 0, cells = 0, slow = false;

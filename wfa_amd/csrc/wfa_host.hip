@@ -144,6 +144,10 @@ struct wfahip_ctx {
                                                   // 0 never, 1 for batches of at least opt_duo_min_pairs (below that its start-up -- a wave takes one new pair
                                                   // per step -- costs more than the fuller rows give: 1e5 pairs 2.6 vs 2.3 ms), 2 always
     int64_t       opt_duo_min_pairs        = 200000;
+    int64_t       opt_duo_short            = 0;   // 1 / 2: batches of short reads (<= 240 bases) use it too, with eight pairs per fetch.  Off: measured
+                                                  // SLOWER than the batched 8-lane instance (1e5 x 150 bp: forward 0.317 vs 0.249 ms, 1e6: 1.60 vs 1.43 ms, plus the
+                                                  // packing kernel) -- a 150-base pair lives ten steps, so a wave restructures on nearly every step
+    int64_t       opt_duo_short_min_pairs  = 50000;
     int64_t       opt_census               = 0;   // 1: the sub-wave forward kernels count the wavefront words they store (REC_CELLS, timing.cells_stored)
     int64_t       opt_learn                = 1;   // 1: long pairs start on the arena level the previous call of the same kind ended on
     uint64_t      learn_key                = 0;   // workload class of the last call that used the team kernel
@@ -452,6 +456,10 @@ static int set_option_impl(wfahip_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_duo = value;
     else if (k == "duo_min_pairs")
         ctx->opt_duo_min_pairs = value;
+    else if (k == "duo_short")
+        ctx->opt_duo_short = value;
+    else if (k == "duo_short_min_pairs")
+        ctx->opt_duo_short_min_pairs = value;
     else if (k == "blk_mid")
         ctx->opt_blk_mid = value;
     else if (k == "pair_fast")
@@ -845,9 +853,11 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                                  ((ctx->opt_blk_batch != 0 && max_len < 200 && seq_words <= 16) ||
                                   (ctx->opt_narrow_long != 0 && (size_t)seq_words * 2 * 4 * 8 + 16 <= 8 * 1024));
             // reads of 240+ bases: the variable-lanes kernel (its slots hold at most 126 packed words per sequence)
-            const bool duo1    = can_d && ctx->opt_blk == 16 && !narrow1 && seq_words > 16 &&
-                                 (ctx->opt_duo >= 2 || (ctx->opt_duo == 1 && (int64_t)n_pairs >= ctx->opt_duo_min_pairs)) &&
-                                 4u + 2u * ((seq_words + 1u) & ~1u) <= 256u;
+            const bool duo_long  = !narrow1 && seq_words > 16 &&
+                                   (ctx->opt_duo >= 2 || (ctx->opt_duo == 1 && (int64_t)n_pairs >= ctx->opt_duo_min_pairs));
+            const bool duo_short = seq_words <= 16 && ctx->opt_duo != 0 &&
+                                   (ctx->opt_duo_short >= 2 || (ctx->opt_duo_short == 1 && (int64_t)n_pairs >= ctx->opt_duo_short_min_pairs));
+            const bool duo1    = can_d && ctx->opt_blk == 16 && (duo_long || duo_short) && 4u + 2u * ((seq_words + 1u) & ~1u) <= 256u;
             const int  kind1   = duo1 ? 8 : narrow1 ? 6 : (can_d ? (ctx->opt_blk == 8 ? 4 : 3) : (can_c ? 2 : 1));
             // Pilot: on a large batch with wf-adaptive off the first 4 096 pairs go first.  When most of them leave the
             // 64-diagonal window the rest does not start there only to be handed on: it goes straight to the
