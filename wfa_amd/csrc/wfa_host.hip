@@ -770,7 +770,7 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                 if ((kind == 3 && !blk_batch && !list && ctx->opt_prepack != 0) || kind == 8) {
                     const uint32_t pw = 4u + 2u * P.lds_seq_words;
                     if ((rc2 = ensure(ctx, ctx->prepack, (size_t)chunk * pw * 4))) return rc2;
-                    hipLaunchKernelGGL(wfa_prepack_kernel, dim3((uint32_t)cn), dim3(std::min<uint32_t>(256u, (2u * P.lds_seq_words + 63u) & ~63u)), 0, st, P,
+                    hipLaunchKernelGGL(wfa_prepack_kernel, dim3((uint32_t)((cn + 4 * PREPACK_PAIRS - 1) / (4 * PREPACK_PAIRS))), dim3(256), 0, st, P,
                                        static_cast<uint32_t *>(ctx->prepack.p), P.lds_seq_words, pw);
                     HIP_TRY(hipGetLastError());
                     P.prepack = static_cast<const uint32_t *>(ctx->prepack.p), P.prepack_words = pw;
@@ -958,9 +958,9 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             // once, backtrace included) than through another forward + backtrace pass; beyond that the LDS-ring
             // kernel's throughput wins.
             const uint64_t resident_generic = (uint64_t)ctx->num_cus * 32;
-            if (kind1 == 6 || kind1 == 8) {  // band / arena failures of the 32-diagonal instance -> the 64-diagonal one; pairs the
-                                             // variable-lanes kernel handed on (no park record free, or a band wider than a
-                                             // row) -> a 64-diagonal window of their own
+            if (kind1 == 6) {  // band / arena failures of the 32-diagonal instance -> the 64-diagonal one.  (What the variable-lanes
+                               // kernel hands on -- a band wider than a row, rarely no park record free: 0.08 % of 1 kbp pairs --
+                               // goes straight to the 128-diagonal instance below: one retry pass instead of two.)
                 std::vector<uint32_t> lst;
                 std::vector<uint64_t> keep, r2;
                 for (uint64_t e : redo1) {
