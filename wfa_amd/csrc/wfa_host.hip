@@ -101,6 +101,9 @@ struct wfahip_ctx {
     size_t        pack_pin_bytes = 0;
     int64_t       opt_autopack             = 1;   // 1: wfahip_align_batch 2-bit packs large pure-ACGT batches on host threads while earlier slices upload
     DevBuf        one_ctl;                   // ... and its control words: queue head / redo count / ops cursor, then the done queue of the streamed backtrace
+    int64_t       opt_arena_budget_pct     = 60;  // long-pair ladder: percent of device memory its arenas may take (80 / 85 / 90: five or six slots
+                                                  // instead of four for the configs[4] pairs -- the main launch of 32 pairs 2 875 -> 1 949 / 2 074 / 1 744 ms --
+                                                  // but 2 / 1 / 3 of them then outgrow the smaller slots and their re-run takes 1.1 s: no gain, measured)
     int64_t       opt_pair_fast            = 1;   // 1: wfahip_align_pair uses its two-launch path when the pair allows it
     DevBuf        in_packed;                 // host entry with pre-packed input: the 2-bit words as uploaded (unpacked into in_blob on the device)
     // wfahip_submit / wfahip_collect: pairs handed in one at a time, aligned as one batch
@@ -206,6 +209,11 @@ uint32_t gcd_u32(uint32_t a, uint32_t b) {
     return a;
 }
 
+// Share of device memory the arenas of the long-pair ladder may take: 0.6 -> four 43 GiB slots for the hard 100 kbp
+// semi-global pairs (a team of workgroups each).  Option arena_budget_pct; more slots were measured and lose to the
+// re-runs of the pairs that outgrow them (see the option).
+inline double ladder_budget(const wfahip_ctx *ctx) { return std::min(0.9, std::max(0.1, (double)ctx->opt_arena_budget_pct / 100.0)); }
+
 struct LaunchCfg {
     int      waves;        // 1, 4 or 16 waves per pair
     int      mode;         // 0 = 2-bit LDS, 1 = bytes in global memory
@@ -268,18 +276,18 @@ int make_cfg(wfahip_ctx *ctx, uint32_t max_len, int mode, int level, uint64_t n_
     if (ctx->opt_arena_bytes_per_slot > 0) base_words = std::max<uint64_t>(4096, ctx->opt_arena_bytes_per_slot / 4);
     // the ladder: x8, x8, then x2 per level -- a slot of a long pair is tens of GB by then, and every doubling
     // halves the number of pairs that can be in flight (level 3 of a 100 kbp semi-global pair: 21.6 GB)
-    // Once at most four slots fit the budget (tens of GB per pair), a level is "one slot fewer", and a slot takes
-    // its whole share of the budget: 4 x 43 GB, 3 x 57, 2 x 86, 1 x 172 on a 288 GB device instead of 4 x 39, 2 x 79,
-    // 1 x 157 -- every slot dropped is a team of workgroups less in flight.
-    const uint64_t budget_words = (uint64_t)((double)ctx->total_mem * 0.6) / 4ull;
+    // Once at most six slots fit the budget (tens of GB per pair), a level is "one slot fewer", and a slot takes
+    // its whole share of the budget: 5 x 46 GB, 4 x 57, 3 x 76, 2 x 115, 1 x 230 on a 288 GB device with the budget at
+    // 80 % (round 2, 60 %: 4 x 43, 3 x 57, 2 x 86, 1 x 172) -- every slot dropped is a team of workgroups less in flight.
+    const uint64_t budget_words = (uint64_t)((double)ctx->total_mem * ladder_budget(ctx)) / 4ull;
     uint64_t       words        = base_words;
     auto snap = [&](uint64_t w) {
         const uint64_t fit = w ? budget_words / w : 0;
-        return (fit >= 1 && fit <= 4 && ctx->opt_arena_bytes_per_slot <= 0) ? budget_words / fit : w;  // (not an explicit size)
+        return (fit >= 1 && fit <= 6 && ctx->opt_arena_bytes_per_slot <= 0) ? budget_words / fit : w;  // (not an explicit size)
     };
     for (int i = 0; i < level; i++) {
         const uint64_t fit = budget_words / words;
-        if (fit >= 2 && fit <= 4)
+        if (fit >= 2 && fit <= 6)
             words = budget_words / (fit - 1);
         else
             words *= (i < 2 ? 8 : 2);
@@ -464,6 +472,8 @@ static int set_option_impl(wfahip_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_blk_mid = value;
     else if (k == "pair_fast")
         ctx->opt_pair_fast = value;
+    else if (k == "arena_budget_pct")
+        ctx->opt_arena_budget_pct = value;
     else if (k == "autopack")
         ctx->opt_autopack = value;
     else if (k == "learn")
@@ -1129,7 +1139,7 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             team_n = (uint32_t)std::min<uint64_t>(n_work, std::max<uint32_t>(1, cus / t0));
             team_T = ctx->opt_team_wgs > 0 ? t0 : cus / team_n;
             // one arena per team
-            const uint64_t budget = (uint64_t)((double)ctx->total_mem * 0.6);
+            const uint64_t budget = (uint64_t)((double)ctx->total_mem * ladder_budget(ctx));
             while (team_n > 1 && (uint64_t)team_n * cfg.arena_words * 4ull > budget) team_n--;
             if ((uint64_t)team_n * cfg.arena_words * 4ull > budget) cr = 2;
             if (ctx->opt_team_wgs == 0) team_T = std::min<uint32_t>(cus / team_n, 2 * t0);  // ~2 cells per thread and stripe
@@ -1161,8 +1171,8 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
         DevBuf &jarena = ctx->bt_pending ? ctx->arena2 : ctx->arena;
         // Long pairs climbing the ladder: take the whole arena budget once instead of freeing and re-allocating a
         // bigger buffer at every level (hipMalloc / hipFree of tens of GB cost more than the alignments).
-        if (team_T > 0 && job.level >= 2 && jarena.bytes < (size_t)((double)ctx->total_mem * 0.6))
-            (void)ensure(ctx, jarena, (size_t)((double)ctx->total_mem * 0.6));
+        if (team_T > 0 && job.level >= 2 && jarena.bytes < (size_t)((double)ctx->total_mem * ladder_budget(ctx)))
+            (void)ensure(ctx, jarena, (size_t)((double)ctx->total_mem * ladder_budget(ctx)));
         rc = ensure(ctx, jarena, (size_t)cfg.arena_words * 4ull * cfg.slots);
         if (rc == WFAHIP_ERR_OOM && cfg.slots > 1) {  // shrink once
             cfg.slots = std::max<uint32_t>(1, cfg.slots / 4);
