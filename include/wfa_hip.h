@@ -18,6 +18,18 @@
  *
  * Threading: one wfahip_ctx may be used by one thread at a time; different contexts may be used
  * concurrently (mirrors "one Aligner per goroutine", wfa.go:73-78).
+ *
+ * First call of a workload: a context allocates its device buffers on demand and keeps them -- wavefront arenas sized
+ * for the batch (64 KB per 1 kbp pair: 61 GiB for a million pairs), staging buffers, the page-locked blocks of the
+ * host entry.  hipMalloc of tens of GB and hipHostMalloc of hundreds of MB take SECONDS (2.5-4 s measured for the first
+ * 1e6 x 1 kbp call of a context against 20-60 ms for every later one), so a service should align one batch of its
+ * largest expected shape right after wfahip_create, before it takes traffic; later calls of the same or a smaller shape
+ * allocate nothing.  A context also LEARNS per class of batches (length bucket, penalties, wf-adaptive): the arena level
+ * long pairs need, the rows per pair and the window width that high-error batches need.  What is learned changes only
+ * how fast a call is, never its results (options "learn", and the tests of it, say how).
+ *
+ * Results are owned by the library: every array of a wfahip_results is handed back through wfahip_results_free, never
+ * free()d by the caller (blocks circulate through a cache and are page-locked while they do).
  */
 #ifndef WFA_HIP_H
 #define WFA_HIP_H
@@ -29,7 +41,7 @@
 extern "C" {
 #endif
 
-#define WFAHIP_VERSION 200 /* 0.2.0 */
+#define WFAHIP_VERSION 300 /* 0.3.0 */
 
 /* whole-call return codes (0 = success, negative = failure) */
 enum {
@@ -38,7 +50,9 @@ enum {
     WFAHIP_ERR_BAD_ARG     = -2,
     WFAHIP_ERR_OOM         = -3,
     WFAHIP_ERR_HIP         = -4,
-    WFAHIP_ERR_UNSUPPORTED = -5, /* penalties the reference itself cannot align (mismatch == 0, gap_open + gap_ext == 0); non-ACGT input to the packer */
+    WFAHIP_ERR_UNSUPPORTED = -5, /* mismatch == 0 or gap_open + gap_ext == 0 (the reference's own backtrace does not
+                                    terminate for mismatch == 0 when first bases differ, and next() would read the row it is writing);
+                                    non-ACGT input to the packer */
     WFAHIP_ERR_INTERNAL    = -6
 };
 
