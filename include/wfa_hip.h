@@ -125,6 +125,9 @@ typedef struct wfahip_ctx wfahip_ctx;
 
 int         wfahip_version(void);
 const char *wfahip_strerror(int code);
+/* detail of the most recent WFAHIP_ERR_HIP / WFAHIP_ERR_OOM / WFAHIP_ERR_INTERNAL on a context (the failing runtime call and its
+ * message; "" if none): for logs -- the code is what a binding acts on.  Valid until the next call on the context. */
+const char *wfahip_last_error(const wfahip_ctx *ctx);
 int         wfahip_device_count(void);
 
 /* One context per GPU (one process per GPU in multi-GPU jobs).  device_id < 0 = current device. */

@@ -556,6 +556,8 @@ struct CompactView {
         if (fmt == 4u) return ld(256ull * idx + ((uint32_t)k & 255u));
         if (fmt == 5u) return ld(32ull * idx + ((uint32_t)k & 31u));
         if (fmt == 6u) return ld(128ull * idx + ((uint32_t)k & 127u));
+        if (fmt == 7u)  // fmt 3's tiles with 16-bit words (wfa_duo_kernel: reads under 2 048 bases)
+            return reinterpret_cast<const uint16_t *>(A)[512ull * (idx >> 3) + (((uint32_t)k & 60u) << 3) + ((idx & 7u) << 2) + ((uint32_t)k & 3u)];
         const uint4 e = *reinterpret_cast<const uint4 *>(A + cap - 4ull * (idx + 1));
         const int   lo = (int)e.y, w = (int)e.z;
         if (w <= 0 || k < lo || k >= lo + w) return 0u;

@@ -28,8 +28,8 @@
 //   * a parked pair resumes from LDS.
 //
 // Everything else -- the rejection-free WF_NEXT with the decisions shifted in under the offset, the first-window +
-// candidate-at-a-time WF_EXTEND, the branch-free band / wf-adaptive reductions, the arena (CompactView fmt 3: tiles of
-// 8 scores x 64 diagonals, diagonal k at slot k & 63) and pair_meta for wfa_backtrace_kernel -- is wfa_blk_kernel's,
+// candidate-at-a-time WF_EXTEND, the branch-free band / wf-adaptive reductions, the arena tiles of 8 scores x 64
+// diagonals (here with 16-bit words, CompactView fmt 7) and pair_meta for wfa_backtrace_kernel -- is wfa_blk_kernel's,
 // with the group size a per-lane value instead of a template argument.  Results do not depend on which pairs share a
 // wave: the band of a row is a function of the pair alone as long as its window holds it, and a pair whose band cannot
 // be held is handed on (ST_REDO_BAND) and recomputed from scratch by the retry rung.
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) void wfa_duo_kernel(const KParam
     const int       minwf    = (int)P.min_wf_len;
     const bool      adaptive = P.adaptive != 0;
     const uint32_t  seed_si  = P.dx;  // the mismatch seed M[x][0] belongs to step x/g
-    const int       rows_cap = (int)(cap / 64);
+    const int       rows_cap = (int)(cap / 32);  // 16-bit words: a score's 64 diagonals are 32 words
 
     // ---- per-pair state (identical in the lanes of a pair)
     int       st = 0;  // 0 = free half, 1 = running
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) void wfa_duo_kernel(const KParam
         for (int p = 0; p < PP; p++) lim[p] = imax2(1, imin2(n + k0 + p, m)), lmx[p] = imax2(n + k0 + p, m);
         lq   = lds + sbuf * PW + 4u;
         lt   = lq + SW;
-        rowp = P.arena + (uint64_t)pidx * cap + (uint64_t)(si >> 3) * 512u + (si & 7u) * 4u;
+        rowp = P.arena + (uint64_t)pidx * cap + (uint64_t)(si >> 3) * 256u + (si & 7u) * 2u;
     };
     const auto clear_rings = [&]() {
 #pragma unroll
@@ -548,14 +548,19 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) void wfa_duo_kernel(const KParam
                 if (want && k0 + p == 0 && nM[p] == 0u)
                     nM[p] = 1u, wd[p] = first_eq ? BLK_SEED_MATCH : BLK_SEED_MISMATCH, cc[p] = CENSUS ? 1u : 0u;
         }
-        // ------------------------------------------------------------ store the row's words (CompactView fmt 3)
+        // ------------------------------------------------------------ store the row's words (CompactView fmt 7)
+        // 16-bit words -- a pre-extension offset below 4 096 and the four decisions: this kernel's reads are under 2 048
+        // bases -- in tiles of 8 scores x 64 diagonals (1 KB), inside a tile [diagonal / 4][score & 7][diagonal & 3]: a
+        // lane's four diagonals are one 8-byte store, and a 64-byte piece of a line holds 8 scores of 4 diagonals.  Half
+        // the bytes of fmt 3 to write here and to fetch in the backtrace's walk (round 3; WRITE_SIZE was 31 GB per
+        // 1e6 pairs with 32-bit words).
         const bool no_room = run && (int)si >= rows_cap;
         {
             uint32_t anyc = 0u;
 #pragma unroll
             for (int p = 0; p < PP; p++) anyc |= nM[p];
             if (run && !no_room && anyc != 0u)
-                *reinterpret_cast<uint4 *>(rowp + (((uint32_t)k0 & 63u) << 3)) = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+                *reinterpret_cast<uint2 *>(rowp + (((uint32_t)k0 & 60u) << 2)) = make_uint2(wd[0] | (wd[1] << 16), wd[2] | (wd[3] << 16));
         }
         WFA_STAMP(2);  // next + store
 
@@ -703,8 +708,8 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) void wfa_duo_kernel(const KParam
             DuoRed::max_add(dummy, cs, wide);
             cells += keepl ? (uint32_t)cs : 0u;
         }
-        rowp += 4;
-        rowp += (((uint32_t)(uintptr_t)rowp & 0x70u) == 0u) ? 480 : 0;  // past the tile's 8th score: next tile
+        rowp += 2;
+        rowp += (((uint32_t)(uintptr_t)rowp & 0x38u) == 0u) ? 240 : 0;  // past the tile's 8th score: next tile
 
         // ------------------------------------------------------------ the new row enters the rings
 #pragma unroll

@@ -48,8 +48,10 @@ using namespace wfa;
     try {                                   \
         return (expr);                      \
     } catch (const std::bad_alloc &) {      \
+        if (std::getenv("WFAHIP_DEBUG_TIMING")) std::fprintf(stderr, "[wfahip] std::bad_alloc caught at the C-ABI (%s:%d)\n", __FILE__, __LINE__); \
         return WFAHIP_ERR_OOM;              \
     } catch (...) {                         \
+        if (std::getenv("WFAHIP_DEBUG_TIMING")) std::fprintf(stderr, "[wfahip] exception caught at the C-ABI (%s:%d)\n", __FILE__, __LINE__); \
         return WFAHIP_ERR_INTERNAL;         \
     }
 
@@ -501,6 +503,8 @@ extern "C" int wfahip_last_timing(const wfahip_ctx *ctx, wfahip_timing *out) {
 
 extern "C" void wfahip_free(void *p) { std::free(p); }
 
+extern "C" const char *wfahip_last_error(const wfahip_ctx *ctx) { return ctx ? ctx->last_error : ""; }
+
 static int check_params(const wfahip_params *p) {
     if (!p) return WFAHIP_ERR_BAD_ARG;
     // Mismatch == 0: the reference's own loop does not terminate when the first bases differ (the seed is then a
@@ -698,9 +702,10 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             // 1 kbp; 256-diagonal window (kind 5, the retry rung): 128 words per base = 500 scores at 1 kbp
             const uint64_t words        = kind == 5   ? std::max<uint64_t>((words_dir * 16 * arena_mult + 511) & ~511ull, 8192)
                                           : kind == 9 ? std::max<uint64_t>((words_dir * 4 * arena_mult + 511) & ~511ull, 4096)
+                                          : kind == 8 ? std::max<uint64_t>((words_dir * arena_mult + 511) & ~511ull, 1024)  // 16-bit words
                                           : kind >= 3 ? std::max<uint64_t>((words_dir * 2 * arena_mult + 511) & ~511ull, 2048)
                                                       : words_dir;
-            P.arena_words = words, P.compact_fmt = kind == 6 ? 5u : kind == 5 ? 4u : kind == 9 ? 6u : (kind >= 3 ? (WFA_BLK_TILED ? 3u : 1u) : 0u);
+            P.arena_words = words, P.compact_fmt = kind == 8 ? 7u : kind == 6 ? 5u : kind == 5 ? 4u : kind == 9 ? 6u : (kind >= 3 ? (WFA_BLK_TILED ? 3u : 1u) : 0u);
             const uint32_t waves_lds    = (uint32_t)std::min<size_t>(32, LDS_MAX_BYTES / lds_bytes);
             const bool     overlap      = ctx->opt_overlap != 0;
             uint32_t       waves_per_cu = kind == 8 ? std::min<uint32_t>(waves_lds, 4 * WFA_DUO_WAVES)
@@ -1093,13 +1098,13 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
     if (!packed_done) {
         Job j;
         j.mode = ctx->force_mode == 1 ? 1 : 0, j.level = 0, j.all = true;
-        // The learned level is a HINT about speed, never about results: a call may start there, but (a) every fourth call of
+        // The learned level is a HINT about speed, never about results: a call may start there, but (a) every sixteenth call of
         // the class starts one level lower, so that one hard batch does not pin the class to large slots and few teams
         // for ever (a start level can only be confirmed or raised by the call that uses it), and (b) a start level whose
         // slot does not fit this call's lengths is stepped down below instead of failing the pairs.
         if (ctx->opt_learn && !debug_single && ctx->learn_key == lkey && ctx->opt_team_min_len > 0 && max_len >= (uint64_t)ctx->opt_team_min_len) {
             j.level = ctx->learn_level;
-            if (j.level > 0 && (++ctx->learn_calls & 3u) == 0u) j.level -= 1;
+            if (j.level > 0 && (++ctx->learn_calls & 15u) == 0u) j.level -= 1;  // (a probe that fails costs a launch: 72 ms of a 94 ms call on 500 x 50 kbp)
             j.hint = j.level > 0;
         }
         ctx->timing.reserved = (uint32_t)j.level;  // (start level of the long-pair ladder: tests of the learned hint read it)
@@ -1302,7 +1307,10 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
     const uint64_t cursor   = (uint64_t)hctrl[2] | ((uint64_t)hctrl[3] << 32);
     ctx->timing.ops_written = cursor;
     if (ops_needed) *ops_needed = cursor;
-    if (cursor > ops_cap) return WFAHIP_ERR_OOM;
+    if (cursor > ops_cap) {
+        if (std::getenv("WFAHIP_DEBUG_TIMING")) std::fprintf(stderr, "[wfahip] CIGAR op buffer too small: %llu needed, %llu there\n", (unsigned long long)cursor, (unsigned long long)ops_cap);
+        return WFAHIP_ERR_OOM;
+    }
     return WFAHIP_OK;
 }
 
@@ -1662,7 +1670,7 @@ static int align_batch_impl(wfahip_ctx *ctx, const wfahip_params *p, const uint8
     const auto t_dev = now();
     // CIGAR ops are merged runs: a first guess of (n+m)/4 + 8 per pair, grown on demand (at most n+m+2 each)
     uint64_t ops_cap = sum_len / 4 + 8 * n_pairs + 1024;
-    for (int attempt = 0; attempt < 3; attempt++) {
+    for (int attempt = 0; attempt < 6; attempt++) {
         if ((rc = ensure(ctx, ctx->out_ops, ops_cap * 8))) return rc;
         uint64_t needed = 0;
         if (sliced && attempt == 0) {
@@ -1874,7 +1882,9 @@ static int align_batch_impl(wfahip_ctx *ctx, const wfahip_params *p, const uint8
         rc = align_device(ctx, p, d_blob, blob_bytes, d_qoff, d_qlen, d_toff, d_tlen, n_pairs, max_len, ctx->out_rec.p, ctx->out_ops.p,
                           ops_cap, &needed, st, false);
         if (rc == WFAHIP_ERR_OOM && needed > ops_cap) {
-            ops_cap = needed + 1024;
+            // (with headroom: what a call needs is not the same on every attempt -- a context learns the rows and the window a
+            // class of pairs needs while it runs, and the retry passes it takes, each reserving op slots, change with that)
+            ops_cap = needed + needed / 3 + 1024;
             continue;
         }
         break;
