@@ -432,7 +432,7 @@ def find_profile(config, kname):
         except Exception:
             continue
         # (the blocked kernel has two instances: the timed steps run the one without the census, "..., false>")
-        for name, grids in sorted(pm.items(), key=lambda kv: 0 if ", false>" in kv[0] else 1):
+        for name, grids in sorted(pm.items(), key=lambda kv: 0 if "false>" in kv[0] else 1):
             if kname in name:
                 g0 = max(grids.values(), key=lambda d: d.get("WRITE_SIZE_KB", 0))
                 if "FETCH_SIZE_KB" in g0 and "WRITE_SIZE_KB" in g0:
