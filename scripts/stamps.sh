@@ -6,7 +6,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $REPO
 mkdir -p /tmp/wfa_stamps/wfa_amd/lib
 cp -r wfa_amd/*.py /tmp/wfa_stamps/wfa_amd/
-hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DWFA_STAMPS $WFA_EXTRA -shared -o /tmp/wfa_stamps/wfa_amd/lib/libwfahip.so wfa_amd/csrc/wfa_host.hip wfa_amd/csrc/wfa_gen.cpp wfa_amd/csrc/wfa_multi.cpp
+hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -mllvm -amdgpu-atomic-optimizer-strategy=None -DWFA_STAMPS $WFA_EXTRA -shared -o /tmp/wfa_stamps/wfa_amd/lib/libwfahip.so wfa_amd/csrc/wfa_host.hip wfa_amd/csrc/wfa_gen.cpp wfa_amd/csrc/wfa_multi.cpp
 cd /tmp/wfa_stamps && python3 - "$@" <<'PY'
 import sys, numpy as np
 sys.path.insert(0, "/tmp/wfa_stamps")

@@ -237,9 +237,6 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) void wfa_duo_kernel(const KParam
             pf_idx = pf_ld_idx, pf = (pf | PF_STAGED) & ~PF_LD;
         }
         if ((pf & (PF_TOK | PF_LD)) == PF_TOK) {  // the queue entry claimed an iteration ago: its slot's words into registers
-            // (the atomic below is inline assembly, so the compiler does not know a result is outstanding: it was issued a
-            // whole score step ago, and this wait also covers nothing the step would not have waited for by now)
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_tok)::"memory");
             pf_ld_idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)pf_tok);
             const bool have = pf_ld_idx < P.chunk_n;
             if (have) {
@@ -250,11 +247,14 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) void wfa_duo_kernel(const KParam
             pf = (pf & ~PF_TOK) | (have ? PF_LD : PF_DRY);
         }
         if ((pf & (PF_TOK | PF_DRY)) == 0u) {
-            // One queue entry, by lane 0, result NOT awaited here.  (atomicAdd() would be turned into a wave-aggregated
-            // atomic followed at once by s_waitcnt + v_readfirstlane -- a memory round trip during which the wave's
-            // eight pairs stand still, every four steps.)
-            if (lane == 0)
-                asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=v"(pf_tok) : "v"(0u), "v"(FP), "s"(P.queue_head) : "memory");
+            // FP queue entries, by lane 0, result NOT awaited here: the library is built with
+            // -mllvm -amdgpu-atomic-optimizer-strategy=None (Makefile).  With LLVM's atomic optimizer on, this atomicAdd()
+            // becomes a wave-aggregated atomic followed AT ONCE by s_waitcnt + v_readfirstlane -- a memory round trip during
+            // which the wave's pairs stand still, every four steps; without it the wait sits where the token is read, a
+            // score step later.  (An earlier form issued the atomic as inline assembly: same timing, but the compiler then
+            // does not know the result is outstanding, and a register copy or a spill of it before the wait would read
+            // garbage.  Correct either way with this form; the flag only buys the overlap.)
+            if (lane == 0) pf_tok = atomicAdd(P.queue_head, FP);
             pf |= PF_TOK;
         }
         // ---------------------------------------------------------------- does anything have to change?
