@@ -273,7 +273,8 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) void wfa_duo_kernel(const KParam
         }
         const unsigned long long m_ev = __ballot(touch || narrowable);
         m_free = __ballot(st == 0);
-        if (!(m_ev != 0ull || (m_free != 0ull && (park_used != 0u || (pf & PF_STAGED) != 0u)))) break;
+        // (expected: nothing to do -- tells the register allocator that what follows is the cold side of the loop)
+        if (__builtin_expect(!(m_ev != 0ull || (m_free != 0ull && (park_used != 0u || (pf & PF_STAGED) != 0u))), 1)) break;
         WFA_EVT(1, 1);
         {
             // ------------------------------------------------------------ what each pair wants
@@ -498,7 +499,7 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) void wfa_duo_kernel(const KParam
         const uint32_t a_edge = dn1(Mo[PP - 1]), b_edge = dn1(I[PP - 1]);
         const uint32_t c_edge = up1(Mo[0]), d_edge = up1(D[0]);
         const bool     slow_any = __ballot(run && slow) != 0ull;
-        if (!slow_any) {
+        if (__builtin_expect(!slow_any, 1)) {
 #pragma unroll
             for (int p = 0; p < PP; p++) {
                 const uint32_t a = p ? Mo[p - 1] : a_edge, b = p ? I[p - 1] : b_edge;
@@ -620,7 +621,7 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) void wfa_duo_kernel(const KParam
         int      ilo = 0, ihi = -1;  // band to keep (window-relative)
         bool     anyM = false;
         uint32_t csum = 0u;
-        if (!hit_any) {
+        if (__builtin_expect(!hit_any, 1)) {
             int glo = BK_BIG, ghi = -BK_BIG, mind = BK_BIG, dd[PP];
 #pragma unroll
             for (int p = PP - 1; p >= 0; p--) glo = nz[p] ? PP * j + p : glo;
