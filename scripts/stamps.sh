@@ -6,7 +6,10 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $REPO
 mkdir -p /tmp/wfa_stamps/wfa_amd/lib
 cp -r wfa_amd/*.py /tmp/wfa_stamps/wfa_amd/
-hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -mllvm -amdgpu-atomic-optimizer-strategy=None -DWFA_STAMPS $WFA_EXTRA -shared -o /tmp/wfa_stamps/wfa_amd/lib/libwfahip.so wfa_amd/csrc/wfa_host.hip wfa_amd/csrc/wfa_gen.cpp wfa_amd/csrc/wfa_multi.cpp
+F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -DWFA_STAMPS $WFA_EXTRA"
+hipcc $F -mllvm -amdgpu-atomic-optimizer-strategy=None -c -o /tmp/wfa_stamps/duo.o wfa_amd/csrc/wfa_duo.hip
+for f in wfa_host.hip wfa_gen.cpp wfa_multi.cpp; do hipcc $F -c -o /tmp/wfa_stamps/${f%.*}.o wfa_amd/csrc/$f; done
+hipcc -fPIC --offload-arch=gfx950 -shared -o /tmp/wfa_stamps/wfa_amd/lib/libwfahip.so /tmp/wfa_stamps/wfa_host.o /tmp/wfa_stamps/wfa_gen.o /tmp/wfa_stamps/wfa_multi.o /tmp/wfa_stamps/duo.o
 cd /tmp/wfa_stamps && python3 - "$@" <<'PY'
 import sys, numpy as np
 sys.path.insert(0, "/tmp/wfa_stamps")

@@ -1075,7 +1075,7 @@ WFA_DEV uint32_t prepack_word(const uint8_t *blob, uint64_t off, uint32_t len, u
 // (a wave per pair, PREPACK_PAIRS pairs per wave: one workgroup per pair was bound by the dispatch of a million tiny
 // workgroups -- 1.01 ms for 2.5 GB of traffic)
 constexpr int PREPACK_PAIRS = 4;
-__global__ __launch_bounds__(256) void wfa_prepack_kernel(const KParams P, uint32_t *out, uint32_t SW, uint32_t PW) {
+WFA_KERNEL_LINKAGE __global__ __launch_bounds__(256) void wfa_prepack_kernel(const KParams P, uint32_t *out, uint32_t SW, uint32_t PW) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv   = blockIdx.x * 4u + (threadIdx.x >> 6);
     for (uint32_t k = 0; k < (uint32_t)PREPACK_PAIRS; k++) {

@@ -1,0 +1,15 @@
+// wfa_duo.hip -- translation unit of wfa_duo_kernel: built with LLVM's atomic optimizer off (wfa_duo_cfg.hpp, Makefile).
+#define WFA_KERNEL_LINKAGE static
+#include "wfa_duo.hpp"
+
+namespace wfa {
+
+hipError_t wfa_launch_duo(const KParams &P, uint32_t grid, size_t lds_bytes, hipStream_t st, bool census) {
+    if (census)
+        hipLaunchKernelGGL((wfa_duo_kernel<true>), dim3(grid), dim3(64), lds_bytes, st, P);
+    else
+        hipLaunchKernelGGL((wfa_duo_kernel<false>), dim3(grid), dim3(64), lds_bytes, st, P);
+    return hipGetLastError();
+}
+
+}  // namespace wfa

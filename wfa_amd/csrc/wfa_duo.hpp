@@ -35,39 +35,9 @@
 // be held is handed on (ST_REDO_BAND) and recomputed from scratch by the retry rung.
 #pragma once
 #include "wfa_blk.hpp"
+#include "wfa_duo_cfg.hpp"
 
 namespace wfa {
-
-#ifndef WFA_DUO_WAVES
-#define WFA_DUO_WAVES 4  // waves per SIMD the kernel is compiled for
-#endif
-#ifndef WFA_DUO_PARK
-#define WFA_DUO_PARK 4
-#endif
-#ifndef WFA_DUO_WIDEN_AT
-#define WFA_DUO_WIDEN_AT 26
-#endif
-#ifndef WFA_DUO_NARROW_AT
-#define WFA_DUO_NARROW_AT 21
-#endif
-constexpr int DUO_PARK       = WFA_DUO_PARK;           // park records per wave
-constexpr int DUO_PARK_WORDS = 8 * 12 + 16;            // rings of 8 lanes, two 16-bit offsets per word (reads under 2 048 bases) + 16 scalars
-constexpr int DUO_BUFS       = 8 + 1 + DUO_PARK;       // sequence buffers per wave: running pairs, staging, parked pairs (one pair per fetch)
-constexpr int DUO_FETCH_MAX  = 8;                      // short reads: pairs per fetch (as many prepacked slots as one 16-byte load per lane covers)
-constexpr int DUO_WIDEN_AT   = WFA_DUO_WIDEN_AT;       // a narrow pair whose band spans more diagonals than this widens (a recentred band must fit 32 - 6)
-constexpr int DUO_NARROW_AT  = WFA_DUO_NARROW_AT;      // a wide pair whose band spans at most this many narrows
-constexpr int DUO_WIDE_MAX   = 56;                     // a wide pair whose band spans more is handed on
-
-// pairs one fetch brings in: the slots of consecutive queue entries are contiguous in the prepack buffer, and one
-// 16-byte load per lane covers 256 words -- eight slots of a 150-base pair, one of a 1 kbp pair
-__host__ __device__ inline uint32_t duo_fetch_pairs(uint32_t prepack_words) {
-    const uint32_t f = 256u / prepack_words;
-    return f < 1u ? 1u : (f > (uint32_t)DUO_FETCH_MAX ? (uint32_t)DUO_FETCH_MAX : f);
-}
-__host__ __device__ inline uint32_t duo_bufs(uint32_t prepack_words) { return 8u + duo_fetch_pairs(prepack_words) + (uint32_t)DUO_PARK; }
-__host__ __device__ inline uint32_t duo_lds_words(uint32_t prepack_words) {
-    return duo_bufs(prepack_words) * prepack_words + (uint32_t)DUO_PARK * DUO_PARK_WORDS;
-}
 
 // Group reductions: three butterfly stages inside the 8 lanes of a half row, and a fourth (row_mirror) whose result
 // only the lanes of a 16-lane pair keep.

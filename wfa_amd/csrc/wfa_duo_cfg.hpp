@@ -1,0 +1,47 @@
+// wfa_duo_cfg.hpp -- sizes of wfa_duo_kernel (wfa_duo.hpp) that the host needs too, and its launcher.
+// The kernel lives in a translation unit of its own (wfa_duo.hip) because it is compiled with
+// -mllvm -amdgpu-atomic-optimizer-strategy=None: its prefetch claims queue entries with an atomicAdd whose result must
+// NOT be waited for on the spot, and LLVM's atomic optimizer turns a uniform atomicAdd into a wave-aggregated atomic
+// followed at once by s_waitcnt + v_readfirstlane.  The other kernels want the optimizer: the lane-per-pair backtrace
+// reserves its CIGAR op slots with one atomicAdd per lane, which the optimizer folds into one per wave (with the flag on
+// the whole library that kernel went from 1.2 to 19 ms).
+#pragma once
+#include "wfa_common.hpp"
+
+namespace wfa {
+
+#ifndef WFA_DUO_WAVES
+#define WFA_DUO_WAVES 4  // waves per SIMD the kernel is compiled for
+#endif
+#ifndef WFA_DUO_PARK
+#define WFA_DUO_PARK 4
+#endif
+#ifndef WFA_DUO_WIDEN_AT
+#define WFA_DUO_WIDEN_AT 26
+#endif
+#ifndef WFA_DUO_NARROW_AT
+#define WFA_DUO_NARROW_AT 21
+#endif
+constexpr int DUO_PARK       = WFA_DUO_PARK;           // park records per wave
+constexpr int DUO_PARK_WORDS = 8 * 12 + 16;            // rings of 8 lanes, two 16-bit offsets per word (reads under 2 048 bases) + 16 scalars
+constexpr int DUO_BUFS       = 8 + 1 + DUO_PARK;       // sequence buffers per wave: running pairs, staging, parked pairs (one pair per fetch)
+constexpr int DUO_FETCH_MAX  = 8;                      // short reads: pairs per fetch (as many prepacked slots as one 16-byte load per lane covers)
+constexpr int DUO_WIDEN_AT   = WFA_DUO_WIDEN_AT;       // a narrow pair whose band spans more diagonals than this widens (a recentred band must fit 32 - 6)
+constexpr int DUO_NARROW_AT  = WFA_DUO_NARROW_AT;      // a wide pair whose band spans at most this many narrows
+constexpr int DUO_WIDE_MAX   = 56;                     // a wide pair whose band spans more is handed on
+
+// pairs one fetch brings in: the slots of consecutive queue entries are contiguous in the prepack buffer, and one
+// 16-byte load per lane covers 256 words -- eight slots of a 150-base pair, one of a 1 kbp pair
+__host__ __device__ inline uint32_t duo_fetch_pairs(uint32_t prepack_words) {
+    const uint32_t f = 256u / prepack_words;
+    return f < 1u ? 1u : (f > (uint32_t)DUO_FETCH_MAX ? (uint32_t)DUO_FETCH_MAX : f);
+}
+__host__ __device__ inline uint32_t duo_bufs(uint32_t prepack_words) { return 8u + duo_fetch_pairs(prepack_words) + (uint32_t)DUO_PARK; }
+__host__ __device__ inline uint32_t duo_lds_words(uint32_t prepack_words) {
+    return duo_bufs(prepack_words) * prepack_words + (uint32_t)DUO_PARK * DUO_PARK_WORDS;
+}
+
+// launches wfa_duo_kernel<census> (wfa_duo.hip)
+hipError_t wfa_launch_duo(const KParams &P, uint32_t grid, size_t lds_bytes, hipStream_t st, bool census);
+
+}  // namespace wfa

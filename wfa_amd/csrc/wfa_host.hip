@@ -8,7 +8,7 @@
 #include "wfa_packed.hpp"
 #include "wfa_reg.hpp"
 #include "wfa_blk.hpp"
-#include "wfa_duo.hpp"
+#include "wfa_duo_cfg.hpp"
 #include "wfa_team.hpp"
 #include "wfa_finalize.hpp"
 #include "wfa_gen_dev.hpp"
@@ -795,10 +795,8 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                 // (tests: the sub-wave kernels zero nothing -- no word the backtrace reads may be one they did not write)
                 if (ctx->opt_arena_poison) HIP_TRY(hipMemsetAsync(P.arena, 0xA5, (size_t)(words * 4ull * cn), st));
                 HIP_TRY(hipEventRecord(evFa, st));
-                if (kind == 8 && P.census)
-                    hipLaunchKernelGGL((wfa_duo_kernel<true>), dim3(grid), dim3(64), lds_bytes, st, P);
-                else if (kind == 8)
-                    hipLaunchKernelGGL((wfa_duo_kernel<false>), dim3(grid), dim3(64), lds_bytes, st, P);
+                if (kind == 8)
+                    HIP_TRY(wfa_launch_duo(P, grid, lds_bytes, st, P.census != 0));
                 else if (kind == 5)
                     hipLaunchKernelGGL((wfa_blk_kernel<64, 1>), dim3(grid), dim3(64), lds_bytes, st, P);
                 else if (kind == 9)

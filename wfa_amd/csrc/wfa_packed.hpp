@@ -70,7 +70,7 @@ WFA_DEV uint32_t sub_sum(uint32_t v) {
     return v;
 }
 
-__global__ __launch_bounds__(64, 7) void wfa_packed_kernel(const KParams P) {
+WFA_KERNEL_LINKAGE __global__ __launch_bounds__(64, 7) void wfa_packed_kernel(const KParams P) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int lane = threadIdx.x, j = lane & 31, sub = lane >> 5;
     const int lead = sub << 5;
@@ -326,7 +326,7 @@ WFA_DEV void backtrace_one(const KParams &P, uint32_t idx, uint32_t s_final, uin
 // here.  A pair that was handed on (ST_REDO_*) gets its record from the pass that finishes it -- which may already
 // be running beside this kernel, so this kernel must not touch that record.
 // Streamed mode (P.done_q != nullptr): the finished pairs are the done_q entries the streaming kernel has not taken.
-__global__ __launch_bounds__(256) void wfa_backtrace_kernel(const KParams P) {
+WFA_KERNEL_LINKAGE __global__ __launch_bounds__(256) void wfa_backtrace_kernel(const KParams P) {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= P.chunk_n) return;
     const uint4 meta = P.pair_meta[idx];
