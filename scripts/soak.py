@@ -16,14 +16,17 @@ thr = max(8, (os.cpu_count() or 8) // 2)
 bad = 0
 for seed, length, err, ad in ((101, 1000, 0.05, (10, 50, 1)), (102, 1000, 0.08, (10, 50, 1)), (103, 600, 0.03, (10, 50, 1)),
                               (104, 2000, 0.05, (10, 50, 1)), (105, 1000, 0.05, (20, 100, 1)), (106, 300, 0.10, None),
-                              (107, 150, 0.03, None), (108, 100, 0.06, (10, 50, 1)), (109, 230, 0.04, None)):
+                              (107, 150, 0.03, None), (108, 100, 0.06, (10, 50, 1)), (109, 230, 0.04, None),
+                              # round 3: shapes that exercise wfa_duo_kernel's widen / narrow / park paths and the learned rows / windows
+                              (110, 1000, 0.10, (10, 50, 1)), (111, 1500, 0.04, (10, 50, 1)), (112, 400, 0.06, (10, 50, 1)),
+                              (113, 1000, 0.02, (10, 50, 1)), (114, 1000, 0.05, (4, 20, 1)), (115, 800, 0.15, (10, 50, 1))):
     nn = n * 1000 // length if length > 1000 else n
     data = w.generate_pairs(seed=seed, n_pairs=nn, length=length, error_rate=err, n_threads=32)
     t0 = time.perf_counter()
     want = O.align_batch(T._oracle_params(True, ad), *data, n_threads=thr)
     t1 = time.perf_counter()
     al = T._aligner(True, ad)
-    for rep in range(2):
+    for rep in range(3):  # (the context learns rows / windows from the first call: the later ones take other passes)
         got = al.align_arrays(*data)
         t = al.last_timing()
         try:
