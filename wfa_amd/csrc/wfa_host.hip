@@ -167,7 +167,7 @@ struct wfahip_ctx {
     // 5 = wfa_blk_kernel<64,1> (256), learned when most pairs of a call were handed on because of their band
     uint64_t      band_key                 = 0;
     int           band_kind                = 0;
-    uint32_t      band_calls               = 0;   // (every eighth call of the class starts on the 64-diagonal pass again: data changes)
+    uint32_t      band_calls               = 0;   // (every sixteenth call of the class starts on its natural first pass again: data changes)
     int64_t       opt_blk_mid              = 1;   // 1: band failures of the 64-diagonal kernels try the 128-diagonal instance before the 256-diagonal one   // calls of that class since the level was learned (every 4th one probes one level lower)
     int64_t       opt_mem_limit            = 0;   // tests: pretend the device has this many bytes (arena budgets follow)
     int           force_mode               = -1;  // debug: start the ladder in this mode
@@ -930,7 +930,9 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             // a class of batches whose pairs were mostly handed on for their band the last time starts on the window that
             // took them (1 kbp at 20 % error: every pair needs ~100 diagonals)
             if (wide_ok && done_pairs == 0 && ctx->band_key == rkey && ctx->band_kind != 0 && (kind1 == 3 || kind1 == 8) &&
-                (ctx->band_kind == 5 || ctx->opt_blk_mid != 0) && (++ctx->band_calls & 7u) != 0u)
+                (ctx->band_kind == 5 || ctx->band_kind == 3 || ctx->opt_blk_mid != 0) &&
+                !(ctx->band_kind == 3 && ctx->opt_duo >= 2) &&  // (option duo = 2: the variable-lanes kernel whatever was learned)
+                (++ctx->band_calls & 15u) != 0u)
                 kind_rest = ctx->band_kind;
             if (!skip_rest) {
                 std::vector<uint64_t> more;
@@ -945,7 +947,11 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                     (kind_rest == 5 ? redo_w : redo1).insert((kind_rest == 5 ? redo_w : redo1).end(), more.begin(), more.end());
                 }
                 if ((kind_rest == 3 || kind_rest == 8) && P.adaptive && n_band * 2 > n_pairs - done_pairs) ctx->band_key = rkey, ctx->band_kind = 9;
-                else if ((kind_rest == 3 || kind_rest == 8) && ctx->band_key == rkey) ctx->band_kind = 0;
+                // (bands mostly wider than 32 diagonals: the variable-lanes kernel then runs its pairs wide, parks and resumes for
+                // nothing and hands on more than the plain 64-diagonal kernel would -- 1e6 x 1 kbp @8 %: 53-71 ms against 46)
+                else if (kind_rest == 8 && n_band * 50 > n_pairs - done_pairs) ctx->band_key = rkey, ctx->band_kind = 3;
+                else if (kind_rest == 8 && ctx->band_key == rkey) ctx->band_kind = 0;
+                else if (kind_rest == 3 && kind1 == 3 && ctx->band_key == rkey) ctx->band_kind = 0;
                 done_pairs = n_pairs;
             }
             if (std::getenv("WFAHIP_DEBUG_TIMING") && P.done_ctl) {
