@@ -339,7 +339,7 @@ def run_rank(args):
     achieved = alg_bytes / (main_k_ms * 1e-3) / 1e9 if main_k_ms > 0 else 0.0  # GB/s over the dominant kernel's launches of one step
 
     KNAMES = ["wfa_generic_kernel<1, 0>", "wfa_packed_kernel", "wfa_reg_kernel<2, 4, 1>", "wfa_blk_kernel<16",
-              "wfa_blk_kernel<8", "wfa_blk_kernel<64", "wfa_blk_kernel<8, 8, false, 4", "wfa_team_kernel", "wfa_duo_kernel", "wfa_blk_kernel<32"]
+              "wfa_blk_kernel<8", "wfa_blk_kernel<64", "wfa_blk_kernel<8, 8, false, 4", "wfa_team_kernel", "wfa_duo_kernel", "wfa_blk_kernel<32", "wfa_lane_kernel"]
     kname = KNAMES[min(int(timing.main_kernel_kind), len(KNAMES) - 1)]
 
     out = None

@@ -1078,11 +1078,14 @@ constexpr int PREPACK_PAIRS = 4;
 WFA_KERNEL_LINKAGE __global__ __launch_bounds__(256) void wfa_prepack_kernel(const KParams P, uint32_t *out, uint32_t SW, uint32_t PW) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv   = blockIdx.x * 4u + (threadIdx.x >> 6);
-    for (uint32_t k = 0; k < (uint32_t)PREPACK_PAIRS; k++) {
-        const uint32_t wi = wv * (uint32_t)PREPACK_PAIRS + k;
-        if (wi >= P.chunk_n) return;
-        const uint32_t pr = P.work ? P.work[wi] : P.chunk_first + wi;
-        const uint32_t nq = P.q_len[pr], mt = P.t_len[pr];
+    // short reads (a slot of at most 32 words): two pairs side by side, 32 lanes each
+    const uint32_t LP = 2u * SW <= 32u ? 32u : 64u, side = lane / LP, v0 = lane % LP, n_side = 64u / LP;
+    for (uint32_t k = 0; k < (uint32_t)PREPACK_PAIRS; k += n_side) {
+        const uint32_t wi = wv * (uint32_t)PREPACK_PAIRS + k + side;
+        if (wv * (uint32_t)PREPACK_PAIRS + k >= P.chunk_n) return;
+        const bool     have = wi < P.chunk_n;
+        const uint32_t pr = have ? (P.work ? P.work[wi] : P.chunk_first + wi) : 0u;
+        const uint32_t nq = have ? P.q_len[pr] : 0u, mt = have ? P.t_len[pr] : 0u;
         uint32_t       status = ST_PENDING;
         if (nq == 0 || mt == 0)
             status = ST_EMPTY;  // wfa.go:204-206
@@ -1092,15 +1095,16 @@ WFA_KERNEL_LINKAGE __global__ __launch_bounds__(256) void wfa_prepack_kernel(con
             status = ST_REDO_LDS;
         uint32_t *const slot = out + (uint64_t)wi * PW;
         bool            bad  = false;
-        if (status == ST_PENDING) {
+        if (have && status == ST_PENDING) {
             const uint64_t qo = P.q_off[pr], to = P.t_off[pr];
-            for (uint32_t v = lane; v < 2u * SW; v += 64u) {
+            for (uint32_t v = v0; v < 2u * SW; v += LP) {
                 const bool isq = v < SW;
                 slot[4u + v]   = prepack_word(P.blob, isq ? qo : to, isq ? nq : mt, isq ? v : v - SW, bad);
             }
         }
-        if (__ballot(bad) != 0ull) status = ST_REDO_BYTES;  // a byte outside ACGT: the byte-compare path takes the pair
-        if (lane == 0u) slot[0] = nq, slot[1] = mt, slot[2] = status, slot[3] = 0u;
+        const unsigned long long bm = __ballot(bad), mine = LP == 64u ? ~0ull : (0xFFFFFFFFull << (32u * side));
+        if ((bm & mine) != 0ull) status = ST_REDO_BYTES;  // a byte outside ACGT: the byte-compare path takes the pair
+        if (have && v0 == 0u) slot[0] = nq, slot[1] = mt, slot[2] = status, slot[3] = 0u;
     }
 }
 

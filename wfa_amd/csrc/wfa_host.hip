@@ -9,6 +9,7 @@
 #include "wfa_reg.hpp"
 #include "wfa_blk.hpp"
 #include "wfa_duo_cfg.hpp"
+#include "wfa_lane.hpp"
 #include "wfa_team.hpp"
 #include "wfa_finalize.hpp"
 #include "wfa_gen_dev.hpp"
@@ -153,6 +154,13 @@ struct wfahip_ctx {
                                                   // SLOWER than the batched 8-lane instance (1e5 x 150 bp: forward 0.317 vs 0.249 ms, 1e6: 1.60 vs 1.43 ms, plus the
                                                   // packing kernel) -- a 150-base pair lives ten steps, so a wave restructures on nearly every step
     int64_t       opt_duo_short_min_pairs  = 50000;
+    bool          redo_was_empty           = false;  // the last pass that asked for its redo list found it empty
+    int64_t       opt_compact_call_bases   = 50000000;  // first passes over at most this many bases (pairs x longest read) keep their backtrace
+                                                        // kernel on the call's stream (no event wait on the second one): 0 = never
+    int64_t       opt_lane                 = 1;   // reads of at most 240 bases start on wfa_lane_kernel (a lane per pair): 0 never, 1 for batches of
+                                                  // at least opt_lane_min_pairs, 2 always
+    int64_t       opt_lane_min_pairs       = 32768;  // (below ~30 000 pairs a generation of 64 pairs per wave leaves most of the GPU idle for as
+                                                     // long as its slowest pair runs: 16 000 x 150 bases 0.192 ms against 0.157 on the 8-lane kernel)
     int64_t       opt_census               = 0;   // 1: the sub-wave forward kernels count the wavefront words they store (REC_CELLS, timing.cells_stored)
     int64_t       opt_learn                = 1;   // 1: long pairs start on the arena level the previous call of the same kind ended on
     uint64_t      learn_key                = 0;   // workload class of the last call that used the team kernel
@@ -466,6 +474,12 @@ static int set_option_impl(wfahip_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_duo = value;
     else if (k == "duo_min_pairs")
         ctx->opt_duo_min_pairs = value;
+    else if (k == "compact_call_bases")
+        ctx->opt_compact_call_bases = value;
+    else if (k == "lane")
+        ctx->opt_lane = value;
+    else if (k == "lane_min_pairs")
+        ctx->opt_lane_min_pairs = value;
     else if (k == "duo_short")
         ctx->opt_duo_short = value;
     else if (k == "duo_short_min_pairs")
@@ -555,13 +569,28 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
     if (rc) return rc;
     uint32_t *d_ctrl = static_cast<uint32_t *>(ctx->ctrl.p);
     // control words (+ the redo list, sorted by pair, when `ent` is given) in one round trip through pinned memory
+    // Small calls are bound by the gaps between their few GPU operations (1e5 x 150-base pairs: a third of the call), so they
+    // shed what they can: the control words are zeroed once (ctrl_zeroed: nothing has touched them since the memset at
+    // the start), the backtrace kernel follows the forward kernel on the same stream instead of waiting for an event on
+    // the second one, and the control words fetched behind it serve as the call's final ones when nothing ran after them
+    // (ctrl_fresh; hc_last).
+    bool     ctrl_zeroed = true, ctrl_fresh = false;
+    uint32_t hc_last[CTRL_WORDS] = {0};
     const auto fetch_ctrl = [&](uint32_t *hc, std::vector<uint64_t> *ent) -> int {
         HIP_TRY(hipMemcpyAsync(ctx->hpin + HPIN_CTRL, d_ctrl, CTRL_WORDS * 4, hipMemcpyDeviceToHost, st));
         const size_t head = std::min<size_t>(HPIN_REDO_ENT * 8, ctx->redo.bytes);
-        if (ent) HIP_TRY(hipMemcpyAsync(ctx->hpin + HPIN_REDO, ctx->redo.p, head, hipMemcpyDeviceToHost, st));
+        // (the head of the redo list rides along -- unless the class of batches handed nothing on the last time: then it is
+        // fetched only if this call did, and a clean call has one copy less to wait for)
+        const bool with_head = ent && !ctx->redo_was_empty;
+        if (with_head) HIP_TRY(hipMemcpyAsync(ctx->hpin + HPIN_REDO, ctx->redo.p, head, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         std::memcpy(hc, ctx->hpin + HPIN_CTRL, CTRL_WORDS * 4);
         if (ent) {
+            if (!with_head && hc[1] != 0u) {
+                HIP_TRY(hipMemcpyAsync(ctx->hpin + HPIN_REDO, ctx->redo.p, head, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+            }
+            ctx->redo_was_empty = hc[1] == 0u;
             const size_t n = hc[1], nh = std::min<size_t>(n, head / 8);
             ent->assign(n, 0);
             if (nh) std::memcpy(ent->data(), ctx->hpin + HPIN_REDO, nh * 8);
@@ -691,24 +720,29 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             // kind 8 (wfa_duo_kernel): sequences come pre-packed, slot = 4 header words + 2 x (even) words per sequence
             const uint32_t duo_sw       = (seq_words + 1u) & ~1u, duo_pw = 4u + 2u * duo_sw;
             if (kind == 8 && (duo_pw > 256u || blk_batch)) return WFAHIP_ERR_INTERNAL;
-            const size_t   lds_bytes    = kind == 8 ? (size_t)duo_lds_words(duo_pw) * 4
+            if (kind == 10 && (seq_words > (uint32_t)LN_SEQ_WORDS || list)) return WFAHIP_ERR_INTERNAL;
+            const uint32_t lane_sw      = (seq_words + 1u) & ~1u;  // kind 10 (wfa_lane_kernel): words per sequence in its slots and in LDS
+            const size_t   lds_bytes    = kind == 10 ? (size_t)64 * lane_stride_words(lane_sw) * 4
+                                          : kind == 8 ? (size_t)duo_lds_words(duo_pw) * 4
                                           : kind == 9 ? (size_t)seq_words * 2 * 4 * 2 + 16
                                           : blk_batch ? (size_t)(kind == 6 ? 8 : 4) * BLK_BATCH * (2 * seq_words + 8) * 4 + 16
                                           : kind == 6 ? (size_t)seq_words * 2 * 4 * 8 + 16
                                           : kind == 5 ? (size_t)seq_words * 2 * 4 + 16
                                                       : (kind >= 3 ? lds_d : (kind == 2 ? lds_c : lds_b));
-            const uint32_t pairs_wave   = kind == 5 ? 1 : kind == 9 ? 2 : (kind == 4 || kind == 6 || kind == 8 ? 8 : (kind >= 2 ? 4 : 2));
+            const uint32_t pairs_wave   = kind == 10 ? 64 : kind == 5 ? 1 : kind == 9 ? 2 : (kind == 4 || kind == 6 || kind == 8 ? 8 : (kind >= 2 ? 4 : 2));
             // blocked kernels: fixed-pitch arena, no directory.  64-diagonal window: 16 words per base = 250 scores at
             // 1 kbp; 256-diagonal window (kind 5, the retry rung): 128 words per base = 500 scores at 1 kbp
             const uint64_t words        = kind == 5   ? std::max<uint64_t>((words_dir * 16 * arena_mult + 511) & ~511ull, 8192)
                                           : kind == 9 ? std::max<uint64_t>((words_dir * 4 * arena_mult + 511) & ~511ull, 4096)
                                           : kind == 8 ? std::max<uint64_t>((words_dir * arena_mult + 511) & ~511ull, 1024)  // 16-bit words
+                                          : kind == 10 ? std::max<uint64_t>((words_dir * arena_mult + 511) & ~511ull, 1024)  // rows of 32 x 16 bit
                                           : kind >= 3 ? std::max<uint64_t>((words_dir * 2 * arena_mult + 511) & ~511ull, 2048)
                                                       : words_dir;
-            P.arena_words = words, P.compact_fmt = kind == 8 ? 7u : kind == 6 ? 5u : kind == 5 ? 4u : kind == 9 ? 6u : (kind >= 3 ? (WFA_BLK_TILED ? 3u : 1u) : 0u);
+            P.arena_words = words, P.compact_fmt = kind == 10 ? 8u : kind == 8 ? 7u : kind == 6 ? 5u : kind == 5 ? 4u : kind == 9 ? 6u : (kind >= 3 ? (WFA_BLK_TILED ? 3u : 1u) : 0u);
             const uint32_t waves_lds    = (uint32_t)std::min<size_t>(32, LDS_MAX_BYTES / lds_bytes);
             const bool     overlap      = ctx->opt_overlap != 0;
-            uint32_t       waves_per_cu = kind == 8 ? std::min<uint32_t>(waves_lds, 4 * WFA_DUO_WAVES)
+            uint32_t       waves_per_cu = kind == 10 ? std::min<uint32_t>(waves_lds, 8)
+                                          : kind == 8 ? std::min<uint32_t>(waves_lds, 4 * WFA_DUO_WAVES)
                                           : kind == 4 ? std::min<uint32_t>(waves_lds, 12)
                                           : kind >= 2 ? std::min<uint32_t>(waves_lds, 20)
                                                       : (overlap ? std::min<uint32_t>(waves_lds, 24) : waves_lds);
@@ -732,7 +766,9 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             if (arena_buf.bytes < (size_t)(words * 4ull * chunk * n_buf)) rc2 = ensure(ctx, arena_buf, (size_t)(words * 4ull * chunk_alloc * n_buf));
             if (rc2) return rc2;
             if (meta_buf.bytes < chunk * 16 * n_buf && (rc2 = ensure(ctx, meta_buf, chunk_alloc * 16 * n_buf))) return rc2;
-            detach_bt = detach_bt && n_chunks == 1 && ctx->opt_tail_overlap != 0;
+            detach_bt = detach_bt && n_chunks == 1 && ctx->opt_tail_overlap != 0 &&
+                        (count * (uint64_t)max_len > (uint64_t)ctx->opt_compact_call_bases || ctx->opt_compact_call_bases <= 0);
+            ctrl_fresh = false;
             // streamed backtrace: a few waves walk finished pairs while the forward kernel is still running
             // (off unless asked for since round 2: with the forward pass at 20 ms per 1e6 pairs the write-through row
             // stores of the streaming instance cost more than the backtrace kernel they save -- 3e6 x 1 kbp pairs in two
@@ -752,7 +788,8 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                 HIP_TRY(hipEventCreate(&e));
                 ctx->evpool.push_back(e);
             }
-            HIP_TRY(hipMemsetAsync(d_ctrl, 0, 8, st));  // queue_head, redo_count
+            if (!ctrl_zeroed) HIP_TRY(hipMemsetAsync(d_ctrl, 0, 8, st));  // queue_head, redo_count
+            ctrl_zeroed = false;
             hipStream_t st_bt = (n_buf == 2 || detach_bt) ? ctx->stream2 : st;
             for (uint64_t c = 0; c < n_chunks; c++) {
                 const uint64_t c0 = c * chunk, cn = std::min<uint64_t>(chunk, count - c0);
@@ -781,8 +818,9 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                 }
                 // the chunk's sequences 2-bit packed up front (unbatched 16-lane first pass over a range of pairs)
                 P.prepack = nullptr, P.prepack_words = 0;
-                P.lds_seq_words = kind == 8 ? duo_sw : seq_words;
-                if ((kind == 3 && !blk_batch && !list && ctx->opt_prepack != 0) || kind == 8) {
+                P.lds_seq_words = kind == 10 ? lane_sw : kind == 8 ? duo_sw : seq_words;
+                if (kind == 10) P.sub_lds_words = lane_stride_words(lane_sw);
+                if ((kind == 3 && !blk_batch && !list && ctx->opt_prepack != 0) || kind == 8 || kind == 10) {
                     const uint32_t pw = 4u + 2u * P.lds_seq_words;
                     if ((rc2 = ensure(ctx, ctx->prepack, (size_t)chunk * pw * 4))) return rc2;
                     hipLaunchKernelGGL(wfa_prepack_kernel, dim3((uint32_t)((cn + 4 * PREPACK_PAIRS - 1) / (4 * PREPACK_PAIRS))), dim3(256), 0, st, P,
@@ -797,6 +835,10 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                 HIP_TRY(hipEventRecord(evFa, st));
                 if (kind == 8)
                     HIP_TRY(wfa_launch_duo(P, grid, lds_bytes, st, P.census != 0));
+                else if (kind == 10 && P.census)
+                    hipLaunchKernelGGL((wfa_lane_kernel<true>), dim3(grid), dim3(64), lds_bytes, st, P);
+                else if (kind == 10)
+                    hipLaunchKernelGGL((wfa_lane_kernel<false>), dim3(grid), dim3(64), lds_bytes, st, P);
                 else if (kind == 5)
                     hipLaunchKernelGGL((wfa_blk_kernel<64, 1>), dim3(grid), dim3(64), lds_bytes, st, P);
                 else if (kind == 9)
@@ -834,7 +876,7 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipEventRecord(evFb, st));
                 if (st_bt != st) HIP_TRY(hipStreamWaitEvent(st_bt, evFb, 0));
-                HIP_TRY(hipEventRecord(evBa, st_bt));
+                if (st_bt != st) HIP_TRY(hipEventRecord(evBa, st_bt));  // (same stream: the backtrace starts where the forward kernel ends)
                 hipLaunchKernelGGL(wfa_backtrace_kernel, dim3((uint32_t)((cn + 255) / 256)), dim3(256), 0, st_bt, P);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipEventRecord(evBb, st_bt));
@@ -843,18 +885,21 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                 for (uint64_t c = (n_chunks >= 2 ? n_chunks - 2 : 0); c < n_chunks; c++)
                     HIP_TRY(hipStreamWaitEvent(st, ctx->evpool[4 * c + 3], 0));
             uint32_t hc[CTRL_WORDS];
+            if (!detach_bt) HIP_TRY(hipEventRecord(ctx->ev1, st));  // (the end of the call if nothing follows)
             if ((rc2 = fetch_ctrl(hc, &redo_out))) return rc2;  // (detach_bt: the forward kernel is done, the backtrace may still run)
             if (detach_bt) ctx->bt_pending = true;
+            else ctrl_fresh = true, std::memcpy(hc_last, hc, sizeof hc_last);
             for (uint64_t c = 0; c < n_chunks; c++) {
                 float msF = 0, msB = 0;
                 HIP_TRY(hipEventElapsedTime(&msF, ctx->evpool[4 * c], ctx->evpool[4 * c + 1]));
-                if (!detach_bt) HIP_TRY(hipEventElapsedTime(&msB, ctx->evpool[4 * c + 2], ctx->evpool[4 * c + 3]));
+                if (!detach_bt) HIP_TRY(hipEventElapsedTime(&msB, ctx->evpool[4 * c + (st_bt != st ? 2 : 1)], ctx->evpool[4 * c + 3]));
                 ctx->timing.kernel_ms += msF + msB;
                 if (!list) ctx->timing.main_kernel_ms += msF, ctx->timing.n_main_launches++;
                 ctx->timing.n_launches += 2;
             }
             P.work = nullptr;
             P.lds_seq_words = seq_words;
+            P.sub_lds_words = (uint32_t)sub_words;
             return WFAHIP_OK;
         };
 
@@ -871,7 +916,10 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             const bool duo_short = seq_words <= 16 && ctx->opt_duo != 0 &&
                                    (ctx->opt_duo_short >= 2 || (ctx->opt_duo_short == 1 && (int64_t)n_pairs >= ctx->opt_duo_short_min_pairs));
             const bool duo1    = can_d && ctx->opt_blk == 16 && (duo_long || duo_short) && 4u + 2u * ((seq_words + 1u) & ~1u) <= 256u;
-            const int  kind1   = duo1 ? 8 : narrow1 ? 6 : (can_d ? (ctx->opt_blk == 8 ? 4 : 3) : (can_c ? 2 : 1));
+            // short reads (at most 240 bases): a lane per pair
+            const bool lane1   = can_d && ctx->opt_blk == 16 && seq_words <= (uint32_t)LN_SEQ_WORDS &&
+                                 (ctx->opt_lane >= 2 || (ctx->opt_lane == 1 && (int64_t)n_pairs >= ctx->opt_lane_min_pairs));
+            const int  kind1   = (duo1 && duo_short) ? 8 : lane1 ? 10 : duo1 ? 8 : narrow1 ? 6 : (can_d ? (ctx->opt_blk == 8 ? 4 : 3) : (can_c ? 2 : 1));
             // Pilot: on a large batch with wf-adaptive off the first 4 096 pairs go first.  When most of them leave the
             // 64-diagonal window the rest does not start there only to be handed on: it goes straight to the
             // wave-per-pair kernel (256 diagonals) if that one takes most of the pilot's leftovers, else to the
@@ -977,14 +1025,14 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             // once, backtrace included) than through another forward + backtrace pass; beyond that the LDS-ring
             // kernel's throughput wins.
             const uint64_t resident_generic = (uint64_t)ctx->num_cus * 32;
-            if (kind1 == 6) {  // band / arena failures of the 32-diagonal instance -> the 64-diagonal one.  (What the variable-lanes
+            if (kind1 == 6 || kind1 == 10) {  // band / arena failures of the 32-diagonal instance -> the 64-diagonal one.  (What the variable-lanes
                                // kernel hands on -- a band wider than a row, rarely no park record free: 0.08 % of 1 kbp pairs --
                                // goes straight to the 128-diagonal instance below: one retry pass instead of two.)
                 std::vector<uint32_t> lst;
                 std::vector<uint64_t> keep, r2;
                 for (uint64_t e : redo1) {
                     const uint32_t stw = (uint32_t)(e >> 32);
-                    if (stw == ST_REDO_BAND || (stw == ST_REDO_ARENA && kind1 == 6)) lst.push_back((uint32_t)e);
+                    if (stw == ST_REDO_BAND || stw == ST_REDO_ARENA) lst.push_back((uint32_t)e);
                     else keep.push_back(e);
                 }
                 if (!lst.empty()) {
@@ -1116,6 +1164,7 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
     }
 
     while (!jobs.empty()) {
+        ctrl_fresh = false, ctrl_zeroed = false;
         Job job = std::move(jobs.front());
         jobs.pop_front();
         const uint64_t n_work = job.all ? n_pairs : job.pairs.size();
@@ -1291,7 +1340,8 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
         ctx->learn_key = lkey, ctx->learn_level = learned_now;
     }
     if (ctx->bt_pending) HIP_TRY(hipStreamWaitEvent(st, ctx->evBtB, 0));
-    HIP_TRY(hipEventRecord(ctx->ev1, st));
+    if (!no_memory.empty() || ctx->bt_pending) ctrl_fresh = false;
+    if (!ctrl_fresh) HIP_TRY(hipEventRecord(ctx->ev1, st));
 
     for (uint32_t pid : no_memory) {
         uint32_t recw[REC_WORDS] = {0};
@@ -1299,7 +1349,8 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
         HIP_TRY(hipMemcpyAsync(P.rec + (uint64_t)pid * REC_WORDS, recw, sizeof recw, hipMemcpyHostToDevice, st));
     }
     uint32_t hctrl[CTRL_WORDS];
-    if ((rc = fetch_ctrl(hctrl, nullptr))) return rc;
+    if (ctrl_fresh) std::memcpy(hctrl, hc_last, sizeof hctrl);
+    else if ((rc = fetch_ctrl(hctrl, nullptr))) return rc;
     float ms = 0;
     if (ctx->bt_pending) {
         HIP_TRY(hipEventElapsedTime(&ms, ctx->evBtA, ctx->evBtB));

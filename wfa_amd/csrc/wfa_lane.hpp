@@ -1,0 +1,248 @@
+// wfa_lane.hpp -- kernel F: ONE LANE PER PAIR, for short reads (at most 240 bases).
+//
+// The sub-wave kernels give a pair 8 lanes x 4 diagonals and make a wave step through eight pairs together; a 150-base
+// pair at 2 % error lives eleven score steps with ~8 cells each, so most of a wave's time is the start and the end of
+// pairs and the lanes of cells that do not exist (profiles/r03_c2_*: 713 vector instructions per pair, 60 % of the
+// wave-cycles waiting, 2.1 wave-steps per pair against 1.25).  Here every lane runs its own pair from the first score to
+// the last -- 64 pairs per wave, a "generation" -- cell by cell in ascending diagonal order:
+//   * the last four M rows and the last I and D rows live in LDS as BYTES (an offset is at most 240; 0 = absent), one
+//     32-slot ring per row (slot = diagonal & 31), 192 bytes per lane; the row of score step i replaces M[i-4] IN PLACE
+//     and I / D replace themselves in place: a cell needs M[i-4][k-1], M[i-4][k+1], I[k-1] and D[k+1], so in ascending
+//     order the only values overwritten too early are the two "k-1" ones, and those are carried in registers from the
+//     cell before.  Every slot outside the kept band of the row it belongs to holds ZERO (the rings start zeroed, a step
+//     writes every cell of its range, what wf-adaptive drops is zeroed, and a row's range covers the kept bands of its
+//     sources +-1 -- so it overwrites all that an older occupant of its ring kept): the loads need no range checks;
+//   * both sequences 2-bit packed in LDS (2 x lds_seq_words words per lane), from the pre-packed slots of
+//     wfa_prepack_kernel (one queue atomic per generation: entries base .. base + 63);
+//   * every cell by the EXACT rules of next() -- rejections (> m, offset - k > n), the k-range clamp, mismatch-wins ties,
+//     backTrace's unbounded recomputation of the pre-extension offset (wfa.go:549-700,766-817): the same formulas as the
+//     exact path of wfa_blk_kernel -- then WF_EXTEND by 16-base windows (SeqView<0>::lcp), termination, and the band /
+//     wf-adaptive of reduce() as two serial passes over the row (wfa.go:461-540);
+//   * one 16-bit backtrace word per cell (blk_word: pre-extension offset + the four decisions) straight to the pair's
+//     arena slot, rows of 32 halfwords (CompactView fmt 8), and pair_meta for wfa_backtrace_kernel -- unchanged behind it.
+// A lane's stride in LDS is odd (49 + 2 x lds_seq_words words: 73 for 150-base reads -- eight waves per CU), so the 64
+// lanes of an access at the same ring slot fall on different banks.
+// A pair whose row would span more than 30 diagonals (32 slots less the k-1 and k+1 a cell reads), or which runs out of arena rows, is handed on (ST_REDO_BAND /
+// ST_REDO_ARENA) to the sub-wave kernels like any pair that leaves a window.
+// Global alignment, penalties shaped 2 : 4 : 1 (x : o+e : e in units of g), like the other sub-wave kernels.
+#pragma once
+#include "wfa_device.hpp"
+
+namespace wfa {
+
+constexpr int LN_W          = 30;   // diagonals a row may span (32 ring slots)
+constexpr int LN_SEQ_WORDS  = 16;   // most packed words per sequence incl. the pad word: reads of at most 240 bases
+constexpr int LN_RING_WORDS = 48;   // 32 (M ring: 4 rows x 32 bytes) + 8 (I) + 8 (D)
+// words of LDS a lane owns when a sequence takes sw (even) packed words: odd
+constexpr uint32_t lane_stride_words(uint32_t sw) { return (uint32_t)LN_RING_WORDS + 2u * sw + 1u; }
+
+template <bool CENSUS>
+__global__ __launch_bounds__(64) void wfa_lane_kernel(const KParams P) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int lane = threadIdx.x;
+    const uint32_t        SW   = P.lds_seq_words;  // (even: a slot is a whole number of 16-byte units)
+    uint32_t *const       base = lds + (uint32_t)lane * P.sub_lds_words;
+    uint8_t *const        H    = reinterpret_cast<uint8_t *>(base);  // M rows at byte 32 r, I at 128, D at 160
+    uint32_t *const       lq = base + LN_RING_WORDS, *const lt = lq + SW;
+    const uint64_t        cap      = P.arena_words;
+    const int             rows_cap = (int)(cap / 16);
+    const int             mdd = (int)P.max_dist_diff, minwf = (int)P.min_wf_len;
+    const bool            adaptive = P.adaptive != 0;
+    const uint32_t        seed_si  = P.dx;
+    constexpr int         BIG = 0x3FFFFFFF;
+
+    for (;;) {
+        // ------------------------------------------------------------ a generation: 64 queue entries, one per lane
+        uint32_t gbase = 0;
+        if (lane == 0) gbase = atomicAdd(P.queue_head, 64u);
+        gbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)gbase);
+        if (gbase >= P.chunk_n) break;
+        const uint32_t wi = gbase + (uint32_t)lane;
+        bool           active = wi < P.chunk_n;
+        int            n = 0, m = 0;
+        if (active) {
+            const uint4 *const slot = reinterpret_cast<const uint4 *>(P.prepack + (uint64_t)wi * P.prepack_words);
+            const uint4        hdr  = slot[0];
+            n = (int)hdr.x, m = (int)hdr.y;
+            if (hdr.z != ST_PENDING) {  // empty / too long / longer than 240 bases / a byte outside ACGT: no alignment here
+                P.pair_meta[wi] = make_uint4(hdr.z, 0u, 0u, 0u);
+                if (hdr.z >= ST_REDO_BYTES) push_redo(P, P.work ? P.work[wi] : P.chunk_first + wi, hdr.z);
+                active = false;
+            } else {
+                for (uint32_t i = 0; i < SW / 2u; i++) {
+                    const uint4 v = slot[1 + i];
+                    lq[4 * i] = v.x, lq[4 * i + 1] = v.y, lq[4 * i + 2] = v.z, lq[4 * i + 3] = v.w;  // (q words, then t words: contiguous)
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < LN_RING_WORDS; i++) base[i] = 0u;
+        const int   Ak = m - n;
+        const bool  first_eq = ((lq[0] ^ lt[0]) & 3u) == 0u;  // q[0] == t[0] (wfa.go:155)
+        SeqView<0>  sv;
+        sv.q = lq, sv.t = lt, sv.n = n, sv.m = m;
+        uint16_t *const A16 = reinterpret_cast<uint16_t *>(P.arena + (uint64_t)wi * cap);
+        // kept bands of the M rows of the last four score steps (lo1 / hi1: the newest, which is also the I and D rows' band)
+        int      lo1 = BIG, hi1 = -BIG, lo2 = BIG, hi2 = -BIG, lo3 = BIG, hi3 = -BIG, lo4 = BIG, hi4 = -BIG;
+        uint32_t fail = 0u;          // ST_REDO_* of a pair this kernel hands on
+        uint32_t si = 0, cells = 0;  // (si: the same for every lane of the wave that is still running -- a generation starts together)
+
+        // ------------------------------------------------------------ score steps
+        while (__ballot(active) != 0ull) {
+            const int R0 = (int)(si & 3u), R2 = (int)((si + 2u) & 3u);  // ring slots of M[s-o-e] (replaced by this step's row) and M[s-x]
+            // range of next() (wfa.go:557-563): sources' ranges +-1, clamped to the matrix
+            int lo = imin2(imin2(lo4, lo2), lo1), hi = imax2(imax2(hi4, hi2), hi1);
+            const bool want_seed = active && ((si == 0u && first_eq) || (si == seed_si && !first_eq));
+            bool       any_src = hi >= lo;
+            lo = any_src ? lo - 1 : 0, hi = any_src ? hi + 1 : 0;
+            if (!any_src && !want_seed) lo = 1, hi = 0;  // nothing to compute at this score
+            lo = imax2(lo, -(n - 1)), hi = imin2(hi, m - 1);
+            if (want_seed) lo = imin2(lo, 0), hi = imax2(hi, 0);
+            // (handed on after the generation: a load or an atomic in this loop would make every step wait for the arena
+            // stores of the step before -- one counter for loads and stores)
+            if (active && (int)si >= rows_cap) fail = ST_REDO_ARENA, active = false;
+            if (active && hi - lo + 1 > LN_W) fail = ST_REDO_BAND, active = false;
+            uint8_t *const       Mo = H + 32 * R0;
+            const uint8_t *const Mx = H + 32 * R2;
+            uint8_t *const       Ir = H + 128, *const Dr = H + 160;
+            uint16_t *const      arow = A16 + (size_t)si * 32u;
+
+            // ------------------------------------------------------------ cells, ascending k (wfa.go:572-699)
+            // A cell whose extension is longer than two 16-base windows keeps its lane for another round of the loop while the
+            // other lanes go on to their next cells: the wave pays the longest SUM of windows of a row, not the longest run
+            // of every cell.
+            int      k = lo;
+            uint32_t a0 = 0u, b0 = 0u, self_mo = 0u;  // M[s-o-e][k-1], I[s-e][k-1] and M[s-o-e][k] as they were before this step
+            // (the four ring reads of a cell are issued when the cell before it is stored: a round trip to LDS less in the
+            // chain of every round)
+            uint32_t nc0 = 0u, nd0 = 0u, nx0 = 0u, nis = 0u;
+            if (active && k <= hi) {
+                self_mo = Mo[k & 31];  // (the slots of k - 1 hold zero: two below every kept band)
+                nc0 = Mo[(k + 1) & 31], nd0 = Dr[(k + 1) & 31], nx0 = Mx[k & 31], nis = Ir[k & 31];
+            }
+            uint32_t fl = 0u;                // 1: the pair ends at this score, 2: a cell sits at a sequence end, 4: the row has an M cell
+            int      glo = BIG, ghi = -BIG;  // tight range of the M cells set (M.Lo / M.Hi of the new wavefront, wfa.go:242)
+            int      mind = BIG, maxd = -BIG;  // wf-adaptive: distances of the usable entries (wfa.go:478-497)
+            uint32_t h = 0u, wd = 0u, Isk = 0u, Dsk = 0u, c0s = 0u, is_s = 0u, pend = 0u;  // the cell being extended
+            int      lim = 0;
+            for (;;) {
+                const bool go = active && k <= hi;
+                if (__ballot(go) == 0ull) break;
+                if (go && pend == 0u) {
+                    const uint32_t c0 = nc0, d0 = nd0, x0 = nx0;
+                    is_s = nis;  // I[s-e][k]: the next cell's k-1 source
+                    c0s  = c0;
+                    // rejections: > m (not >=) for I and X sources, offset - k > n for D and X sources
+                    const uint32_t a = (int)a0 > m ? 0u : a0, b = (int)b0 > m ? 0u : b0;
+                    const uint32_t c = (int)c0 - k > n ? 0u : c0, d = (int)d0 - k > n ? 0u : d0;
+                    const uint32_t x = ((int)x0 > m || (int)x0 - k > n) ? 0u : x0;
+                    const uint32_t mi = umax2(a, b);
+                    Isk = mi + (mi != 0u ? 1u : 0u);
+                    Dsk = umax2(c, d);
+                    const uint32_t x1  = x + (x != 0u ? 1u : 0u);
+                    uint32_t       Msk = umax2(umax2(Isk, Dsk), x1);
+                    const bool fromX = x != 0u && Msk == x1;  // wfa.go:657-693: the mismatch wins a tie, then the insertion
+                    const bool fromI = !fromX && Msk == Isk;
+                    // backTrace recomputes the pre-extension offset from the un-rejected sources (wfa.go:766-817)
+                    const uint32_t mu = umax2(a0, b0), Iu = mu + (mu != 0u ? 1u : 0u), Du = umax2(c0, d0);
+                    const uint32_t Xu = x0 + (x0 != 0u ? 1u : 0u);
+                    const bool     iext = a < b, dext = c < d;
+                    const uint32_t o0   = (fromI && iext) ? Iu : ((!fromX && !fromI && dext) ? Du : umax2(umax2(Iu, Du), Xu));
+                    wd = blk_word(o0, iext, dext, fromX, fromI);
+                    // seeds of initComponents (wfa.go:155-160)
+                    if (want_seed && k == 0 && Msk == 0u) Msk = 1u, wd = first_eq ? BLK_SEED_MATCH : BLK_SEED_MISMATCH;
+                    h = Msk, lim = imax2(1, imin2(n + k, m));
+                    pend = 1u;
+                }
+                if (go) {
+                    // (the ring reads of the NEXT cell, early: they have the whole extension to arrive.  None of them is the
+                    // slot this cell is stored to, and a lane that stays on its cell reads the same slots again)
+                    nc0 = Mo[(k + 2) & 31], nd0 = Dr[(k + 2) & 31], nx0 = Mx[(k + 1) & 31], nis = Ir[(k + 1) & 31];
+                    // WF_EXTEND (wfa.go:381-458): 32 bases a round, from three words of each sequence read in one go
+                    bool      done = true;
+                    const int rem  = lim - (int)h;
+                    if (h != 0u && rem > 0) {
+                        const int      v = (int)h - k, wq = v >> 4, wt = (int)h >> 4;
+                        uint32_t       q0 = lq[wq], q1 = lq[wq + 1], q2 = lq[wq + 2], t0 = lt[wt], t1 = lt[wt + 1], t2 = lt[wt + 2];
+                        asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(t0), "+v"(t1), "+v"(t2));  // (all six in one round trip)
+                        const uint32_t sq = (uint32_t)(v & 15) * 2u, stt = (uint32_t)(h & 15u) * 2u;
+                        const uint32_t xa = __funnelshift_r(q0, q1, sq) ^ __funnelshift_r(t0, t1, stt);
+                        const uint32_t xb = __funnelshift_r(q1, q2, sq) ^ __funnelshift_r(t1, t2, stt);
+                        const int      adv = xa != 0u ? (__builtin_ctz(xa) >> 1) : (xb != 0u ? 16 + (__builtin_ctz(xb) >> 1) : 32);
+                        done = adv < 32 || adv >= rem;
+                        h += (uint32_t)imin2(adv, rem);
+                    }
+                    if (done) {
+                        const bool nz = h != 0u;
+                        arow[k & 31] = (uint16_t)wd;  // (a word of a cell that does not exist is never read)
+                        glo = nz ? imin2(glo, k) : glo, ghi = nz ? k : ghi;
+                        fl |= (nz ? 4u : 0u) | ((nz && (int)h >= lim) ? 2u : 0u) | ((nz && k == Ak && (int)h >= m) ? 1u : 0u);
+                        if (nz && (int)h < lim) {  // a usable entry of wf-adaptive: inside both sequences
+                            const int dd = imax2(n + k, m) - (int)h;
+                            mind = imin2(mind, dd), maxd = imax2(maxd, dd);
+                        }
+                        Mo[k & 31] = (uint8_t)h, Ir[k & 31] = (uint8_t)Isk, Dr[k & 31] = (uint8_t)Dsk;
+                        a0 = self_mo, self_mo = c0s, b0 = is_s;
+                        k += 1, pend = 0u;
+                    }
+                }
+            }
+            const bool term = (fl & 1u) != 0u, ghit = (fl & 2u) != 0u, anyM = (fl & 4u) != 0u;
+
+            // ------------------------------------------------------------ band of the row + wf-adaptive (wfa.go:461-540)
+            int ilo = glo, ihi = ghi;
+            if (__ballot(active && !term && adaptive && anyM && (ghi - glo + 1) >= minwf) != 0ull) {
+                const bool want = active && !term && adaptive && anyM && (ghi - glo + 1) >= minwf;
+                const int  thr   = mind + mdd;
+                const bool found = want && mind != BIG && maxd > thr;  // some distance fails (wfa.go:507)
+                if (__ballot(found) != 0ull) {
+                    int first_ok = BIG, last_ok = -BIG, leadp = BIG + 1;  // leadp: last usable entry before first_ok (it fails)
+                    bool have_lead = false;
+                    for (int kk = glo; __ballot(found && kk <= ghi) != 0ull; kk++) {
+                        if (found && kk <= ghi) {
+                            const int h = (int)Mo[kk & 31], lim = imax2(1, imin2(n + kk, m));
+                            if (h != 0 && h < lim) {
+                                const int d = imax2(n + kk, m) - h;
+                                if (d <= thr) {
+                                    if (first_ok == BIG) first_ok = kk;
+                                    last_ok = kk;
+                                } else if (first_ok == BIG) {
+                                    leadp = kk, have_lead = true;
+                                }
+                            }
+                        }
+                    }
+                    // wfa.go:509-524: _lo = one past the last failing entry of the leading run (holes between it and the first
+                    // non-failing entry stay when a cell of the pair sits at a sequence end; else they are holes either way)
+                    if (found) ilo = ghit ? (have_lead ? leadp + 1 : glo) : first_ok, ihi = last_ok;
+                }
+            }
+            const bool keepl = active && anyM && ihi >= ilo;
+            // what wf-adaptive dropped holds zero from here on (cells outside [glo, ghi] never held anything: no M cell, so no I
+            // or D cell either)
+            if (__ballot(active && anyM && (ilo > glo || ihi < ghi)) != 0ull) {
+                for (int kk = glo; __ballot(active && anyM && kk <= ghi) != 0ull; kk++)
+                    if (active && anyM && kk <= ghi && (kk < ilo || kk > ihi)) Mo[kk & 31] = 0, Ir[kk & 31] = 0, Dr[kk & 31] = 0;
+            }
+            if (CENSUS && keepl) {
+                for (int kk = ilo; kk <= ihi; kk++) cells += (Mo[kk & 31] != 0) + (Ir[kk & 31] != 0) + (Dr[kk & 31] != 0);
+            }
+            // (the I / D rows exist where wf-adaptive kept the M row: Delete of wfa.go:526-535; an I or D cell never exists
+            // without the M cell of its diagonal -- M[s][k] >= I[s][k], D[s][k])
+            lo4 = lo3, hi4 = hi3, lo3 = lo2, hi3 = hi2, lo2 = lo1, hi2 = hi1;
+            lo1 = keepl ? ilo : BIG, hi1 = keepl ? ihi : -BIG;
+            if (active && term) {
+                const uint32_t hf = Mo[Ak & 31];
+                P.pair_meta[wi]   = make_uint4(ST_OK, si * P.g, hf, (CENSUS && P.census) ? cells : 0u);
+                active            = false;
+            }
+            si += 1u;
+        }
+        if (fail != 0u) {
+            P.pair_meta[wi] = make_uint4(fail, 0u, 0u, 0u);
+            push_redo(P, P.work ? P.work[wi] : P.chunk_first + wi, fail);
+        }
+    }
+}
+
+}  // namespace wfa
