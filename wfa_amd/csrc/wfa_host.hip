@@ -835,10 +835,14 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                 HIP_TRY(hipEventRecord(evFa, st));
                 if (kind == 8)
                     HIP_TRY(wfa_launch_duo(P, grid, lds_bytes, st, P.census != 0));
+                else if (kind == 10 && P.census && P.adaptive)
+                    hipLaunchKernelGGL((wfa_lane_kernel<true, true>), dim3(grid), dim3(64), lds_bytes, st, P);
                 else if (kind == 10 && P.census)
-                    hipLaunchKernelGGL((wfa_lane_kernel<true>), dim3(grid), dim3(64), lds_bytes, st, P);
+                    hipLaunchKernelGGL((wfa_lane_kernel<true, false>), dim3(grid), dim3(64), lds_bytes, st, P);
+                else if (kind == 10 && P.adaptive)
+                    hipLaunchKernelGGL((wfa_lane_kernel<false, true>), dim3(grid), dim3(64), lds_bytes, st, P);
                 else if (kind == 10)
-                    hipLaunchKernelGGL((wfa_lane_kernel<false>), dim3(grid), dim3(64), lds_bytes, st, P);
+                    hipLaunchKernelGGL((wfa_lane_kernel<false, false>), dim3(grid), dim3(64), lds_bytes, st, P);
                 else if (kind == 5)
                     hipLaunchKernelGGL((wfa_blk_kernel<64, 1>), dim3(grid), dim3(64), lds_bytes, st, P);
                 else if (kind == 9)

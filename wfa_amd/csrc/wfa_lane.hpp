@@ -36,7 +36,7 @@ constexpr int LN_RING_WORDS = 48;   // 32 (M ring: 4 rows x 32 bytes) + 8 (I) + 
 // words of LDS a lane owns when a sequence takes sw (even) packed words: odd
 constexpr uint32_t lane_stride_words(uint32_t sw) { return (uint32_t)LN_RING_WORDS + 2u * sw + 1u; }
 
-template <bool CENSUS>
+template <bool CENSUS, bool ADAPTIVE>
 __global__ __launch_bounds__(64) void wfa_lane_kernel(const KParams P) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int lane = threadIdx.x;
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(64) void wfa_lane_kernel(const KParams P) {
     const uint64_t        cap      = P.arena_words;
     const int             rows_cap = (int)(cap / 16);
     const int             mdd = (int)P.max_dist_diff, minwf = (int)P.min_wf_len;
-    const bool            adaptive = P.adaptive != 0;
+    constexpr bool        adaptive = ADAPTIVE;  // (= P.adaptive: an instance each, the cell loop of the plain one does not track distances)
     const uint32_t        seed_si  = P.dx;
     constexpr int         BIG = 0x3FFFFFFF;
 
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(64) void wfa_lane_kernel(const KParams P) {
                         arow[k & 31] = (uint16_t)wd;  // (a word of a cell that does not exist is never read)
                         glo = nz ? imin2(glo, k) : glo, ghi = nz ? k : ghi;
                         fl |= (nz ? 4u : 0u) | ((nz && (int)h >= lim) ? 2u : 0u) | ((nz && k == Ak && (int)h >= m) ? 1u : 0u);
-                        if (nz && (int)h < lim) {  // a usable entry of wf-adaptive: inside both sequences
+                        if (ADAPTIVE && nz && (int)h < lim) {  // a usable entry of wf-adaptive: inside both sequences
                             const int dd = imax2(n + k, m) - (int)h;
                             mind = imin2(mind, dd), maxd = imax2(maxd, dd);
                         }
