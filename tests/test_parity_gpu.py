@@ -937,6 +937,8 @@ def _expected_compact_words(dump, x, o, e):
 def _arena_slot(fmt, i, k):
     if fmt in (3, 7):  # (fmt 7: the same tiles with 16-bit words -- the caller views the arena as uint16)
         return (i >> 3) * 512 + (((k & 63) >> 2) << 5) + ((i & 7) << 2) + (k & 3)
+    if fmt == 8:       # (wfa_lane_kernel: 32 halfwords per score)
+        return i * 32 + (k & 31)
     return i * {1: 64, 4: 256, 5: 32, 6: 128}[fmt] + (k & ({1: 63, 4: 255, 5: 31, 6: 127}[fmt]))
 
 
@@ -946,6 +948,18 @@ def _arena_slot(fmt, i, k):
 @pytest.mark.parametrize("census", [0, 1])
 @pytest.mark.parametrize("duo", [0, 1])
 def test_blocked_kernel_arena_word_for_word(built, length, err, pen, ad, fmt, census, duo):
+    _arena_word_check(length, err, pen, ad, fmt, census, duo, 0)
+
+
+@pytest.mark.parametrize("length,err,pen,ad", [(150, 0.02, (4, 6, 2), None), (120, 0.06, (4, 6, 2), (10, 50, 1)), (230, 0.04, (2, 3, 1), (5, 20, 1)),
+                                               (60, 0.10, (8, 12, 4), None)])
+@pytest.mark.parametrize("census", [0, 1])
+def test_lane_kernel_arena_word_for_word(built, length, err, pen, ad, census):
+    """The same for wfa_lane_kernel (a lane per pair, short reads): rows of 32 halfwords."""
+    _arena_word_check(length, err, pen, ad, 8, census, 0, 1)
+
+
+def _arena_word_check(length, err, pen, ad, fmt, census, duo, lane):
     """The dominant kernel's stored state, not only its results: every compact backtrace word wfa_blk_kernel leaves in
     HBM (M tag, I and D tag bits, pre-extension offset) against what the oracle's wavefronts imply -- visited by the
     backtrace or not.  Covers wf-adaptive pruning (deleted cells must not be there with a source role), ragged lengths
@@ -964,15 +978,16 @@ def test_blocked_kernel_arena_word_for_word(built, length, err, pen, ad, fmt, ce
     if fmt == 5 and duo:
         pytest.skip("short reads stay on the batched 8-lane instance")
     al.set_option("duo", 2 * duo)  # wfa_duo_kernel (8 or 16 lanes per pair) writes the same arena as wfa_blk_kernel<16,1>
+    al.set_option("lane", 2 * lane)
     got = al.align_arrays(blob, q_off, q_len, t_off, t_len)
-    assert al.last_timing().main_kernel_kind == (6 if fmt == 5 else (8 if duo else 3))
+    assert al.last_timing().main_kernel_kind == (10 if lane else 6 if fmt == 5 else (8 if duo else 3))
     g = np.gcd.reduce([pen[0], pen[1] + pen[2], pen[2]])
     oa = O.Aligner(O.make_params(*pen, global_alignment=True, adaptive=ad))
     checked = pairs = 0
     for i in range(n):
         words, f, meta = al.debug_compact_arena(i)
         assert f == (7 if duo else fmt)
-        if f == 7:
+        if f in (7, 8):
             words = words.view(np.uint16)
         if meta[0] != 0:  # handed on to another kernel (band / arena): its slot is not the final state
             continue
@@ -1182,3 +1197,79 @@ def test_mid_window_arena_word_for_word(built):
         pairs += 1
     assert pairs >= n // 2 and checked > 50 * pairs, (pairs, checked)
     al.close()
+
+
+@pytest.mark.parametrize("length,err,n", [(150, 0.02, 40000), (150, 0.02, 7), (100, 0.06, 30000), (230, 0.03, 5000), (60, 0.1, 20000),
+                                          (150, 0.15, 8000), (30, 0.05, 70), (150, 0.02, 65)])
+@pytest.mark.parametrize("ad", [(10, 50, 1), None])
+def test_lane_kernel_batches(built, length, err, n, ad):
+    """wfa_lane_kernel (short reads, a lane per pair, 64 pairs per wave and generation): full generations, a single
+    partial one, error rates at which most pairs outgrow the 28-diagonal rows and are handed on.  Twice through the
+    same aligner over a poisoned arena (the kernel zeroes nothing but its LDS rings), every field and CIGAR op."""
+    import wfa_amd as w
+    from oracle import oracle as O
+    data = w.generate_pairs(seed=77 + length + n % 91, n_pairs=n, length=length, error_rate=err, n_threads=8)
+    want = O.align_batch(_oracle_params(True, ad), *data, n_threads=max(8, (os.cpu_count() or 8) // 2))
+    al = _aligner(True, ad)
+    al.set_option("lane", 2)
+    al.set_option("arena_poison", 1)
+    for rep in range(2):
+        got = al.align_arrays(*data)
+        assert al.last_timing().main_kernel_kind == 10
+        assert_batch_equal(got, want, f"lane L={length} err={err} n={n} ad={ad} rep={rep}")
+    al.close()
+
+
+def test_lane_kernel_ragged_lengths_and_penalties(built):
+    """Ragged lengths 1..240, overhangs (the exact WF_NEXT at sequence ends), empty / lowercase / non-ACGT entries inside
+    generations, other penalty sets of the 2 : 4 : 1 shape, three wf-adaptive settings; and the default routing: a
+    batch of at least lane_min_pairs short pairs starts on the kernel, a smaller one on the 8-lane instance."""
+    import wfa_amd as w
+    from oracle import oracle as O
+    rng = np.random.default_rng(5)
+    qs, ts = [], []
+    for i in range(5000):
+        L = int(rng.integers(1, 240))
+        q = bytes(b"ACGT"[c] for c in rng.integers(0, 4, L))
+        t = bytearray(q)
+        for _ in range(int(rng.integers(0, 1 + L // 10))):
+            pos, kind = int(rng.integers(0, len(t))), int(rng.integers(0, 3))
+            if kind == 0:
+                t[pos] = b"ACGT"[int(rng.integers(0, 4))]
+            elif kind == 1:
+                t.insert(pos, b"ACGT"[int(rng.integers(0, 4))])
+            elif len(t) > 1:
+                del t[pos]
+        if i % 7 == 0:
+            extra = bytes(b"ACGT"[c] for c in rng.integers(0, 4, int(rng.integers(1, 60))))
+            t = (extra + bytes(t)) if i % 2 else (bytes(t) + extra)
+        t = bytes(t[:240])
+        if i % 17 == 5:
+            q = b""
+        elif i % 17 == 9:
+            t = t.lower()
+        elif i % 17 == 13:
+            q = (q[:len(q) // 2] + b"N" + q[len(q) // 2:])[:240]
+        elif i % 23 == 7:
+            q, t = b"A", b"CA"
+        qs.append(q), ts.append(t)
+    data = w.make_blob(qs, ts)
+    for ad in ((10, 50, 1), None, (5, 10, 1)):
+        for pen in ((4, 6, 2), (2, 3, 1), (6, 9, 3)):
+            want = O.align_batch(_oracle_params(True, ad, pen), *data, n_threads=max(8, (os.cpu_count() or 8) // 2))
+            al = _aligner(True, ad, pen)
+            al.set_option("lane", 2)
+            al.set_option("arena_poison", 1)
+            got = al.align_arrays(*data)
+            t = al.last_timing()
+            assert t.main_kernel_kind == 10 and t.n_retried_pairs > 0  # (bands wider than a row, non-ACGT bytes: handed on)
+            assert_batch_equal(got, want, f"lane ragged ad={ad} pen={pen}")
+            al.close()
+    if os.environ.get("WFA_TEST_OPTS"):
+        return  # (forced options: the default routing is not what runs)
+    for n, kind in ((40000, 10), (20000, 6)):
+        data = w.generate_pairs(seed=3, n_pairs=n, length=150, error_rate=0.02, n_threads=8)
+        al = _aligner(True, None)
+        al.align_arrays(*data)
+        assert al.last_timing().main_kernel_kind == kind, (n, al.last_timing().main_kernel_kind)
+        al.close()

@@ -154,6 +154,8 @@ struct wfahip_ctx {
                                                   // SLOWER than the batched 8-lane instance (1e5 x 150 bp: forward 0.317 vs 0.249 ms, 1e6: 1.60 vs 1.43 ms, plus the
                                                   // packing kernel) -- a 150-base pair lives ten steps, so a wave restructures on nearly every step
     int64_t       opt_duo_short_min_pairs  = 50000;
+    bool          ctrl_clean               = false;  // the control words are zero: the last call zeroed them on ctrl_clean_stream as it left
+    hipStream_t   ctrl_clean_stream        = nullptr;
     bool          redo_was_empty           = false;  // the last pass that asked for its redo list found it empty
     int64_t       opt_compact_call_bases   = 50000000;  // first passes over at most this many bases (pairs x longest read) keep their backtrace
                                                         // kernel on the call's stream (no event wait on the second one): 0 = never
@@ -630,7 +632,10 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
     P.rec = static_cast<uint32_t *>(d_rec);
     P.ops = static_cast<uint64_t *>(d_ops), P.ops_cap = ops_cap;
 
-    HIP_TRY(hipMemsetAsync(d_ctrl, 0, CTRL_WORDS * 4, st));
+    // (a call that ended well leaves the control words zeroed for the next one -- a memset the GPU runs while the host is
+    // on its way back to the caller, instead of one the first kernel of the next call waits for)
+    if (!(ctx->ctrl_clean && ctx->ctrl_clean_stream == st)) HIP_TRY(hipMemsetAsync(d_ctrl, 0, CTRL_WORDS * 4, st));
+    ctx->ctrl_clean = false;
     if (ops_cursor0) {
         HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_ctrl + 2), (int)(uint32_t)ops_cursor0, 1, st));
         HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_ctrl + 3), (int)(uint32_t)(ops_cursor0 >> 32), 1, st));
@@ -881,7 +886,7 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                 HIP_TRY(hipEventRecord(evFb, st));
                 if (st_bt != st) HIP_TRY(hipStreamWaitEvent(st_bt, evFb, 0));
                 if (st_bt != st) HIP_TRY(hipEventRecord(evBa, st_bt));  // (same stream: the backtrace starts where the forward kernel ends)
-                hipLaunchKernelGGL(wfa_backtrace_kernel, dim3((uint32_t)((cn + 255) / 256)), dim3(256), 0, st_bt, P);
+                hipLaunchKernelGGL(wfa_backtrace_kernel, dim3((uint32_t)((cn + BT_THREADS - 1) / BT_THREADS)), dim3(BT_THREADS), 0, st_bt, P);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipEventRecord(evBb, st_bt));
             }
@@ -1366,6 +1371,7 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
     const uint64_t cursor   = (uint64_t)hctrl[2] | ((uint64_t)hctrl[3] << 32);
     ctx->timing.ops_written = cursor;
     if (ops_needed) *ops_needed = cursor;
+    if (!debug_single && hipMemsetAsync(d_ctrl, 0, CTRL_WORDS * 4, st) == hipSuccess) ctx->ctrl_clean = true, ctx->ctrl_clean_stream = st;
     if (cursor > ops_cap) {
         if (std::getenv("WFAHIP_DEBUG_TIMING")) std::fprintf(stderr, "[wfahip] CIGAR op buffer too small: %llu needed, %llu there\n", (unsigned long long)cursor, (unsigned long long)ops_cap);
         return WFAHIP_ERR_OOM;

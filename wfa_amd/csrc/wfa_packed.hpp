@@ -295,7 +295,16 @@ WFA_KERNEL_LINKAGE __global__ __launch_bounds__(64, 7) void wfa_packed_kernel(co
 // Backtrace (wfa.go:703-983) + process() statistics + result record of ONE finished pair of the sub-wave pipeline
 // (global alignment only): idx = the pair's index in the chunk (= its arena slot), h_end = extended offset of the
 // end cell M[s_final][m - n].
-WFA_DEV void backtrace_one(const KParams &P, uint32_t idx, uint32_t s_final, uint32_t h_end, uint32_t cells, bool coherent) {
+// entries of the ops region of a pair of final score s: 2 * score / min(x, e) + 8, rounded up to the writer's store group
+// (with the buffer aligned every region ends on a store boundary)
+WFA_DEV uint32_t ops_bound(const KParams &P, uint32_t s_final) {
+    return (2u * (s_final / P.min_xe) + 8u + OpsWriterRev::GROUP - 1u) & ~(OpsWriterRev::GROUP - 1u);
+}
+
+// off_given: where the pair's ops region starts (the caller has carved it), or OPS_OFF_OWN: carve it here
+constexpr uint64_t OPS_OFF_OWN = ~0ull;
+WFA_DEV void backtrace_one(const KParams &P, uint32_t idx, uint32_t s_final, uint32_t h_end, uint32_t cells, bool coherent,
+                           uint64_t off_given = OPS_OFF_OWN) {
     const uint32_t  pair = P.work ? P.work[idx] : P.chunk_first + idx;
     uint32_t *const rec  = P.rec + (uint64_t)pair * REC_WORDS;
     const int       n = (int)P.q_len[pair], m = (int)P.t_len[pair];
@@ -303,10 +312,9 @@ WFA_DEV void backtrace_one(const KParams &P, uint32_t idx, uint32_t s_final, uin
     cv.A = P.arena + (uint64_t)idx * P.arena_words, cv.cap = P.arena_words, cv.g = P.g, cv.n_ent = s_final / P.g + 1u;
     cv.fmt = P.compact_fmt, cv.coherent = coherent;
 
-    // ops region: bound = 2 * score / min(x, e) + 8 entries, carved from the shared ops buffer
-    // (a multiple of the writer's store group: with the buffer aligned every region ends on a store boundary)
-    const uint32_t bound = (2u * (s_final / P.min_xe) + 8u + OpsWriterRev::GROUP - 1u) & ~(OpsWriterRev::GROUP - 1u);
-    const uint64_t off   = atomicAdd(P.ops_cursor, (unsigned long long)bound);
+    // ops region: carved from the shared ops buffer
+    const uint32_t bound = ops_bound(P, s_final);
+    const uint64_t off   = off_given != OPS_OFF_OWN ? off_given : atomicAdd(P.ops_cursor, (unsigned long long)bound);
     OpsWriterRev   ow;
     const bool     fits = off + bound <= P.ops_cap;
     ow.init(P.ops + off, fits ? bound : 0u);
@@ -326,24 +334,50 @@ WFA_DEV void backtrace_one(const KParams &P, uint32_t idx, uint32_t s_final, uin
 // here.  A pair that was handed on (ST_REDO_*) gets its record from the pass that finishes it -- which may already
 // be running beside this kernel, so this kernel must not touch that record.
 // Streamed mode (P.done_q != nullptr): the finished pairs are the done_q entries the streaming kernel has not taken.
-WFA_KERNEL_LINKAGE __global__ __launch_bounds__(256) void wfa_backtrace_kernel(const KParams P) {
-    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= P.chunk_n) return;
-    const uint4 meta = P.pair_meta[idx];
-    if (meta.x != ST_OK && meta.x < ST_REDO_BYTES) {
+// The ops regions of a workgroup's pairs are carved with ONE atomic: every wave adding its own total to the one cursor
+// serialized 1 563 waves of 1e5 short pairs at the L2 -- 20 of the kernel's 41 us went to waiting for that atomic's return.
+constexpr int BT_THREADS = 512;
+WFA_KERNEL_LINKAGE __global__ __launch_bounds__(BT_THREADS) void wfa_backtrace_kernel(const KParams P) {
+    __shared__ uint32_t           wsum[BT_THREADS / 64];
+    __shared__ unsigned long long wbase;
+    const uint32_t idx  = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool     have = idx < P.chunk_n;
+    uint4          meta = make_uint4(ST_PENDING, 0u, 0u, 0u);
+    if (have) meta = P.pair_meta[idx];
+    if (have && meta.x != ST_OK && meta.x < ST_REDO_BYTES) {
         const uint32_t pair = P.work ? P.work[idx] : P.chunk_first + idx;
         const uint4    z    = make_uint4(0u, 0u, 0u, 0u);
         uint4 *r4           = reinterpret_cast<uint4 *>(P.rec + (uint64_t)pair * REC_WORDS);
         r4[0] = make_uint4(meta.x, 0u, 0u, 0u), r4[1] = z, r4[2] = z, r4[3] = z;
     }
+    // what this thread walks: slot, final score, final offset, cells
+    bool     walk = have && meta.x == ST_OK;
+    uint32_t slot = idx, s_final = meta.y, h_end = meta.z, cells = meta.w;
     if (P.done_q) {
-        const uint4 e = P.done_q[idx];
-        if (e.x != 0u && e.x != DONE_TAKEN && (e.x & DONE_NOT_OK) == 0u) {
-            backtrace_one(P, e.x - 1u, e.y, e.z, e.w, false);
-        }
-    } else if (meta.x == ST_OK) {
-        backtrace_one(P, idx, meta.y, meta.z, meta.w, false);
+        const uint4 e = have ? P.done_q[idx] : make_uint4(0u, 0u, 0u, 0u);
+        walk = e.x != 0u && e.x != DONE_TAKEN && (e.x & DONE_NOT_OK) == 0u;
+        slot = e.x - 1u, s_final = e.y, h_end = e.z, cells = e.w;
     }
+    const uint32_t bound = walk ? ops_bound(P, s_final) : 0u;
+    // exclusive scan of `bound` over the workgroup
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    uint32_t       incl = bound;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d, 64);
+        if ((int)lane >= d) incl += up;
+    }
+    if (lane == 63u) wsum[wv] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long tot = 0;
+        for (uint32_t w = 0; w < blockDim.x / 64u; w++) tot += wsum[w];
+        wbase = tot ? atomicAdd(P.ops_cursor, tot) : 0ull;
+    }
+    __syncthreads();
+    uint64_t off = wbase + (incl - bound);
+    for (uint32_t w = 0; w < wv; w++) off += wsum[w];
+    if (walk) backtrace_one(P, slot, s_final, h_end, cells, false, off);
 }
 
 // Streaming backtrace (called by waves of wfa_blk_kernel<.., STREAM = true>): the done_q entries are taken in
