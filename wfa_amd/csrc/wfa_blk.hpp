@@ -1086,6 +1086,7 @@ WFA_KERNEL_LINKAGE __global__ __launch_bounds__(256) void wfa_prepack_kernel(con
         const bool     have = wi < P.chunk_n;
         const uint32_t pr = have ? (P.work ? P.work[wi] : P.chunk_first + wi) : 0u;
         const uint32_t nq = have ? P.q_len[pr] : 0u, mt = have ? P.t_len[pr] : 0u;
+        const uint64_t qo = have ? P.q_off[pr] : 0ull, to = have ? P.t_off[pr] : 0ull;  // (with the lengths: one round trip, not two)
         uint32_t       status = ST_PENDING;
         if (nq == 0 || mt == 0)
             status = ST_EMPTY;  // wfa.go:204-206
@@ -1096,7 +1097,6 @@ WFA_KERNEL_LINKAGE __global__ __launch_bounds__(256) void wfa_prepack_kernel(con
         uint32_t *const slot = out + (uint64_t)wi * PW;
         bool            bad  = false;
         if (have && status == ST_PENDING) {
-            const uint64_t qo = P.q_off[pr], to = P.t_off[pr];
             for (uint32_t v = v0; v < 2u * SW; v += LP) {
                 const bool isq = v < SW;
                 slot[4u + v]   = prepack_word(P.blob, isq ? qo : to, isq ? nq : mt, isq ? v : v - SW, bad);

@@ -51,11 +51,17 @@ __global__ __launch_bounds__(64) void wfa_lane_kernel(const KParams P) {
     const uint32_t        seed_si  = P.dx;
     constexpr int         BIG = 0x3FFFFFFF;
 
+    bool first_gen = true;
     for (;;) {
         // ------------------------------------------------------------ a generation: 64 queue entries, one per lane
-        uint32_t gbase = 0;
-        if (lane == 0) gbase = atomicAdd(P.queue_head, 64u);
-        gbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)gbase);
+        // (the first generation of every wave is its own index: a thousand waves asking the one queue word at the start of the
+        // launch are served one after the other -- the last of them some 10 us late; the queue hands out what follows)
+        uint32_t gbase = blockIdx.x * 64u;
+        if (!first_gen) {
+            if (lane == 0) gbase = atomicAdd(P.queue_head, 64u);
+            gbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)gbase) + gridDim.x * 64u;
+        }
+        first_gen = false;
         if (gbase >= P.chunk_n) break;
         const uint32_t wi = gbase + (uint32_t)lane;
         bool           active = wi < P.chunk_n;
