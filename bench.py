@@ -215,6 +215,9 @@ def run_rank(args):
             L.check(L.lib().wfahip_set_option(al._ctx, key.encode(), int(val)), "wfahip_set_option")
         prm = al._params()
         lib = L.lib()
+        # (the device pointers of the resident batch: looked up once, not in every step -- the call is the C-ABI's)
+        dev_ptrs = (d_blob.data_ptr(), blob.size, d_qoff.data_ptr(), d_qlen.data_ptr(), d_toff.data_ptr(), d_tlen.data_ptr(),
+                    d_rec.data_ptr(), d_ops.data_ptr())
         stream = torch.cuda.current_stream(dev).cuda_stream
     pending = [None]  # the result gather in flight (multi-GPU)
     gather_bytes = [0]
@@ -228,9 +231,8 @@ def run_rank(args):
             n_ops = n
         else:
             needed = C.c_uint64()
-            rc = lib.wfahip_align_batch_device(al._ctx, C.byref(prm), d_blob.data_ptr(), blob.size, d_qoff.data_ptr(),
-                                               d_qlen.data_ptr(), d_toff.data_ptr(), d_tlen.data_ptr(), n, max_len,
-                                               d_rec.data_ptr(), d_ops.data_ptr(), ops_cap, C.byref(needed), stream)
+            rc = lib.wfahip_align_batch_device(al._ctx, C.byref(prm), *dev_ptrs[:2], *dev_ptrs[2:6], n, max_len,
+                                               *dev_ptrs[6:], ops_cap, C.byref(needed), stream)
             L.check(rc, "wfahip_align_batch_device")
             lib.wfahip_last_timing(al._ctx, C.byref(timing))
             n_ops = int(needed.value)

@@ -1038,6 +1038,13 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
 // with two shift-or steps; a byte outside ACGT shows when the code's canonical letter (one v_perm_b32 through "ACTG")
 // differs from the byte.  (Round 2's version ran stage_word(), ~100 instructions per word, and was bound by them:
 // 0.89 ms; the forward kernels' own refill still uses stage_word.)  slot = {n, m, status, 0, q words [SW], t words [SW]}.
+// four bases (the bytes of w) as eight bits; bad |= a byte outside ACGT
+WFA_DEV uint32_t prepack_dword(uint32_t w, bool &bad) {
+    const uint32_t x = (w >> 1) & 0x03030303u;
+    bad |= __builtin_amdgcn_perm(0u, 0x47544341u, x) != w;  // code -> 'A' 'C' 'T' 'G'
+    const uint32_t y = x | (x >> 6);
+    return (y & 0xFu) | ((y >> 12) & 0xF0u);
+}
 WFA_DEV uint32_t prepack_word(const uint8_t *blob, uint64_t off, uint32_t len, uint32_t jw, bool &bad) {
     const uint32_t nw = (len + 15u) >> 4;
     if (jw >= nw) return 0u;
@@ -1063,11 +1070,7 @@ WFA_DEV uint32_t prepack_word(const uint8_t *blob, uint64_t off, uint32_t len, u
             const uint32_t km = mb >= 4u ? 0xFFFFFFFFu : ((1u << (8u * mb)) - 1u);
             w = (w & km) | (0x41414141u & ~km);
         }
-        const uint32_t x = (w >> 1) & 0x03030303u;
-        bad |= __builtin_amdgcn_perm(0u, 0x47544341u, x) != w;  // code -> 'A' 'C' 'T' 'G'
-        uint32_t y = x | (x >> 6);
-        y          = (y & 0xFu) | ((y >> 12) & 0xF0u);
-        word |= y << (8 * i);
+        word |= prepack_dword(w, bad) << (8 * i);
     }
     return word;
 }

@@ -161,6 +161,7 @@ struct wfahip_ctx {
                                                         // kernel on the call's stream (no event wait on the second one): 0 = never
     int64_t       opt_lane                 = 1;   // reads of at most 240 bases start on wfa_lane_kernel (a lane per pair): 0 never, 1 for batches of
                                                   // at least opt_lane_min_pairs, 2 always
+    int64_t       opt_lane_pack            = 1;   // 1: the lanes of wfa_lane_kernel pack the bytes of their pairs themselves, 0: wfa_prepack_kernel before it
     int64_t       opt_lane_min_pairs       = 32768;  // (below ~30 000 pairs a generation of 64 pairs per wave leaves most of the GPU idle for as
                                                      // long as its slowest pair runs: 16 000 x 150 bases 0.192 ms against 0.157 on the 8-lane kernel)
     int64_t       opt_census               = 0;   // 1: the sub-wave forward kernels count the wavefront words they store (REC_CELLS, timing.cells_stored)
@@ -480,6 +481,8 @@ static int set_option_impl(wfahip_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_compact_call_bases = value;
     else if (k == "lane")
         ctx->opt_lane = value;
+    else if (k == "lane_pack")
+        ctx->opt_lane_pack = value;
     else if (k == "lane_min_pairs")
         ctx->opt_lane_min_pairs = value;
     else if (k == "duo_short")
@@ -825,7 +828,7 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                 P.prepack = nullptr, P.prepack_words = 0;
                 P.lds_seq_words = kind == 10 ? lane_sw : kind == 8 ? duo_sw : seq_words;
                 if (kind == 10) P.sub_lds_words = lane_stride_words(lane_sw);
-                if ((kind == 3 && !blk_batch && !list && ctx->opt_prepack != 0) || kind == 8 || kind == 10) {
+                if ((kind == 3 && !blk_batch && !list && ctx->opt_prepack != 0) || kind == 8 || (kind == 10 && ctx->opt_lane_pack == 0)) {
                     const uint32_t pw = 4u + 2u * P.lds_seq_words;
                     if ((rc2 = ensure(ctx, ctx->prepack, (size_t)chunk * pw * 4))) return rc2;
                     hipLaunchKernelGGL(wfa_prepack_kernel, dim3((uint32_t)((cn + 4 * PREPACK_PAIRS - 1) / (4 * PREPACK_PAIRS))), dim3(256), 0, st, P,

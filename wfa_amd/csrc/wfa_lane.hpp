@@ -27,6 +27,7 @@
 // Global alignment, penalties shaped 2 : 4 : 1 (x : o+e : e in units of g), like the other sub-wave kernels.
 #pragma once
 #include "wfa_device.hpp"
+#include "wfa_blk.hpp"  // prepack_word(), prepack_dword()
 
 namespace wfa {
 
@@ -35,6 +36,50 @@ constexpr int LN_SEQ_WORDS  = 16;   // most packed words per sequence incl. the 
 constexpr int LN_RING_WORDS = 48;   // 32 (M ring: 4 rows x 32 bytes) + 8 (I) + 8 (D)
 // words of LDS a lane owns when a sequence takes sw (even) packed words: odd
 constexpr uint32_t lane_stride_words(uint32_t sw) { return (uint32_t)LN_RING_WORDS + 2u * sw + 1u; }
+
+// 2-bit packs the len (>= 16) bases at src (16-byte aligned) into dst[0 .. SW): every 16-byte chunk of the sequence in ONE
+// round of loads (independent, so a lane pays their latency once), the bytes of a last partial chunk by the dwords that
+// hold them -- nothing past the end of the sequence is read.  Returns true when it saw a byte outside ACGT.
+WFA_DEV bool lane_pack_seq(const uint8_t *src, uint32_t len, uint32_t *dst, uint32_t SW) {
+    const uint32_t nfull = len >> 4, nb = len & 15u, ntd = (nb + 3u) >> 2;
+    // four bases as eight bits; diff collects (canonical letter ^ byte): nonzero = a byte outside ACGT
+    const auto pk = [](uint32_t w, uint32_t &diff) -> uint32_t {
+        const uint32_t x = (w >> 1) & 0x03030303u;
+        diff |= __builtin_amdgcn_perm(0u, 0x47544341u, x) ^ w;  // code -> 'A' 'C' 'T' 'G'
+        const uint32_t y = x | (x >> 6);
+        return (y & 0xFu) | ((y >> 12) & 0xF0u);
+    };
+    const uint32_t *const tp = reinterpret_cast<const uint32_t *>(nb != 0u ? src + 16u * nfull : src);
+    uint32_t              td[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) td[i] = tp[(uint32_t)i < ntd ? i : 0];
+    uint32_t bad = 0u, bad_t = 0u, wt = 0u;  // wt: the partial chunk, bytes past the end count as 'A' (code 0)
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t mb = nb > 4u * i ? (nb - 4u * i < 4u ? nb - 4u * i : 4u) : 0u;
+        const uint32_t km = mb >= 4u ? 0xFFFFFFFFu : ((1u << (8u * mb)) - 1u);
+        wt |= pk((td[i] & km) | (0x41414141u & ~km), bad_t) << (8 * i);
+    }
+    bad = nb != 0u ? bad_t : 0u;
+    // (eight chunks a round: 32 registers of loads in flight, two rounds for the longest read)
+#pragma unroll 1
+    for (int j0 = 0; j0 < LN_SEQ_WORDS; j0 += 8) {
+        uint4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = reinterpret_cast<const uint4 *>(src)[(uint32_t)(j0 + j) < nfull ? j0 + j : 0];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            uint32_t       bj = 0u;
+            const uint32_t wf = pk(v[j].x, bj) | (pk(v[j].y, bj) << 8) | (pk(v[j].z, bj) << 16) | (pk(v[j].w, bj) << 24);
+            const bool     full = (uint32_t)(j0 + j) < nfull;
+            bad |= full ? bj : 0u;
+            const uint32_t w = full ? wf : (((uint32_t)(j0 + j) == nfull && nb != 0u) ? wt : 0u);
+            if ((uint32_t)(j0 + j) < SW) dst[j0 + j] = w;
+        }
+        asm volatile("" ::: "memory");
+    }
+    return bad != 0u;
+}
 
 template <bool CENSUS, bool ADAPTIVE>
 __global__ __launch_bounds__(64) void wfa_lane_kernel(const KParams P) {
@@ -66,19 +111,57 @@ __global__ __launch_bounds__(64) void wfa_lane_kernel(const KParams P) {
         const uint32_t wi = gbase + (uint32_t)lane;
         bool           active = wi < P.chunk_n;
         int            n = 0, m = 0;
-        if (active) {
-            const uint4 *const slot = reinterpret_cast<const uint4 *>(P.prepack + (uint64_t)wi * P.prepack_words);
-            const uint4        hdr  = slot[0];
-            n = (int)hdr.x, m = (int)hdr.y;
-            if (hdr.z != ST_PENDING) {  // empty / too long / longer than 240 bases / a byte outside ACGT: no alignment here
-                P.pair_meta[wi] = make_uint4(hdr.z, 0u, 0u, 0u);
-                if (hdr.z >= ST_REDO_BYTES) push_redo(P, P.work ? P.work[wi] : P.chunk_first + wi, hdr.z);
-                active = false;
-            } else {
-                for (uint32_t i = 0; i < SW / 2u; i++) {
-                    const uint4 v = slot[1 + i];
-                    lq[4 * i] = v.x, lq[4 * i + 1] = v.y, lq[4 * i + 2] = v.z, lq[4 * i + 3] = v.w;  // (q words, then t words: contiguous)
+        if (P.prepack) {  // slots of wfa_prepack_kernel
+            if (active) {
+                const uint4 *const slot = reinterpret_cast<const uint4 *>(P.prepack + (uint64_t)wi * P.prepack_words);
+                const uint4        hdr  = slot[0];
+                n = (int)hdr.x, m = (int)hdr.y;
+                if (hdr.z != ST_PENDING) {  // empty / too long / longer than 240 bases / a byte outside ACGT: no alignment here
+                    P.pair_meta[wi] = make_uint4(hdr.z, 0u, 0u, 0u);
+                    if (hdr.z >= ST_REDO_BYTES) push_redo(P, P.work ? P.work[wi] : P.chunk_first + wi, hdr.z);
+                    active = false;
+                } else {
+                    for (uint32_t i = 0; i < SW / 2u; i++) {
+                        const uint4 v = slot[1 + i];
+                        lq[4 * i] = v.x, lq[4 * i + 1] = v.y, lq[4 * i + 2] = v.z, lq[4 * i + 3] = v.w;  // (q words, then t words: contiguous)
+                    }
                 }
+            }
+        } else {
+            // every lane packs the bytes of its own pair: a kernel of its own for that cost 21 us + a launch per 1e5 pairs.
+            // (Sequences that start on a 16-byte boundary and hold at least 16 bases -- what the packing helpers of the
+            // bindings produce; a wave that meets anything else packs word by word, a round trip per word.)
+            uint32_t st0 = ST_PENDING, pair = 0u, nq = 0u, mt = 0u;
+            uint64_t qo = 0ull, to = 0ull;
+            if (active) {
+                pair = P.work ? P.work[wi] : P.chunk_first + wi;
+                nq = P.q_len[pair], mt = P.t_len[pair], qo = P.q_off[pair], to = P.t_off[pair];
+                if (nq == 0u || mt == 0u)
+                    st0 = ST_EMPTY;  // wfa.go:204-206
+                else if (nq > 0x1FFFFFFFu || mt > 0x1FFFFFFFu)
+                    st0 = ST_TOO_LONG;  // wfa.go:207-209
+                else if (((nq > mt ? nq : mt) + 15u) / 16u + 1u > SW)
+                    st0 = ST_REDO_LDS;
+            }
+            const bool           pk = active && st0 == ST_PENDING;
+            const uint8_t *const qs = P.blob + (pk ? qo : 0ull), *const tq = P.blob + (pk ? to : 0ull);
+            const bool           fast = ((reinterpret_cast<uintptr_t>(qs) | reinterpret_cast<uintptr_t>(tq)) & 15u) == 0u && nq >= 16u && mt >= 16u;
+            bool                 bad  = false;
+            if (__ballot(pk && !fast) == 0ull) {
+                if (pk) {
+                    bad = lane_pack_seq(qs, nq, lq, SW);
+                    asm volatile("" ::: "memory");
+                    bad |= lane_pack_seq(tq, mt, lt, SW);
+                }
+            } else if (pk) {
+                for (uint32_t j = 0; j < SW; j++) lq[j] = prepack_word(P.blob, qo, nq, j, bad), lt[j] = prepack_word(P.blob, to, mt, j, bad);
+            }
+            if (pk && bad) st0 = ST_REDO_BYTES;  // the byte-compare path takes the pair
+            n = (int)nq, m = (int)mt;
+            if (active && st0 != ST_PENDING) {
+                P.pair_meta[wi] = make_uint4(st0, 0u, 0u, 0u);
+                if (st0 >= ST_REDO_BYTES) push_redo(P, pair, st0);
+                active = false;
             }
         }
 #pragma unroll
@@ -180,7 +263,10 @@ __global__ __launch_bounds__(64) void wfa_lane_kernel(const KParams P) {
                     }
                     if (done) {
                         const bool nz = h != 0u;
-                        arow[k & 31] = (uint16_t)wd;  // (a word of a cell that does not exist is never read)
+                        // (a word of a cell that does not exist is never read.  Measured instead of this 2-byte store per cell: two
+                        // cells per 4-byte store, and the row collected in LDS and written as 16-byte quarters -- no gain, and the
+                        // second costs a wave per CU)
+                        arow[k & 31] = (uint16_t)wd;
                         glo = nz ? imin2(glo, k) : glo, ghi = nz ? k : ghi;
                         fl |= (nz ? 4u : 0u) | ((nz && (int)h >= lim) ? 2u : 0u) | ((nz && k == Ak && (int)h >= m) ? 1u : 0u);
                         if (ADAPTIVE && nz && (int)h < lim) {  // a usable entry of wf-adaptive: inside both sequences
