@@ -718,8 +718,10 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
         uint64_t arena_mult = (ctx->rows_key == rkey && ctx->opt_packed_arena_bytes <= 0) ? ctx->rows_scale : 1;  // rows per pair, in units of the default
         auto forward_pass = [&](int kind, const std::vector<uint32_t> *list, uint64_t first_pair, uint64_t count,
                                 std::vector<uint64_t> &redo_out, bool detach_bt) -> int {
-            DevBuf &arena_buf = ctx->bt_pending ? ctx->arena2 : ctx->arena;
-            DevBuf &meta_buf  = ctx->bt_pending ? ctx->meta2 : ctx->meta;
+            // (retry passes take the second pair of buffers: the first pass's backtrace may still be reading the first -- and
+            // wfahip_debug_compact_arena shows what the first pass left)
+            DevBuf &arena_buf = (ctx->bt_pending || list) ? ctx->arena2 : ctx->arena;
+            DevBuf &meta_buf  = (ctx->bt_pending || list) ? ctx->meta2 : ctx->meta;
             // short reads: the blocked kernel stages BLK_BATCH pairs per group at a time
             // (kind 6: eight pairs per wave, 32-diagonal window; only with the batched refill)
             const bool     blk_batch    = (kind == 3 || kind == 6) && seq_words <= 16 && ctx->opt_blk_batch != 0;
@@ -1238,7 +1240,9 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             }
             continue;
         }
-        DevBuf &jarena = ctx->bt_pending ? ctx->arena2 : ctx->arena;
+        // (after a sub-wave first pass the ladder takes the second arena: that pass's backtrace kernel may still be reading
+        // the first, and wfahip_debug_compact_arena shows what it left)
+        DevBuf &jarena = (ctx->bt_pending || packed_done) ? ctx->arena2 : ctx->arena;
         // Long pairs climbing the ladder: take the whole arena budget once instead of freeing and re-allocating a
         // bigger buffer at every level (hipMalloc / hipFree of tens of GB cost more than the alignments).
         if (team_T > 0 && job.level >= 2 && jarena.bytes < (size_t)((double)ctx->total_mem * ladder_budget(ctx)))

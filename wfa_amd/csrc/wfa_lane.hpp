@@ -12,18 +12,27 @@
 //     cell before.  Every slot outside the kept band of the row it belongs to holds ZERO (the rings start zeroed, a step
 //     writes every cell of its range, what wf-adaptive drops is zeroed, and a row's range covers the kept bands of its
 //     sources +-1 -- so it overwrites all that an older occupant of its ring kept): the loads need no range checks;
-//   * both sequences 2-bit packed in LDS (2 x lds_seq_words words per lane), from the pre-packed slots of
-//     wfa_prepack_kernel (one queue atomic per generation: entries base .. base + 63);
+//   * both sequences 2-bit packed in LDS (2 x lds_seq_words words per lane), packed by the lane itself from the bytes of
+//     its pair (lane_pack_seq: all 16-byte chunks of a sequence in one round of loads; option lane_pack = 0: from the
+//     slots of wfa_prepack_kernel).  A wave's first generation is entries 64 x its index, the queue hands out the rest
+//     (one atomic per generation);
 //   * every cell by the EXACT rules of next() -- rejections (> m, offset - k > n), the k-range clamp, mismatch-wins ties,
 //     backTrace's unbounded recomputation of the pre-extension offset (wfa.go:549-700,766-817): the same formulas as the
-//     exact path of wfa_blk_kernel -- then WF_EXTEND by 16-base windows (SeqView<0>::lcp), termination, and the band /
-//     wf-adaptive of reduce() as two serial passes over the row (wfa.go:461-540);
+//     exact path of wfa_blk_kernel -- then WF_EXTEND 32 bases a round (three words of each sequence in one round trip to
+//     LDS; a cell with a longer run keeps its lane for another round while the other lanes go on to their next cells, so
+//     the wave pays the longest SUM of rounds of a row, not every cell's longest run), termination, and the band /
+//     wf-adaptive of reduce() (wfa.go:461-540): the distances are collected as the cells are stored, the leading / trailing
+//     failures found in one more pass over the row when a distance fails;
 //   * one 16-bit backtrace word per cell (blk_word: pre-extension offset + the four decisions) straight to the pair's
 //     arena slot, rows of 32 halfwords (CompactView fmt 8), and pair_meta for wfa_backtrace_kernel -- unchanged behind it.
 // A lane's stride in LDS is odd (49 + 2 x lds_seq_words words: 73 for 150-base reads -- eight waves per CU), so the 64
 // lanes of an access at the same ring slot fall on different banks.
-// A pair whose row would span more than 30 diagonals (32 slots less the k-1 and k+1 a cell reads), or which runs out of arena rows, is handed on (ST_REDO_BAND /
-// ST_REDO_ARENA) to the sub-wave kernels like any pair that leaves a window.
+// A pair whose row would span more than 30 diagonals (32 slots less the k-1 and k+1 a cell reads), or which runs out of
+// arena rows, is handed on (ST_REDO_BAND / ST_REDO_ARENA) to the sub-wave kernels like any pair that leaves a window.
+// What bounds it (profiles/r03_c2_*): a lone wave gets one instruction issued per ~10 cycles (every instruction waits
+// for the one before it), and LDS allows two waves per SIMD -- so the kernel takes what ONE generation takes, ~100 us for
+// 64 x 150-base pairs, whether the launch holds a thousand pairs or a hundred thousand; fewer instructions per round is
+// what makes it faster (two cells per round side by side was measured: slower).
 // Global alignment, penalties shaped 2 : 4 : 1 (x : o+e : e in units of g), like the other sub-wave kernels.
 #pragma once
 #include "wfa_device.hpp"
