@@ -400,8 +400,9 @@ def run_rank(args):
                 # 1.333 ns at 4 waves per SIMD (wfa_duo_kernel), 1.079 ns at 5 (wfa_blk_kernel<16,1>), 1.080 ns at 8.
                 peak = 256 * 4 * 2.4e9 / 2 / 1e9
                 ach = pm["valu_insts"] / (main_k_ms * 1e-3) / 1e9
-                waves = 4 if "duo" in kname else (5 if kname.startswith("wfa_blk_kernel<16") else 4)
-                ns_per = {4: 1.333, 5: 1.079, 8: 1.080}[waves]
+                # (wfa_lane_kernel: LDS allows two waves per SIMD -- 1.799 ns, the same row of the probe at that occupancy)
+                waves = 2 if "lane" in kname else 4 if "duo" in kname else (5 if kname.startswith("wfa_blk_kernel<16") else 4)
+                ns_per = {2: 1.799, 4: 1.333, 5: 1.079, 8: 1.080}[waves]
                 attainable = 256 * 4 / ns_per
                 roof["secondary"] = {"bound": "valu-issue", "achieved": ach, "peak": peak, "unit": "G wave-instr/s",
                                      "frac": ach / peak, "valu_wave_insts_per_launch": pm["valu_insts"],
