@@ -1295,3 +1295,59 @@ def test_lane_kernel_ragged_lengths_and_penalties(built):
         al.align_arrays(*data)
         assert al.last_timing().main_kernel_kind == kind, (n, al.last_timing().main_kernel_kind)
         al.close()
+
+
+@pytest.mark.parametrize("seed", list(range(300, 312)))
+def test_fuzz_short_reads(built, seed):
+    """Seeded random short-read batches through wfa_lane_kernel and what it hands on to: penalties (2:4:1 shapes, which the
+    kernel takes, and others, which it must leave alone), wf-adaptive parameters down to a minimum length of 1, lengths
+    1-240 with up to 20 % edits, its packing paths (own, packing kernel; aligned and unaligned blobs), arenas too small
+    for the pair (rows run out: handed on), small calls with and without the detached backtrace, poisoned arenas."""
+    import wfa_amd as w
+    from oracle import oracle as O
+    rng = np.random.default_rng(seed)
+    pens = [(4, 6, 2), (2, 3, 1), (8, 12, 4), (6, 9, 3), (1, 1, 1), (3, 5, 2)]
+    for _ in range(5):
+        pen = pens[int(rng.integers(0, len(pens)))]
+        ad = None if rng.integers(0, 3) == 0 else (int(rng.integers(1, 24)), int(rng.integers(1, 120)), 1)
+        n = int(rng.integers(64, 3000))
+        max_l = int(rng.choice([60, 150, 240]))
+        parts, q_off, q_len, t_off, t_len = [], [], [], [], []
+        pos = 0
+        unaligned = bool(rng.integers(0, 3) == 0)
+        for i in range(n):
+            L = int(rng.integers(1, max_l + 1))
+            q = rng.integers(0, 4, L)
+            t = list(q)
+            for _e in range(int(L * rng.uniform(0, 0.2))):
+                kind, p = int(rng.integers(0, 3)), int(rng.integers(0, max(1, len(t))))
+                if kind == 0 and t:
+                    t[p] = int(rng.integers(0, 4))
+                elif kind == 1:
+                    t.insert(p, int(rng.integers(0, 4)))
+                elif len(t) > 1:
+                    del t[p]
+            qb, tb = bytes(b"ACGT"[c] for c in q), (bytes(b"ACGT"[c] for c in t) or b"G")[:240]
+            for s_, offs, lens in ((qb, q_off, q_len), (tb, t_off, t_len)):
+                pad = int(rng.integers(0, 5)) if unaligned else (-pos) % 16
+                parts.append(b"#" * pad)
+                pos += pad
+                offs.append(pos), lens.append(len(s_)), parts.append(s_)
+                pos += len(s_)
+        parts.append(b"#" * 32)
+        data = (np.frombuffer(b"".join(parts), dtype=np.uint8), np.array(q_off, np.uint64), np.array(q_len, np.uint32),
+                np.array(t_off, np.uint64), np.array(t_len, np.uint32))
+        opts = {"lane": 2, "lane_pack": int(rng.integers(0, 2)), "compact_call_bases": int(rng.choice([0, 50000000])),
+                "arena_poison": 1}
+        if rng.integers(0, 4) == 0:
+            opts["packed_arena_bytes"] = int(rng.choice([1024, 2048, 4096]))
+        al = _aligner(True, ad, pen)
+        for k, v in opts.items():
+            al.set_option(k, v)
+        want = O.align_batch(_oracle_params(True, ad, pen), *data, n_threads=8)
+        for rep in range(2):
+            got = al.align_arrays(*data)
+            assert_batch_equal(got, want, f"fuzz short seed={seed} pen={pen} ad={ad} n={n} max_l={max_l} unaligned={unaligned} opts={opts} rep={rep}")
+        shaped = pen[0] * 2 == pen[1] + pen[2] and pen[2] * 2 == pen[0]
+        assert (al.last_timing().main_kernel_kind == 10) == shaped, (pen, al.last_timing().main_kernel_kind)
+        al.close()
