@@ -22,6 +22,8 @@ for seed, length, err, ad in ((101, 1000, 0.05, (10, 50, 1)), (102, 1000, 0.08, 
                               (113, 1000, 0.02, (10, 50, 1)), (114, 1000, 0.05, (4, 20, 1)), (115, 800, 0.15, (10, 50, 1)),
                               # wfa_lane_kernel (a lane per pair; with 107-109): full generations, rows near its 30-diagonal limit
                               (116, 150, 0.02, (10, 50, 1)), (117, 60, 0.05, None), (118, 200, 0.05, (10, 50, 1))):
+    if os.environ.get("SOAK_SEEDS") and str(seed) not in os.environ["SOAK_SEEDS"].split(","):
+        continue  # (SOAK_SEEDS=107,108,...: only those shapes)
     nn = n * 1000 // length if length > 1000 else n
     data = w.generate_pairs(seed=seed, n_pairs=nn, length=length, error_rate=err, n_threads=32)
     t0 = time.perf_counter()

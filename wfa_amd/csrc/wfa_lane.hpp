@@ -204,6 +204,28 @@ __global__ __launch_bounds__(64) void wfa_lane_kernel(const KParams P) {
             const uint8_t *const Mx = H + 32 * R2;
             uint8_t *const       Ir = H + 128, *const Dr = H + 160;
             uint16_t *const      arow = A16 + (size_t)si * 32u;
+            uint32_t ghit_w = 0u;              // wf-adaptive: a cell of the row sits at a sequence end (nonzero)
+            int      glo = BIG, ghi = -BIG;    // tight range of the M cells set (M.Lo / M.Hi of the new wavefront, wfa.go:242)
+            int      mind = BIG, maxd = -BIG;  // wf-adaptive: distances of the usable entries (wfa.go:478-497)
+
+            // ------------------------------------------------------------ the seed of initComponents (wfa.go:155-160)
+            // Score 0 when the first bases agree, else score x: nothing exists at lower scores, so the row is this one cell
+            // on diagonal 0 -- done here, and the cell loop below carries no test for it.
+            if (__ballot(want_seed) != 0ull) {
+                if (want_seed) {
+                    uint32_t  h0   = 1u;
+                    const int lim0 = imin2(n, m);
+                    if ((int)h0 < lim0) h0 += (uint32_t)sv.lcp(1, 1);  // WF_EXTEND (wfa.go:381-458)
+                    Mo[0] = (uint8_t)h0, Ir[0] = 0, Dr[0] = 0;
+                    arow[0] = (uint16_t)(first_eq ? BLK_SEED_MATCH : BLK_SEED_MISMATCH);
+                    glo = 0, ghi = 0;
+                    if (ADAPTIVE) {
+                        if ((int)h0 < lim0) mind = maxd = imax2(n, m) - (int)h0;
+                        ghit_w = (int)h0 >= lim0 ? 1u : 0u;
+                    }
+                    lo = 1, hi = 0;  // (no other cell)
+                }
+            }
 
             // ------------------------------------------------------------ cells, ascending k (wfa.go:572-699)
             // A cell whose extension is longer than two 16-base windows keeps its lane for another round of the loop while the
@@ -218,9 +240,6 @@ __global__ __launch_bounds__(64) void wfa_lane_kernel(const KParams P) {
                 self_mo = Mo[k & 31];  // (the slots of k - 1 hold zero: two below every kept band)
                 nc0 = Mo[(k + 1) & 31], nd0 = Dr[(k + 1) & 31], nx0 = Mx[k & 31], nis = Ir[k & 31];
             }
-            uint32_t fl = 0u;                // 1: the pair ends at this score, 2: a cell sits at a sequence end, 4: the row has an M cell
-            int      glo = BIG, ghi = -BIG;  // tight range of the M cells set (M.Lo / M.Hi of the new wavefront, wfa.go:242)
-            int      mind = BIG, maxd = -BIG;  // wf-adaptive: distances of the usable entries (wfa.go:478-497)
             uint32_t h = 0u, wd = 0u, Isk = 0u, Dsk = 0u, c0s = 0u, is_s = 0u, pend = 0u;  // the cell being extended
             int      lim = 0;
             for (;;) {
@@ -248,8 +267,7 @@ __global__ __launch_bounds__(64) void wfa_lane_kernel(const KParams P) {
                     const uint32_t o0   = (fromI && iext) ? Iu : ((!fromX && !fromI && dext) ? Du : umax2(umax2(Iu, Du), Xu));
                     wd = blk_word(o0, iext, dext, fromX, fromI);
                     // seeds of initComponents (wfa.go:155-160)
-                    if (want_seed && k == 0 && Msk == 0u) Msk = 1u, wd = first_eq ? BLK_SEED_MATCH : BLK_SEED_MISMATCH;
-                    h = Msk, lim = imax2(1, imin2(n + k, m));
+                    h = Msk, lim = imin2(n + k, m);  // (>= 1: k >= -(n - 1))
                     pend = 1u;
                 }
                 if (go) {
@@ -277,10 +295,12 @@ __global__ __launch_bounds__(64) void wfa_lane_kernel(const KParams P) {
                         // second costs a wave per CU)
                         arow[k & 31] = (uint16_t)wd;
                         glo = nz ? imin2(glo, k) : glo, ghi = nz ? k : ghi;
-                        fl |= (nz ? 4u : 0u) | ((nz && (int)h >= lim) ? 2u : 0u) | ((nz && k == Ak && (int)h >= m) ? 1u : 0u);
-                        if (ADAPTIVE && nz && (int)h < lim) {  // a usable entry of wf-adaptive: inside both sequences
-                            const int dd = imax2(n + k, m) - (int)h;
-                            mind = imin2(mind, dd), maxd = imax2(maxd, dd);
+                        if (ADAPTIVE) {
+                            if (nz && (int)h < lim) {  // a usable entry of wf-adaptive: inside both sequences
+                                const int dd = imax2(n + k, m) - (int)h;
+                                mind = imin2(mind, dd), maxd = imax2(maxd, dd);
+                            }
+                            ghit_w |= (nz && (int)h >= lim) ? 1u : 0u;
                         }
                         Mo[k & 31] = (uint8_t)h, Ir[k & 31] = (uint8_t)Isk, Dr[k & 31] = (uint8_t)Dsk;
                         a0 = self_mo, self_mo = c0s, b0 = is_s;
@@ -288,7 +308,10 @@ __global__ __launch_bounds__(64) void wfa_lane_kernel(const KParams P) {
                     }
                 }
             }
-            const bool term = (fl & 1u) != 0u, ghit = (fl & 2u) != 0u, anyM = (fl & 4u) != 0u;
+            // the row has an M cell; the pair ends at this score when its cell on the final diagonal has reached the end of t
+            // (wfa.go:228-236; a slot between glo and ghi holds this row's cell or zero)
+            const bool anyM = ghi >= glo, ghit = ghit_w != 0u;
+            const bool term = active && anyM && Ak >= glo && Ak <= ghi && (int)Mo[Ak & 31] >= m;
 
             // ------------------------------------------------------------ band of the row + wf-adaptive (wfa.go:461-540)
             int ilo = glo, ihi = ghi;
