@@ -547,9 +547,9 @@ struct CompactView {
     WFA_DEV uint32_t ld(uint64_t i) const {
         return coherent ? __hip_atomic_load(A + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : A[i];
     }
-    WFA_DEV uint32_t word(uint32_t s, int k) const {
-        if (s % g != 0u) return 0u;
-        const uint32_t idx = s / g;
+    // word of score index idx = score / g (the walk steps in index units: every penalty is a multiple of g, so a score it
+    // reaches is one too, and it pays no division per step; an index that has wrapped below zero is >= n_ent: absent)
+    WFA_DEV uint32_t word(uint32_t idx, int k) const {
         if (idx >= n_ent) return 0u;
         if (fmt == 3u) return ld(512ull * (idx >> 3) + (((uint32_t)k & 60u) << 3) + ((idx & 7u) << 2) + ((uint32_t)k & 3u));
         if (fmt == 1u) return ld(64ull * idx + ((uint32_t)k & 63u));
@@ -565,9 +565,9 @@ struct CompactView {
         if (w <= 0 || k < lo || k >= lo + w) return 0u;
         return A[e.x + (uint32_t)(k - lo)];
     }
-    // tag of the cell of component comp (0 = M, 1 = I, 2 = D) at (s, k); 0 = absent
-    WFA_DEV uint32_t tag(int comp, uint32_t s, int k, uint32_t &off0) const {
-        const uint32_t wd = word(s, k);
+    // tag of the cell of component comp (0 = M, 1 = I, 2 = D) at (score index idx, k); 0 = absent
+    WFA_DEV uint32_t tag(int comp, uint32_t idx, int k, uint32_t &off0) const {
+        const uint32_t wd = word(idx, k);
         if (fmt != 0u) return blk_tag(wd, comp, off0);  // the blocked kernels' word; fmt 0: compact_word()
         off0              = wd >> 7;
         if (comp == 0) return wd & TAG_MASK;
@@ -831,7 +831,9 @@ WFA_DEV void back_trace_compact(const CompactView &cv, int lenQ, int lenT, uint3
     bool     previousFromM = true, firstMatch = true;
     int      comp = 0;  // component the current cell lives in
     uint32_t off0 = 0;
-    uint32_t wfaType = cv.tag(0, s, k, off0);  // wfa.go:738-742
+    uint32_t       si = s / cv.g;  // score index; the penalties in index units:
+    const uint32_t dxi = px / cv.g, doei = (po + pe) / cv.g, dei = pe / cv.g;
+    uint32_t wfaType = cv.tag(0, si, k, off0);  // wfa.go:738-742
 
     if (h < lenT)  // wfa.go:746-750
         ow.add('I', (uint32_t)lenT - (uint32_t)h);
@@ -867,17 +869,17 @@ WFA_DEV void back_trace_compact(const CompactView &cv, int lenQ, int lenT, uint3
         previousFromM = true;           // wfa.go:885-909
         bool stop     = false;
         switch (wfaType) {
-        case TAG_MISMATCH: s -= px; h--; break;
-        case TAG_INS_OPEN: s -= po + pe; k--; h--; break;
-        case TAG_INS_EXT: s -= pe; k--; h--; previousFromM = false; break;
-        case TAG_DEL_OPEN: s -= po + pe; k++; break;
-        case TAG_DEL_EXT: s -= pe; k++; previousFromM = false; break;
+        case TAG_MISMATCH: si -= dxi; h--; break;
+        case TAG_INS_OPEN: si -= doei; k--; h--; break;
+        case TAG_INS_EXT: si -= dei; k--; h--; previousFromM = false; break;
+        case TAG_DEL_OPEN: si -= doei; k++; break;
+        case TAG_DEL_EXT: si -= dei; k++; previousFromM = false; break;
         default: stop = true; break;
         }
         if (stop) break;
         v = h - k;
         uint32_t       noff0;
-        const uint32_t nt = cv.tag(M0, s, k, noff0);  // wfa.go:915-920: a missing cell ends the walk, the old
+        const uint32_t nt = cv.tag(M0, si, k, noff0);  // wfa.go:915-920: a missing cell ends the walk, the old
         if (nt == 0u) break;                           // tag stays in wfaType for the tail below
         wfaType = nt, off0 = noff0, comp = M0;
     }
