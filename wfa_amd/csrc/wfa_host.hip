@@ -719,9 +719,11 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
         auto forward_pass = [&](int kind, const std::vector<uint32_t> *list, uint64_t first_pair, uint64_t count,
                                 std::vector<uint64_t> &redo_out, bool detach_bt) -> int {
             // (retry passes take the second pair of buffers: the first pass's backtrace may still be reading the first -- and
-            // wfahip_debug_compact_arena shows what the first pass left)
-            DevBuf &arena_buf = (ctx->bt_pending || list) ? ctx->arena2 : ctx->arena;
-            DevBuf &meta_buf  = (ctx->bt_pending || list) ? ctx->meta2 : ctx->meta;
+            // wfahip_debug_compact_arena shows what the first pass left.  Unless the first pair is large and free: two large
+            // arenas side by side are for overlap, not for a snapshot)
+            const bool second = ctx->bt_pending || (list && ctx->arena.bytes <= ctx->total_mem / 10);
+            DevBuf &arena_buf = second ? ctx->arena2 : ctx->arena;
+            DevBuf &meta_buf  = second ? ctx->meta2 : ctx->meta;
             // short reads: the blocked kernel stages BLK_BATCH pairs per group at a time
             // (kind 6: eight pairs per wave, 32-diagonal window; only with the batched refill)
             const bool     blk_batch    = (kind == 3 || kind == 6) && seq_words <= 16 && ctx->opt_blk_batch != 0;
@@ -1242,7 +1244,7 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
         }
         // (after a sub-wave first pass the ladder takes the second arena: that pass's backtrace kernel may still be reading
         // the first, and wfahip_debug_compact_arena shows what it left)
-        DevBuf &jarena = (ctx->bt_pending || packed_done) ? ctx->arena2 : ctx->arena;
+        DevBuf &jarena = (ctx->bt_pending || (packed_done && ctx->arena.bytes <= ctx->total_mem / 10)) ? ctx->arena2 : ctx->arena;
         // Long pairs climbing the ladder: take the whole arena budget once instead of freeing and re-allocating a
         // bigger buffer at every level (hipMalloc / hipFree of tens of GB cost more than the alignments).
         if (team_T > 0 && job.level >= 2 && jarena.bytes < (size_t)((double)ctx->total_mem * ladder_budget(ctx)))
@@ -2332,9 +2334,10 @@ static int align_pair_impl(wfahip_ctx *ctx, const wfahip_params *p, const uint8_
             hipLaunchKernelGGL(wfa_backtrace_kernel, dim3(1), dim3(256), 0, st, P);
         } else {
             // ONE launch: the streaming instance of the forward kernel -- the wave pushes its finished pair to the done
-            // queue and, once the pair queue is empty, walks it itself (stream_backtrace at the end of the kernel).  The
-            // walk's ~100 dependent arena reads then hit the L2 of the XCD that has just written those rows, instead of
-            // missing in the L2 of whichever XCD a second kernel lands on (~1.3 us each).
+            // queue and, once the pair queue is empty, walks it itself (stream_backtrace at the end of the kernel): one
+            // launch and its gap less than forward kernel + backtrace kernel (298 against 304 us for a 1 kbp pair).  The walk
+            // itself is 66-77 us either way: one lane, ~250 instructions per CIGAR op -- not its reads (walking a copy of the
+            // rows in LDS took as long).
             P.done_ctl = d_ctrl + 64, P.done_q = reinterpret_cast<uint4 *>(d_ctrl + 128), P.n_stream_wgs = 0;
             P.stream_wait = 2000000;  // 20 ms of the 100 MHz clock
             hipLaunchKernelGGL((wfa_blk_kernel<16, 1, true, 0, false>), dim3(1), dim3(64), (size_t)seq_words * 2 * 4 * 4 + 16, st, P);
