@@ -1045,15 +1045,19 @@ WFA_DEV uint32_t prepack_dword(uint32_t w, bool &bad) {
     const uint32_t y = x | (x >> 6);
     return (y & 0xFu) | ((y >> 12) & 0xF0u);
 }
-WFA_DEV uint32_t prepack_word(const uint8_t *blob, uint64_t off, uint32_t len, uint32_t jw, bool &bad) {
+// The two halves of prepack_word(): the loads of word jw (into d; sh / nb: byte shift and number of bases; nb = 0: no such
+// word), and the arithmetic on them.  Apart so that a caller can have the loads of several words in flight at once.
+WFA_DEV void prepack_fetch(const uint8_t *blob, uint64_t off, uint32_t len, uint32_t jw, uint32_t (&d)[5], uint32_t &sh, uint32_t &nb) {
     const uint32_t nw = (len + 15u) >> 4;
-    if (jw >= nw) return 0u;
+    sh = 0u, nb = 0u;
+#pragma unroll
+    for (int i = 0; i < 5; i++) d[i] = 0u;
+    if (jw >= nw) return;
     const uintptr_t a  = (uintptr_t)(blob + off) + 16ull * jw;
     const uint32_t *p  = (const uint32_t *)(a & ~(uintptr_t)3);
-    const uint32_t  sh = (uint32_t)(a & 3) * 8u;
-    const uint32_t  nb = (len - 16u * jw) < 16u ? (len - 16u * jw) : 16u;
+    sh = (uint32_t)(a & 3) * 8u;
+    nb = (len - 16u * jw) < 16u ? (len - 16u * jw) : 16u;
     const uint32_t  nd = ((uint32_t)(a & 3) + nb + 3u) >> 2;  // dwords that hold valid bytes: 1..5
-    uint32_t        d[5];
     if ((a & 15) == 0 && nb == 16u) {  // 16 whole bases at a 16-byte boundary (the usual layout): one 16-byte load, a KB per wave and instruction
         const uint4 v = *reinterpret_cast<const uint4 *>(a);
         d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w, d[4] = 0u;
@@ -1061,6 +1065,9 @@ WFA_DEV uint32_t prepack_word(const uint8_t *blob, uint64_t off, uint32_t len, u
 #pragma unroll
         for (int i = 0; i < 5; i++) d[i] = ((uint32_t)i < nd) ? p[i] : 0u;
     }
+}
+WFA_DEV uint32_t prepack_finish(const uint32_t (&d)[5], uint32_t sh, uint32_t nb, bool &bad) {
+    if (nb == 0u) return 0u;
     uint32_t word = 0u;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -1074,6 +1081,11 @@ WFA_DEV uint32_t prepack_word(const uint8_t *blob, uint64_t off, uint32_t len, u
     }
     return word;
 }
+WFA_DEV uint32_t prepack_word(const uint8_t *blob, uint64_t off, uint32_t len, uint32_t jw, bool &bad) {
+    uint32_t d[5], sh, nb;
+    prepack_fetch(blob, off, len, jw, d, sh, nb);
+    return prepack_finish(d, sh, nb, bad);
+}
 
 // (a wave per pair, PREPACK_PAIRS pairs per wave: one workgroup per pair was bound by the dispatch of a million tiny
 // workgroups -- 1.01 ms for 2.5 GB of traffic)
@@ -1083,13 +1095,27 @@ WFA_KERNEL_LINKAGE __global__ __launch_bounds__(256) void wfa_prepack_kernel(con
     const uint32_t wv   = blockIdx.x * 4u + (threadIdx.x >> 6);
     // short reads (a slot of at most 32 words): two pairs side by side, 32 lanes each
     const uint32_t LP = 2u * SW <= 32u ? 32u : 64u, side = lane / LP, v0 = lane % LP, n_side = 64u / LP;
+    // (the lengths and offsets of the NEXT pair are loaded while this one is packed, and a lane has the loads of two words
+    // in flight: the kernel was half the time waiting for a round trip with nothing else under way -- 3.2 TB/s)
+    struct Hd { uint32_t nq, mt; uint64_t qo, to; };
+    const auto load_hd = [&](uint32_t k) -> Hd {
+        const uint32_t wi = wv * (uint32_t)PREPACK_PAIRS + k + side;
+        Hd h = {0u, 0u, 0ull, 0ull};
+        if (k < (uint32_t)PREPACK_PAIRS && wi < P.chunk_n) {
+            const uint32_t pr = P.work ? P.work[wi] : P.chunk_first + wi;
+            h.nq = P.q_len[pr], h.mt = P.t_len[pr], h.qo = P.q_off[pr], h.to = P.t_off[pr];
+        }
+        return h;
+    };
+    Hd nxt = load_hd(0);
     for (uint32_t k = 0; k < (uint32_t)PREPACK_PAIRS; k += n_side) {
         const uint32_t wi = wv * (uint32_t)PREPACK_PAIRS + k + side;
         if (wv * (uint32_t)PREPACK_PAIRS + k >= P.chunk_n) return;
         const bool     have = wi < P.chunk_n;
-        const uint32_t pr = have ? (P.work ? P.work[wi] : P.chunk_first + wi) : 0u;
-        const uint32_t nq = have ? P.q_len[pr] : 0u, mt = have ? P.t_len[pr] : 0u;
-        const uint64_t qo = have ? P.q_off[pr] : 0ull, to = have ? P.t_off[pr] : 0ull;  // (with the lengths: one round trip, not two)
+        const Hd       cur  = nxt;
+        nxt                 = load_hd(k + n_side);
+        const uint32_t nq = cur.nq, mt = cur.mt;
+        const uint64_t qo = cur.qo, to = cur.to;
         uint32_t       status = ST_PENDING;
         if (nq == 0 || mt == 0)
             status = ST_EMPTY;  // wfa.go:204-206
@@ -1100,9 +1126,14 @@ WFA_KERNEL_LINKAGE __global__ __launch_bounds__(256) void wfa_prepack_kernel(con
         uint32_t *const slot = out + (uint64_t)wi * PW;
         bool            bad  = false;
         if (have && status == ST_PENDING) {
-            for (uint32_t v = v0; v < 2u * SW; v += LP) {
-                const bool isq = v < SW;
-                slot[4u + v]   = prepack_word(P.blob, isq ? qo : to, isq ? nq : mt, isq ? v : v - SW, bad);
+            for (uint32_t v = v0; v < 2u * SW; v += 2u * LP) {
+                const uint32_t va = v, vb = v + LP;  // (vb >= 2 SW: past the slot -- fetched as "no such word", not stored)
+                const bool     qa = va < SW, qb = vb < SW, hb = vb < 2u * SW;
+                uint32_t       da[5], db[5], sha, shb, nba, nbb;
+                prepack_fetch(P.blob, qa ? qo : to, qa ? nq : mt, qa ? va : va - SW, da, sha, nba);
+                prepack_fetch(P.blob, qb ? qo : to, hb ? (qb ? nq : mt) : 0u, qb ? vb : vb - SW, db, shb, nbb);
+                slot[4u + va] = prepack_finish(da, sha, nba, bad);
+                if (hb) slot[4u + vb] = prepack_finish(db, shb, nbb, bad);
             }
         }
         const unsigned long long bm = __ballot(bad), mine = LP == 64u ? ~0ull : (0xFFFFFFFFull << (32u * side));
