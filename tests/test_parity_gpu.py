@@ -1351,3 +1351,25 @@ def test_fuzz_short_reads(built, seed):
         shaped = pen[0] * 2 == pen[1] + pen[2] and pen[2] * 2 == pen[0]
         assert (al.last_timing().main_kernel_kind == 10) == shaped, (pen, al.last_timing().main_kernel_kind)
         al.close()
+
+
+@pytest.mark.parametrize("chunk_pairs", [1000, 4097])
+def test_lane_kernel_several_chunks(built, chunk_pairs):
+    """wfa_lane_kernel over a pass of several chunks (two arena buffers in turn, the backtrace kernel of a chunk beside the
+    forward kernel of the next): every chunk's waves start from their own index again, pairs are addressed from the
+    chunk's first."""
+    import wfa_amd as w
+    from oracle import oracle as O
+    data = w.generate_pairs(seed=41, n_pairs=9000, length=150, error_rate=0.03, n_threads=8)
+    for ad in ((10, 50, 1), None):
+        want = O.align_batch(_oracle_params(True, ad), *data, n_threads=max(8, (os.cpu_count() or 8) // 2))
+        al = _aligner(True, ad)
+        al.set_option("lane", 2)
+        al.set_option("chunk_pairs", chunk_pairs)
+        al.set_option("arena_poison", 1)
+        for rep in range(2):
+            got = al.align_arrays(*data)
+            t = al.last_timing()
+            assert t.main_kernel_kind == 10 and t.n_main_launches == -(-9000 // chunk_pairs), t
+            assert_batch_equal(got, want, f"lane chunks={chunk_pairs} ad={ad} rep={rep}")
+        al.close()
