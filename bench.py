@@ -78,6 +78,13 @@ def parse_args(argv=None):
                     help="N ranks on fewer GPUs (rank r uses GPU r mod device_count): every rank runs the real kernels on "
                          "its own shard, the record gather goes over gloo through host copies (two RCCL ranks cannot share "
                          "a device).  For exercising the sharded path on a 1-GPU box; not a scaling measurement")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="N = 1: create the RCCL process group anyway (world size 1) and run every collective of the multi-GPU "
+                         "path -- barrier, the asynchronous record gather, the max-over-ranks reduction, the rank census -- on "
+                         "device tensors, so the `nccl` lines of this file execute on a 1-GPU box")
+    ap.add_argument("--other-configs", type=int, default=None,
+                    help="1: after the timed region of the default (c3, N = 1) run, short legs of c2, k10, l5 and c5s on the same "
+                         "GPU, reported under config.other_configs (default: 1 for the default run, else 0)")
     ap.add_argument("--dump-records", default=None,
                     help="rank 0 writes the records gathered in the last timed step (all ranks, pair order) to this .npy file")
     args = ap.parse_args(argv)
@@ -104,6 +111,10 @@ def parse_args(argv=None):
         args.steps = DEFAULT_STEPS[args.config]  # (timed regions of ~5 s; c5s ~3 s)
     if args.warmup is None:
         args.warmup = 1 if args.config == "c5s" else 3
+    if args.other_configs is None:
+        plain = (args.config == "c3" and args.gpus == 1 and not args.dry and not args.opt and args.pairs == c["pairs"] and
+                 args.total_pairs == c["total"] and args.length == c["length"] and args.error == c["error"])
+        args.other_configs = 1 if plain else 0
     return args
 
 
@@ -156,8 +167,13 @@ def run_rank(args):
     # tensors handed to collectives: HBM for RCCL, host copies for gloo (--share-gpus: the records are staged through
     # the host, because two RCCL ranks cannot sit on one device)
     cdev = dev if backend == "nccl" else torch.device("cpu")
-    if world > 1:
+    # collectives run with more than one rank -- or with ONE when --force-collective asks for the process group anyway
+    coll = world > 1 or (bool(args.force_collective) and not dry)
+    if coll:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(args.master_port or free_port()))
+            os.environ.setdefault("RANK", "0"), os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -168,7 +184,7 @@ def run_rank(args):
     import __graft_entry__ as entry
     if rank == 0:  # one rank builds (a no-op when the in-tree library is current), the others wait for it
         entry.build()
-    if world > 1:
+    if coll:
         dist.barrier()
     if rank != 0:
         entry.build()
@@ -236,7 +252,7 @@ def run_rank(args):
             L.check(rc, "wfahip_align_batch_device")
             lib.wfahip_last_timing(al._ctx, C.byref(timing))
             n_ops = int(needed.value)
-        if world > 1:
+        if coll:
             # Result gather onto rank 0 over RCCL/xGMI (fixed-size records; with --gather-ops the padded op arrays
             # too).  It is started here and completed before the next one starts (or at the end of the timed
             # region), so the exchange of batch i runs beside the alignment of batch i+1; the send buffers are
@@ -261,7 +277,7 @@ def run_rank(args):
             pending[0] = None
 
     def sync_all():
-        if world > 1:
+        if coll:
             dist.barrier()
         if not dry:
             torch.cuda.synchronize(dev)
@@ -285,13 +301,13 @@ def run_rank(args):
     sync_all()
     elapsed = time.perf_counter() - t0
     tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-    if world > 1:
+    if coll:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     elapsed = float(tt.item())
 
     # one more gather on its own, timed (how long the exchange takes when nothing hides it)
     gather_ms = None
-    if world > 1:
+    if coll:
         sync_all()
         t1 = time.perf_counter()
         rec_out = d_rec if args.gather_ops else d_rec[:, :L.REC_OPS_OFF_LO]
@@ -340,8 +356,6 @@ def run_rank(args):
     main_k_ms = float(np.mean(main_ms)) if main_ms else 0.0
     achieved = alg_bytes / (main_k_ms * 1e-3) / 1e9 if main_k_ms > 0 else 0.0  # GB/s over the dominant kernel's launches of one step
 
-    KNAMES = ["wfa_generic_kernel<1, 0>", "wfa_packed_kernel", "wfa_reg_kernel<2, 4, 1>", "wfa_blk_kernel<16",
-              "wfa_blk_kernel<8", "wfa_blk_kernel<64", "wfa_blk_kernel<8, 8, false, 4", "wfa_team_kernel", "wfa_duo_kernel", "wfa_blk_kernel<32", "wfa_lane_kernel"]
     kname = KNAMES[min(int(timing.main_kernel_kind), len(KNAMES) - 1)]
 
     out = None
@@ -360,12 +374,13 @@ def run_rank(args):
                            f"wf-adaptive {'off' if args.no_adaptive else '10/50/1'}, seed {args.seed}",
                "config": args.config, "pairs_per_gpu": n, "pairs_per_rank": pairs_per_rank, "total_pairs_per_step": n_all,
                "length": args.length, "error_rate": args.error,
-               "parallelism": f"pair-sharded x{world}", "ranks_seen_by_collective": n_seen, "backend": "none (1 GPU)" if world == 1 else backend,
+               "parallelism": f"pair-sharded x{world}", "ranks_seen_by_collective": n_seen, "backend": backend if coll else "none (1 GPU)",
+               "collective_forced": bool(coll and world == 1),
                "gpus_shared": (f"{world} ranks on {torch.cuda.device_count()} GPU(s): sharded path exercised, NOT a scaling measurement"
                                if share and world > 1 else None),
                "status_ok": int(ok.sum()), "setup_steps": setup_steps,
-               "gather": "none (1 GPU)" if world == 1 else ("records + CIGAR ops" if args.gather_ops else "records"),
-               "gather_bytes_per_rank_step": gather_bytes[0] if world > 1 else 0, "gather_ms_standalone": gather_ms,
+               "gather": ("records + CIGAR ops" if args.gather_ops else "records") if coll else "none (1 GPU)",
+               "gather_bytes_per_rank_step": gather_bytes[0] if coll else 0, "gather_ms_standalone": gather_ms,
                "gathered_records_complete": gathered_ok,
                "gcells_per_s": value * args.length * args.length / 1e9,
                "kernel_ms_per_step": k_ms, "main_kernel_ms": main_k_ms, "launches_per_step": int(timing.n_launches),
@@ -413,12 +428,101 @@ def run_rank(args):
             out["roofline"] = roof
         if not dry and world == 1:
             extras(args, out, w, L, al, blob, q_off, q_len, t_off, t_len, rec, n)
-        print(json.dumps(out), flush=True)
     if al is not None:
         w.RecycleAligner(al)
-    if world > 1:
+        al = None
+    if rank == 0:
+        if not dry and world == 1 and args.other_configs:
+            # the other configurations, driver-observed: short legs on the same GPU after the headline's timed region (its
+            # context and buffers released first: the configs[4] sample alone takes 60 % of HBM for its arenas)
+            del d_blob, d_qoff, d_toff, d_qlen, d_tlen, d_rec, d_ops
+            torch.cuda.empty_cache()
+            out["config"]["other_configs"] = other_configs(w, L, torch, dev, dev_index)
+        print(json.dumps(out), flush=True)
+    if coll:
         dist.barrier()
         dist.destroy_process_group()
+
+
+KNAMES = ["wfa_generic_kernel", "wfa_packed_kernel", "wfa_reg_kernel<2, 4, 1>", "wfa_blk_kernel<16",
+          "wfa_blk_kernel<8", "wfa_blk_kernel<64", "wfa_blk_kernel<8, 8, false, 4", "wfa_team_kernel", "wfa_duo_kernel", "wfa_blk_kernel<32", "wfa_lane_kernel"]
+# legs of config.other_configs: (config, timed steps, warm-up steps)
+OTHER_LEGS = [("c2", 300, 5), ("k10", 30, 4), ("l5", 12, 3), ("c5s", 2, 1)]
+
+
+def other_configs(w, L, torch, dev, dev_index):
+    """Short legs of the other configurations (BASELINE configs[1], the reference's 10 % and 50 kbp rows, the configs[4]
+    sample): the same step as the headline -- sequences resident in HBM -> records + CIGAR ops in HBM through
+    wfahip_align_batch_device --, a few steps each, with the dominant kernel's share of the HBM roofline computed the same way
+    (algorithmic bytes from an untimed census pass / its launches' duration in a step).  One failing leg does not take
+    the headline line with it: it is reported as {"error": ...}."""
+    import ctypes as C
+    import numpy as np
+    res = {}
+    for name, steps, warmup in OTHER_LEGS:
+        c = CONFIGS[name]
+        t_leg = time.perf_counter()
+        al = None
+        try:
+            n = c["pairs"]
+            blob, q_off, q_len, t_off, t_len = w.generate_pairs(c["seed"], n, c["length"], c["error"], n_threads=min(32, os.cpu_count() or 8))
+            max_len = int(max(q_len.max(), t_len.max()))
+            sum_len = int(q_len.astype(np.int64).sum() + t_len.astype(np.int64).sum())
+            ops_cap = int(sum_len * max(0.25, 3.0 * c["error"])) + 8 * n + 1024
+            if c["semi_global"] or c["length"] >= 20000:
+                ops_cap = sum_len + 2 * n + 1024
+            d = [torch.from_numpy(a).to(dev) for a in (blob, q_off.view(np.int64), q_len.view(np.int32), t_off.view(np.int64), t_len.view(np.int32))]
+            d_rec = torch.zeros((n, L.REC_WORDS), dtype=torch.int32, device=dev)
+            d_ops = torch.zeros(ops_cap, dtype=torch.int64, device=dev)
+            al = w.New(w.DefaultPenalties, w.Options(GlobalAlignment=not c["semi_global"]), device=dev_index)
+            if c["adaptive"]:
+                assert al.AdaptiveReduction(w.DefaultAdaptiveOption) is None
+            prm, lib, timing = al._params(), L.lib(), L.Timing()
+            stream = torch.cuda.current_stream(dev).cuda_stream
+
+            def step():
+                needed = C.c_uint64()
+                L.check(lib.wfahip_align_batch_device(al._ctx, C.byref(prm), d[0].data_ptr(), blob.size, d[1].data_ptr(), d[2].data_ptr(),
+                                                      d[3].data_ptr(), d[4].data_ptr(), n, max_len, d_rec.data_ptr(), d_ops.data_ptr(),
+                                                      ops_cap, C.byref(needed), stream), f"wfahip_align_batch_device ({name})")
+                lib.wfahip_last_timing(al._ctx, C.byref(timing))
+
+            for _ in range(warmup):
+                step()
+            torch.cuda.synchronize(dev)
+            main_ms = []
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+                main_ms.append(timing.main_kernel_ms)
+            torch.cuda.synchronize(dev)
+            elapsed = time.perf_counter() - t0
+            kind = int(timing.main_kernel_kind)
+            L.check(lib.wfahip_set_option(al._ctx, b"census", 1), "census")
+            step()
+            torch.cuda.synchronize(dev)
+            rec = d_rec.cpu().numpy().view(np.uint32)
+            cells = int(rec[:, L.REC_CELLS_LO].astype(np.uint64).sum()) + (int(rec[:, L.REC_CELLS_HI].astype(np.uint64).sum()) << 32)
+            n_ops = int(rec[:, L.REC_OPS_LEN].astype(np.uint64).sum())
+            alg_bytes = 4 * cells + sum_len + 64 * n + 8 * n_ops
+            mk = float(np.mean(main_ms))
+            res[name] = {"workload": f"{n} x {c['length']} bp @{c['error']:.0%}, {'semi-global' if c['semi_global'] else 'global'}, "
+                                     f"wf-adaptive {'10/50/1' if c['adaptive'] else 'off'}, seed {c['seed']}",
+                         "value": n * steps / elapsed, "unit": "pairs/s", "steps": steps, "warmup": warmup,
+                         "ms_per_step": elapsed / steps * 1e3, "kernel": KNAMES[min(kind, len(KNAMES) - 1)], "kernel_ms": mk,
+                         "roofline": {"bound": "hbm", "frac": (alg_bytes / (mk * 1e-3) / 8e12) if mk > 0 else None,
+                                      "algorithmic_bytes_per_launch": alg_bytes, "peak": 8000.0, "unit": "GB/s"},
+                         "status_ok": int((rec[:, L.REC_STATUS] == 0).sum()), "pairs": n,
+                         "retried_pairs": int(timing.n_retried_pairs), "leg_s": None}
+            del d, d_rec, d_ops
+        except Exception as e:  # noqa: BLE001 -- reported, not raised: the headline line must still be printed
+            res[name] = {"error": f"{type(e).__name__}: {e}"}
+        finally:
+            if al is not None:
+                w.RecycleAligner(al)
+            torch.cuda.empty_cache()
+        res[name]["leg_s"] = time.perf_counter() - t_leg
+    return res
 
 
 def find_profile(config, kname):

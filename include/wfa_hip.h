@@ -119,7 +119,7 @@ typedef struct {
                                   5 = wfa_blk_kernel<64>, 6 = wfa_blk_kernel<8, 8, false, 4> (short reads), 7 = wfa_team_kernel,
                                   8 = wfa_duo_kernel (8 or 16 lanes per pair), 9 = wfa_blk_kernel<32> (128 diagonals),
                                   10 = wfa_lane_kernel (a lane per pair, short reads) */
-    uint32_t reserved;         /* arena level the long-pair ladder of this call started on (0 unless a learned hint applied) */
+    uint32_t ladder_start_level; /* arena level the long-pair ladder of this call started on (0 unless a learned hint applied) */
 } wfahip_timing;
 
 typedef struct wfahip_ctx wfahip_ctx;

@@ -64,7 +64,7 @@ for first in range(0, n_total, call):
                   [hops[ops_off[i]:ops_off[i] + ops_len[i]].copy() for i in range(8)])
     tm = al.last_timing()
     print(f"[c5_full] pairs {first + n}/{n_total}: this call {time.perf_counter() - t0:.1f} s, launches {tm.n_launches}, retried {tm.n_retried_pairs}, "
-          f"arena {tm.arena_bytes / 2**30:.0f} GiB, start level {tm.reserved}; so far {(first + n) / t_align:.2f} pairs/s", file=sys.stderr, flush=True)
+          f"arena {tm.arena_bytes / 2**30:.0f} GiB, start level {tm.ladder_start_level}; so far {(first + n) / t_align:.2f} pairs/s", file=sys.stderr, flush=True)
 scores = np.concatenate(scores)
 # the oracle on the first 8 pairs (the c5s sample)
 from oracle import oracle as O

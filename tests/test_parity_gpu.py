@@ -1147,13 +1147,13 @@ def test_learned_start_level_is_only_a_hint(built):
     al = _aligner(False, (10, 50, 1))
     al.set_option("mem_limit", 3 << 30)
     assert_batch_equal(al.align_arrays(*hard), want["hard"], "hard, first call")
-    assert al.last_timing().reserved == 0  # nothing learned yet
+    assert al.last_timing().ladder_start_level == 0  # nothing learned yet
     assert_batch_equal(al.align_arrays(*hard), want["hard"], "hard, second call")
-    learned = al.last_timing().reserved
+    learned = al.last_timing().ladder_start_level
     starts = []
     for i in range(18):
         assert_batch_equal(al.align_arrays(*easy), want["easy"], f"easy call {i} after the hard one")
-        starts.append(al.last_timing().reserved)
+        starts.append(al.last_timing().ladder_start_level)
     if learned > 0:
         assert min(starts) < learned and starts[-1] < learned, (learned, starts)  # the hint decays
     assert_batch_equal(al.align_arrays(*hard), want["hard"], "hard again")

@@ -58,6 +58,79 @@ def test_two_ranks_share_one_gpu_against_oracle(built, tmp_path, total):
         assert np.array_equal(a, b), (f, np.nonzero(a != b)[0][:5])
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.timeout(600)
+def test_one_rank_rccl_gather_against_oracle(built, tmp_path):
+    """The RCCL branch of the result gather, executed: ONE rank with backend `nccl` on the GPU (tests/nccl_one_rank.py, a
+    child process) gathers the records -- and, second form, the CIGAR op arrays -- of a real 2 000-pair alignment from
+    device tensors; what rank 0 received must be the oracle's results (the pairs' ops addressed through the gathered
+    OPS_OFF fields).  The sharding model: wfa.go:73-78 (one aligner per worker, pairs independent)."""
+    import wfa_amd as w
+    from wfa_amd import _lib as L
+    from oracle import oracle as O
+    n, seed = 2000, 44
+    out = str(tmp_path / "gathered.npz")
+    env = _clean_env()
+    env["MASTER_PORT"] = str(_free_port())
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "nccl_one_rank.py"), out, str(n), str(seed)],
+                       env=env, capture_output=True, text=True, timeout=550)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    g = np.load(out)
+    data = w.generate_pairs(seed=seed, n_pairs=n, length=1000, error_rate=0.05)
+    want = O.align_batch(O.make_params(adaptive=(10, 50, 1)), *data, n_threads=8, want_ops=True)
+    assert g["rec_only"].shape == (n, L.REC_OPS_OFF_LO) and g["rec_full"].shape == (n, L.REC_WORDS)
+    assert int(g["ops_only_len"]) == 0 and int(g["census"][0]) == n and float(g["reduced"][0]) == 1.25
+    for rec in (g["rec_only"].view(np.uint32), g["rec_full"].view(np.uint32)):
+        assert (rec[:, L.REC_STATUS] == 0).all()
+        for f, col in (("score", L.REC_SCORE), ("tbegin", L.REC_TBEGIN), ("tend", L.REC_TEND), ("qbegin", L.REC_QBEGIN),
+                       ("qend", L.REC_QEND), ("align_len", L.REC_ALIGN_LEN), ("matches", L.REC_MATCHES), ("gaps", L.REC_GAPS),
+                       ("gap_regions", L.REC_GAP_REGIONS), ("ops_len", L.REC_OPS_LEN)):
+            assert np.array_equal(rec[:, col].astype(np.int64), getattr(want, f).astype(np.int64)), f
+    rec, ops = g["rec_full"].view(np.uint32), g["ops"].view(np.uint64)
+    assert ops.shape[0] == int(g["n_ops"])
+    off = rec[:, L.REC_OPS_OFF_LO].astype(np.uint64) | (rec[:, L.REC_OPS_OFF_HI].astype(np.uint64) << np.uint64(32))
+    for i in range(n):
+        assert np.array_equal(ops[int(off[i]):int(off[i]) + int(rec[i, L.REC_OPS_LEN])], want.pair_ops(i)), i
+
+
+@pytest.mark.timeout(900)
+def test_bench_force_collective_runs_the_nccl_lines(built, tmp_path):
+    """bench.py --gpus 1 --force-collective: the process group is RCCL with one rank, and every collective of the multi-GPU
+    path (barriers, the asynchronous record gather beside the next step, the max-over-ranks reduction, the rank census) runs
+    on device tensors; the gathered records equal the oracle's."""
+    import wfa_amd as w
+    from wfa_amd import _lib as L
+    from oracle import oracle as O
+    total = 20001
+    dump = str(tmp_path / "records.npy")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-collective", "--config", "c4",
+                        "--total-pairs", str(total), "--steps", "3", "--warmup", "1", "--cpu-sample", "0", "--host-entry", "0",
+                        "--latency", "0", "--dump-records", dump], env=_clean_env(), capture_output=True, text=True, timeout=850)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    c = out["config"]
+    assert out["n_gpus"] == 1 and c["backend"] == "nccl" and c["collective_forced"] is True
+    assert c["pairs_per_rank"] == [total] and c["gathered_records_complete"] is True and c["gather_ms_standalone"] > 0
+    assert c["gather_bytes_per_rank_step"] == total * L.REC_OPS_OFF_LO * 4
+    rec = np.load(dump).view(np.uint32)
+    assert rec.shape == (total, L.REC_OPS_OFF_LO)
+    data = w.generate_pairs(seed=4, n_pairs=total, length=1000, error_rate=0.05)
+    want = O.align_batch(O.make_params(adaptive=(10, 50, 1)), *data, n_threads=max(8, (os.cpu_count() or 8) // 2), want_ops=False)
+    assert (rec[:, L.REC_STATUS] == 0).all()
+    for f, col in (("score", L.REC_SCORE), ("tbegin", L.REC_TBEGIN), ("tend", L.REC_TEND), ("qbegin", L.REC_QBEGIN),
+                   ("qend", L.REC_QEND), ("align_len", L.REC_ALIGN_LEN), ("matches", L.REC_MATCHES), ("gaps", L.REC_GAPS),
+                   ("gap_regions", L.REC_GAP_REGIONS)):
+        assert np.array_equal(rec[:, col].astype(np.int64), getattr(want, f).astype(np.int64)), f
+
+
 @pytest.mark.timeout(1500)
 def test_config4_full_count_on_one_gpu(built):
     """configs[3]'s 1e7 x 1 kbp pairs, one GPU: every pair OK; CIGAR cost == score and both sequences consumed (computed on

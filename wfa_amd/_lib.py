@@ -48,7 +48,7 @@ class Timing(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("total_ms", C.c_double), ("n_launches", C.c_uint32),
                 ("n_retried_pairs", C.c_uint32), ("cells_stored", C.c_uint64), ("ops_written", C.c_uint64),
                 ("arena_bytes", C.c_uint64), ("main_kernel_ms", C.c_double), ("n_main_launches", C.c_uint32),
-                ("n_packed_pairs", C.c_uint32), ("main_kernel_kind", C.c_uint32), ("reserved", C.c_uint32)]
+                ("n_packed_pairs", C.c_uint32), ("main_kernel_kind", C.c_uint32), ("ladder_start_level", C.c_uint32)]
 
 
 class Row(C.Structure):

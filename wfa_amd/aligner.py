@@ -148,7 +148,7 @@ class Timing:
     n_main_launches: int = 0
     n_packed_pairs: int = 0
     main_kernel_kind: int = 0
-    reserved: int = 0  # arena level the long-pair ladder started on (learned hint)
+    ladder_start_level: int = 0  # arena level the long-pair ladder started on (learned hint)
 
 
 def make_blob(qs: Sequence[bytes], ts: Sequence[bytes]):
@@ -286,7 +286,7 @@ class Aligner:
         t = L.Timing()
         L.check(L.lib().wfahip_last_timing(self._ctx, C.byref(t)))
         return Timing(t.kernel_ms, t.total_ms, t.n_launches, t.n_retried_pairs, t.cells_stored, t.ops_written,
-                      t.arena_bytes, t.main_kernel_ms, t.n_main_launches, t.n_packed_pairs, t.main_kernel_kind, t.reserved)
+                      t.arena_bytes, t.main_kernel_ms, t.n_main_launches, t.n_packed_pairs, t.main_kernel_kind, t.ladder_start_level)
 
     def set_option(self, key: str, value: int) -> None:
         L.check(L.lib().wfahip_set_option(self._ctx, key.encode(), int(value)), f"set_option({key})")

@@ -1090,7 +1090,8 @@ WFA_DEV uint32_t prepack_word(const uint8_t *blob, uint64_t off, uint32_t len, u
 // (a wave per pair, PREPACK_PAIRS pairs per wave: one workgroup per pair was bound by the dispatch of a million tiny
 // workgroups -- 1.01 ms for 2.5 GB of traffic)
 constexpr int PREPACK_PAIRS = 4;
-WFA_KERNEL_LINKAGE __global__ __launch_bounds__(256) void wfa_prepack_kernel(const KParams P, uint32_t *out, uint32_t SW, uint32_t PW) {
+#ifndef WFA_NO_AUX_KERNELS
+__global__ __launch_bounds__(256) void wfa_prepack_kernel(const KParams P, uint32_t *out, uint32_t SW, uint32_t PW) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv   = blockIdx.x * 4u + (threadIdx.x >> 6);
     // short reads (a slot of at most 32 words): two pairs side by side, 32 lanes each
@@ -1141,5 +1142,7 @@ WFA_KERNEL_LINKAGE __global__ __launch_bounds__(256) void wfa_prepack_kernel(con
         if (have && v0 == 0u) slot[0] = nq, slot[1] = mt, slot[2] = status, slot[3] = 0u;
     }
 }
+
+#endif  // WFA_NO_AUX_KERNELS
 
 }  // namespace wfa

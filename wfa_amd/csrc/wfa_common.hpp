@@ -9,10 +9,7 @@
 #include <stdint.h>
 
 // Kernels that are not templates are defined in headers that more than one translation unit includes (wfa_host.hip and
-// wfa_duo.hip): the unit that does not launch them makes them internal (wfa_duo.hip defines this as `static`).
-#ifndef WFA_KERNEL_LINKAGE
-#define WFA_KERNEL_LINKAGE
-#endif
+// wfa_duo.hip): the unit that does not launch them defines WFA_NO_AUX_KERNELS and gets the device functions only.
 
 namespace wfa {
 

@@ -1,5 +1,7 @@
 // wfa_duo.hip -- translation unit of wfa_duo_kernel: built with LLVM's atomic optimizer off (wfa_duo_cfg.hpp, Makefile).
-#define WFA_KERNEL_LINKAGE static
+// (the non-template kernels of the shared headers -- wfa_packed_kernel, wfa_backtrace_kernel, wfa_prepack_kernel -- are launched from
+// wfa_host.hip only: this unit takes the device functions and leaves those kernels out)
+#define WFA_NO_AUX_KERNELS 1
 #include "wfa_duo.hpp"
 
 namespace wfa {

@@ -256,7 +256,9 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) void wfa_duo_kernel(const KParam
             else if (narrowable) act = 3;
             const int Wn  = act == 2 ? 64 : (act == 3 ? 32 : Wc);
             const int kbn = (((ulo + uhi + 1 - Wn) >> 1) + 2) & ~3;  // the band in the middle of the new window, base a multiple of 4
-            if (act != 0 && act != 4 && !(ulo - kbn >= 1 && uhi - kbn <= Wn - 2)) act = (Wn == 32) ? 2 : 4;  // (cannot happen below the thresholds)
+            // (cannot happen below the thresholds; if it ever did, the pair is handed on -- kbn was computed for Wn, so no other
+            // move may be made of this request)
+            if (act != 0 && act != 4 && !(ulo - kbn >= 1 && uhi - kbn <= Wn - 2)) act = 4;
             // ------------------------------------------------------------ widening: who takes whose half
             const int  o_act = other_half(act), o_kb = other_half(kb), o_kbn = other_half(kbn);
             const bool o_wide = other_half(wide ? 1 : 0) != 0;

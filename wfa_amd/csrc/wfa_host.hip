@@ -156,6 +156,7 @@ struct wfahip_ctx {
     int64_t       opt_duo_short_min_pairs  = 50000;
     bool          ctrl_clean               = false;  // the control words are zero: the last call zeroed them on ctrl_clean_stream as it left
     hipStream_t   ctrl_clean_stream        = nullptr;
+    hipEvent_t    ctrl_clean_ev            = nullptr;  // ... recorded behind that memset: a call on ANOTHER stream waits for it before it touches them
     bool          redo_was_empty           = false;  // the last pass that asked for its redo list found it empty
     int64_t       opt_compact_call_bases   = 50000000;  // first passes over at most this many bases (pairs x longest read) keep their backtrace
                                                         // kernel on the call's stream (no event wait on the second one): 0 = never
@@ -372,7 +373,7 @@ static int create_impl(int device_id, wfahip_ctx **out) {
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
         hipEventCreate(&ctx->evA) != hipSuccess || hipEventCreate(&ctx->evB) != hipSuccess ||
         hipEventCreate(&ctx->evC) != hipSuccess || hipEventCreate(&ctx->evBtA) != hipSuccess ||
-        hipEventCreate(&ctx->evBtB) != hipSuccess ||
+        hipEventCreate(&ctx->evBtB) != hipSuccess || hipEventCreateWithFlags(&ctx->ctrl_clean_ev, hipEventDisableTiming) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void **>(&ctx->hpin), HPIN_WORDS * 4, hipHostMallocDefault) != hipSuccess) {
         wfahip_destroy(ctx);  // (releases whichever streams / events were created)
         return WFAHIP_ERR_HIP;
@@ -406,6 +407,7 @@ extern "C" void wfahip_destroy(wfahip_ctx *ctx) {
     if (ctx->evC) (void)hipEventDestroy(ctx->evC);
     if (ctx->evBtA) (void)hipEventDestroy(ctx->evBtA);
     if (ctx->evBtB) (void)hipEventDestroy(ctx->evBtB);
+    if (ctx->ctrl_clean_ev) (void)hipEventDestroy(ctx->ctrl_clean_ev);
     for (hipEvent_t e : ctx->evpool) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
@@ -637,6 +639,10 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
 
     // (a call that ended well leaves the control words zeroed for the next one -- a memset the GPU runs while the host is
     // on its way back to the caller, instead of one the first kernel of the next call waits for)
+    // (the next call on the SAME stream finds them zero.  On another stream -- the host entry on the context's stream, then the
+    // device entry on a caller's -- that memset may still be pending: the new stream waits for it first, or it could land in
+    // the middle of this call and reset the pair queue and the ops cursor under the kernels)
+    if (ctx->ctrl_clean && ctx->ctrl_clean_stream != st) HIP_TRY(hipStreamWaitEvent(st, ctx->ctrl_clean_ev, 0));
     if (!(ctx->ctrl_clean && ctx->ctrl_clean_stream == st)) HIP_TRY(hipMemsetAsync(d_ctrl, 0, CTRL_WORDS * 4, st));
     ctx->ctrl_clean = false;
     if (ops_cursor0) {
@@ -773,9 +779,14 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             // (retry passes: how many pairs are handed on varies a little from call to call -- which pairs share a wave
             // is a matter of timing -- so their buffers get a quarter of headroom instead of being re-allocated, tens
             // of milliseconds for a few GB, whenever a call needs a few pairs more than the one before)
-            const uint64_t chunk_alloc = list ? chunk + chunk / 4 + 64 : chunk;
+            // (the headroom stays inside the budget the chunk was sized by, and an allocation that fails with it is tried again
+            // at the exact size: a budget-bound retry pass must not fail where the plain size would have fitted)
+            const uint64_t chunk_alloc = list ? std::max<uint64_t>(chunk, std::min<uint64_t>(chunk + chunk / 4 + 64, budget / (words * 4ull))) : chunk;
             int rc2 = WFAHIP_OK;
-            if (arena_buf.bytes < (size_t)(words * 4ull * chunk * n_buf)) rc2 = ensure(ctx, arena_buf, (size_t)(words * 4ull * chunk_alloc * n_buf));
+            if (arena_buf.bytes < (size_t)(words * 4ull * chunk * n_buf)) {
+                rc2 = ensure(ctx, arena_buf, (size_t)(words * 4ull * chunk_alloc * n_buf));
+                if (rc2 == WFAHIP_ERR_OOM && chunk_alloc > chunk) rc2 = ensure(ctx, arena_buf, (size_t)(words * 4ull * chunk * n_buf));
+            }
             if (rc2) return rc2;
             if (meta_buf.bytes < chunk * 16 * n_buf && (rc2 = ensure(ctx, meta_buf, chunk_alloc * 16 * n_buf))) return rc2;
             detach_bt = detach_bt && n_chunks == 1 && ctx->opt_tail_overlap != 0 &&
@@ -1175,7 +1186,7 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             if (j.level > 0 && (++ctx->learn_calls & 15u) == 0u) j.level -= 1;  // (a probe that fails costs a launch: 72 ms of a 94 ms call on 500 x 50 kbp)
             j.hint = j.level > 0;
         }
-        ctx->timing.reserved = (uint32_t)j.level;  // (start level of the long-pair ladder: tests of the learned hint read it)
+        ctx->timing.ladder_start_level = (uint32_t)j.level;  // (start level of the long-pair ladder: tests of the learned hint read it)
         jobs.push_back(std::move(j));
     }
 
@@ -1380,7 +1391,10 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
     const uint64_t cursor   = (uint64_t)hctrl[2] | ((uint64_t)hctrl[3] << 32);
     ctx->timing.ops_written = cursor;
     if (ops_needed) *ops_needed = cursor;
-    if (!debug_single && hipMemsetAsync(d_ctrl, 0, CTRL_WORDS * 4, st) == hipSuccess) ctx->ctrl_clean = true, ctx->ctrl_clean_stream = st;
+    if (!debug_single && hipMemsetAsync(d_ctrl, 0, CTRL_WORDS * 4, st) == hipSuccess && hipEventRecord(ctx->ctrl_clean_ev, st) == hipSuccess)
+        ctx->ctrl_clean = true, ctx->ctrl_clean_stream = st;
+    else if (!debug_single)
+        (void)hipStreamSynchronize(st);  // (a memset without its event must not stay pending)
     if (cursor > ops_cap) {
         if (std::getenv("WFAHIP_DEBUG_TIMING")) std::fprintf(stderr, "[wfahip] CIGAR op buffer too small: %llu needed, %llu there\n", (unsigned long long)cursor, (unsigned long long)ops_cap);
         return WFAHIP_ERR_OOM;

@@ -70,7 +70,8 @@ WFA_DEV uint32_t sub_sum(uint32_t v) {
     return v;
 }
 
-WFA_KERNEL_LINKAGE __global__ __launch_bounds__(64, 7) void wfa_packed_kernel(const KParams P) {
+#ifndef WFA_NO_AUX_KERNELS  // (wfa_duo.hip includes this header for the device functions only)
+__global__ __launch_bounds__(64, 7) void wfa_packed_kernel(const KParams P) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int lane = threadIdx.x, j = lane & 31, sub = lane >> 5;
     const int lead = sub << 5;
@@ -292,6 +293,8 @@ WFA_KERNEL_LINKAGE __global__ __launch_bounds__(64, 7) void wfa_packed_kernel(co
 #endif
 }
 
+#endif  // WFA_NO_AUX_KERNELS
+
 // Backtrace (wfa.go:703-983) + process() statistics + result record of ONE finished pair of the sub-wave pipeline
 // (global alignment only): idx = the pair's index in the chunk (= its arena slot), h_end = extended offset of the
 // end cell M[s_final][m - n].
@@ -337,7 +340,8 @@ WFA_DEV void backtrace_one(const KParams &P, uint32_t idx, uint32_t s_final, uin
 // The ops regions of a workgroup's pairs are carved with ONE atomic: every wave adding its own total to the one cursor
 // serialized 1 563 waves of 1e5 short pairs at the L2 -- 20 of the kernel's 41 us went to waiting for that atomic's return.
 constexpr int BT_THREADS = 512;
-WFA_KERNEL_LINKAGE __global__ __launch_bounds__(BT_THREADS) void wfa_backtrace_kernel(const KParams P) {
+#ifndef WFA_NO_AUX_KERNELS
+__global__ __launch_bounds__(BT_THREADS) void wfa_backtrace_kernel(const KParams P) {
     __shared__ uint32_t           wsum[BT_THREADS / 64];
     __shared__ unsigned long long wbase;
     const uint32_t idx  = blockIdx.x * blockDim.x + threadIdx.x;
@@ -379,6 +383,8 @@ WFA_KERNEL_LINKAGE __global__ __launch_bounds__(BT_THREADS) void wfa_backtrace_k
     for (uint32_t w = 0; w < wv; w++) off += wsum[w];
     if (walk) backtrace_one(P, slot, s_final, h_end, cells, false, off);
 }
+
+#endif  // WFA_NO_AUX_KERNELS
 
 // Streaming backtrace (called by waves of wfa_blk_kernel<.., STREAM = true>): the done_q entries are taken in
 // completion order while the forward waves of the same launch are still running.  The walk is a chain of dependent
