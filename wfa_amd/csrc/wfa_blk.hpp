@@ -298,10 +298,23 @@ WFA_DEV void blk_push_not_ok(const KParams &P, uint32_t pidx) {
 // CENSUS: count the wavefront words a pair stores (REC_CELLS: the roofline accounting of bench.py and the tests' cross-
 // check between kernels).  It is instrumentation, not part of the alignment, and costs 4 % of the forward pass
 // (23.3 vs 24.3 ms per 1e6 x 1 kbp pairs): off unless the context's option "census" asks for it.
-template <int G, int BATCH, bool STREAM = false, int PPT = 0, bool CENSUS = true>
-__global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16 && BATCH == 1 && !CENSUS && (!STREAM || WFA_BLK_STREAM_WAVES5) ? WFA_BLK_WAVES : 4))) void wfa_blk_kernel(const KParams P) {
+//
+// LONG (round 4): reads of any length.  The plain instances keep BOTH whole sequences of a pair in LDS, which stops them at
+// ~10 kbp (and at two waves per SIMD well before that); here a pair keeps a WINDOW of P.lds_seq_words packed words (4 096
+// bases at 256 words) of each sequence around the band -- the band only moves forward, and under wf-adaptive the cells of a
+// row lie within ~120 bases of each other -- and refills it from the pair's pre-packed slot (wfa_prepack_kernel) as the
+// band advances.  Window word i of the query holds packed word qb + i, of the target word tb + i, the two bases tied
+// together by the window's diagonal centre (qb16 = tb16 - kc16), so that ONE test on a cell's offset h (lo <= h <= hi) says
+// whether both 16-base windows WF_EXTEND reads for it (wfa.go:408-454) are resident.  A cell outside -- or a match run
+// that reaches the window's end -- takes the slow form of WF_EXTEND (long_extend): reposition the window at the lowest
+// pending cell (all G lanes of the pair load the two windows in one round of 16-byte loads), extend what is inside, repeat
+// until no cell is pending.  It always makes progress, so nothing is ever handed on for its length; results are those of
+// the plain instances because WF_EXTEND computes the same full LCP either way.
+template <int G, int BATCH, bool STREAM = false, int PPT = 0, bool CENSUS = true, bool LONG = false>
+__global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16 && BATCH == 1 && !CENSUS && !LONG && (!STREAM || WFA_BLK_STREAM_WAVES5) ? WFA_BLK_WAVES : 4))) void wfa_blk_kernel(const KParams P) {
     static_assert(!STREAM || (G == 16 && BATCH == 1), "streamed backtrace: 16 lanes per pair, unbatched refill");
     static_assert(PPT == 0 || (G == 8 && PPT == 4), "diagonals per lane can only be overridden for the 8-lane narrow instance");
+    static_assert(!LONG || (BATCH == 1 && !STREAM && PPT == 0 && G >= 16), "sliding sequence windows: unbatched, pre-packed input");
     constexpr int PP  = PPT ? PPT : (G >= 32 ? 4 : 64 / G);  // diagonals per lane
     constexpr int NG  = 64 / G;                // pairs per wave
 #ifdef WFA_BLK_W
@@ -349,6 +362,14 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
     bool       pend = false;  // STREAM: the pair just finished still has to be pushed (its score index, end offset and
                               // cell count wait in si, Ak and cells, which are dead until the next pair starts)
     uint32_t  *rowp = nullptr;  // row of the current score in the pair's arena slot (64 words per score)
+    // LONG: the pair's sequence windows.  lqo / lto: LDS index of packed word 0 of the query / target (window base minus the
+    // window's first word: lds[lqo + w] is packed word w while it is resident); [lo16, hi16]: offsets h whose two 16-base
+    // windows are resident on every diagonal of the diagonal window; kc16: the diagonal the two bases are tied by
+    int        lqo = 0, lto = 0, lo16 = 1, hi16 = 0, kc16 = 0;
+    const int  CW  = (int)P.lds_seq_words;                       // LONG: words per sequence window (a multiple of 4 G)
+    const int  SWp = LONG ? (int)((P.prepack_words - 4u) / 2u) : 0;  // LONG: words per sequence in a pre-packed slot (a multiple of 4)
+    constexpr int LDM = (G * (PPT ? PPT : (G >= 32 ? 4 : 64 / G))) / 2 + 128;  // LONG: half the diagonal window + the drift of its centre a window tolerates
+    constexpr int LMARGIN = 128;                                 // LONG: bases kept below the cell a window is positioned at
 
     uint32_t M[4][PP], I[PP], D[PP];  // offsets, 0 = absent; M[i & 3] = row of step i
     int      rlo[4], rhi[4];          // band of each kept M row (absolute k); empty = (BIG, -BIG)
@@ -378,6 +399,54 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
         }
 #pragma unroll
         for (int p = 0; p < PP; p++) I[p] = D[p] = 0u;
+    };
+
+    // 16-base windows of the query at base v / the target at base h (LONG: through the sliding windows)
+    const auto winq = [&](int v) -> uint32_t {
+        if constexpr (LONG) {
+            const int w = lqo + (v >> 4);
+            return __funnelshift_r(lds[w], lds[w + 1], (uint32_t)(v & 15) * 2u);
+        } else {
+            return SeqView<0>::win16(lq, v);
+        }
+    };
+    const auto wint = [&](int h) -> uint32_t {
+        if constexpr (LONG) {
+            const int w = lto + (h >> 4);
+            return __funnelshift_r(lds[w], lds[w + 1], (uint32_t)(h & 15) * 2u);
+        } else {
+            return SeqView<0>::win16(lt, h);
+        }
+    };
+    // LONG: the groups with `mine` set load their two sequence windows so that offset hm lies LMARGIN bases above the lower
+    // end of what is resident (hm, kb, pidx: the same in all lanes of a group).  Bases may be negative (the first window of a
+    // pair starts below base 0) or reach past the packed words: those words read as zero and are never compared -- a cell's
+    // room ends at the sequence ends.
+    const auto reposition = [&](bool mine, int hm) __attribute__((always_inline)) {
+        if constexpr (LONG) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            if (mine) {
+                kc16            = (kb + W / 2) & ~63;
+                const int tb16  = (hm - LDM - LMARGIN) & ~63, qb16 = tb16 - kc16;
+                const int tbw   = tb16 >> 4, qbw = qb16 >> 4;  // multiples of 4 words
+                const uint32_t *const slot = P.prepack + (uint64_t)pidx * P.prepack_words + 4u;
+                uint32_t *const dq = lds + grp * GW, *const dt = dq + CW;
+                for (int i = 4 * j; i < CW; i += 4 * G) {
+                    const int  wq = qbw + i, wt = tbw + i;
+                    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+                    const uint4 a = (wq >= 0 && wq < SWp) ? *reinterpret_cast<const uint4 *>(slot + wq) : z;
+                    const uint4 b = (wt >= 0 && wt < SWp) ? *reinterpret_cast<const uint4 *>(slot + SWp + wt) : z;
+                    *reinterpret_cast<uint4 *>(dq + i) = a;
+                    *reinterpret_cast<uint4 *>(dt + i) = b;
+                }
+                lqo  = (int)(grp * GW) - qbw;
+                lto  = (int)(grp * GW) + CW - tbw;
+                lo16 = tb16 + LDM;
+                hi16 = tb16 + 16 * CW - 32 - LDM;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
     };
 
 #ifdef WFA_STAMPS
@@ -587,7 +656,9 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
                 }
                 const bool stage = got && status == ST_PENDING;
                 bool       bad   = false;
-                if (P.prepack) {
+                if constexpr (LONG) {
+                    // (nothing to copy here: the windows are loaded below, once the pair's window base is known)
+                } else if (P.prepack) {
                     if (stage) {  // every refilling group copies its own 2 SW words, all groups side by side
                         uint32_t *const dst = const_cast<uint32_t *>(lq);
                         for (uint32_t w = (uint32_t)j; w < 2u * SW; w += (uint32_t)G) dst[w] = slot[4u + w];
@@ -624,10 +695,14 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
                     si = 0, cells = 0, slow = false;
                     kb   = -(W / 2) + PP * imax2(-(3 * W / 8) / PP, imin2((3 * W / 8) / PP, Ak / (2 * PP)));  // k = 0 (the seed) inside, biased towards Ak
                     rowp = P.arena + (uint64_t)pidx * cap;
-                    first_eq = ((lq[0] ^ lt[0]) & 3u) == 0u;  // q[0] == t[0] (wfa.go:155)
+                    if constexpr (LONG) first_eq = ((slot[4] ^ slot[4 + SWp]) & 3u) == 0u;
+                    else first_eq = ((lq[0] ^ lt[0]) & 3u) == 0u;  // q[0] == t[0] (wfa.go:155)
                     set_window();
                     clear_rings();
                     st = 1;
+                }
+                if constexpr (LONG) {
+                    if (__ballot(stage && !bad) != 0ull) reposition(stage && !bad, 1);  // the seed cell's offset is 1
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -741,13 +816,27 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
 
             // ------------------------------------------------------------ WF_EXTEND (wfa.go:381-458), first 16 bases
             uint32_t cmask = 0u;  // positions whose first window matched completely and may go on
+            uint32_t lpend = 0u;  // LONG: positions whose extension waits for their sequence window
+            bool     lslow = false;
+            if constexpr (LONG) {
+                // every cell that has room must find both its 16-base windows resident; one outside (the band has moved on,
+                // or back) sends the wave through long_extend below with all its cells pending
+                bool oob = false;
+#pragma unroll
+                for (int p = 0; p < PP; p++) {
+                    const int h = (int)nM[p];
+                    oob |= h != 0 && lim[p] - h > 0 && (h < lo16 || h > hi16);
+                }
+                lslow = __ballot(run && oob) != 0ull;
+            }
+            if (!lslow) {
 #pragma unroll
             for (int p = 0; p < PP; p++) {
                 const int      h    = (int)nM[p];
                 const int      rem  = lim[p] - h;  // bases left on this diagonal; <= 0: at / past an end (wfa.go:404)
                 const uint32_t room = h ? (uint32_t)imax2(rem, 0) : 0u;  // (nothing for an absent cell)
                 const int      v    = h - (k0 + p);  // absent cells read a harmless word (LDS reads cannot fault)
-                const uint32_t xr   = SeqView<0>::win16(lq, v) ^ SeqView<0>::win16(lt, h);
+                const uint32_t xr   = winq(v) ^ wint(h);
                 // (v_ffbl_b32 of 0 is 0xFFFFFFFF: a window that matched completely runs to the end of the room)
                 const uint32_t run  = umin2(ffbl_raw(xr) >> 1, room);
                 nM[p] += umin2(run, 16u);
@@ -763,18 +852,62 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
                     if (psel == p) h = (int)nM[p], lm = lim[p];
                 const int kd = k0 + psel;
                 bool      go = cmask != 0u;
+                if constexpr (LONG) {  // (a run that has reached the end of the window waits for the next one)
+                    if (go && h > hi16) lpend |= 1u << psel, go = false;
+                }
                 do {
                     WFA_EVT(6, 1);
                     const int      rem = lm - h;
-                    const uint32_t xr  = SeqView<0>::win16(lq, h - kd) ^ SeqView<0>::win16(lt, h);
+                    const uint32_t xr  = winq(h - kd) ^ wint(h);
                     const uint32_t cnt = umin2(ffbl_raw(xr) >> 1, (uint32_t)imin2(imax2(rem, 0), 16));
                     h += go ? (int)cnt : 0;
                     go = go && xr == 0u && rem > 16;
+                    if constexpr (LONG) {
+                        if (go && h > hi16) lpend |= 1u << psel, go = false;
+                    }
                 } while (__ballot(go) != 0ull);
 #pragma unroll
                 for (int p = 0; p < PP; p++)
                     if (psel == p) nM[p] = (uint32_t)h;
                 cmask &= cmask - 1u;
+            }
+            }
+            if constexpr (LONG) {
+                if (lslow) {  // nothing has been extended yet: every cell with room is pending
+#pragma unroll
+                    for (int p = 0; p < PP; p++)
+                        if (run && nM[p] != 0u && lim[p] - (int)nM[p] > 0) lpend |= 1u << p;
+                }
+                // long_extend: until no cell is pending -- the pairs whose lowest pending cell is not inside their window
+                // reposition it there; every pending cell inside its window is extended, 16 bases a round, until a
+                // mismatch, the end of its room (done) or the end of the window (still pending).  The lowest pending
+                // cell of a pair always moves on or finishes, so the loop ends; which pairs share the wave changes
+                // nothing but the number of rounds.
+                while (__ballot(lpend != 0u) != 0ull) {
+                    int hm = BK_BIG;
+#pragma unroll
+                    for (int p = 0; p < PP; p++) hm = ((lpend >> p) & 1u) ? imin2(hm, (int)nM[p]) : hm;
+                    hm = -Red::max1(-hm);
+                    const bool move = hm != BK_BIG && (hm < lo16 || hm > hi16);
+                    if (__ballot(move) != 0ull) reposition(move, hm);
+#pragma unroll
+                    for (int p = 0; p < PP; p++) {
+                        int        h  = (int)nM[p];
+                        const int  kd = k0 + p, lm = lim[p];
+                        bool       go = ((lpend >> p) & 1u) != 0u && h >= lo16 && h <= hi16, fin = false;
+                        while (__ballot(go) != 0ull) {
+                            const int      rem  = lm - h;
+                            const uint32_t xr   = winq(h - kd) ^ wint(h);
+                            const uint32_t cnt  = umin2(ffbl_raw(xr) >> 1, (uint32_t)imin2(imax2(rem, 0), 16));
+                            const bool     done = xr != 0u || rem <= 16;
+                            h += go ? (int)cnt : 0;
+                            fin = fin || (go && done);
+                            go  = go && !done && h <= hi16;
+                        }
+                        nM[p] = (uint32_t)h;
+                        if (fin) lpend &= ~(1u << p);
+                    }
+                }
             }
             WFA_STAMP(2); WFA_MARK(2);  // extend
 
@@ -978,6 +1111,12 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
                     }
                     kb += dn ? -Ops::SHIFT_D : (up ? Ops::SHIFT_D : 0);
                     set_window();
+                    if constexpr (LONG) {
+                        // the sequence windows are tied together at diagonal kc16: once the diagonal window has drifted further
+                        // from it than [lo16, hi16] allows for, they count as empty and the next WF_EXTEND positions them anew
+                        const int dk = kb + W / 2 - kc16;
+                        if (dk < -128 || dk > 128) lo16 = 1, hi16 = 0;
+                    }
                     if (__ballot(wide) != 0ull) {  // the band does not fit the window: hand the pair on
                         if (wide && j == 0) {
                             P.pair_meta[pidx] = make_uint4(ST_REDO_BAND, 0u, 0u, 0u);

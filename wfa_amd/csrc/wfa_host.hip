@@ -165,6 +165,10 @@ struct wfahip_ctx {
     int64_t       opt_lane_pack            = 1;   // 1: the lanes of wfa_lane_kernel pack the bytes of their pairs themselves, 0: wfa_prepack_kernel before it
     int64_t       opt_lane_min_pairs       = 32768;  // (below ~30 000 pairs a generation of 64 pairs per wave leaves most of the GPU idle for as
                                                      // long as its slowest pair runs: 16 000 x 150 bases 0.192 ms against 0.157 on the 8-lane kernel)
+    int64_t       opt_long                 = 1;   // 1: global pairs longer than opt_long_min_len (penalties shaped 2:4:1) take the sub-wave kernels with sliding
+                                                  // sequence windows (wfa_blk_kernel<.., LONG>): four pairs per wave at any read length
+    int64_t       opt_long_min_len         = 4000;   // (below it both whole sequences of a pair fit the plain instances' LDS at full occupancy)
+    int64_t       opt_long_window_words    = 256; // packed words per sequence window: 4 096 bases
     int64_t       opt_census               = 0;   // 1: the sub-wave forward kernels count the wavefront words they store (REC_CELLS, timing.cells_stored)
     int64_t       opt_learn                = 1;   // 1: long pairs start on the arena level the previous call of the same kind ended on
     uint64_t      learn_key                = 0;   // workload class of the last call that used the team kernel
@@ -475,6 +479,12 @@ static int set_option_impl(wfahip_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_narrow_long = value;
     else if (k == "census")
         ctx->opt_census = value;
+    else if (k == "long")
+        ctx->opt_long = value;
+    else if (k == "long_min_len")
+        ctx->opt_long_min_len = value;
+    else if (k == "long_window_words")
+        ctx->opt_long_window_words = (value >= 64 && value <= 4096 && value % 256 == 0) ? value : 256;
     else if (k == "duo")
         ctx->opt_duo = value;
     else if (k == "duo_min_pairs")
@@ -669,7 +679,9 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
         // the kernels hand the longer ones on themselves (ST_REDO_LDS) and the generic / team kernels take them.
         constexpr uint32_t SUB_LEN_LIMIT = 10200;
         uint32_t           sub_len       = max_len;
-        if (max_len > SUB_LEN_LIMIT && n_pairs >= 256) {
+        // long reads: the blocked kernels with sliding sequence windows (kinds 11 / 12 / 13 = 64 / 128 / 256 diagonals)
+        const bool can_long = ctx->opt_long != 0 && ctx->opt_blk == 16 && dx == 2 && doe == 4 && de == 1 && (int64_t)max_len > ctx->opt_long_min_len;
+        if (max_len > SUB_LEN_LIMIT && n_pairs >= 256 && !can_long) {
             std::vector<uint32_t> ql(n_pairs), tl(n_pairs);
             HIP_TRY(hipMemcpyAsync(ql.data(), d_q_len, n_pairs * 4, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipMemcpyAsync(tl.data(), d_t_len, n_pairs * 4, hipMemcpyDeviceToHost, st));
@@ -694,8 +706,8 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
         const size_t   lds_d     = (size_t)seq_words * 2 * 4 * (ctx->opt_blk == 8 ? 8 : 4) + 16;  // blocked kernel
         const bool     can_b     = lds_b <= 20 * 1024;
         const bool     can_c     = ctx->opt_reg && dx == 2 && doe == 4 && de == 1 && lds_c <= 20 * 1024;
-        const bool     can_d     = ctx->opt_blk && dx == 2 && doe == 4 && de == 1 && sub_len < 32768 &&
-                               lds_d <= (ctx->opt_blk == 8 ? 40 : 20) * 1024;
+        const bool     can_d     = can_long || (ctx->opt_blk && dx == 2 && doe == 4 && de == 1 && sub_len < 32768 &&
+                                              lds_d <= (ctx->opt_blk == 8 ? 40 : 20) * 1024);
         uint64_t       words_dir = std::max<uint64_t>(1024, 8ull * sub_len);  // compact rows: 1 word per diagonal
         if (ctx->opt_packed_arena_bytes > 0) words_dir = std::max<uint64_t>(1024, ctx->opt_packed_arena_bytes / 4);
         words_dir = (words_dir + 7) & ~7ull;
@@ -740,26 +752,34 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             if (kind == 8 && (duo_pw > 256u || blk_batch)) return WFAHIP_ERR_INTERNAL;
             if (kind == 10 && (seq_words > (uint32_t)LN_SEQ_WORDS || list)) return WFAHIP_ERR_INTERNAL;
             const uint32_t lane_sw      = (seq_words + 1u) & ~1u;  // kind 10 (wfa_lane_kernel): words per sequence in its slots and in LDS
-            const size_t   lds_bytes    = kind == 10 ? (size_t)64 * lane_stride_words(lane_sw) * 4
+            // kinds 11 / 12 / 13: kinds 3 / 9 / 5 with sliding sequence windows (long reads): pre-packed slots of long_sw words per
+            // sequence in HBM, long_cw words of each in LDS
+            const bool     is_long      = kind >= 11 && kind <= 13;
+            const uint32_t long_sw      = (seq_words + 3u) & ~3u, long_cw = (uint32_t)ctx->opt_long_window_words;
+            if (is_long && !can_long) return WFAHIP_ERR_INTERNAL;
+            const int      bkind        = kind == 11 ? 3 : kind == 12 ? 9 : kind == 13 ? 5 : kind;  // (arena format and pairs per wave)
+            const size_t   lds_bytes    = is_long ? (size_t)(kind == 11 ? 4 : kind == 12 ? 2 : 1) * 2 * long_cw * 4 + 16
+                                          : kind == 10 ? (size_t)64 * lane_stride_words(lane_sw) * 4
                                           : kind == 8 ? (size_t)duo_lds_words(duo_pw) * 4
                                           : kind == 9 ? (size_t)seq_words * 2 * 4 * 2 + 16
                                           : blk_batch ? (size_t)(kind == 6 ? 8 : 4) * BLK_BATCH * (2 * seq_words + 8) * 4 + 16
                                           : kind == 6 ? (size_t)seq_words * 2 * 4 * 8 + 16
                                           : kind == 5 ? (size_t)seq_words * 2 * 4 + 16
                                                       : (kind >= 3 ? lds_d : (kind == 2 ? lds_c : lds_b));
-            const uint32_t pairs_wave   = kind == 10 ? 64 : kind == 5 ? 1 : kind == 9 ? 2 : (kind == 4 || kind == 6 || kind == 8 ? 8 : (kind >= 2 ? 4 : 2));
+            const uint32_t pairs_wave   = kind == 10 ? 64 : bkind == 5 ? 1 : bkind == 9 ? 2 : (kind == 4 || kind == 6 || kind == 8 ? 8 : (kind >= 2 ? 4 : 2));
             // blocked kernels: fixed-pitch arena, no directory.  64-diagonal window: 16 words per base = 250 scores at
             // 1 kbp; 256-diagonal window (kind 5, the retry rung): 128 words per base = 500 scores at 1 kbp
-            const uint64_t words        = kind == 5   ? std::max<uint64_t>((words_dir * 16 * arena_mult + 511) & ~511ull, 8192)
-                                          : kind == 9 ? std::max<uint64_t>((words_dir * 4 * arena_mult + 511) & ~511ull, 4096)
+            const uint64_t words        = bkind == 5   ? std::max<uint64_t>((words_dir * 16 * arena_mult + 511) & ~511ull, 8192)
+                                          : bkind == 9 ? std::max<uint64_t>((words_dir * 4 * arena_mult + 511) & ~511ull, 4096)
                                           : kind == 8 ? std::max<uint64_t>((words_dir * arena_mult + 511) & ~511ull, 1024)  // 16-bit words
                                           : kind == 10 ? std::max<uint64_t>((words_dir * arena_mult + 511) & ~511ull, 1024)  // rows of 32 x 16 bit
                                           : kind >= 3 ? std::max<uint64_t>((words_dir * 2 * arena_mult + 511) & ~511ull, 2048)
                                                       : words_dir;
-            P.arena_words = words, P.compact_fmt = kind == 10 ? 8u : kind == 8 ? 7u : kind == 6 ? 5u : kind == 5 ? 4u : kind == 9 ? 6u : (kind >= 3 ? (WFA_BLK_TILED ? 3u : 1u) : 0u);
+            P.arena_words = words, P.compact_fmt = kind == 10 ? 8u : kind == 8 ? 7u : kind == 6 ? 5u : bkind == 5 ? 4u : bkind == 9 ? 6u : (kind >= 3 ? (WFA_BLK_TILED ? 3u : 1u) : 0u);
             const uint32_t waves_lds    = (uint32_t)std::min<size_t>(32, LDS_MAX_BYTES / lds_bytes);
             const bool     overlap      = ctx->opt_overlap != 0;
-            uint32_t       waves_per_cu = kind == 10 ? std::min<uint32_t>(waves_lds, 8)
+            uint32_t       waves_per_cu = is_long ? std::min<uint32_t>(waves_lds, 16)
+                                          : kind == 10 ? std::min<uint32_t>(waves_lds, 8)
                                           : kind == 8 ? std::min<uint32_t>(waves_lds, 4 * WFA_DUO_WAVES)
                                           : kind == 4 ? std::min<uint32_t>(waves_lds, 12)
                                           : kind >= 2 ? std::min<uint32_t>(waves_lds, 20)
@@ -841,9 +861,9 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                 }
                 // the chunk's sequences 2-bit packed up front (unbatched 16-lane first pass over a range of pairs)
                 P.prepack = nullptr, P.prepack_words = 0;
-                P.lds_seq_words = kind == 10 ? lane_sw : kind == 8 ? duo_sw : seq_words;
+                P.lds_seq_words = is_long ? long_sw : kind == 10 ? lane_sw : kind == 8 ? duo_sw : seq_words;
                 if (kind == 10) P.sub_lds_words = lane_stride_words(lane_sw);
-                if ((kind == 3 && !blk_batch && !list && ctx->opt_prepack != 0) || kind == 8 || (kind == 10 && ctx->opt_lane_pack == 0)) {
+                if ((kind == 3 && !blk_batch && !list && ctx->opt_prepack != 0) || kind == 8 || (kind == 10 && ctx->opt_lane_pack == 0) || is_long) {
                     const uint32_t pw = 4u + 2u * P.lds_seq_words;
                     if ((rc2 = ensure(ctx, ctx->prepack, (size_t)chunk * pw * 4))) return rc2;
                     hipLaunchKernelGGL(wfa_prepack_kernel, dim3((uint32_t)((cn + 4 * PREPACK_PAIRS - 1) / (4 * PREPACK_PAIRS))), dim3(256), 0, st, P,
@@ -851,6 +871,7 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                     HIP_TRY(hipGetLastError());
                     P.prepack = static_cast<const uint32_t *>(ctx->prepack.p), P.prepack_words = pw;
                 }
+                if (is_long) P.lds_seq_words = long_cw;  // (the forward kernel's sequence windows; the slots hold long_sw words per sequence)
                 if (n_buf == 2 && c >= 2) HIP_TRY(hipStreamWaitEvent(st, ctx->evpool[4 * (c - 2) + 3], 0));  // buffer free
                 if (c > 0) HIP_TRY(hipMemsetAsync(d_ctrl, 0, 4, st));  // queue_head only (chunk 0: cleared with redo_count above)
                 // (tests: the sub-wave kernels zero nothing -- no word the backtrace reads may be one they did not write)
@@ -858,6 +879,14 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                 HIP_TRY(hipEventRecord(evFa, st));
                 if (kind == 8)
                     HIP_TRY(wfa_launch_duo(P, grid, lds_bytes, st, P.census != 0));
+                else if (kind == 11 && P.census)
+                    hipLaunchKernelGGL((wfa_blk_kernel<16, 1, false, 0, true, true>), dim3(grid), dim3(64), lds_bytes, st, P);
+                else if (kind == 11)
+                    hipLaunchKernelGGL((wfa_blk_kernel<16, 1, false, 0, false, true>), dim3(grid), dim3(64), lds_bytes, st, P);
+                else if (kind == 12)
+                    hipLaunchKernelGGL((wfa_blk_kernel<32, 1, false, 0, true, true>), dim3(grid), dim3(64), lds_bytes, st, P);
+                else if (kind == 13)
+                    hipLaunchKernelGGL((wfa_blk_kernel<64, 1, false, 0, true, true>), dim3(grid), dim3(64), lds_bytes, st, P);
                 else if (kind == 10 && P.census && P.adaptive)
                     hipLaunchKernelGGL((wfa_lane_kernel<true, true>), dim3(grid), dim3(64), lds_bytes, st, P);
                 else if (kind == 10 && P.census)
@@ -946,7 +975,9 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             // short reads (at most 240 bases): a lane per pair
             const bool lane1   = can_d && ctx->opt_blk == 16 && seq_words <= (uint32_t)LN_SEQ_WORDS &&
                                  (ctx->opt_lane >= 2 || (ctx->opt_lane == 1 && (int64_t)n_pairs >= ctx->opt_lane_min_pairs));
-            const int  kind1   = (duo1 && duo_short) ? 8 : lane1 ? 10 : duo1 ? 8 : narrow1 ? 6 : (can_d ? (ctx->opt_blk == 8 ? 4 : 3) : (can_c ? 2 : 1));
+            const int  kind1   = can_long ? 11 : (duo1 && duo_short) ? 8 : lane1 ? 10 : duo1 ? 8 : narrow1 ? 6 : (can_d ? (ctx->opt_blk == 8 ? 4 : 3) : (can_c ? 2 : 1));
+            // the rungs above the 64-diagonal first pass: 128 and 256 diagonals (long reads: the same with sliding sequence windows)
+            const int  kind_mid = can_long ? 12 : 9, kind_wide = can_long ? 13 : 5, kind_64 = can_long ? 11 : 3;
             // Pilot: on a large batch with wf-adaptive off the first 4 096 pairs go first.  When most of them leave the
             // 64-diagonal window the rest does not start there only to be handed on: it goes straight to the
             // wave-per-pair kernel (256 diagonals) if that one takes most of the pilot's leftovers, else to the
@@ -970,7 +1001,7 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                 const size_t n_in = lst.size();
                 std::vector<uint64_t> r2;
                 if (!from_mid && ctx->opt_blk_mid != 0) {
-                    const int rcm = forward_pass(9, &lst, 0, lst.size(), r2, false);
+                    const int rcm = forward_pass(kind_mid, &lst, 0, lst.size(), r2, false);
                     if (rcm) return rcm;
                     ctx->timing.n_packed_pairs += (uint32_t)(lst.size() - r2.size());
                     mid_in += lst.size();
@@ -983,7 +1014,7 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                     r2.clear();
                     if (lst.empty()) return 1;
                 }
-                const int rcw = forward_pass(5, &lst, 0, lst.size(), r2, false);
+                const int rcw = forward_pass(kind_wide, &lst, 0, lst.size(), r2, false);
                 if (rcw) return rcw;  // WFAHIP_ERR_* (negative): the whole call fails, no pair is silently dropped
                 ctx->timing.n_packed_pairs += (uint32_t)(lst.size() - r2.size());
                 redo_w.insert(redo_w.end(), r2.begin(), r2.end());
@@ -998,35 +1029,36 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                 if (redo1.size() * 2 > pilot) {
                     const int wv = wide_ok ? wide_pass(redo1) : 2;
                     if (wv < 0) return wv;
-                    if (wv == 1) kind_rest = 5;
+                    if (wv == 1) kind_rest = kind_wide;
                     else skip_rest = true;
                 }
             }
             // a class of batches whose pairs were mostly handed on for their band the last time starts on the window that
             // took them (1 kbp at 20 % error: every pair needs ~100 diagonals)
-            if (wide_ok && done_pairs == 0 && ctx->band_key == rkey && ctx->band_kind != 0 && (kind1 == 3 || kind1 == 8) &&
+            // (band_kind is kept in terms of the plain instances -- 3 / 9 / 5 -- and mapped to this call's rungs)
+            if (wide_ok && done_pairs == 0 && ctx->band_key == rkey && ctx->band_kind != 0 && (kind1 == 3 || kind1 == 8 || kind1 == 11) &&
                 (ctx->band_kind == 5 || ctx->band_kind == 3 || ctx->opt_blk_mid != 0) &&
                 !(ctx->band_kind == 3 && ctx->opt_duo >= 2) &&  // (option duo = 2: the variable-lanes kernel whatever was learned)
                 (++ctx->band_calls & 15u) != 0u)
-                kind_rest = ctx->band_kind;
+                kind_rest = ctx->band_kind == 5 ? kind_wide : ctx->band_kind == 9 ? kind_mid : kind_64;
             if (!skip_rest) {
                 std::vector<uint64_t> more;
                 if ((rc = forward_pass(kind_rest, nullptr, done_pairs, n_pairs - done_pairs, more, true))) return rc;
                 n_first_fail += more.size();
                 uint64_t n_band = 0;
                 for (uint64_t e : more) n_band += (uint32_t)(e >> 32) == ST_REDO_BAND;
-                if (kind_rest == 9) {
+                if (kind_rest == kind_mid) {
                     mid_in += n_pairs - done_pairs, mid_fail += n_band;
                     if ((rc = wide_pass(more, true)) < 0) return rc;  // -> the 256-diagonal instance
                 } else {
-                    (kind_rest == 5 ? redo_w : redo1).insert((kind_rest == 5 ? redo_w : redo1).end(), more.begin(), more.end());
+                    (kind_rest == kind_wide ? redo_w : redo1).insert((kind_rest == kind_wide ? redo_w : redo1).end(), more.begin(), more.end());
                 }
-                if ((kind_rest == 3 || kind_rest == 8) && P.adaptive && n_band * 2 > n_pairs - done_pairs) ctx->band_key = rkey, ctx->band_kind = 9;
+                if ((kind_rest == 3 || kind_rest == 8 || kind_rest == 11) && P.adaptive && n_band * 2 > n_pairs - done_pairs) ctx->band_key = rkey, ctx->band_kind = 9;
                 // (bands mostly wider than 32 diagonals: the variable-lanes kernel then runs its pairs wide, parks and resumes for
                 // nothing and hands on more than the plain 64-diagonal kernel would -- 1e6 x 1 kbp @8 %: 53-71 ms against 46)
                 else if (kind_rest == 8 && n_band * 50 > n_pairs - done_pairs) ctx->band_key = rkey, ctx->band_kind = 3;
                 else if (kind_rest == 8 && ctx->band_key == rkey) ctx->band_kind = 0;
-                else if (kind_rest == 3 && kind1 == 3 && ctx->band_key == rkey) ctx->band_kind = 0;
+                else if (kind_rest == kind_64 && kind1 == kind_64 && ctx->band_key == rkey) ctx->band_kind = 0;
                 done_pairs = n_pairs;
             }
             if (std::getenv("WFAHIP_DEBUG_TIMING") && P.done_ctl) {
@@ -1089,7 +1121,7 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                 if (!lst.empty() && arena_mult <= 8 && ctx->opt_packed_arena_bytes <= 0) {
                     const uint64_t keep_mult = arena_mult;
                     arena_mult *= 4;
-                    rc = forward_pass((kind_rest == 5 || kind_rest == 9) ? kind_rest : 3, &lst, 0, lst.size(), r2, false);
+                    rc = forward_pass((kind_rest == kind_wide || kind_rest == kind_mid) ? kind_rest : kind_64, &lst, 0, lst.size(), r2, false);
                     arena_mult = keep_mult;
                     if (rc) return rc;
                     ctx->timing.n_packed_pairs += (uint32_t)(lst.size() - r2.size());
