@@ -44,11 +44,13 @@ CONFIGS = {
     "k10": dict(pairs=100_000, length=1000, error=0.10, seed=10, semi_global=False, adaptive=True, total=0, cpu=60_000),
     "k20": dict(pairs=100_000, length=1000, error=0.20, seed=20, semi_global=False, adaptive=True, total=0, cpu=25_000),
     "l5": dict(pairs=500, length=50_000, error=0.05, seed=55, semi_global=False, adaptive=True, total=0, cpu=500),
+    # ... and the same pairs in a number that fills the GPU (2e4 x 50 kbp: 5 000 waves of four pairs)
+    "L5": dict(pairs=20_000, length=50_000, error=0.05, seed=55, semi_global=False, adaptive=True, total=0, cpu=200),
     "l10": dict(pairs=500, length=50_000, error=0.10, seed=510, semi_global=False, adaptive=True, total=0, cpu=300),
     "l20": dict(pairs=500, length=50_000, error=0.20, seed=520, semi_global=False, adaptive=True, total=0, cpu=120),
 }
 # steps of the default run: timed regions of a few seconds
-DEFAULT_STEPS = {"c3": 250, "c2": 10000, "c4": 25, "c5s": 4, "k10": 400, "k20": 150, "l5": 150, "l10": 60, "l20": 25}
+DEFAULT_STEPS = {"c3": 250, "c2": 10000, "c4": 25, "c5s": 4, "k10": 400, "k20": 150, "l5": 150, "L5": 20, "l10": 60, "l20": 25}
 
 
 def parse_args(argv=None):
@@ -401,7 +403,7 @@ def run_rank(args):
                     "traffic_source": pm["source"] if pm else None, "traffic_stale": pm["stale"] if pm else None,
                     "frac_on_traffic": (traffic / (main_k_ms * 1e-3) / 8e12) if (traffic and main_k_ms > 0) else None,
                     "algorithmic_bytes_per_launch": alg_bytes,
-                    "kernel": (pm["kernel"] if pm else None) or (kname + (", ..>" if kname.startswith("wfa_blk_kernel") else "")),
+                    "kernel": (pm["kernel"] if pm else None) or (kname + (", ..>" if kname.startswith("wfa_blk_kernel") and not kname.endswith(">") else "")),
                     "kernel_ms": main_k_ms, "all_kernels_ms": k_ms,
                     "note": "achieved = algorithmic bytes of one step / duration of the dominant kernel's launches in "
                             "that step (HIP events on the launch stream); peak = 8 TB/s HBM3E spec; the forward kernel is "
@@ -445,7 +447,9 @@ def run_rank(args):
 
 
 KNAMES = ["wfa_generic_kernel", "wfa_packed_kernel", "wfa_reg_kernel<2, 4, 1>", "wfa_blk_kernel<16",
-          "wfa_blk_kernel<8", "wfa_blk_kernel<64", "wfa_blk_kernel<8, 8, false, 4", "wfa_team_kernel", "wfa_duo_kernel", "wfa_blk_kernel<32", "wfa_lane_kernel"]
+          "wfa_blk_kernel<8", "wfa_blk_kernel<64", "wfa_blk_kernel<8, 8, false, 4", "wfa_team_kernel", "wfa_duo_kernel", "wfa_blk_kernel<32", "wfa_lane_kernel",
+          "wfa_blk_kernel<16, 1, false, 0, false, true>", "wfa_blk_kernel<32, 1, false, 0, true, true>", "wfa_blk_kernel<64, 1, false, 0, true, true>",
+          "wfa_blk_kernel<64, 1, false, 1, true, true>", "wfa_blk_kernel<64, 1, false, 2, true, true>"]
 # legs of config.other_configs: (config, timed steps, warm-up steps)
 OTHER_LEGS = [("c2", 300, 5), ("k10", 30, 4), ("l5", 12, 3), ("c5s", 2, 1)]
 

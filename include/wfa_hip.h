@@ -118,7 +118,9 @@ typedef struct {
     uint32_t main_kernel_kind; /* 0 = wfa_generic_kernel, 1 = wfa_packed_kernel, 2 = wfa_reg_kernel, 3 = wfa_blk_kernel<16>, 4 = wfa_blk_kernel<8>,
                                   5 = wfa_blk_kernel<64>, 6 = wfa_blk_kernel<8, 8, false, 4> (short reads), 7 = wfa_team_kernel,
                                   8 = wfa_duo_kernel (8 or 16 lanes per pair), 9 = wfa_blk_kernel<32> (128 diagonals),
-                                  10 = wfa_lane_kernel (a lane per pair, short reads) */
+                                  10 = wfa_lane_kernel (a lane per pair, short reads), 11 / 12 / 13 = wfa_blk_kernel<16 / 32 / 64, .., LONG>
+                                  (sliding sequence windows: reads of any length, 64 / 128 / 256 diagonals), 14 / 15 = wfa_blk_kernel<64, 1, false, 1 / 2, .., LONG>
+                                  (a wave per pair, one / two diagonals per lane: batches too small to fill the GPU) */
     uint32_t ladder_start_level; /* arena level the long-pair ladder of this call started on (0 unless a learned hint applied) */
 } wfahip_timing;
 

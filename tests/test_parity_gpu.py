@@ -1373,3 +1373,104 @@ def test_lane_kernel_several_chunks(built, chunk_pairs):
             assert t.main_kernel_kind == 10 and t.n_main_launches == -(-9000 // chunk_pairs), t
             assert_batch_equal(got, want, f"lane chunks={chunk_pairs} ad={ad} rep={rep}")
         al.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Round 4: long reads on the sub-wave kernels (wfa_blk_kernel<.., LONG>: sliding 2-bit sequence windows in LDS).
+# The rules being windowed are WF_EXTEND's (wfa.go:381-458): whatever the window does, a cell gets its full LCP.
+def _mutate(rng, s, rate):
+    """s with ~rate of its bases edited (mismatch / insertion / deletion, equally likely)."""
+    out = bytearray()
+    for c in s:
+        r = rng.random()
+        if r < rate / 3:
+            out.append(rng.choice(b"ACGT".replace(bytes([c]), b"")))
+        elif r < 2 * rate / 3:
+            out.append(c)
+            out.append(rng.choice(b"ACGT"))
+        elif r < rate:
+            continue
+        else:
+            out.append(c)
+    return bytes(out)
+
+
+def _long_window_cases(seed):
+    import random
+    rng = random.Random(seed)
+    rnd = lambda n: bytes(rng.choice(b"ACGT") for _ in range(n))
+    qs, ts = [], []
+    for ln, rate in ((4100, 0.05), (6000, 0.02), (9000, 0.08), (12000, 0.05), (20000, 0.03), (30000, 0.06), (17000, 0.10), (8000, 0.15)):
+        q = rnd(ln)
+        qs.append(q), ts.append(_mutate(rng, q, rate))
+    q = rnd(21000)
+    qs.append(q), ts.append(q)                                  # identical: one match run through every window to the END of both sequences
+    qs.append(q), ts.append(q[:20000])                          # ... the run ends at the end of the target, the query hangs over
+    qs.append(q[:20500]), ts.append(q)                          # ... and the other way round
+    qs.append(q), ts.append(q[:9000] + b"T" + q[9001:])         # a run of 9 000, a mismatch in the middle of a window, a run of 12 000
+    qs.append(q), ts.append(q[:8192] + _mutate(rng, q[8192:], 0.05))   # a run that ends exactly on a window's 64-base grid
+    qs.append(q[:15000] + rnd(40) + q[15000:]), ts.append(q)    # a 40-base insertion far from the start (the band moves 40 diagonals at once)
+    qs.append(q), ts.append(q[:5000] + q[5300:])                # a 300-base deletion: band failure of the 64-diagonal window -> 128 -> 256 diagonals
+    qs.append(rnd(7000)), ts.append(rnd(7000))                  # unrelated sequences (arena rows run out; the band grows)
+    qs.append(q[:4001] + b"N" + q[4002:6000]), ts.append(q[:6000])   # a byte outside ACGT: the byte path takes the pair
+    qs.append(q[:5000].lower()), ts.append(q[:5000])            # lowercase against uppercase (wfa.go:408-454 compares raw bytes)
+    qs.append(rnd(300)), ts.append(rnd(5000))                   # a short read against a long one
+    qs.append(q[:4200]), ts.append(b"")                         # empty (ErrEmptySeq)
+    return qs, ts
+
+
+@pytest.mark.parametrize("adaptive", [(10, 50, 1), None, (4, 10, 1)])
+@pytest.mark.parametrize("window_words,first", [(256, 11), (64, 11), (64, 12), (256, 13), (64, 14), (64, 15), (256, 0)])
+def test_long_window_kernel_cases(built, adaptive, window_words, first):
+    """Pairs of 4-30 kbp through the sliding-window instances: every field and every CIGAR op against the oracle.  The
+    cases put match runs across window refills, a run up to the very end of both sequences, refills at a sequence end
+    with an overhang, band failures that climb the 128- and 256-diagonal rungs, and pairs the path must hand on.  With 64-word
+    windows (1 024 bases, 480 of them usable) every pair repositions its windows dozens of times."""
+    from oracle import oracle as O
+    import wfa_amd as w
+    qs, ts = _long_window_cases(4)
+    data = w.make_blob(qs, ts)
+    al = _aligner(True, adaptive)
+    al.set_option("long_window_words", window_words)
+    al.set_option("long_first", first)  # (0: by batch size -- a batch this small starts with a wave per pair, 128 diagonals)
+    got = al.align_arrays(*data)
+    assert al.last_timing().main_kernel_kind == (first or 15)  # the sliding-window instance asked for was the first pass
+    want = O.align_batch(_oracle_params(True, adaptive), *data, n_threads=8)
+    assert_batch_equal(got, want, f"long windows {adaptive} {window_words}")
+    again = al.align_arrays(*data)
+    assert_batch_equal(again, want, "second call")
+    al.close()
+
+
+def test_long_window_kernel_batch(built):
+    """A batch that fills waves and queues (600 pairs of 5-12 kbp at 2-8 % error, ragged lengths, a few unaligned blob
+    offsets): every wave refills, repositions and finishes pairs at different steps.  Twice over a poisoned arena."""
+    import random
+    from oracle import oracle as O
+    import wfa_amd as w
+    rng = random.Random(11)
+    qs, ts = [], []
+    for i in range(600):
+        ln = rng.randint(5000, 12000)
+        q = bytes(rng.choice(b"ACGT") for _ in range(ln))
+        qs.append(q), ts.append(_mutate(rng, q, rng.choice((0.02, 0.05, 0.08))))
+    data = w.make_blob(qs, ts)
+    al = _aligner(True, (10, 50, 1))
+    al.set_option("arena_poison", 1)
+    al.set_option("long_first", 11)
+    want = O.align_batch(_oracle_params(True, (10, 50, 1)), *data, n_threads=8)
+    for rep in range(2):
+        got = al.align_arrays(*data)
+        assert al.last_timing().main_kernel_kind == 11
+        assert_batch_equal(got, want, f"long batch, pass {rep}")
+    al.set_option("long_wave_bt", 0)  # ... and with the lane-per-pair backtrace kernel behind the same forward pass
+    assert_batch_equal(al.align_arrays(*data), want, "lane-per-pair backtrace")
+    al.set_option("long_wave_bt", 2)  # ... and the wave-per-pair one whatever the batch size
+    assert_batch_equal(al.align_arrays(*data), want, "wave-per-pair backtrace")
+    al.set_option("long_wave_bt", 1)
+    # the same pairs on the plain whole-sequence path (option long = 0): the two paths agree with each other too
+    al.set_option("long", 0)
+    plain = al.align_arrays(*data)
+    assert al.last_timing().main_kernel_kind != 11
+    assert_batch_equal(plain, want, "long = 0")
+    al.close()

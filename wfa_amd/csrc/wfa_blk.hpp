@@ -313,8 +313,9 @@ WFA_DEV void blk_push_not_ok(const KParams &P, uint32_t pidx) {
 template <int G, int BATCH, bool STREAM = false, int PPT = 0, bool CENSUS = true, bool LONG = false>
 __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16 && BATCH == 1 && !CENSUS && !LONG && (!STREAM || WFA_BLK_STREAM_WAVES5) ? WFA_BLK_WAVES : 4))) void wfa_blk_kernel(const KParams P) {
     static_assert(!STREAM || (G == 16 && BATCH == 1), "streamed backtrace: 16 lanes per pair, unbatched refill");
-    static_assert(PPT == 0 || (G == 8 && PPT == 4), "diagonals per lane can only be overridden for the 8-lane narrow instance");
-    static_assert(!LONG || (BATCH == 1 && !STREAM && PPT == 0 && G >= 16), "sliding sequence windows: unbatched, pre-packed input");
+    static_assert(PPT == 0 || (G == 8 && PPT == 4) || (G == 64 && (PPT == 1 || PPT == 2)),
+                  "diagonals per lane can only be overridden for the 8-lane narrow instance and the lone-pair instances");
+    static_assert(!LONG || (BATCH == 1 && !STREAM && (PPT == 0 || G == 64) && G >= 16), "sliding sequence windows: unbatched, pre-packed input");
     constexpr int PP  = PPT ? PPT : (G >= 32 ? 4 : 64 / G);  // diagonals per lane
     constexpr int NG  = 64 / G;                // pairs per wave
 #ifdef WFA_BLK_W
@@ -323,7 +324,12 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
     constexpr int W   = G * PP;   // window width in diagonals: 64 (G = 16, 8), 128 (G = 32) or 256 (G = 64); also the arena's row pitch
 #endif
     constexpr bool TILED = WFA_BLK_TILED != 0 && W == 64;  // arena layout: CompactView fmt 3 (else fmt 1 / 4: plain rows)
+    // G = 64 with ONE or TWO diagonals per lane (round 4): the whole wave on one pair with a 64- / 128-diagonal window -- a quarter /
+    // half of the instructions of a step of the four-diagonals-per-lane instances.  For pairs that are alone on their SIMD
+    // anyway (one Align call; a few hundred long reads): there the step time is the latency of one wave's instruction
+    // stream, not the GPU's throughput.
     using Ops         = typename std::conditional<(G == 8 && PP == 4), BlkOps8n, BlkOps<G>>::type;
+    constexpr int SHD = G >= 32 ? PP : Ops::SHIFT_D;  // diagonals per window shift (G >= 32: the shifts move one lane)
 #ifdef WFA_MARKS
 #define WFA_MARK(i) asm volatile("; ##MARK " #i)
 #else
@@ -794,7 +800,12 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
 #pragma unroll
                 for (int p = 0; p < PP; p++) anyc |= nM[p];
                 if (run && !no_room && anyc != 0u) {
-                    if constexpr (TILED) {
+                    if constexpr (PP < 4) {
+                        // one or two diagonals per lane: a 4- or 8-byte store (the same tiles / plain rows)
+                        uint32_t *const row = TILED ? rowp + (((uint32_t)k0 & 60u) << 3) + ((uint32_t)k0 & 3u) : rowp + ((uint32_t)k0 & (uint32_t)(W - 1));
+                        if constexpr (PP == 1) *row = wd[0];
+                        else *reinterpret_cast<uint2 *>(row) = make_uint2(wd[0], wd[PP - 1]);
+                    } else if constexpr (TILED) {
                         // tile of 8 scores x 64 diagonals: [diagonal / 4][score & 7][diagonal & 3] (CompactView fmt 3)
                         uint32_t *const row = rowp + (((uint32_t)k0 & 63u) << 3);
                         if constexpr (STREAM)
@@ -1093,7 +1104,7 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
                 if (__ballot(need_dn || need_up) != 0ull) {
                     const int  ulo  = imin2(imin2(rlo[0], rlo[1]), imin2(rlo[2], rlo[3]));
                     const int  uhi  = imax2(imax2(rhi[0], rhi[1]), imax2(rhi[2], rhi[3]));
-                    const bool wide = (need_dn && (need_up || uhi >= kb - Ops::SHIFT_D + W - 1)) || (need_up && ulo <= kb + Ops::SHIFT_D);
+                    const bool wide = (need_dn && (need_up || uhi >= kb - SHD + W - 1)) || (need_up && ulo <= kb + SHD);
                     const bool dn = need_dn && !wide, up = need_up && !wide;
 #pragma unroll
                     for (int d = 0; d < 4; d++)
@@ -1109,7 +1120,7 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
                         I[p]             = dn ? a : (up ? b : I[p]);
                         D[p]             = dn ? c : (up ? d : D[p]);
                     }
-                    kb += dn ? -Ops::SHIFT_D : (up ? Ops::SHIFT_D : 0);
+                    kb += dn ? -SHD : (up ? SHD : 0);
                     set_window();
                     if constexpr (LONG) {
                         // the sequence windows are tied together at diagonal kc16: once the diagonal window has drifted further

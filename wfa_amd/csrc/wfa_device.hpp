@@ -457,6 +457,8 @@ struct OpsWriterRev {
     static constexpr uint32_t GROUP = WFA_OPS_GROUP;
     uint64_t  hist[GROUP > 1 ? GROUP - 1 : 1];   // hist[i] = the op flushed i+1 flushes ago
     bool      grouped;
+    bool      active = true;                     // false: count and keep statistics, store nothing (the lanes of a wave that walks
+                                                 // one pair together all run the writer; one of them stores)
     WFA_DEV void init(uint64_t *b, uint32_t c) {
         buf = b, cap = c, n = 0, cur = 0, overflow = false, seenM = false;
         grouped = GROUP > 1 && (reinterpret_cast<uintptr_t>(b + c) & (8u * GROUP - 1u)) == 0u;
@@ -477,7 +479,8 @@ struct OpsWriterRev {
     WFA_DEV void flush() {
         if (cur == 0) return;
         if (n < cap) {
-            if (!grouped) {
+            if (!active) {
+            } else if (!grouped) {
                 buf[cap - 1 - n] = cur;
             } else if ((n & (GROUP - 1u)) == GROUP - 1u) {
                 ulonglong2 *d = reinterpret_cast<ulonglong2 *>(buf + (cap - 1 - n));
@@ -510,7 +513,7 @@ struct OpsWriterRev {
     }
     // process() with no M op at all: begin = end = 0 -> only the first op of the forward list counts
     WFA_DEV void finish() {
-        if (grouped && n <= cap) {  // the newest entries that did not fill a store
+        if (grouped && n <= cap && active) {  // the newest entries that did not fill a store
             const uint32_t r = n & (GROUP - 1u);
 #pragma unroll
             for (uint32_t i = 0; i + 1 < GROUP; i++)
@@ -578,6 +581,47 @@ struct CompactView {
         const uint32_t t = (wd >> 5) & 3u;
         return t == 1u ? TAG_DEL_OPEN : (t == 2u ? TAG_DEL_EXT : 0u);
     }
+};
+
+// The blocked kernels' arenas seen by a whole WAVE that walks one pair together (every lane runs the same walk on the same
+// values): a region of 32 score indices x 32 diagonals (4 KB) lives in LDS, loaded by the 64 lanes in one round of 16-byte
+// loads -- whole 128-byte lines of the tiled layout -- whenever the walk asks for a cell outside it.  A step of the walk
+// descends 1, 2 or 4 score indices and moves at most one diagonal, so a region lasts ~10 CIGAR ops: one DRAM round trip
+// per ~10 ops instead of one per op (the lane-per-pair walk of a 50 kbp pair is a chain of ~5 000 dependent misses).
+struct CompactViewWave {
+    const uint32_t *A;
+    uint64_t        cap;
+    uint32_t        g, n_ent, fmt;
+    uint32_t       *reg;          // LDS, 1 024 words: [score index - r0][diagonal - d0]
+    mutable int     r0 = -64, d0 = 0;  // the region holds score indices [r0, r0 + 32) x diagonals [d0, d0 + 32)
+    WFA_DEV uint64_t widx(uint32_t idx, int k) const {  // word index of (score index, diagonal), CompactView's layouts
+        if (fmt == 3u) return 512ull * (idx >> 3) + (((uint32_t)k & 60u) << 3) + ((idx & 7u) << 2) + ((uint32_t)k & 3u);
+        if (fmt == 1u) return 64ull * idx + ((uint32_t)k & 63u);
+        if (fmt == 4u) return 256ull * idx + ((uint32_t)k & 255u);
+        return 128ull * idx + ((uint32_t)k & 127u);  // fmt 6
+    }
+    WFA_DEV void refill(uint32_t idx, int k) const {
+        r0 = (int)(idx & ~7u) - 24;  // the cell's tile row on top: 25-32 rows to descend through
+        d0 = (k - 16) & ~3;
+        const int lane = threadIdx.x & 63;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int q = lane + 64 * r, row = q >> 3, si = r0 + row, kk = d0 + 4 * (q & 7);
+            uint4     v = make_uint4(0u, 0u, 0u, 0u);
+            if (si >= 0 && (uint32_t)si < n_ent) v = *reinterpret_cast<const uint4 *>(A + widx((uint32_t)si, kk));
+            *reinterpret_cast<uint4 *>(reg + 4 * q) = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    WFA_DEV uint32_t word(uint32_t idx, int k) const {
+        if (idx >= n_ent) return 0u;
+        if ((uint32_t)((int)idx - r0) >= 32u || (uint32_t)(k - d0) >= 32u) refill(idx, k);
+        return reg[((int)idx - r0) * 32 + (k - d0)];
+    }
+    WFA_DEV uint32_t tag(int comp, uint32_t idx, int k, uint32_t &off0) const { return blk_tag(word(idx, k), comp, off0); }
 };
 
 WFA_DEV uint32_t op_letter(uint32_t tag) {  // wfaOps = ".IIDDXMH" (wfa_backtrace_types.go:37)
@@ -821,8 +865,8 @@ WFA_DEV void back_trace(const View &av, int lenQ, int lenT, uint32_t s, int Ak, 
 // cell M[s][Ak].  Same control flow as back_trace(); the source recomputation is replaced by the stored off0
 // (M cells) -- for a cell reached inside the I or D component the reference only tests its offset0 against 0,
 // and it cannot be 0 there: an InsExt/InsOpen (DelExt/DelOpen) tag is only given when that source existed.
-template <class Writer>
-WFA_DEV void back_trace_compact(const CompactView &cv, int lenQ, int lenT, uint32_t s, int Ak, uint32_t h_start,
+template <class View, class Writer>
+WFA_DEV void back_trace_compact(const View &cv, int lenQ, int lenT, uint32_t s, int Ak, uint32_t h_start,
                                 uint32_t px, uint32_t po, uint32_t pe, Writer &ow, TraceOut &out) {
     out.score  = s;
     out.tbegin = out.tend = out.qbegin = out.qend = 0;

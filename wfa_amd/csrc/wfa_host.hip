@@ -169,6 +169,8 @@ struct wfahip_ctx {
                                                   // sequence windows (wfa_blk_kernel<.., LONG>): four pairs per wave at any read length
     int64_t       opt_long_min_len         = 4000;   // (below it both whole sequences of a pair fit the plain instances' LDS at full occupancy)
     int64_t       opt_long_window_words    = 256; // packed words per sequence window: 4 096 bases
+    int64_t       opt_long_first           = 0;   // 0: by batch size; 11 / 12 / 13: long reads start on the 64- / 128- / 256-diagonal instance
+    int64_t       opt_long_wave_bt         = 1;   // 1: the backtrace of those pairs is walked by a wave per pair (0: a lane per pair, like short pairs)
     int64_t       opt_census               = 0;   // 1: the sub-wave forward kernels count the wavefront words they store (REC_CELLS, timing.cells_stored)
     int64_t       opt_learn                = 1;   // 1: long pairs start on the arena level the previous call of the same kind ended on
     uint64_t      learn_key                = 0;   // workload class of the last call that used the team kernel
@@ -481,10 +483,14 @@ static int set_option_impl(wfahip_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_census = value;
     else if (k == "long")
         ctx->opt_long = value;
+    else if (k == "long_first")
+        ctx->opt_long_first = value;
+    else if (k == "long_wave_bt")
+        ctx->opt_long_wave_bt = value;
     else if (k == "long_min_len")
         ctx->opt_long_min_len = value;
     else if (k == "long_window_words")
-        ctx->opt_long_window_words = (value >= 64 && value <= 4096 && value % 256 == 0) ? value : 256;
+        ctx->opt_long_window_words = (value >= 64 && value <= 4096 && value % 4 == 0) ? value : 256;  // (64 words: a window every ~500 bases -- tests)
     else if (k == "duo")
         ctx->opt_duo = value;
     else if (k == "duo_min_pairs")
@@ -754,11 +760,12 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             const uint32_t lane_sw      = (seq_words + 1u) & ~1u;  // kind 10 (wfa_lane_kernel): words per sequence in its slots and in LDS
             // kinds 11 / 12 / 13: kinds 3 / 9 / 5 with sliding sequence windows (long reads): pre-packed slots of long_sw words per
             // sequence in HBM, long_cw words of each in LDS
-            const bool     is_long      = kind >= 11 && kind <= 13;
+            // kinds 14 / 15: the whole wave on ONE pair with one / two diagonals per lane (64 / 128 diagonals): batches too small to fill the GPU
+            const bool     is_long      = kind >= 11 && kind <= 15;
             const uint32_t long_sw      = (seq_words + 3u) & ~3u, long_cw = (uint32_t)ctx->opt_long_window_words;
             if (is_long && !can_long) return WFAHIP_ERR_INTERNAL;
-            const int      bkind        = kind == 11 ? 3 : kind == 12 ? 9 : kind == 13 ? 5 : kind;  // (arena format and pairs per wave)
-            const size_t   lds_bytes    = is_long ? (size_t)(kind == 11 ? 4 : kind == 12 ? 2 : 1) * 2 * long_cw * 4 + 16
+            const int      bkind        = (kind == 11 || kind == 14) ? 3 : (kind == 12 || kind == 15) ? 9 : kind == 13 ? 5 : kind;  // (arena format)
+            const size_t   lds_bytes    = is_long ? (size_t)(kind == 11 ? 4 : kind == 12 ? 2 : 1) * 2 * long_cw * 4
                                           : kind == 10 ? (size_t)64 * lane_stride_words(lane_sw) * 4
                                           : kind == 8 ? (size_t)duo_lds_words(duo_pw) * 4
                                           : kind == 9 ? (size_t)seq_words * 2 * 4 * 2 + 16
@@ -766,7 +773,7 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                                           : kind == 6 ? (size_t)seq_words * 2 * 4 * 8 + 16
                                           : kind == 5 ? (size_t)seq_words * 2 * 4 + 16
                                                       : (kind >= 3 ? lds_d : (kind == 2 ? lds_c : lds_b));
-            const uint32_t pairs_wave   = kind == 10 ? 64 : bkind == 5 ? 1 : bkind == 9 ? 2 : (kind == 4 || kind == 6 || kind == 8 ? 8 : (kind >= 2 ? 4 : 2));
+            const uint32_t pairs_wave   = kind >= 13 ? 1 : kind == 10 ? 64 : bkind == 5 ? 1 : bkind == 9 ? 2 : (kind == 4 || kind == 6 || kind == 8 ? 8 : (kind >= 2 ? 4 : 2));
             // blocked kernels: fixed-pitch arena, no directory.  64-diagonal window: 16 words per base = 250 scores at
             // 1 kbp; 256-diagonal window (kind 5, the retry rung): 128 words per base = 500 scores at 1 kbp
             const uint64_t words        = bkind == 5   ? std::max<uint64_t>((words_dir * 16 * arena_mult + 511) & ~511ull, 8192)
@@ -887,6 +894,10 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                     hipLaunchKernelGGL((wfa_blk_kernel<32, 1, false, 0, true, true>), dim3(grid), dim3(64), lds_bytes, st, P);
                 else if (kind == 13)
                     hipLaunchKernelGGL((wfa_blk_kernel<64, 1, false, 0, true, true>), dim3(grid), dim3(64), lds_bytes, st, P);
+                else if (kind == 14)
+                    hipLaunchKernelGGL((wfa_blk_kernel<64, 1, false, 1, true, true>), dim3(grid), dim3(64), lds_bytes, st, P);
+                else if (kind == 15)
+                    hipLaunchKernelGGL((wfa_blk_kernel<64, 1, false, 2, true, true>), dim3(grid), dim3(64), lds_bytes, st, P);
                 else if (kind == 10 && P.census && P.adaptive)
                     hipLaunchKernelGGL((wfa_lane_kernel<true, true>), dim3(grid), dim3(64), lds_bytes, st, P);
                 else if (kind == 10 && P.census)
@@ -933,7 +944,13 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                 HIP_TRY(hipEventRecord(evFb, st));
                 if (st_bt != st) HIP_TRY(hipStreamWaitEvent(st_bt, evFb, 0));
                 if (st_bt != st) HIP_TRY(hipEventRecord(evBa, st_bt));  // (same stream: the backtrace starts where the forward kernel ends)
-                hipLaunchKernelGGL(wfa_backtrace_kernel, dim3((uint32_t)((cn + BT_THREADS - 1) / BT_THREADS)), dim3(BT_THREADS), 0, st_bt, P);
+                // long pairs, up to two waves per SIMD of them: a wave per pair walks an LDS region of the arena (3.2 against 5.7 ms
+                // for 500 x 50 kbp).  Beyond that the lane-per-pair kernel wins: the walk is bound by instructions, and there one
+                // instruction serves 64 pairs (2e4 x 50 kbp: 15 against 47 ms)
+                if (is_long && (ctx->opt_long_wave_bt >= 2 || (ctx->opt_long_wave_bt == 1 && cn <= (uint64_t)ctx->num_cus * 8)))
+                    hipLaunchKernelGGL(wfa_backtrace_wave_kernel, dim3((uint32_t)((cn + BTW_WAVES - 1) / BTW_WAVES)), dim3(64 * BTW_WAVES), 0, st_bt, P);
+                else
+                    hipLaunchKernelGGL(wfa_backtrace_kernel, dim3((uint32_t)((cn + BT_THREADS - 1) / BT_THREADS)), dim3(BT_THREADS), 0, st_bt, P);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipEventRecord(evBb, st_bt));
             }
@@ -1041,19 +1058,29 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                 !(ctx->band_kind == 3 && ctx->opt_duo >= 2) &&  // (option duo = 2: the variable-lanes kernel whatever was learned)
                 (++ctx->band_calls & 15u) != 0u)
                 kind_rest = ctx->band_kind == 5 ? kind_wide : ctx->band_kind == 9 ? kind_mid : kind_64;
+            // Long reads in batches too small to fill the GPU start on the wider windows: 500 pairs are 500 waves of one pair each
+            // (a wave alone on its SIMD steps in the same ~1.5 us whether it holds one pair or four), and nothing is handed on for
+            // its band -- a fifth of 50 kbp pairs at 5 % error leave a 64-diagonal window at some score
+            if (can_long && done_pairs == 0 && kind_rest == 11 && wide_ok) {
+                const uint64_t simds = (uint64_t)ctx->num_cus * 4;
+                if (ctx->opt_long_first >= 11 && ctx->opt_long_first <= 15) kind_rest = (int)ctx->opt_long_first;
+                else if (n_pairs <= simds) kind_rest = 15;  // (a wave per pair, two diagonals per lane: 128 diagonals at half the instructions of a step)
+                else if (n_pairs <= 4 * simds) kind_rest = 12;
+            }
             if (!skip_rest) {
                 std::vector<uint64_t> more;
                 if ((rc = forward_pass(kind_rest, nullptr, done_pairs, n_pairs - done_pairs, more, true))) return rc;
                 n_first_fail += more.size();
                 uint64_t n_band = 0;
                 for (uint64_t e : more) n_band += (uint32_t)(e >> 32) == ST_REDO_BAND;
-                if (kind_rest == kind_mid) {
+                if (kind_rest == kind_mid || kind_rest == 15) {
                     mid_in += n_pairs - done_pairs, mid_fail += n_band;
                     if ((rc = wide_pass(more, true)) < 0) return rc;  // -> the 256-diagonal instance
                 } else {
                     (kind_rest == kind_wide ? redo_w : redo1).insert((kind_rest == kind_wide ? redo_w : redo1).end(), more.begin(), more.end());
                 }
                 if ((kind_rest == 3 || kind_rest == 8 || kind_rest == 11) && P.adaptive && n_band * 2 > n_pairs - done_pairs) ctx->band_key = rkey, ctx->band_kind = 9;
+                else if (kind_rest == 15 && P.adaptive && n_band * 2 > n_pairs - done_pairs) ctx->band_key = rkey, ctx->band_kind = 5;  // (128 diagonals were not enough)
                 // (bands mostly wider than 32 diagonals: the variable-lanes kernel then runs its pairs wide, parks and resumes for
                 // nothing and hands on more than the plain 64-diagonal kernel would -- 1e6 x 1 kbp @8 %: 53-71 ms against 46)
                 else if (kind_rest == 8 && n_band * 50 > n_pairs - done_pairs) ctx->band_key = rkey, ctx->band_kind = 3;
@@ -1121,7 +1148,7 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                 if (!lst.empty() && arena_mult <= 8 && ctx->opt_packed_arena_bytes <= 0) {
                     const uint64_t keep_mult = arena_mult;
                     arena_mult *= 4;
-                    rc = forward_pass((kind_rest == kind_wide || kind_rest == kind_mid) ? kind_rest : kind_64, &lst, 0, lst.size(), r2, false);
+                    rc = forward_pass((kind_rest == kind_wide || kind_rest == kind_mid || kind_rest >= 14) ? kind_rest : kind_64, &lst, 0, lst.size(), r2, false);
                     arena_mult = keep_mult;
                     if (rc) return rc;
                     ctx->timing.n_packed_pairs += (uint32_t)(lst.size() - r2.size());
