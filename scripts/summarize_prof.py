@@ -20,7 +20,7 @@ print("== PMC (per dispatch, summed over dispatches of the same kernel) ==")
 acc = collections.defaultdict(float); cnt = collections.Counter()
 for f, r in rows("pmc_*/**/*counter_collection.csv"):
     if "wfa" in r.get("Kernel_Name", ""):
-        key = (r["Kernel_Name"][:50], r["Counter_Name"], r.get("Grid_Size", ""))
+        key = (r["Kernel_Name"][:90], r["Counter_Name"], r.get("Grid_Size", ""))
         acc[key] += float(r["Counter_Value"]); cnt[key] += 1
 for k in sorted(acc):
     print(k, "sum", acc[k], "dispatches", cnt[k])

@@ -138,6 +138,8 @@ struct wfahip_ctx {
     int64_t       opt_team_solo_max        = TEAM_SOLO_MAX;  // rows up to this width are done by one workgroup
     int64_t       opt_team_wave            = 1;              // rows up to 64 diagonals are done by one wave (LDS ring)
     int64_t       opt_team_strict          = 1;              // agent-scope release in every team barrier (0: see wfa_team.hpp)
+    int64_t       opt_team_xcd             = 1;              // 1: teams of one XCD's CUs (blockIdx % 8); 2: ... and a team that finds itself on one XCD keeps its
+                                                             // rows in that XCD's L2 (plain stores, no release in its barriers: measured 1.5 %, off)
     int64_t       opt_arena_poison         = 0;              // tests: fill the arena with a pattern before every long-pair launch
     int64_t       opt_pilot                = 1;  // 1: a 4 096-pair pilot decides whether a large batch uses the sub-wave kernels
     int64_t       opt_tail_overlap         = 1;  // 1: retry passes overlap the backtrace kernel of the first pass
@@ -471,6 +473,8 @@ static int set_option_impl(wfahip_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_team_wave = value;
     else if (k == "team_strict")
         ctx->opt_team_strict = value;
+    else if (k == "team_xcd")
+        ctx->opt_team_xcd = value;
     else if (k == "arena_poison")
         ctx->opt_arena_poison = value;
     else if (k == "fail_pass")
@@ -1349,9 +1353,13 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             if (cfg.lds_bytes > 48 * 1024)
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)cfg.lds_bytes));
-            hipLaunchKernelGGL(kfn, dim3(team_n * team_T), dim3(TEAM_THREADS), cfg.lds_bytes, st, P,
+            // teams of one XCD's CUs (team = blockIdx % 8) when at most eight teams run and the CUs divide by eight
+            const bool     xmap   = ctx->opt_team_xcd != 0 && ctx->opt_team_wgs == 0 && team_n <= 8 && ctx->num_cus % 8 == 0 && ctx->num_cus >= 16;
+            const uint32_t grid_t = xmap ? (uint32_t)ctx->num_cus : team_n * team_T;
+            if (xmap) team_T = (uint32_t)ctx->num_cus / 8u;
+            hipLaunchKernelGGL(kfn, dim3(grid_t), dim3(TEAM_THREADS), cfg.lds_bytes, st, P,
                                static_cast<uint32_t *>(ctx->team_ctl.p), team_T, (uint32_t)std::max<int64_t>(0, ctx->opt_team_solo_max),
-                               team_wave_rows, (uint32_t)(ctx->opt_team_strict != 0));
+                               team_wave_rows, (uint32_t)(ctx->opt_team_strict != 0) | (xmap ? 2u : 0u) | (xmap && ctx->opt_team_xcd >= 2 ? 4u : 0u) | (team_n << 16));
             HIP_TRY(hipGetLastError());
         } else {
             // wave mode of the generic kernel: directory ring + ring of the last rows in LDS, if they fit
@@ -1388,6 +1396,12 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                              t, a[18] / 100.0, a[19] / 100.0, a[20] / 100.0);
             }
 #endif
+            if (std::getenv("WFAHIP_DEBUG_TIMING")) {
+                uint32_t n_xl = 0;
+                for (uint32_t t = 0; t < team_n; t++) n_xl += tc[(size_t)t * TEAM_CTL_WORDS + 11];
+                for (uint32_t t = 0; t < team_n; t++) std::fprintf(stderr, "[wfahip]   team %u: XCC ids seen, as a mask: 0x%x\n", t, tc[(size_t)t * TEAM_CTL_WORDS + 3]);
+                std::fprintf(stderr, "[wfahip] team kernel: %u teams of %u workgroups, %u of them on one XCD each\n", team_n, team_T, n_xl);
+            }
             for (uint32_t t = 0; t < team_n; t++)
                 if (tc[(size_t)t * TEAM_CTL_WORDS + 1] != 0u) {
                     std::snprintf(ctx->last_error, sizeof ctx->last_error, "team kernel: barrier timeout in team %u", t);

@@ -49,7 +49,7 @@ namespace wfa {
 constexpr int TEAM_THREADS   = 1024;
 constexpr int TEAM_RING      = WAVE_DIR_RING;  // directory entries every workgroup keeps in LDS (sources reach back < 64 scores)
 constexpr int TEAM_CTL_WORDS = 128;  // per team, in global memory: [0] barrier count [1] abort [2] work index
-                                     // [3] - [4] command [5] score [6..7] arena top [8..9] end-cell key (u64) [10] end flags [12..13] stored cells (u64)
+                                     // [3] XCC ids of the team (mask) [4] command [5] score [6..7] arena top [8..9] end-cell key (u64) [10] end flags [11] team on one XCD [12..13] stored cells (u64)
                                      // [16 + 16*set ..] three reduction sets [64..] diagnostic stamps
 constexpr uint32_t TEAM_SPIN_LIMIT = 1u << 24;
 #ifndef WFA_TEAM_U
@@ -76,7 +76,19 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
     uint32_t *const wring = reinterpret_cast<uint32_t *>(ring + TEAM_RING);
 
     const int      tid = threadIdx.x, lane = tid & 63;
-    const uint32_t team = blockIdx.x / T, b = blockIdx.x % T;
+    // Teams of one XCD's CUs (round 4; `strict` bit 1, n_teams in its upper half): team = blockIdx % 8.  Workgroups are dealt
+    // round-robin over the eight XCDs, so such a team normally sits on ONE XCD, whose L2 all its CUs share.  A team of 32 CUs
+    // steps as fast as one of 50 (a wide step is a chain of round trips, not throughput: 8 x 100 kbp 610 -> 589 ms).  Bit 2
+    // (option team_xcd = 2, off by default) adds the LOCAL protocol: every workgroup reports its XCC id, and a team that finds all
+    // of them equal (`xl`) stores its rows plain -- they stay in the XCD's L2, where the team's sc1 loads find them -- and
+    // drops the release from its barriers; any other placement runs the memory-side protocol unchanged.  Measured: 589 -> 580
+    // ms, 1.5 % -- the release and the memory side are not what a step waits for -- so the default keeps the protocol that
+    // round 2's soak covers.  Teams beyond the number of arena slots leave at once.
+    const bool     xmap    = (strict & 2u) != 0u, xl_ok = (strict & 4u) != 0u;
+    const uint32_t n_teams = strict >> 16;
+    strict &= 1u;
+    const uint32_t team = xmap ? blockIdx.x % 8u : blockIdx.x / T, b = xmap ? blockIdx.x / 8u : blockIdx.x % T;
+    if (xmap && team >= n_teams) return;
     uint32_t *const ctl = team_ctl + (uint64_t)team * TEAM_CTL_WORDS;
     uint32_t *const A   = P.arena + (uint64_t)team * P.arena_words;
     const uint64_t cap  = P.arena_words;
@@ -98,13 +110,14 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
 #endif
     uint32_t bar_target = 0;  // barriers are counted: the n-th one completes at n*T arrivals
     bool     aborted    = false;
+    bool     xl         = false;  // this team's workgroups share one XCD (checked below): rows travel through its L2
     auto team_barrier = [&](bool fenced) {
         __syncthreads();
         if (tid == 0) {
             bar_target += T;
             if (fenced)
                 __threadfence();
-            else if (strict)
+            else if (strict && !xl)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // (team_strict, the default: see the header comment)
             bool bad = false;
             // the last workgroup to arrive sees the full count in the value its own atomic returns.  The count runs
@@ -137,6 +150,15 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
         for (int i = 0; i < 12; i++) __hip_atomic_store(w + i, (uint32_t)v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
 
+    // ---- where the team's workgroups sit: one bit per XCC id seen (ctl[3]: zero at launch)
+    if (xmap) {
+        if (tid == 0) atomicOr(&ctl[3], 1u << (__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | ((4 - 1) << 11)) & 15u));  // HW_REG_XCC_ID [3:0]
+        team_barrier(true);
+        if (aborted) return;
+        const uint32_t seen = __hip_atomic_load(&ctl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        xl = xl_ok && (seen & (seen - 1u)) == 0u;
+        if (b == 0 && tid == 0) ctl[11] = xl ? 1u : 0u;  // (diagnostics: WFAHIP_DEBUG_TIMING prints it)
+    }
     for (;;) {
         // ---- the team's next pair: workgroup 0 pulls it, the barrier publishes it
         if (b == 0 && tid == 0) {
@@ -213,10 +235,13 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
                 if (lead_wg) store_dir(dir_ptr(idx), base, lo_, w_, stride);
             }
         };
-        // arena words: coherent (memory-side) in team mode, plain (L2-cached) in solo mode
+        // arena words: coherent (memory-side) in team mode, plain (L2-cached) in solo mode.  A team on one XCD (xl) stores
+        // plain too: the line stays in the XCD's L2 (an sc1 store drops it), where the team's sc1 loads -- they bypass the
+        // reader's L1 only -- find it; a store is in that L2 when the storing wave's vmcnt has returned, which every barrier
+        // waits for (__syncthreads), so no write-back stands between the rows and the barrier's arrive
         auto ldw = [&](const uint32_t *p_) { return teamed ? ald(p_) : *p_; };
         auto stw = [&](uint32_t *p_, uint32_t v_) {
-            if (teamed)
+            if (teamed && !xl)
                 ast(p_, v_);
             else
                 *p_ = v_;
