@@ -120,7 +120,8 @@ typedef struct {
                                   8 = wfa_duo_kernel (8 or 16 lanes per pair), 9 = wfa_blk_kernel<32> (128 diagonals),
                                   10 = wfa_lane_kernel (a lane per pair, short reads), 11 / 12 / 13 = wfa_blk_kernel<16 / 32 / 64, .., LONG>
                                   (sliding sequence windows: reads of any length, 64 / 128 / 256 diagonals), 14 / 15 = wfa_blk_kernel<64, 1, false, 1 / 2, .., LONG>
-                                  (a wave per pair, one / two diagonals per lane: batches too small to fill the GPU) */
+                                  (a wave per pair, one / two diagonals per lane: batches too small to fill the GPU),
+                                  16 = wfa_blk_kernel<64, 1, false, 1, false, false> (wfahip_align_pair: one launch, forward pass and backtrace) */
     uint32_t ladder_start_level; /* arena level the long-pair ladder of this call started on (0 unless a learned hint applied) */
 } wfahip_timing;
 

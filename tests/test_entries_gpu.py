@@ -155,7 +155,7 @@ def test_align_pair_entry(built):
         for q, t in cases:
             r = al.Align(q, t)
             tm = al.last_timing()
-            fast += tm.n_launches == 1 and tm.main_kernel_kind == 3  # (ONE launch of the blocked kernel: only the fast path does that)
+            fast += tm.n_launches == 1 and tm.main_kernel_kind == 16  # (ONE launch of the lone-pair instance: only the fast path does that)
             want = oa.align(q, t)
             assert (r.Score, r.CIGAR(False), r.QBegin, r.QEnd, r.TBegin, r.TEnd, r.AlignLen, r.Matches, r.Gaps, r.GapRegions) == \
                    (want.score, want.cigar, want.qbegin, want.qend, want.tbegin, want.tend, want.align_len, want.matches, want.gaps,
@@ -165,6 +165,11 @@ def test_align_pair_entry(built):
             assert fast > (len(cases) // 2 if ad else len(cases) // 3), fast
         else:
             assert fast == 0
+        # round 3's fast path (one launch of the four-pairs-per-wave streaming instance, a lane walking the backtrace) is kept
+        al.set_option("pair_fast", 3)
+        for q, t in cases[:40]:
+            r, want = al.Align(q, t), oa.align(q, t)
+            assert (r.Score, r.CIGAR(False), r.QBegin, r.QEnd, r.TBegin, r.TEnd) == (want.score, want.cigar, want.qbegin, want.qend, want.tbegin, want.tend)
         # the same pairs with the fast path switched off: the batch entry alone
         al.set_option("pair_fast", 0)
         for q, t in cases[:40]:

@@ -945,7 +945,25 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
             int      ilo = 0, ihi = -1;  // band to keep (window-relative)
             bool     anyM = false;
             uint32_t csum = 0u;
-            if (!hit_any) {
+            if constexpr (G == 64 && PP == 1) {
+              if (!hit_any) {
+                // A lane per diagonal, lanes in diagonal order: the row's range and the band wf-adaptive keeps are the first /
+                // last set bit of a ballot (scalar code), and the minimum distance is the one real reduction of the step
+                const unsigned long long bm = __ballot(nz[0]);
+                const int  d0   = lmx[0] - (int)nM[0];
+                const int  mind = wave_min(nz[0] ? d0 : BK_BIG);
+                anyM            = bm != 0ull;
+                const int  glo  = anyM ? (int)__builtin_ctzll(bm) : BK_BIG, ghi = anyM ? 63 - (int)__builtin_clzll(bm) : -BK_BIG;
+                const bool want = run && adaptive && anyM && (ghi - glo + 1) >= minwf;
+                const int  thr  = want ? mind + mdd : BK_BIG;
+                const unsigned long long bo = __ballot(nz[0] && d0 <= thr);
+                ilo = bo != 0ull ? (int)__builtin_ctzll(bo) : BK_BIG, ihi = bo != 0ull ? 63 - (int)__builtin_clzll(bo) : -BK_BIG;
+                const bool keep = j >= ilo && j <= ihi;
+                nM[0] = keep ? nM[0] : 0u, nI[0] = keep ? nI[0] : 0u, nD[0] = keep ? nD[0] : 0u;
+                csum += keep ? cc[0] : 0u;
+              }
+            }
+            if (!hit_any && !(G == 64 && PP == 1)) {
                 // No cell of the wave sits at a sequence end (97 % of the steps): every M cell is usable, so the
                 // tight range of M (M.Lo/M.Hi, the wf-adaptive trigger of wfa.go:242) is [first, last usable entry],
                 // and with the threshold at +infinity when wf-adaptive does not run, [first_ok, last_ok] IS the
@@ -979,7 +997,7 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
                     nM[p] = keep ? nM[p] : 0u, nI[p] = keep ? nI[p] : 0u, nD[p] = keep ? nD[p] : 0u;
                     csum += keep ? cc[p] : 0u;  // (the words of deleted cells stay as they are: nothing ever reads them)
                 }
-            } else {
+            } else if (hit_any) {
                 // ------------------------------------------------------------ tight range of the M cells = M.Lo/M.Hi
                 int glo = BK_BIG, ghi = -BK_BIG;  // window-relative index of the lane's first / last M cell
 #pragma unroll
@@ -1179,6 +1197,17 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
         // The queue is exhausted and this wave's pairs are done (the last refill pushed their entries): help with the
         // backtrace of the pairs still in flight elsewhere.
         stream_backtrace(P);
+    }
+    if constexpr (G == 64 && PP == 1 && !LONG) {
+        // wfahip_align_pair: the wave walks the backtrace of the pairs of its launch itself -- one launch for the whole Align.
+        // The sequences in LDS are dead by now: their place is the walk's arena region (the host reserves 4 KB).  The arena
+        // rows were stored by this very wave; the release / acquire pair makes them its loads' too.
+        if (P.fuse_bt) {
+            __threadfence();
+            for (uint32_t idx = blockIdx.x; idx < P.chunk_n; idx += gridDim.x) backtrace_wave_one(P, idx, lds);
+            // (one wave, one pair: the control words go back to zero here, so the next Align starts without a memset of its own)
+            if (lane == 0 && gridDim.x == 1u) *P.queue_head = 0u, *P.redo_count = 0u, *P.ops_cursor = 0ull;
+        }
     }
 }
 

@@ -100,6 +100,8 @@ struct KParams {
     uint32_t  wave_rows;             // wfa_generic_kernel: rows of its wave mode's LDS ring (a power of two), 0 = wave mode off
     uint32_t  wave_bt;               // wfa_generic_kernel: 1 = the LDS directory window exists (backtrace walked by a wave)
     uint32_t  census;                // sub-wave forward kernels: report the number of stored wavefront words (REC_CELLS), else 0
+    uint32_t  fuse_bt;               // wfa_blk_kernel<64, 1, false, 1> (one pair, wfahip_align_pair): 1 = the wave walks its pair's backtrace itself when
+                                     // the pair queue is empty (one launch for the whole Align)
     uint32_t  compact_fmt;           // compact arena layout (CompactView): 0 = rows + directory; no directory: 1 = 64 words
                                      // per score, diagonal k at slot k & 63; 3 = tiles of 8 scores x 64 diagonals;
                                      // 4 = 256 words per score, slot k & 255; 5 = 32 words per score, slot k & 31

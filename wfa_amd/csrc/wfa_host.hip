@@ -103,11 +103,13 @@ struct wfahip_ctx {
     uint32_t     *pack_pin   = nullptr;      // host entry: page-locked home of the 2-bit words it packs itself, slice by slice
     size_t        pack_pin_bytes = 0;
     int64_t       opt_autopack             = 1;   // 1: wfahip_align_batch 2-bit packs large pure-ACGT batches on host threads while earlier slices upload
+    bool          one_ctl_clean = false;     // ... whose control words the last call's kernel left zeroed
     DevBuf        one_ctl;                   // ... and its control words: queue head / redo count / ops cursor, then the done queue of the streamed backtrace
     int64_t       opt_arena_budget_pct     = 60;  // long-pair ladder: percent of device memory its arenas may take (80 / 85 / 90: five or six slots
                                                   // instead of four for the configs[4] pairs -- the main launch of 32 pairs 2 875 -> 1 949 / 2 074 / 1 744 ms --
                                                   // but 2 / 1 / 3 of them then outgrow the smaller slots and their re-run takes 1.1 s: no gain, measured)
-    int64_t       opt_pair_fast            = 1;   // 1: wfahip_align_pair uses its two-launch path when the pair allows it
+    int64_t       opt_pair_fast            = 1;   // wfahip_align_pair, when the pair allows it: 1 = one launch of the lone-pair instance (a lane per diagonal, the wave walks its
+                                                  // own backtrace); 3 = round 3's one launch of the four-pairs-per-wave streaming instance; 2 = that kernel + the backtrace kernel; 0 = the batch entry
     DevBuf        in_packed;                 // host entry with pre-packed input: the 2-bit words as uploaded (unpacked into in_blob on the device)
     // wfahip_submit / wfahip_collect: pairs handed in one at a time, aligned as one batch
     std::vector<uint8_t>  sub_blob;
@@ -2371,7 +2373,7 @@ static int align_pair_impl(wfahip_ctx *ctx, const wfahip_params *p, const uint8_
     const uint64_t ops_bound = 2 * (worst / std::max(1u, min_xe)) + 64;
     const bool fast = ctx->opt_pair_fast != 0 && ctx->opt_packed != 0 && ctx->opt_blk == 16 && ctx->force_mode < 0 && p->global_alignment &&
                       p->gap_ext != 0 && p->mismatch / g == 2 && (p->gap_open + p->gap_ext) / g == 4 && p->gap_ext / g == 1 &&
-                      (size_t)seq_words * 2 * 4 * 4 + 16 <= 20 * 1024 && img <= ONE_IMG_MAX &&
+                      (size_t)seq_words * 2 * 4 * (ctx->opt_pair_fast == 1 ? 1 : 4) + 16 <= (ctx->opt_pair_fast == 1 ? 64 : 20) * 1024 && img <= ONE_IMG_MAX &&
                       ONE_OPS_OFF + ops_bound * 8 <= ONE_PIN_BYTES;
     if (fast) {
         HIP_TRY(hipSetDevice(ctx->device));
@@ -2415,10 +2417,19 @@ static int align_pair_impl(wfahip_ctx *ctx, const wfahip_params *p, const uint8_
         P.pair_meta = static_cast<uint4 *>(ctx->meta.p);
         P.dx = 2, P.doe = 4, P.de = 1, P.dm = 5, P.di = 2, P.min_xe = min_xe;
         P.lds_seq_words = seq_words, P.chunk_first = 0, P.chunk_n = 1, P.n_work = 1;
-        HIP_TRY(hipMemsetAsync(d_ctrl, 0, 1024, st));
+        // (the lone-pair instance leaves its control words zeroed: only the first call, or one after another path, clears them)
+        if (!(ctx->opt_pair_fast == 1 && ctx->one_ctl_clean)) HIP_TRY(hipMemsetAsync(d_ctrl, 0, 1024, st));
+        ctx->one_ctl_clean = false;
         if (ctx->opt_pair_fast == 2) {  // forward kernel, then the backtrace kernel (kept for comparison: 305 us per 1 kbp pair)
             hipLaunchKernelGGL((wfa_blk_kernel<16, 1, false, 0, false>), dim3(1), dim3(64), (size_t)seq_words * 2 * 4 * 4 + 16, st, P);
             hipLaunchKernelGGL(wfa_backtrace_kernel, dim3(1), dim3(256), 0, st, P);
+        } else if (ctx->opt_pair_fast == 1) {
+            // Round 4, ONE launch of the lone-pair instance: the whole wave on the pair, a lane per diagonal (a quarter of the
+            // instructions of a step of the four-pairs-per-wave kernel -- a lone wave's step is the latency of its own instruction
+            // stream), and the same wave walks the backtrace from an LDS region of the arena when the forward pass is done.
+            P.fuse_bt = 1;
+            hipLaunchKernelGGL((wfa_blk_kernel<64, 1, false, 1, false, false>), dim3(1), dim3(64),
+                               std::max<size_t>((size_t)seq_words * 2 * 4 + 16, 4096 + 16), st, P);
         } else {
             // ONE launch: the streaming instance of the forward kernel -- the wave pushes its finished pair to the done
             // queue and, once the pair queue is empty, walks it itself (stream_backtrace at the end of the kernel): one
@@ -2431,8 +2442,9 @@ static int align_pair_impl(wfahip_ctx *ctx, const wfahip_params *p, const uint8_
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(st));
+        ctx->one_ctl_clean = ctx->opt_pair_fast == 1;
         ctx->timing = wfahip_timing{};
-        ctx->timing.n_launches = ctx->opt_pair_fast == 2 ? 2 : 1, ctx->timing.main_kernel_kind = 3;  // (the batch entry never makes fewer than two launches)
+        ctx->timing.n_launches = ctx->opt_pair_fast == 2 ? 2 : 1, ctx->timing.main_kernel_kind = ctx->opt_pair_fast == 1 ? 16 : 3;  // (the batch entry never makes fewer than two launches)
         if (hrec[REC_STATUS] == ST_OK) {
             const uint64_t off = (uint64_t)hrec[REC_OPS_OFF_LO] | ((uint64_t)hrec[REC_OPS_OFF_HI] << 32);
             const uint32_t len = hrec[REC_OPS_LEN];

@@ -340,6 +340,45 @@ WFA_DEV void backtrace_one(const KParams &P, uint32_t idx, uint32_t s_final, uin
 // The ops regions of a workgroup's pairs are carved with ONE atomic: every wave adding its own total to the one cursor
 // serialized 1 563 waves of 1e5 short pairs at the L2 -- 20 of the kernel's 41 us went to waiting for that atomic's return.
 constexpr int BT_THREADS = 512;
+// One finished pair walked by the 64 lanes of a wave together (idx: its index in the chunk; region: 1 024 words of LDS).
+WFA_DEV void backtrace_wave_one(const KParams &P, uint32_t idx, uint32_t *region) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint4    meta = P.pair_meta[idx];
+    const uint32_t pair = P.work ? P.work[idx] : P.chunk_first + idx;
+    uint4 *const   r4   = reinterpret_cast<uint4 *>(P.rec + (uint64_t)pair * REC_WORDS);
+    if (meta.x != ST_OK) {
+        if (meta.x < ST_REDO_BYTES && lane == 0u) {  // (a pair that was handed on gets its record from the pass that finishes it)
+            const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+            r4[0] = make_uint4(meta.x, 0u, 0u, 0u), r4[1] = z, r4[2] = z, r4[3] = z;
+        }
+        return;
+    }
+    const uint32_t s_final = meta.y, h_end = meta.z, cells = meta.w;
+    const int      n = (int)P.q_len[pair], m = (int)P.t_len[pair];
+    const uint32_t bound = ops_bound(P, s_final);
+    unsigned long long off = 0ull;
+    if (lane == 0u) off = atomicAdd(P.ops_cursor, (unsigned long long)bound);
+    off = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(off >> 32)) << 32) |
+          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)off);
+    CompactViewWave cv;
+    cv.A = P.arena + (uint64_t)idx * P.arena_words, cv.cap = P.arena_words, cv.g = P.g, cv.n_ent = s_final / P.g + 1u;
+    cv.fmt = P.compact_fmt, cv.reg = region;
+    OpsWriterRev ow;
+    const bool   fits = off + bound <= P.ops_cap;
+    ow.init(P.ops + off, fits ? bound : 0u);
+    ow.active = lane == 0u;
+    TraceOut to;
+    back_trace_compact(cv, n, m, s_final, m - n, h_end, P.x, P.o, P.e, ow, to);
+    ow.finish();
+    if (lane == 0u) {
+        const uint64_t first = off + bound - ow.n;
+        r4[0] = make_uint4(ST_OK, to.score, (uint32_t)to.tbegin, (uint32_t)to.tend);
+        r4[1] = make_uint4((uint32_t)to.qbegin, (uint32_t)to.qend, ow.alen, ow.matches);
+        r4[2] = make_uint4(ow.gaps, ow.regions, ow.n, (uint32_t)first);
+        r4[3] = make_uint4((uint32_t)(first >> 32), cells, 0u, s_final);
+    }
+}
+
 #ifndef WFA_NO_AUX_KERNELS
 __global__ __launch_bounds__(BT_THREADS) void wfa_backtrace_kernel(const KParams P) {
     __shared__ uint32_t           wsum[BT_THREADS / 64];
@@ -385,49 +424,17 @@ __global__ __launch_bounds__(BT_THREADS) void wfa_backtrace_kernel(const KParams
 }
 
 
-// The same for LONG pairs (round 4: the sliding-window instances of wfa_blk_kernel): a WAVE per pair.  All 64 lanes run the
-// walk on the same values, the arena cells come from an LDS region the wave loads together (CompactViewWave), lane 0
-// stores the CIGAR ops and the record.  500 x 50 kbp pairs: ~4 500 ops each.
+// The same for LONG pairs (round 4: the sliding-window instances of wfa_blk_kernel) and for the one pair of
+// wfahip_align_pair: a WAVE per pair.  All 64 lanes run the walk on the same values, the arena cells come from an LDS
+// region the wave loads together (CompactViewWave), lane 0 stores the CIGAR ops and the record.  500 x 50 kbp pairs:
+// ~4 500 ops each.
 constexpr int BTW_WAVES = 4;
 __global__ __launch_bounds__(64 * BTW_WAVES) void wfa_backtrace_wave_kernel(const KParams P) {
     __shared__ __attribute__((aligned(16))) uint32_t region[BTW_WAVES][1024];
-    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t wv  = threadIdx.x >> 6;
     const uint32_t idx = blockIdx.x * (uint32_t)BTW_WAVES + wv;
     if (idx >= P.chunk_n) return;
-    const uint4    meta = P.pair_meta[idx];
-    const uint32_t pair = P.work ? P.work[idx] : P.chunk_first + idx;
-    uint4 *const   r4   = reinterpret_cast<uint4 *>(P.rec + (uint64_t)pair * REC_WORDS);
-    if (meta.x != ST_OK) {
-        if (meta.x < ST_REDO_BYTES && lane == 0u) {  // (a pair that was handed on gets its record from the pass that finishes it)
-            const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-            r4[0] = make_uint4(meta.x, 0u, 0u, 0u), r4[1] = z, r4[2] = z, r4[3] = z;
-        }
-        return;
-    }
-    const uint32_t s_final = meta.y, h_end = meta.z, cells = meta.w;
-    const int      n = (int)P.q_len[pair], m = (int)P.t_len[pair];
-    const uint32_t bound = ops_bound(P, s_final);
-    unsigned long long off = 0ull;
-    if (lane == 0u) off = atomicAdd(P.ops_cursor, (unsigned long long)bound);
-    off = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(off >> 32)) << 32) |
-          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)off);
-    CompactViewWave cv;
-    cv.A = P.arena + (uint64_t)idx * P.arena_words, cv.cap = P.arena_words, cv.g = P.g, cv.n_ent = s_final / P.g + 1u;
-    cv.fmt = P.compact_fmt, cv.reg = region[wv];
-    OpsWriterRev ow;
-    const bool   fits = off + bound <= P.ops_cap;
-    ow.init(P.ops + off, fits ? bound : 0u);
-    ow.active = lane == 0u;
-    TraceOut to;
-    back_trace_compact(cv, n, m, s_final, m - n, h_end, P.x, P.o, P.e, ow, to);
-    ow.finish();
-    if (lane == 0u) {
-        const uint64_t first = off + bound - ow.n;
-        r4[0] = make_uint4(ST_OK, to.score, (uint32_t)to.tbegin, (uint32_t)to.tend);
-        r4[1] = make_uint4((uint32_t)to.qbegin, (uint32_t)to.qend, ow.alen, ow.matches);
-        r4[2] = make_uint4(ow.gaps, ow.regions, ow.n, (uint32_t)first);
-        r4[3] = make_uint4((uint32_t)(first >> 32), cells, 0u, s_final);
-    }
+    backtrace_wave_one(P, idx, region[wv]);
 }
 #endif  // WFA_NO_AUX_KERNELS
 
