@@ -380,9 +380,14 @@ def test_mid_length_global(built, length, err, n):
     data = w.generate_pairs(seed=length, n_pairs=n, length=length, error_rate=err, n_threads=8)
     for ad in ((10, 50, 1), None):
         al = _aligner(True, ad)
-        got = al.align_arrays(*data)
-        assert al.last_timing().main_kernel_kind == 3
-        assert_batch_equal(got, O.align_batch(_oracle_params(True, ad), *data, n_threads=8), f"L={length} ad={ad}")
+        want = O.align_batch(_oracle_params(True, ad), *data, n_threads=8)
+        # (round 4: reads beyond 4 000 bases start on the sliding-window instances -- a batch this small with a wave per pair;
+        # option long = 0 keeps them on the whole-sequence instance this test was written for)
+        for long_opt in (1, 0):
+            al.set_option("long", long_opt)
+            got = al.align_arrays(*data)
+            assert al.last_timing().main_kernel_kind == (15 if long_opt and length >= 4000 else 3)
+            assert_batch_equal(got, want, f"L={length} ad={ad} long={long_opt}")
         al.close()
 
 
@@ -397,6 +402,7 @@ def test_streamed_backtrace_mid_length(built, wait_us, chunk_pairs):
     data = w.generate_pairs(seed=44, n_pairs=3000, length=4000, error_rate=0.04, n_threads=8)
     want = O.align_batch(_oracle_params(True, (10, 50, 1)), *data, n_threads=8)
     al = _aligner(True, (10, 50, 1))
+    al.set_option("long", 0)  # (the whole-sequence instance: the streamed backtrace is its)
     al.set_option("bt_stream_min", 1)
     al.set_option("bt_stream_single", 1)
     al.set_option("bt_stream_wait_us", wait_us)

@@ -945,25 +945,39 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
             int      ilo = 0, ihi = -1;  // band to keep (window-relative)
             bool     anyM = false;
             uint32_t csum = 0u;
-            if constexpr (G == 64 && PP == 1) {
+            if constexpr (G == 64 && PP <= 2) {
               if (!hit_any) {
-                // A lane per diagonal, lanes in diagonal order: the row's range and the band wf-adaptive keeps are the first /
-                // last set bit of a ballot (scalar code), and the minimum distance is the one real reduction of the step
-                const unsigned long long bm = __ballot(nz[0]);
-                const int  d0   = lmx[0] - (int)nM[0];
-                const int  mind = wave_min(nz[0] ? d0 : BK_BIG);
-                anyM            = bm != 0ull;
-                const int  glo  = anyM ? (int)__builtin_ctzll(bm) : BK_BIG, ghi = anyM ? 63 - (int)__builtin_clzll(bm) : -BK_BIG;
+                // One or two diagonals per lane, lanes in diagonal order: the row's range and the band wf-adaptive keeps are the
+                // first / last set bits of ballots (scalar code); the minimum distance is the one real reduction of the step
+                int d[PP], dmin = BK_BIG;
+#pragma unroll
+                for (int p = 0; p < PP; p++) d[p] = lmx[p] - (int)nM[p], dmin = nz[p] ? imin2(dmin, d[p]) : dmin;
+                const int mind = wave_min(dmin);
+                int       glo = BK_BIG, ghi = -BK_BIG;
+#pragma unroll
+                for (int p = 0; p < PP; p++) {
+                    const unsigned long long bm = __ballot(nz[p]);
+                    if (bm != 0ull) glo = imin2(glo, PP * (int)__builtin_ctzll(bm) + p), ghi = imax2(ghi, PP * (63 - (int)__builtin_clzll(bm)) + p);
+                }
+                anyM            = ghi >= 0;
                 const bool want = run && adaptive && anyM && (ghi - glo + 1) >= minwf;
                 const int  thr  = want ? mind + mdd : BK_BIG;
-                const unsigned long long bo = __ballot(nz[0] && d0 <= thr);
-                ilo = bo != 0ull ? (int)__builtin_ctzll(bo) : BK_BIG, ihi = bo != 0ull ? 63 - (int)__builtin_clzll(bo) : -BK_BIG;
-                const bool keep = j >= ilo && j <= ihi;
-                nM[0] = keep ? nM[0] : 0u, nI[0] = keep ? nI[0] : 0u, nD[0] = keep ? nD[0] : 0u;
-                csum += keep ? cc[0] : 0u;
+                ilo = BK_BIG, ihi = -BK_BIG;
+#pragma unroll
+                for (int p = 0; p < PP; p++) {
+                    const unsigned long long bo = __ballot(nz[p] && d[p] <= thr);
+                    if (bo != 0ull) ilo = imin2(ilo, PP * (int)__builtin_ctzll(bo) + p), ihi = imax2(ihi, PP * (63 - (int)__builtin_clzll(bo)) + p);
+                }
+#pragma unroll
+                for (int p = 0; p < PP; p++) {
+                    const int  ix   = PP * j + p;
+                    const bool keep = ix >= ilo && ix <= ihi;
+                    nM[p] = keep ? nM[p] : 0u, nI[p] = keep ? nI[p] : 0u, nD[p] = keep ? nD[p] : 0u;
+                    csum += keep ? cc[p] : 0u;
+                }
               }
             }
-            if (!hit_any && !(G == 64 && PP == 1)) {
+            if (!hit_any && !(G == 64 && PP <= 2)) {
                 // No cell of the wave sits at a sequence end (97 % of the steps): every M cell is usable, so the
                 // tight range of M (M.Lo/M.Hi, the wf-adaptive trigger of wfa.go:242) is [first, last usable entry],
                 // and with the threshold at +infinity when wf-adaptive does not run, [first_ok, last_ok] IS the

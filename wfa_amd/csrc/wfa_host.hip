@@ -693,7 +693,9 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
         uint32_t           sub_len       = max_len;
         // long reads: the blocked kernels with sliding sequence windows (kinds 11 / 12 / 13 = 64 / 128 / 256 diagonals)
         const bool can_long = ctx->opt_long != 0 && ctx->opt_blk == 16 && dx == 2 && doe == 4 && de == 1 && (int64_t)max_len > ctx->opt_long_min_len;
-        if (max_len > SUB_LEN_LIMIT && n_pairs >= 256 && !can_long) {
+        // (a batch of mostly short pairs with a few long ones keeps the short pairs' pipeline -- slots, arenas and windows of the
+        // long instances are sized by the longest pair -- and the long ones get a pass of their own behind it: long_first below)
+        if (max_len > SUB_LEN_LIMIT && n_pairs >= 256) {
             std::vector<uint32_t> ql(n_pairs), tl(n_pairs);
             HIP_TRY(hipMemcpyAsync(ql.data(), d_q_len, n_pairs * 4, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipMemcpyAsync(tl.data(), d_t_len, n_pairs * 4, hipMemcpyDeviceToHost, st));
@@ -711,19 +713,25 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             else
                 h_len.clear();
         }
+        const bool     long_first = can_long && sub_len_used == 0;  // the whole batch starts on the sliding-window instances
         const uint32_t seq_words = (sub_len + 15) / 16 + 1;
         const uint64_t sub_words = packed_sub_lds_words(seq_words, dm, di);
+        // what forward_pass sizes slots and arenas by: the class of pairs it is given (the batch's; the long pairs' in their own pass)
+        uint32_t fp_seq_words = seq_words;
         const size_t   lds_b     = (size_t)sub_words * 2 * 4;       // packed kernel: two halves
         const size_t   lds_c     = (size_t)seq_words * 2 * 4 * 4;   // register kernel: four rows, sequences only
         const size_t   lds_d     = (size_t)seq_words * 2 * 4 * (ctx->opt_blk == 8 ? 8 : 4) + 16;  // blocked kernel
         const bool     can_b     = lds_b <= 20 * 1024;
         const bool     can_c     = ctx->opt_reg && dx == 2 && doe == 4 && de == 1 && lds_c <= 20 * 1024;
-        const bool     can_d     = can_long || (ctx->opt_blk && dx == 2 && doe == 4 && de == 1 && sub_len < 32768 &&
-                                              lds_d <= (ctx->opt_blk == 8 ? 40 : 20) * 1024);
-        uint64_t       words_dir = std::max<uint64_t>(1024, 8ull * sub_len);  // compact rows: 1 word per diagonal
-        if (ctx->opt_packed_arena_bytes > 0) words_dir = std::max<uint64_t>(1024, ctx->opt_packed_arena_bytes / 4);
-        words_dir = (words_dir + 7) & ~7ull;
-        P.arena_words   = words_dir;
+        const bool     can_d     = long_first || (ctx->opt_blk && dx == 2 && doe == 4 && de == 1 && sub_len < 32768 &&
+                                                lds_d <= (ctx->opt_blk == 8 ? 40 : 20) * 1024);
+        const auto words_dir_of = [&](uint32_t len) {
+            uint64_t wd = std::max<uint64_t>(1024, 8ull * len);  // compact rows: 1 word per diagonal
+            if (ctx->opt_packed_arena_bytes > 0) wd = std::max<uint64_t>(1024, ctx->opt_packed_arena_bytes / 4);
+            return (wd + 7) & ~7ull;
+        };
+        uint64_t fp_words_dir = words_dir_of(sub_len);
+        P.arena_words   = fp_words_dir;
         P.dx = dx, P.doe = doe, P.de = de, P.dm = dm, P.di = di;
         P.lds_seq_words = seq_words;
         P.sub_lds_words = (uint32_t)sub_words;
@@ -751,6 +759,8 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             // (retry passes take the second pair of buffers: the first pass's backtrace may still be reading the first -- and
             // wfahip_debug_compact_arena shows what the first pass left.  Unless the first pair is large and free: two large
             // arenas side by side are for overlap, not for a snapshot)
+            const uint32_t seq_words = fp_seq_words;  // (shadow the batch's: this pass's class of pairs)
+            const uint64_t words_dir = fp_words_dir;
             const bool second = ctx->bt_pending || (list && ctx->arena.bytes <= ctx->total_mem / 10);
             DevBuf &arena_buf = second ? ctx->arena2 : ctx->arena;
             DevBuf &meta_buf  = second ? ctx->meta2 : ctx->meta;
@@ -770,6 +780,7 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             const bool     is_long      = kind >= 11 && kind <= 15;
             const uint32_t long_sw      = (seq_words + 3u) & ~3u, long_cw = (uint32_t)ctx->opt_long_window_words;
             if (is_long && !can_long) return WFAHIP_ERR_INTERNAL;
+            if (is_long && (uint64_t)seq_words * 16u < (uint64_t)max_len && !list) return WFAHIP_ERR_INTERNAL;  // (slots sized for the short class)
             const int      bkind        = (kind == 11 || kind == 14) ? 3 : (kind == 12 || kind == 15) ? 9 : kind == 13 ? 5 : kind;  // (arena format)
             const size_t   lds_bytes    = is_long ? (size_t)(kind == 11 ? 4 : kind == 12 ? 2 : 1) * 2 * long_cw * 4
                                           : kind == 10 ? (size_t)64 * lane_stride_words(lane_sw) * 4
@@ -998,9 +1009,9 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             // short reads (at most 240 bases): a lane per pair
             const bool lane1   = can_d && ctx->opt_blk == 16 && seq_words <= (uint32_t)LN_SEQ_WORDS &&
                                  (ctx->opt_lane >= 2 || (ctx->opt_lane == 1 && (int64_t)n_pairs >= ctx->opt_lane_min_pairs));
-            const int  kind1   = can_long ? 11 : (duo1 && duo_short) ? 8 : lane1 ? 10 : duo1 ? 8 : narrow1 ? 6 : (can_d ? (ctx->opt_blk == 8 ? 4 : 3) : (can_c ? 2 : 1));
+            const int  kind1   = long_first ? 11 : (duo1 && duo_short) ? 8 : lane1 ? 10 : duo1 ? 8 : narrow1 ? 6 : (can_d ? (ctx->opt_blk == 8 ? 4 : 3) : (can_c ? 2 : 1));
             // the rungs above the 64-diagonal first pass: 128 and 256 diagonals (long reads: the same with sliding sequence windows)
-            const int  kind_mid = can_long ? 12 : 9, kind_wide = can_long ? 13 : 5, kind_64 = can_long ? 11 : 3;
+            const int  kind_mid = long_first ? 12 : 9, kind_wide = long_first ? 13 : 5, kind_64 = long_first ? 11 : 3;
             // Pilot: on a large batch with wf-adaptive off the first 4 096 pairs go first.  When most of them leave the
             // 64-diagonal window the rest does not start there only to be handed on: it goes straight to the
             // wave-per-pair kernel (256 diagonals) if that one takes most of the pilot's leftovers, else to the
@@ -1067,7 +1078,7 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             // Long reads in batches too small to fill the GPU start on the wider windows: 500 pairs are 500 waves of one pair each
             // (a wave alone on its SIMD steps in the same ~1.5 us whether it holds one pair or four), and nothing is handed on for
             // its band -- a fifth of 50 kbp pairs at 5 % error leave a 64-diagonal window at some score
-            if (can_long && done_pairs == 0 && kind_rest == 11 && wide_ok) {
+            if (long_first && done_pairs == 0 && kind_rest == 11 && wide_ok) {
                 const uint64_t simds = (uint64_t)ctx->num_cus * 4;
                 if (ctx->opt_long_first >= 11 && ctx->opt_long_first <= 15) kind_rest = (int)ctx->opt_long_first;
                 else if (n_pairs <= simds) kind_rest = 15;  // (a wave per pair, two diagonals per lane: 128 diagonals at half the instructions of a step)
@@ -1110,6 +1121,35 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             ctx->timing.main_kernel_kind = (uint32_t)kind_rest;
             ctx->timing.n_packed_pairs += (uint32_t)(done_pairs - n_first_fail);
             ctx->timing.n_retried_pairs += (uint32_t)n_first_fail;
+            // Mixed lengths: the long pairs the short pairs' kernels handed on for their length (ST_REDO_LDS) take the
+            // sliding-window instances now -- slots, windows and arenas sized for the batch's longest pair -- by their number:
+            // a wave per pair up to one per SIMD; what leaves its band there tries 256 diagonals; the rest goes down the ladder
+            if (can_long && sub_len_used != 0) {
+                std::vector<uint32_t> lst;
+                std::vector<uint64_t> keep, r2;
+                for (uint64_t e : redo1) ((uint32_t)(e >> 32) == ST_REDO_LDS ? (void)lst.push_back((uint32_t)e) : (void)keep.push_back(e));
+                if (!lst.empty()) {
+                    std::sort(lst.begin(), lst.end());
+                    const uint32_t keep_sw = fp_seq_words;
+                    const uint64_t keep_wd = fp_words_dir, simds = (uint64_t)ctx->num_cus * 4;
+                    fp_seq_words = (max_len + 15) / 16 + 1, fp_words_dir = words_dir_of(max_len);
+                    const int kl = lst.size() <= simds ? 15 : lst.size() <= 4 * simds ? 12 : 11;
+                    rc = forward_pass(kl, &lst, 0, lst.size(), r2, false);
+                    if (rc == WFAHIP_OK) {
+                        ctx->timing.n_packed_pairs += (uint32_t)(lst.size() - r2.size());
+                        lst.clear();
+                        for (uint64_t e : r2) ((uint32_t)(e >> 32) == ST_REDO_BAND ? (void)lst.push_back((uint32_t)e) : (void)keep.push_back(e));
+                        r2.clear();
+                        if (!lst.empty() && (rc = forward_pass(13, &lst, 0, lst.size(), r2, false)) == WFAHIP_OK) {
+                            ctx->timing.n_packed_pairs += (uint32_t)(lst.size() - r2.size());
+                            keep.insert(keep.end(), r2.begin(), r2.end());
+                        }
+                    }
+                    fp_seq_words = keep_sw, fp_words_dir = keep_wd;
+                    if (rc) return rc;
+                    redo1.swap(keep);
+                }
+            }
             Job jb, ja;
             jb.mode = 1, jb.level = 0, jb.all = false;
             ja.mode = 0, ja.level = 0, ja.all = false;
