@@ -6,9 +6,10 @@ pairs at 5 % error per GPU, global alignment, wf-adaptive 10/50/1, penalties 4/6
 the hot path over the rank's batch: raw byte sequences already resident in HBM -> result records + CIGAR ops in HBM.
 
 Other workloads of BASELINE.json, each printing its own JSON line:
-  --config c2    configs[1]: 1e5 x 150 bp @2 %, global, wf-adaptive off, seed 2
+  --config c2    configs[1]: 1e5 x 150 bp @2 %, global, wf-adaptive off, seed 2   (c2m: the same pairs, 1e6 of them)
   --config c4    configs[3]: 1e7 x 1 kbp @5 % IN TOTAL (strong scaling: --total-pairs 10000000), seed 4
   --config c5s   configs[4] sample: 8 x 100 kbp @10 %, semi-global, wf-adaptive 10/50/1, seed 5
+  --config k10 | k20 | l5 | l10 | l20   the reference's published grid (1e5 x 1 kbp, 500 x 50 kbp); L5: 2e4 x 50 kbp
 
 Multi-GPU: one rank per GPU, pairs sharded over ranks, no data-path collective; the only RCCL traffic is the gather of
 the result records (44 bytes per pair) onto rank 0 after every step (--gather-ops ships the CIGAR op arrays too).
@@ -37,6 +38,8 @@ CONFIGS = {
     # name: (pairs, length, error, seed, semi_global, adaptive, total_pairs, cpu_sample)
     "c3": dict(pairs=1_000_000, length=1000, error=0.05, seed=3, semi_global=False, adaptive=True, total=0, cpu=150_000),
     "c2": dict(pairs=100_000, length=150, error=0.02, seed=2, semi_global=False, adaptive=False, total=0, cpu=100_000),
+    # configs[1]'s pairs in a number that fills the GPU (1e5 pairs are less than one pair per lane slot of the chip)
+    "c2m": dict(pairs=1_000_000, length=150, error=0.02, seed=2, semi_global=False, adaptive=False, total=0, cpu=300_000),
     "c4": dict(pairs=0, length=1000, error=0.05, seed=4, semi_global=False, adaptive=True, total=10_000_000, cpu=150_000),
     "c5s": dict(pairs=8, length=100_000, error=0.10, seed=5, semi_global=True, adaptive=True, total=0, cpu=8),
     # the reference's own published grid beyond the headline row (README.md:326-345 = benchmark.tsv:4-19: wfa-go -N -i,
@@ -50,7 +53,7 @@ CONFIGS = {
     "l20": dict(pairs=500, length=50_000, error=0.20, seed=520, semi_global=False, adaptive=True, total=0, cpu=120),
 }
 # steps of the default run: timed regions of a few seconds
-DEFAULT_STEPS = {"c3": 250, "c2": 10000, "c4": 25, "c5s": 4, "k10": 400, "k20": 150, "l5": 150, "L5": 20, "l10": 60, "l20": 25}
+DEFAULT_STEPS = {"c3": 250, "c2": 10000, "c2m": 2000, "c4": 25, "c5s": 4, "k10": 400, "k20": 150, "l5": 150, "L5": 20, "l10": 60, "l20": 25}
 
 
 def parse_args(argv=None):

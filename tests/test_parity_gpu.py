@@ -1480,3 +1480,24 @@ def test_long_window_kernel_batch(built):
     assert al.last_timing().main_kernel_kind != 11
     assert_batch_equal(plain, want, "long = 0")
     al.close()
+
+
+@pytest.mark.parametrize("opts", [{}, {"mem_limit": 4 << 30}, {"team_xcd": 2}, {"team_xcd": 1}, {"team_paged": 0}])
+def test_team_kernel_paged_arena(built, opts):
+    """The team kernel with its arena as ONE pool of pages shared by up to eight teams (round 4): ten 20 kbp semi-global
+    pairs (wide seeded wavefronts, then wave mode) through more teams than the four slots of old, over a poisoned pool;
+    on a device made to look small (mem_limit: the pool runs dry, pairs are handed on and re-run with fewer teams); with the
+    XCD-local protocol; and with one slot per team as before.  Every field and op against the oracle, twice."""
+    import wfa_amd as w
+    from oracle import oracle as O
+    data = w.generate_pairs(seed=77, n_pairs=10, length=20000, error_rate=0.10)
+    want = O.align_batch(_oracle_params(False, (10, 50, 1)), *data, n_threads=8)
+    al = _aligner(False, (10, 50, 1))
+    al.set_option("arena_poison", 1)
+    for k, v in opts.items():
+        al.set_option(k, v)
+    for rep in range(2):
+        got = al.align_arrays(*data)
+        assert al.last_timing().main_kernel_kind == 7  # wfa_team_kernel
+        assert_batch_equal(got, want, f"paged arena {opts} pass {rep}")
+    al.close()

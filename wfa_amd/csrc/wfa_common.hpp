@@ -100,6 +100,13 @@ struct KParams {
     uint32_t  wave_rows;             // wfa_generic_kernel: rows of its wave mode's LDS ring (a power of two), 0 = wave mode off
     uint32_t  wave_bt;               // wfa_generic_kernel: 1 = the LDS directory window exists (backtrace walked by a wave)
     uint32_t  census;                // sub-wave forward kernels: report the number of stored wavefront words (REC_CELLS), else 0
+    // wfa_team_kernel, paged arena (round 4): the teams share ONE pool of pages instead of owning a slot each -- a 100 kbp
+    // semi-global pair takes anything from 0.2 to 43 GB, and slots sized for the worst pair left room for four teams.
+    // page_ctl: [0] lock [1] free pages [2 ..] stack of free page ids, then per team a list of the pages its pair holds;
+    // nullptr = one slot of arena_words per team.  The directories live at the end of the pool, dir_region_words per team.
+    uint32_t *page_ctl;
+    uint32_t  page_words_log2, n_pages;
+    uint64_t  dir_region_words;
     uint32_t  fuse_bt;               // wfa_blk_kernel<64, 1, false, 1> (one pair, wfahip_align_pair): 1 = the wave walks its pair's backtrace itself when
                                      // the pair queue is empty (one launch for the whole Align)
     uint32_t  compact_fmt;           // compact arena layout (CompactView): 0 = rows + directory; no directory: 1 = 64 words

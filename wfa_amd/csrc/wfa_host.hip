@@ -140,6 +140,8 @@ struct wfahip_ctx {
     int64_t       opt_team_solo_max        = TEAM_SOLO_MAX;  // rows up to this width are done by one workgroup
     int64_t       opt_team_wave            = 1;              // rows up to 64 diagonals are done by one wave (LDS ring)
     int64_t       opt_team_strict          = 1;              // agent-scope release in every team barrier (0: see wfa_team.hpp)
+    int64_t       opt_team_paged           = 1;              // 1: the teams share one pool of arena pages (a pair holds what it needs) instead of a slot each
+    DevBuf        page_ctl;                                  // ... its free-page stack and the page lists of the teams
     int64_t       opt_team_xcd             = 1;              // 1: teams of one XCD's CUs (blockIdx % 8); 2: ... and a team that finds itself on one XCD keeps its
                                                              // rows in that XCD's L2 (plain stores, no release in its barriers: measured 1.5 %, off)
     int64_t       opt_arena_poison         = 0;              // tests: fill the arena with a pattern before every long-pair launch
@@ -408,7 +410,7 @@ extern "C" void wfahip_destroy(wfahip_ctx *ctx) {
         if (ctx->pin_ev[i]) (void)hipEventDestroy(ctx->pin_ev[i]);
     }
     for (DevBuf *b : {&ctx->arena, &ctx->fin, &ctx->team_ctl, &ctx->arena2, &ctx->meta2, &ctx->doneq, &ctx->ctrl, &ctx->redo, &ctx->work, &ctx->meta, &ctx->in_blob, &ctx->in_qoff, &ctx->in_qlen,
-                      &ctx->in_toff, &ctx->in_tlen, &ctx->out_rec, &ctx->out_ops, &ctx->in_packed, &ctx->in_small, &ctx->prepack, &ctx->one_ctl})
+                      &ctx->in_toff, &ctx->in_tlen, &ctx->out_rec, &ctx->out_ops, &ctx->in_packed, &ctx->in_small, &ctx->prepack, &ctx->one_ctl, &ctx->page_ctl})
         release(*b);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -477,6 +479,8 @@ static int set_option_impl(wfahip_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_team_strict = value;
     else if (k == "team_xcd")
         ctx->opt_team_xcd = value;
+    else if (k == "team_paged")
+        ctx->opt_team_paged = value;
     else if (k == "arena_poison")
         ctx->opt_arena_poison = value;
     else if (k == "fail_pass")
@@ -1315,6 +1319,11 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             job.level -= 1;
             cr = make_cfg(ctx, max_len, job.mode, job.level, n_work, !P.global_alignment, cfg);
         }
+        // (the paged team kernel has levels beyond "one slot of this level fits": the pool is the whole budget there and a level
+        // halves the teams that share it -- the launch configuration is then that of the last level whose slot fitted)
+        const bool paged_capable = ctx->opt_team_paged != 0 && !debug_single && ctx->opt_team_wgs == 0 && ctx->opt_arena_bytes_per_slot <= 0 &&
+                                   ctx->opt_team_min_len > 0 && max_len >= (uint64_t)ctx->opt_team_min_len && P.e != 0u;
+        for (int lv = job.level; cr == 2 && paged_capable && lv > 0;) cr = make_cfg(ctx, max_len, job.mode, --lv, n_work, !P.global_alignment, cfg);
         if (debug_single) cfg.slots = 1;
         // Wide wavefronts: a team of workgroups per pair (wfa_team_kernel) instead of one workgroup per pair.
         uint32_t team_T = 0, team_n = 0, team_wave_rows = 0;
@@ -1349,6 +1358,49 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                 }
             }
         }
+        // Paged arena of the team kernel: ONE pool for all teams, a pair takes pages as its rows grow.  The ladder level sizes the
+        // pool (as many slot sizes as there are teams) until that reaches the budget; from there a level halves the number of
+        // teams that share it -- down to one team with the whole pool.
+        bool     paged = false;
+        uint64_t pool_words = 0, dir_words = 0;
+        uint32_t page_log = 0, n_pages = 0;
+        if (team_T > 0 && paged_capable) {
+            const uint32_t cus = (uint32_t)std::max(1, ctx->num_cus);
+            const uint32_t t0  = (uint32_t)std::min<uint64_t>(cus, std::max<uint64_t>(2, (2ull * max_len + 8191) / 8192));
+            uint32_t teams = (uint32_t)std::min<uint64_t>(n_work, std::max<uint32_t>(1, std::min<uint32_t>(8u, cus / t0)));
+            const uint64_t budget_w = (uint64_t)((double)ctx->total_mem * ladder_budget(ctx)) / 4ull;
+            // the first level at which `teams` slots no longer fit the budget, and how far this job is beyond it
+            int over = 0;
+            for (int lv = 0; lv <= job.level; lv++) {
+                LaunchCfg c2;
+                const int r2 = make_cfg(ctx, max_len, job.mode, lv, n_work, !P.global_alignment, c2);
+                if (r2 == 2 || (uint64_t)teams * c2.arena_words > budget_w) over++;
+            }
+            // (over = 1: the first level whose slots no longer fit -- all teams, the whole budget; every further level halves the teams)
+            const bool spent = over > 1 && (teams >> (over - 2)) <= 1u;  // the level before already ran ONE team with the whole pool
+            if (over > 1) teams = std::max<uint32_t>(1, teams >> (over - 1));
+            LaunchCfg c0;
+            const int r0 = make_cfg(ctx, max_len, job.mode, job.level, n_work, !P.global_alignment, c0);
+            // a directory entry per score index up to the worst score two sequences of this length can reach (every base a
+            // mismatch or part of one long gap), per team, behind the pages
+            const uint64_t worst_idx = ((uint64_t)(P.x + P.e) * max_len + 2ull * P.oe) / P.g + 64;
+            dir_words = ((uint64_t)DIR_WORDS * worst_idx + 4095) & ~4095ull;
+            const uint64_t dirs = (uint64_t)teams * dir_words;
+            uint64_t rows_words = (r0 == 2 || over > 0) ? (budget_w > dirs ? budget_w - dirs : 0) : std::min<uint64_t>(budget_w, (uint64_t)teams * c0.arena_words);
+            // pages of 1/64 of the rows' share, between "a row and then some" and 256 MB
+            uint64_t pw = 1ull << 20;
+            while (pw < 8ull * max_len) pw <<= 1;
+            while (pw < (64ull << 20) && pw * 64 < rows_words) pw <<= 1;
+            while ((1ull << page_log) < pw) page_log++;
+            n_pages    = (uint32_t)std::min<uint64_t>(rows_words >> page_log, 1u << 20);
+            pool_words = ((uint64_t)n_pages << page_log) + dirs;
+            if (spent) {
+                cr = 2;
+            } else if (n_pages >= teams) {
+                paged = true, team_n = teams, cr = 0;
+                if (ctx->opt_team_wgs == 0) team_T = std::min<uint32_t>(cus / team_n, 2 * t0);
+            }
+        }
         if (cr == 2 || job.level > max_level) {
             if (job.all) {
                 no_memory.resize(n_pairs);
@@ -1365,15 +1417,31 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
         // bigger buffer at every level (hipMalloc / hipFree of tens of GB cost more than the alignments).
         if (team_T > 0 && job.level >= 2 && jarena.bytes < (size_t)((double)ctx->total_mem * ladder_budget(ctx)))
             (void)ensure(ctx, jarena, (size_t)((double)ctx->total_mem * ladder_budget(ctx)));
-        rc = ensure(ctx, jarena, (size_t)cfg.arena_words * 4ull * cfg.slots);
-        if (rc == WFAHIP_ERR_OOM && cfg.slots > 1) {  // shrink once
-            cfg.slots = std::max<uint32_t>(1, cfg.slots / 4);
-            rc        = ensure(ctx, jarena, (size_t)cfg.arena_words * 4ull * cfg.slots);
+        if (paged) {
+            cfg.slots = team_n, cfg.arena_words = pool_words;
+            rc = ensure(ctx, jarena, (size_t)pool_words * 4ull);
+        } else {
+            rc = ensure(ctx, jarena, (size_t)cfg.arena_words * 4ull * cfg.slots);
+            if (rc == WFAHIP_ERR_OOM && cfg.slots > 1) {  // shrink once
+                cfg.slots = std::max<uint32_t>(1, cfg.slots / 4);
+                rc        = ensure(ctx, jarena, (size_t)cfg.arena_words * 4ull * cfg.slots);
+            }
         }
         if (rc) return rc;
-        ctx->timing.arena_bytes = std::max<uint64_t>(ctx->timing.arena_bytes, (uint64_t)cfg.arena_words * 4ull * cfg.slots);
+        ctx->timing.arena_bytes = std::max<uint64_t>(ctx->timing.arena_bytes, paged ? pool_words * 4ull : (uint64_t)cfg.arena_words * 4ull * cfg.slots);
 
         P.arena = static_cast<uint32_t *>(jarena.p), P.arena_words = cfg.arena_words;
+        P.page_ctl = nullptr, P.page_words_log2 = 0, P.n_pages = 0, P.dir_region_words = 0;
+        if (paged) {
+            const size_t pc_words = 2u + (size_t)n_pages + (size_t)team_n * TEAM_MAX_PAGES;
+            if ((rc = ensure(ctx, ctx->page_ctl, pc_words * 4))) return rc;
+            std::vector<uint32_t> init(2u + n_pages);
+            init[0] = 0u, init[1] = n_pages;
+            for (uint32_t i = 0; i < n_pages; i++) init[2u + i] = n_pages - 1u - i;  // (page 0 on top of the stack)
+            HIP_TRY(hipMemcpyAsync(ctx->page_ctl.p, init.data(), init.size() * 4, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipStreamSynchronize(st));  // (`init` is a pageable temporary)
+            P.page_ctl = static_cast<uint32_t *>(ctx->page_ctl.p), P.page_words_log2 = page_log, P.n_pages = n_pages, P.dir_region_words = dir_words;
+        }
         P.lds_seq_words = cfg.lds_seq_words;
         P.n_work        = (uint32_t)n_work;
         if (job.all) {
@@ -1386,7 +1454,7 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
         // (tests: what an earlier launch left in the arena must never be read -- with the same batch run twice a stale
         // read returns the right value and hides itself)
         if (ctx->opt_arena_poison)
-            HIP_TRY(hipMemsetAsync(jarena.p, 0xA5, (size_t)cfg.arena_words * 4ull * cfg.slots, st));
+            HIP_TRY(hipMemsetAsync(jarena.p, 0xA5, paged ? (size_t)pool_words * 4ull : (size_t)cfg.arena_words * 4ull * cfg.slots, st));
         HIP_TRY(hipEventRecord(ctx->evA, st));
         if (team_T > 0) {
             if ((rc = ensure(ctx, ctx->team_ctl, (size_t)team_n * TEAM_CTL_WORDS * 4))) return rc;

@@ -52,6 +52,7 @@ constexpr int TEAM_CTL_WORDS = 128;  // per team, in global memory: [0] barrier 
                                      // [3] XCC ids of the team (mask) [4] command [5] score [6..7] arena top [8..9] end-cell key (u64) [10] end flags [11] team on one XCD [12..13] stored cells (u64)
                                      // [16 + 16*set ..] three reduction sets [64..] diagnostic stamps
 constexpr uint32_t TEAM_SPIN_LIMIT = 1u << 24;
+constexpr int      TEAM_MAX_PAGES  = 1024;  // pages one pair can hold (its list in page_ctl)
 #ifndef WFA_TEAM_U
 #define WFA_TEAM_U 2
 #endif
@@ -90,8 +91,16 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
     const uint32_t team = xmap ? blockIdx.x % 8u : blockIdx.x / T, b = xmap ? blockIdx.x / 8u : blockIdx.x % T;
     if (xmap && team >= n_teams) return;
     uint32_t *const ctl = team_ctl + (uint64_t)team * TEAM_CTL_WORDS;
-    uint32_t *const A   = P.arena + (uint64_t)team * P.arena_words;
-    const uint64_t cap  = P.arena_words;
+    // Paged arena (P.page_ctl != nullptr): the rows of a pair live in pages taken from a pool all teams share -- a pair holds
+    // what it needs (0.2 .. 43 GB at 100 kbp) instead of a slot sized for the worst one, so eight teams run where four slots
+    // fitted.  `base` of a directory entry is a word index into the pool either way; the directory of team t is the
+    // dir_region_words below arena_words - t * dir_region_words.
+    const bool      paged = P.page_ctl != nullptr;
+    uint32_t *const A     = paged ? P.arena : P.arena + (uint64_t)team * P.arena_words;
+    const uint64_t  cap   = paged ? P.arena_words - (uint64_t)team * P.dir_region_words : P.arena_words;
+    const uint32_t  dir_entries = paged ? (uint32_t)(P.dir_region_words / DIR_WORDS) : 0u;
+    const uint64_t  page_words  = 1ull << P.page_words_log2;
+    uint32_t *const my_pages    = paged ? P.page_ctl + 2u + P.n_pages + team * (uint32_t)TEAM_MAX_PAGES : nullptr;
     const uint32_t x = P.x, oe = P.oe, e = P.e, g = P.g;
     const int64_t  stripe = (int64_t)T * G;
 
@@ -159,6 +168,38 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
         xl = xl_ok && (seen & (seen - 1u)) == 0u;
         if (b == 0 && tid == 0) ctl[11] = xl ? 1u : 0u;  // (diagnostics: WFAHIP_DEBUG_TIMING prints it)
     }
+    // ---- pages: a stack of free page ids behind a spin lock (one thread of a team at a time; a pair turns a page every
+    // ~100 wide score steps).  Everything inside the lock is a memory-side access.
+    uint32_t n_pg = 0;  // pages the current pair holds (kept by thread 0 of workgroup 0)
+    auto page_lock = [&]() -> bool {
+        uint32_t spins = 0;
+        for (;;) {
+            uint32_t expect = 0u;
+            if (__hip_atomic_compare_exchange_strong(&P.page_ctl[0], &expect, 1u, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return true;
+            if (++spins > TEAM_SPIN_LIMIT) return false;
+            __builtin_amdgcn_s_sleep(8);
+        }
+    };
+    auto page_unlock = [&]() { __hip_atomic_store(&P.page_ctl[0], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); };
+    auto page_alloc = [&]() -> uint32_t {  // 0xFFFFFFFF: none left
+        if (n_pg >= (uint32_t)TEAM_MAX_PAGES || !page_lock()) return 0xFFFFFFFFu;
+        const uint32_t nf = ald(&P.page_ctl[1]);
+        uint32_t       pg = 0xFFFFFFFFu;
+        if (nf != 0u) pg = ald(&P.page_ctl[2u + nf - 1u]), ast(&P.page_ctl[1], nf - 1u);
+        page_unlock();
+        if (pg != 0xFFFFFFFFu) my_pages[n_pg++] = pg;
+        return pg;
+    };
+    auto page_free_all = [&]() {
+        if (n_pg == 0u) return;
+        if (page_lock()) {
+            uint32_t nf = ald(&P.page_ctl[1]);
+            for (uint32_t i = 0; i < n_pg; i++) ast(&P.page_ctl[2u + nf++], my_pages[i]);
+            ast(&P.page_ctl[1], nf);
+            page_unlock();
+        }  // (a lock that cannot be had: the pages stay out of the pool for the rest of the launch -- slower, never wrong)
+        n_pg = 0u;
+    };
     for (;;) {
         // ---- the team's next pair: workgroup 0 pulls it, the barrier publishes it
         if (b == 0 && tid == 0) {
@@ -220,6 +261,7 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
         const bool glob    = P.global_alignment != 0;
         const int  seed_lo = glob ? 0 : -(n - 1), seed_hi = glob ? 0 : m - 1;
         uint64_t   top     = 0;  // next free arena word (identical in every active workgroup)
+        uint64_t   page_end = 0; // paged arena: end of the page the rows are being written to (0: no page yet)
         uint32_t   n_ent   = 0;
         bool       overflow = false, done = false;
         uint32_t   s_final  = 0;
@@ -292,9 +334,37 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
             if (seeded) lo = imin2(lo, seed_lo), hi = imax2(hi, seed_hi);
 
             const int64_t W = (hi >= lo) ? ((int64_t)hi - lo + 1) : 0;
-            if (top + 3ull * (uint64_t)W + (uint64_t)DIR_WORDS * (si + 2) > cap) {
-                overflow = true;
-                break;
+            if (!paged) {
+                if (top + 3ull * (uint64_t)W + (uint64_t)DIR_WORDS * (si + 2) > cap) {
+                    overflow = true;
+                    break;
+                }
+            } else {
+                if (si + 2u > dir_entries || 3ull * (uint64_t)W > page_words) {
+                    overflow = true;
+                    break;
+                }
+                if (top + 3ull * (uint64_t)W > page_end) {
+                    // the row does not fit the page: the next one.  Every active workgroup gets here with the same values; in team
+                    // mode workgroup 0 takes the page and a fenced barrier hands its id round
+                    uint32_t pg;
+                    if (teamed) {
+                        if (lead_wg && tid == 0) ast(&ctl[112], page_alloc());
+                        team_barrier(true);
+                        if (aborted) return;
+                        pg = ald(&ctl[112]);
+                    } else {
+                        if (tid == 0) red[8] = (int)page_alloc();
+                        __syncthreads();
+                        pg = (uint32_t)red[8];
+                        __syncthreads();
+                    }
+                    if (pg == 0xFFFFFFFFu) {  // the pool is empty: the pair is re-run when fewer teams share it
+                        overflow = true;
+                        break;
+                    }
+                    top = (uint64_t)pg << P.page_words_log2, page_end = top + page_words;
+                }
             }
             __syncthreads();  // everybody has read the ring entries before the slot of this score is rewritten
 
@@ -319,6 +389,7 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
                         if (cmd == TEAM_CMD_RESUME) {
                             s   = ald(&ctl[5]);
                             top = (uint64_t)ald(&ctl[6]) | ((uint64_t)ald(&ctl[7]) << 32);
+                            page_end = (uint64_t)ald(&ctl[113]) | ((uint64_t)ald(&ctl[114]) << 32);
                             const uint32_t si2 = s / g;
                             if (tid < TEAM_RING && (uint32_t)tid < si2) {  // the directory entries the next scores can source
                                 const uint32_t idx = si2 - 1u - (uint32_t)tid;
@@ -339,6 +410,7 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
                 // solo -> team (only workgroup 0 is here): publish where we are and wake the others
                 if (tid == 0) {
                     ast(&ctl[5], s), ast(&ctl[6], (uint32_t)top), ast(&ctl[7], (uint32_t)(top >> 32));
+                    ast(&ctl[113], (uint32_t)page_end), ast(&ctl[114], (uint32_t)(page_end >> 32));
                     ast(&ctl[4], (uint32_t)TEAM_CMD_RESUME);
                 }
                 team_barrier(true);
@@ -357,7 +429,7 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
                     uint32_t ws = s, wn = n_ent, wfin = s_final;
                     uint64_t wtop = top, wcells = 0;
                     const uint32_t wflags =
-                        wave_mode_steps<MODE>(P, sv, A, cap, ring, wring, wave_rows, n, m, glob, ws, wtop, wn, wfin, wcells, wsteps);
+                        wave_mode_steps<MODE>(P, sv, A, cap, ring, wring, wave_rows, n, m, glob, ws, wtop, wn, wfin, wcells, wsteps, page_end, dir_entries);
                     my_cells += wcells;
                     if (tid == 0) {
                         unsigned int *const ur = reinterpret_cast<unsigned int *>(red);
@@ -370,7 +442,8 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
                     s = ur[0], top = (uint64_t)ur[1] | ((uint64_t)ur[2] << 32), n_ent = ur[3];
                     const uint32_t wf = ur[4];
                     if (wf & WAVE_DONE) done = true, s_final = ur[5];
-                    if (wf & WAVE_OVERFLOW) overflow = true;
+                    // (paged arena: "overflow" = the page is full -- the loop head below turns the page -- unless it is the directory)
+                    if ((wf & WAVE_OVERFLOW) && !(paged && s / g + 2u <= dir_entries)) overflow = true;
                 }
                 __syncthreads();
                 TEAM_STAMP(8);
@@ -699,6 +772,7 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
             if (lead_wg && tid == 0) {
                 rec[REC_STATUS] = ST_REDO_ARENA;
                 push_redo(P, pair, ST_REDO_ARENA);
+                if (paged) page_free_all();  // (nobody reads the rows past the barrier above)
             }
             continue;
         }
@@ -758,8 +832,21 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
         // ---- backtrace: wave 0 walks together (same steps, same values in every lane; the directory entries of the
         // scores around the walk sit in LDS -- the ring is free now -- and are loaded 64 at a time); result record: one lane
         __syncthreads();
+        // (paged arena: the ops scratch of the walk is the rest of the last page, or a page of its own when that is too small)
+        uint64_t scratch_end = 0;
+        bool     no_scratch  = false;
+        if (paged) {
+            const uint64_t need = 2ull * ((uint64_t)n + (uint64_t)m + 8ull);
+            if (tid == 0) red[8] = (page_end - top < need) ? (int)page_alloc() : -2;
+            __syncthreads();
+            const int r8 = red[8];
+            if (r8 == -1) no_scratch = true;
+            else if (r8 >= 0) top = (uint64_t)(uint32_t)r8 << P.page_words_log2, page_end = top + page_words;
+            scratch_end = page_end;
+            __syncthreads();
+        }
         if (tid < 64) {
-            if (!wave_backtrace_record(P, A, cap, n_ent, top, ring, reinterpret_cast<unsigned int *>(red), n, m, minS, lastK, glob, rec)) {
+            if (no_scratch || !wave_backtrace_record(P, A, cap, n_ent, top, ring, reinterpret_cast<unsigned int *>(red), n, m, minS, lastK, glob, rec, scratch_end)) {
                 if (tid == 0) {
                     rec[REC_STATUS] = ST_REDO_ARENA;
                     push_redo(P, pair, ST_REDO_ARENA);
@@ -777,6 +864,7 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
             if (tid == 0)
                 for (int i = 6; i < 8; i++) atomicAdd(reinterpret_cast<unsigned long long *>(ctl + 64) + i, tacc[i]), tacc[i] = 0;
 #endif
+            if (paged && tid == 0) page_free_all();  // the pair's pages go back to the pool (the other workgroups wait at the next pair's barrier)
         }
     }
 }

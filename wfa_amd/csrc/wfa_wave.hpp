@@ -22,10 +22,15 @@ enum : uint32_t { WAVE_DONE = 1u, WAVE_OVERFLOW = 2u, WAVE_WIDE = 4u };
 // s is wider than 64 diagonals (WAVE_WIDE: s is the score to redo); every score below s has its directory entry,
 // n_ent counts them.  Called by the 64 lanes of one wave, converged.  `ring` must hold the directory entries of the
 // scores s - g .. s - 64 g (those that exist); the rows the next steps can source are copied from the arena here.
+// row_end / dir_entries: where the rows must end and how many directory entries there is room for.  dir_entries = 0: rows
+// and directory share the slot (the rows grow up from its start, the directory down from `cap`: row_end is ignored); else the
+// rows live in a page of their own that ends at row_end (wfa_team_kernel's paged arena) and WAVE_OVERFLOW means "this page
+// is full", unless the directory is.
 template <int MODE>
 WFA_DEV uint32_t wave_mode_steps(const KParams &P, const SeqView<MODE> &sv, uint32_t *const A, const uint64_t cap, DirEnt *const ring,
                                  uint32_t *const wring, const uint32_t wave_rows, const int n, const int m, const bool glob, uint32_t &s,
-                                 uint64_t &top, uint32_t &n_ent, uint32_t &s_final, uint64_t &my_cells, unsigned long long *n_steps) {
+                                 uint64_t &top, uint32_t &n_ent, uint32_t &s_final, uint64_t &my_cells, unsigned long long *n_steps,
+                                 const uint64_t row_end = 0, const uint32_t dir_entries = 0) {
     const uint32_t x = P.x, oe = P.oe, e = P.e, g = P.g;
     const int      lane = (int)(threadIdx.x & 63u), Ak = m - n;
     const int      seed_lo = glob ? 0 : -(n - 1), seed_hi = glob ? 0 : m - 1;
@@ -84,7 +89,8 @@ WFA_DEV uint32_t wave_mode_steps(const KParams &P, const SeqView<MODE> &sv, uint
         if (su == 0u) wlo = INT32_MAX, whi = INT32_MIN;
         if (wseed) wlo = imin2(wlo, seed_lo), whi = imax2(whi, seed_hi);
         const int64_t WW = (whi >= wlo) ? ((int64_t)whi - wlo + 1) : 0;
-        if (utop + 3ull * (uint64_t)WW + (uint64_t)DIR_WORDS * (sj + 2) > cap) {
+        if (dir_entries == 0u ? utop + 3ull * (uint64_t)WW + (uint64_t)DIR_WORDS * (sj + 2) > cap
+                              : (utop + 3ull * (uint64_t)WW > row_end || sj + 2u > dir_entries)) {
             wflags = WAVE_OVERFLOW;
             break;
         }
@@ -179,15 +185,16 @@ WFA_DEV uint32_t wave_mode_steps(const KParams &P, const SeqView<MODE> &sv, uint
 // statistics of the span first-M .. last-M.  Lane 0 writes the record except REC_CELLS_* and REC_N_SCORES.  Returns
 // false when the ops scratch between the rows and the directory was too small (the caller re-queues the pair).
 // `acc`: four LDS words.  Called by the 64 lanes of one wave, converged.
+// scratch_end = 0: the ops scratch is what lies between the rows (top) and the directory; else [top, scratch_end).
 WFA_DEV bool wave_backtrace_record(const KParams &P, uint32_t *const A, const uint64_t cap, const uint32_t n_ent, const uint64_t top,
                                    DirEnt *const win, unsigned int *const acc, const int n, const int m, const uint32_t minS,
-                                   const int lastK, const bool glob, uint32_t *const rec) {
+                                   const int lastK, const bool glob, uint32_t *const rec, const uint64_t scratch_end = 0) {
     const uint32_t x = P.x, oe = P.oe, e = P.e, g = P.g;
     const int      lane = (int)(threadIdx.x & 63u);
     ArenaViewWave  av;
     av.init(A, cap, g, n_ent, win, (uint32_t)imax2((int)x, imax2((int)oe, (int)e)) / g);
     uint64_t  scratch0 = (top + 1ull) & ~1ull;
-    uint64_t  dir_lo   = cap - (uint64_t)DIR_WORDS * (uint64_t)n_ent;
+    uint64_t  dir_lo   = scratch_end != 0ull ? scratch_end : cap - (uint64_t)DIR_WORDS * (uint64_t)n_ent;
     uint64_t  room     = dir_lo > scratch0 ? (dir_lo - scratch0) / 2ull : 0ull;
     OpsWriter ow;
     ow.init(reinterpret_cast<uint64_t *>(A + scratch0), (uint32_t)(room > 0xFFFFFFFFull ? 0xFFFFFFFFull : room));
