@@ -21,7 +21,10 @@ for seed, length, err, ad in ((101, 1000, 0.05, (10, 50, 1)), (102, 1000, 0.08, 
                               (110, 1000, 0.10, (10, 50, 1)), (111, 1500, 0.04, (10, 50, 1)), (112, 400, 0.06, (10, 50, 1)),
                               (113, 1000, 0.02, (10, 50, 1)), (114, 1000, 0.05, (4, 20, 1)), (115, 800, 0.15, (10, 50, 1)),
                               # wfa_lane_kernel (a lane per pair; with 107-109): full generations, rows near its 30-diagonal limit
-                              (116, 150, 0.02, (10, 50, 1)), (117, 60, 0.05, None), (118, 200, 0.05, (10, 50, 1))):
+                              (116, 150, 0.02, (10, 50, 1)), (117, 60, 0.05, None), (118, 200, 0.05, (10, 50, 1)),
+                              # round 4: the sliding-window instances (wfa_blk_kernel<.., LONG>): GPU-filling batches of 5-50 kbp reads
+                              (119, 8000, 0.05, (10, 50, 1)), (120, 20000, 0.03, (10, 50, 1)), (121, 50000, 0.05, (10, 50, 1)),
+                              (122, 5000, 0.10, (10, 50, 1))):
     if os.environ.get("SOAK_SEEDS") and str(seed) not in os.environ["SOAK_SEEDS"].split(","):
         continue  # (SOAK_SEEDS=107,108,...: only those shapes)
     nn = n * 1000 // length if length > 1000 else n

@@ -459,9 +459,11 @@ struct OpsWriterRev {
     bool      grouped;
     bool      active = true;                     // false: count and keep statistics, store nothing (the lanes of a wave that walks
                                                  // one pair together all run the writer; one of them stores)
+    bool      combine = true;                    // false: every op is stored on its own (a wave's walk: one lane stores, the history
+                                                 // of the write combining is fourteen moves per op for nothing)
     WFA_DEV void init(uint64_t *b, uint32_t c) {
         buf = b, cap = c, n = 0, cur = 0, overflow = false, seenM = false;
-        grouped = GROUP > 1 && (reinterpret_cast<uintptr_t>(b + c) & (8u * GROUP - 1u)) == 0u;
+        grouped = combine && GROUP > 1 && (reinterpret_cast<uintptr_t>(b + c) & (8u * GROUP - 1u)) == 0u;
 #pragma unroll
         for (uint32_t i = 0; i + 1 < GROUP; i++) hist[i] = 0;
         alen = matches = gaps = regions = 0;
@@ -505,9 +507,11 @@ struct OpsWriterRev {
             p_len += cnt;
             if (letter == 'I' || letter == 'D') p_gaps += cnt, p_regions++;
         }
+        if (grouped) {
 #pragma unroll
-        for (uint32_t i = GROUP > 1 ? GROUP - 2 : 0; i > 0; i--) hist[i] = hist[i - 1];
-        hist[0] = cur;
+            for (uint32_t i = GROUP > 1 ? GROUP - 2 : 0; i > 0; i--) hist[i] = hist[i - 1];
+            hist[0] = cur;
+        }
         last    = cur;
         cur     = 0;
     }
@@ -606,13 +610,30 @@ struct CompactViewWave {
         const int lane = threadIdx.x & 63;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        // the four 16-byte loads of a lane in flight TOGETHER: no branch between them (a row outside the arena loads row 0 and
+        // stores zeros), the layout decided once -- one round trip per refill, not four
+        uint4 v[4];
+        bool  ok[4];
+        if (fmt == 3u) {
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int q = lane + 64 * r, row = q >> 3, si = r0 + row, kk = d0 + 4 * (q & 7);
-            uint4     v = make_uint4(0u, 0u, 0u, 0u);
-            if (si >= 0 && (uint32_t)si < n_ent) v = *reinterpret_cast<const uint4 *>(A + widx((uint32_t)si, kk));
-            *reinterpret_cast<uint4 *>(reg + 4 * q) = v;
+            for (int r = 0; r < 4; r++) {
+                const int q = lane + 64 * r, si = r0 + (q >> 3), kk = d0 + 4 * (q & 7);
+                ok[r] = si >= 0 && (uint32_t)si < n_ent;
+                const uint32_t su = ok[r] ? (uint32_t)si : 0u;
+                v[r] = *reinterpret_cast<const uint4 *>(A + 512ull * (su >> 3) + (((uint32_t)kk & 60u) << 3) + ((su & 7u) << 2));
+            }
+        } else {
+            const uint32_t Wd = fmt == 1u ? 64u : (fmt == 4u ? 256u : 128u);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int q = lane + 64 * r, si = r0 + (q >> 3), kk = d0 + 4 * (q & 7);
+                ok[r] = si >= 0 && (uint32_t)si < n_ent;
+                const uint32_t su = ok[r] ? (uint32_t)si : 0u;
+                v[r] = *reinterpret_cast<const uint4 *>(A + (uint64_t)Wd * su + ((uint32_t)kk & (Wd - 1u)));
+            }
         }
+#pragma unroll
+        for (int r = 0; r < 4; r++) *reinterpret_cast<uint4 *>(reg + 4 * (lane + 64 * r)) = ok[r] ? v[r] : make_uint4(0u, 0u, 0u, 0u);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }

@@ -142,8 +142,9 @@ struct wfahip_ctx {
     int64_t       opt_team_strict          = 1;              // agent-scope release in every team barrier (0: see wfa_team.hpp)
     int64_t       opt_team_paged           = 1;              // 1: the teams share one pool of arena pages (a pair holds what it needs) instead of a slot each
     DevBuf        page_ctl;                                  // ... its free-page stack and the page lists of the teams
-    int64_t       opt_team_xcd             = 1;              // 1: teams of one XCD's CUs (blockIdx % 8); 2: ... and a team that finds itself on one XCD keeps its
-                                                             // rows in that XCD's L2 (plain stores, no release in its barriers: measured 1.5 %, off)
+    int64_t       opt_team_xcd             = 2;              // 1: teams of one XCD's CUs (blockIdx % 8); 2 (default): ... and a team that finds itself on one XCD keeps
+                                                             // its rows in that XCD's L2 (plain stores, no release in its barriers): 548 -> 512 ms per 8 x 100 kbp with
+                                                             // eight teams; 310 passes of that sample over a poisoned pool without a deviation (profiles/r04_team_xcd_soak.txt)
     int64_t       opt_arena_poison         = 0;              // tests: fill the arena with a pattern before every long-pair launch
     int64_t       opt_pilot                = 1;  // 1: a 4 096-pair pilot decides whether a large batch uses the sub-wave kernels
     int64_t       opt_tail_overlap         = 1;  // 1: retry passes overlap the backtrace kernel of the first pass

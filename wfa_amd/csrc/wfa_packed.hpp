@@ -365,6 +365,7 @@ WFA_DEV void backtrace_wave_one(const KParams &P, uint32_t idx, uint32_t *region
     cv.fmt = P.compact_fmt, cv.reg = region;
     OpsWriterRev ow;
     const bool   fits = off + bound <= P.ops_cap;
+    ow.combine = false;
     ow.init(P.ops + off, fits ? bound : 0u);
     ow.active = lane == 0u;
     TraceOut to;

@@ -80,11 +80,15 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
     // Teams of one XCD's CUs (round 4; `strict` bit 1, n_teams in its upper half): team = blockIdx % 8.  Workgroups are dealt
     // round-robin over the eight XCDs, so such a team normally sits on ONE XCD, whose L2 all its CUs share.  A team of 32 CUs
     // steps as fast as one of 50 (a wide step is a chain of round trips, not throughput: 8 x 100 kbp 610 -> 589 ms).  Bit 2
-    // (option team_xcd = 2, off by default) adds the LOCAL protocol: every workgroup reports its XCC id, and a team that finds all
+    // (option team_xcd = 2, the default) adds the LOCAL protocol: every workgroup reports its XCC id, and a team that finds all
     // of them equal (`xl`) stores its rows plain -- they stay in the XCD's L2, where the team's sc1 loads find them -- and
-    // drops the release from its barriers; any other placement runs the memory-side protocol unchanged.  Measured: 589 -> 580
-    // ms, 1.5 % -- the release and the memory side are not what a step waits for -- so the default keeps the protocol that
-    // round 2's soak covers.  Teams beyond the number of arena slots leave at once.
+    // drops the release from its barriers; any other placement runs the memory-side protocol unchanged, so nothing depends on
+    // where the dispatcher puts a workgroup.  Why it is sound: within an XCD the L2 is the point of coherence; a plain store is
+    // in it when the storing wave's vmcnt has returned, every barrier drains that (__syncthreads) before its arrive, and the
+    // readers' sc1 loads bypass their own L1.  (Round 2's stale words were write-THROUGH stores overtaken on their way to the
+    // memory side; no store travels that way here.)  Measured with four teams: 589 -> 580 ms; with the eight teams the paged
+    // arena allows: 548 -> 512 ms; 310 passes of the configs[4] sample over a poisoned pool, every one bit-identical to the
+    // memory-side protocol's result.  Teams beyond the number of arena slots leave at once.
     const bool     xmap    = (strict & 2u) != 0u, xl_ok = (strict & 4u) != 0u;
     const uint32_t n_teams = strict >> 16;
     strict &= 1u;
