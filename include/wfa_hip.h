@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define WFAHIP_VERSION 300 /* 0.3.0 */
+#define WFAHIP_VERSION 400 /* 0.4.0 */
 
 /* whole-call return codes (0 = success, negative = failure) */
 enum {
@@ -169,9 +169,12 @@ int  wfahip_align_batch_device(wfahip_ctx *ctx, const wfahip_params *p, const vo
 /* Pre-packed input: the sequences arrive 2-bit packed, 16 bases per uint32 (base i of a
  * sequence in bits 2(i%16).. of word i/16, code = (ascii >> 1) & 3: A 0, C 1, T 2, G 3), every sequence starting at a
  * word boundary and followed by one pad word; pair i is packed[q_woff[i] ..] (q_len[i] bases) vs packed[t_woff[i] ..].
- * A quarter of the bytes cross PCIe; the device expands them into the byte blob the kernels read.  Valid only for
- * pure uppercase ACGT input -- the reference compares raw bytes (wfa.go:408-454), so anything else must use
- * wfahip_align_batch.  wfahip_pack_pairs is the host-side packer (n_threads host threads; returns
+ * A quarter of the bytes cross PCIe.  On the device the words are expanded into the byte blob every kernel of the ladder can
+ * read (wfa_unpack_kernel), and the first pass of a large batch then packs its chunk again into the fixed-stride slots
+ * {n, m, status, -, q words, t words} it fetches from (wfa_prepack_kernel): a pack -> unpack -> pack detour of ~4 GB of HBM
+ * traffic and 1.3 ms per 1e6 x 1 kbp pairs, kept because the retry rungs, the byte path and the long-pair kernels all take
+ * bytes (DESIGN.md section 8 says what removing it needs).  Valid only for pure uppercase ACGT input -- the reference compares
+ * raw bytes (wfa.go:408-454), so anything else must use wfahip_align_batch.  wfahip_pack_pairs is the host-side packer (n_threads host threads; returns
  * WFAHIP_ERR_UNSUPPORTED if a byte outside ACGT is found); packed must hold the sum over all sequences of
  * wfahip_packed_words(len) words.  Results are identical to wfahip_align_batch on the unpacked bytes. */
 uint64_t wfahip_packed_words(uint32_t len);
@@ -193,10 +196,11 @@ int      wfahip_submit(wfahip_ctx *ctx, const uint8_t *q, uint32_t n, const uint
  * ops the CIGAR ops (op<<32 | n, forward order, merged; capacity ops_cap entries), *n_ops their number.  If ops_cap is
  * too small the call returns WFAHIP_ERR_OOM with *n_ops = the capacity needed (at most n + m + 2).  Per-pair failures
  * are statuses in rec[WFAHIP_REC_STATUS] (EMPTY / TOO_LONG), like the batch entry.  A pair whose shape allows it (global,
- * penalties shaped like 4/6/2, lengths up to ~10 kbp) takes two kernel launches and no copy -- the kernels read the
- * sequences from, and write the results to, a page-locked block mapped into the GPU's address space -- 3-4 x less time
- * per call than wfahip_align_batch with n_pairs = 1; every other pair goes through that entry.  Same results either way.
- * A caller that CAN batch should: a batch aligns ~50 million pairs a second, this call a few thousand. */
+ * penalties shaped like 4/6/2, both sequences within ~30 kbp) takes ONE kernel launch and no copy -- a wave with a lane per
+ * diagonal reads the sequences from, and writes record and CIGAR to, a page-locked block mapped into the GPU's address
+ * space, and walks its own backtrace -- 0.17 ms for a 1 kbp pair (round 3: 0.29; wfahip_align_batch with n_pairs = 1: 0.45);
+ * every other pair, and one whose band leaves 64 diagonals, goes through that entry.  Same results either way.
+ * A caller that CAN batch should: a batch aligns ~58 million pairs a second, this call six thousand. */
 int      wfahip_align_pair(wfahip_ctx *ctx, const wfahip_params *p, const uint8_t *q, uint32_t n, const uint8_t *t, uint32_t m,
                            uint32_t *rec, uint64_t *ops, uint64_t ops_cap, uint64_t *n_ops);
 uint64_t wfahip_pending(const wfahip_ctx *ctx);
@@ -259,7 +263,19 @@ int  wfahip_last_timing(const wfahip_ctx *ctx, wfahip_timing *out);
  *                                 0: no release -- 10 % faster on 100 kbp pairs and NOT safe: a row word can be read before
  *                                 its write-through has landed (measured; wfa_team.hpp)
  *   "arena_poison"                tests: fill the arena with a pattern before every forward launch (no kernel may read a word
- *                                 it did not write in this launch) */
+ *                                 it did not write in this launch)
+ *   "team_paged"  0|1             1 (default): the teams of the long-pair kernel share ONE pool of arena pages -- a pair holds what it
+ *                                 needs, up to eight teams run at once -- instead of a slot each sized for the worst pair
+ *   "team_xcd"  0|1|2             teams of one XCD's 32 CUs (1); 2 (default): ... and a team that finds all its workgroups on one
+ *                                 XCD keeps its rows in that XCD's L2 (checked at run time; any other placement: the memory-side protocol)
+ *   "long"  0|1                   1 (default): global pairs longer than "long_min_len" (4 000) bases, penalties shaped 4/6/2, take the
+ *                                 sub-wave kernels with sliding 2-bit sequence windows in LDS (any read length); 0: as in round 3
+ *   "long_first"  0|11..15        which of those instances a batch starts on: 0 = by batch size (<= 1 024 pairs: a wave per pair with
+ *                                 two diagonals per lane; <= 4 096: two pairs per wave, 128 diagonals; else four pairs per wave)
+ *   "long_window_words"           packed words of each sequence a pair keeps in LDS (default 256 = 4 096 bases; 64..4096)
+ *   "long_wave_bt"  0|1|2         backtrace of those pairs by a wave per pair (1: for chunks of at most 2 048 pairs; 2: always; 0: never)
+ *   "pair_fast"  0|1|2|3          wfahip_align_pair: 1 (default) one launch of the lone-pair instance (the wave walks its own
+ *                                 backtrace); 3 / 2: round 3's one- / two-launch paths; 0: the batch entry */
 int  wfahip_set_option(wfahip_ctx *ctx, const char *key, int64_t value);
 
 /* Debug / parity aid: align ONE pair and return every stored wavefront row.  rows[] receives

@@ -27,7 +27,7 @@ import json; d=json.load(open('$OUT/bench_c5s32.json')); print('c5s x 32 pairs: 
   for c in k10 k20 l5 L5 l10 l20; do timeout 900 python bench.py --config $c --host-entry 0 --latency 0 > $OUT/bench_$c.json 2> $OUT/bench_$c.err; summ $c; done
   timeout 300 python scripts/align_latency.py 2>&1 | grep pair_fast | tee $OUT/align_latency.txt
   timeout 600 python bench.py --gpus 1 --force-collective --steps 20 --warmup 3 --host-entry 0 --latency 0 --cpu-sample 0 > $OUT/bench_c3_nccl1.json 2> $OUT/bench_c3_nccl1.err; python3 -c "
-import json; d=json.load(open('$OUT/bench_c3_nccl1.json')); c=d['config']; print('c3 with the RCCL process group (1 rank): value', round(d['value'],1), 'backend', c['backend'], 'gather ms', c['gather_ms_standalone'], 'complete', c['gathered_records_complete'])"
+import json; d=json.loads([l for l in open('$OUT/bench_c3_nccl1.json') if l.startswith('{')][0]); c=d['config']; print('c3 with the RCCL process group (1 rank): value', round(d['value'],1), 'backend', c['backend'], 'gather ms', c['gather_ms_standalone'], 'complete', c['gathered_records_complete'])"
 fi
 if has profiles; then
   timeout 900 bash scripts/profile_bench.sh ${TAG}_c3 > $OUT/prof_c3.log 2>&1

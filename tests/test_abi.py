@@ -19,7 +19,7 @@ def test_exports_match_header(built):
     L = _lib.lib()
     for name in declared:
         assert getattr(L, name) is not None
-    assert L.wfahip_version() == 300
+    assert L.wfahip_version() == 400
 
 
 def test_struct_layouts(built):

@@ -102,7 +102,8 @@ struct KParams {
     uint32_t  census;                // sub-wave forward kernels: report the number of stored wavefront words (REC_CELLS), else 0
     // wfa_team_kernel, paged arena (round 4): the teams share ONE pool of pages instead of owning a slot each -- a 100 kbp
     // semi-global pair takes anything from 0.2 to 43 GB, and slots sized for the worst pair left room for four teams.
-    // page_ctl: [0] lock [1] free pages [2 ..] stack of free page ids, then per team a list of the pages its pair holds;
+    // page_ctl: [0] lock [1] free pages [2] teams waiting for a page [3] teams holding pages [4 ..] stack of free page ids, then
+    // per team a list of the pages its pair holds;
     // nullptr = one slot of arena_words per team.  The directories live at the end of the pool, dir_region_words per team.
     uint32_t *page_ctl;
     uint32_t  page_words_log2, n_pages;

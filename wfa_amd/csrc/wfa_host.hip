@@ -1434,11 +1434,11 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
         P.arena = static_cast<uint32_t *>(jarena.p), P.arena_words = cfg.arena_words;
         P.page_ctl = nullptr, P.page_words_log2 = 0, P.n_pages = 0, P.dir_region_words = 0;
         if (paged) {
-            const size_t pc_words = 2u + (size_t)n_pages + (size_t)team_n * TEAM_MAX_PAGES;
+            const size_t pc_words = 4u + (size_t)n_pages + (size_t)team_n * TEAM_MAX_PAGES;
             if ((rc = ensure(ctx, ctx->page_ctl, pc_words * 4))) return rc;
-            std::vector<uint32_t> init(2u + n_pages);
-            init[0] = 0u, init[1] = n_pages;
-            for (uint32_t i = 0; i < n_pages; i++) init[2u + i] = n_pages - 1u - i;  // (page 0 on top of the stack)
+            std::vector<uint32_t> init(4u + n_pages);
+            init[0] = 0u, init[1] = n_pages, init[2] = 0u, init[3] = 0u;
+            for (uint32_t i = 0; i < n_pages; i++) init[4u + i] = n_pages - 1u - i;  // (page 0 on top of the stack)
             HIP_TRY(hipMemcpyAsync(ctx->page_ctl.p, init.data(), init.size() * 4, hipMemcpyHostToDevice, st));
             HIP_TRY(hipStreamSynchronize(st));  // (`init` is a pageable temporary)
             P.page_ctl = static_cast<uint32_t *>(ctx->page_ctl.p), P.page_words_log2 = page_log, P.n_pages = n_pages, P.dir_region_words = dir_words;
@@ -2301,18 +2301,26 @@ static int align_batch_autopack(wfahip_ctx *ctx, const wfahip_params *p, const u
     q_woff.resize(n_pairs), t_woff.resize(n_pairs);
     uint64_t pos = 0;
     for (uint64_t i = 0; i < n_pairs; i++) {
-        const bool v = q_len[i] <= WFAHIP_MAX_SEQ_LEN && t_len[i] <= WFAHIP_MAX_SEQ_LEN;
+        // (a pair the alignment rejects -- too long, or empty -- is not validated and packs as nothing: exactly the byte entry's rule)
+        const bool v = q_len[i] <= WFAHIP_MAX_SEQ_LEN && t_len[i] <= WFAHIP_MAX_SEQ_LEN && q_len[i] && t_len[i];
         if (v && (q_off[i] > blob_bytes || q_len[i] > blob_bytes - q_off[i] || t_off[i] > blob_bytes || t_len[i] > blob_bytes - t_off[i]))
             return WFAHIP_ERR_BAD_ARG;
         q_woff[i] = pos, pos += wfahip_packed_words(v ? q_len[i] : 0);
         t_woff[i] = pos, pos += wfahip_packed_words(v ? t_len[i] : 0);
     }
+    // (pairs are packed one by one: a batch whose pairs SHARE sequences -- one target against many queries -- would carry every
+    // copy over PCIe; beyond a quarter more than the blob itself the byte path is the cheaper one)
+    if (pos * 16 > blob_bytes + blob_bytes / 4) return WFAHIP_ERR_UNSUPPORTED;
     const size_t need = (size_t)(pos + 4) * 4;
     if (ctx->pack_pin_bytes < need) {
         HIP_TRY(hipSetDevice(ctx->device));
         if (ctx->pack_pin) (void)hipHostFree(ctx->pack_pin);
         ctx->pack_pin = nullptr, ctx->pack_pin_bytes = 0;
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->pack_pin), need + need / 8, hipHostMallocDefault));
+        if (hipHostMalloc(reinterpret_cast<void **>(&ctx->pack_pin), need + need / 8, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->pack_pin = nullptr;
+            return WFAHIP_ERR_UNSUPPORTED;  // (no page-locked memory for the packed words: the byte path needs none)
+        }
         ctx->pack_pin_bytes = need + need / 8;
     }
     uint32_t *const packed = ctx->pack_pin;
@@ -2323,7 +2331,7 @@ static int align_batch_autopack(wfahip_ctx *ctx, const wfahip_params *p, const u
         const auto range = [&](uint64_t a, uint64_t b) {
             bool bd = false;
             for (uint64_t i = a; i < b; i++) {
-                if (!(q_len[i] <= WFAHIP_MAX_SEQ_LEN && t_len[i] <= WFAHIP_MAX_SEQ_LEN)) {
+                if (!(q_len[i] <= WFAHIP_MAX_SEQ_LEN && t_len[i] <= WFAHIP_MAX_SEQ_LEN && q_len[i] && t_len[i])) {
                     packed[q_woff[i]] = 0, packed[t_woff[i]] = 0;
                     continue;
                 }

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
     const uint64_t  cap   = paged ? P.arena_words - (uint64_t)team * P.dir_region_words : P.arena_words;
     const uint32_t  dir_entries = paged ? (uint32_t)(P.dir_region_words / DIR_WORDS) : 0u;
     const uint64_t  page_words  = 1ull << P.page_words_log2;
-    uint32_t *const my_pages    = paged ? P.page_ctl + 2u + P.n_pages + team * (uint32_t)TEAM_MAX_PAGES : nullptr;
+    uint32_t *const my_pages    = paged ? P.page_ctl + 4u + P.n_pages + team * (uint32_t)TEAM_MAX_PAGES : nullptr;
     const uint32_t x = P.x, oe = P.oe, e = P.e, g = P.g;
     const int64_t  stripe = (int64_t)T * G;
 
@@ -185,23 +185,42 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
         }
     };
     auto page_unlock = [&]() { __hip_atomic_store(&P.page_ctl[0], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); };
-    auto page_alloc = [&]() -> uint32_t {  // 0xFFFFFFFF: none left
-        if (n_pg >= (uint32_t)TEAM_MAX_PAGES || !page_lock()) return 0xFFFFFFFFu;
-        const uint32_t nf = ald(&P.page_ctl[1]);
-        uint32_t       pg = 0xFFFFFFFFu;
-        if (nf != 0u) pg = ald(&P.page_ctl[2u + nf - 1u]), ast(&P.page_ctl[1], nf - 1u);
-        page_unlock();
-        if (pg != 0xFFFFFFFFu) my_pages[n_pg++] = pg;
+    // An empty pool is WAITED for as long as some other team that holds pages is still working (its pair will end and give
+    // them back): page_ctl[3] counts the teams that hold pages, page_ctl[2] those that wait.  When every other holder waits
+    // too, nobody can free anything: this team gives up (its pair is re-run by the next ladder level) and its pages let the
+    // others go on.  Failing at once instead cost a 32-pair batch a second launch for the pairs that had run dry.
+    auto page_alloc = [&]() -> uint32_t {  // 0xFFFFFFFF: none to be had
+        if (n_pg >= (uint32_t)TEAM_MAX_PAGES) return 0xFFFFFFFFu;
+        uint32_t pg = 0xFFFFFFFFu, spins = 0;
+        bool     waiting = false;
+        for (;;) {
+            if (!page_lock()) break;
+            const uint32_t nf = ald(&P.page_ctl[1]);
+            if (nf != 0u) pg = ald(&P.page_ctl[4u + nf - 1u]), ast(&P.page_ctl[1], nf - 1u);
+            page_unlock();
+            if (pg != 0xFFFFFFFFu) break;
+            if (!waiting) waiting = true, atomicAdd(&P.page_ctl[2], 1u);
+            const uint32_t holders = ald(&P.page_ctl[3]), waiters = ald(&P.page_ctl[2]);
+            const uint32_t others_holding = holders - (n_pg != 0u ? 1u : 0u), others_waiting = waiters - 1u;
+            if (others_waiting >= others_holding || ++spins > (1u << 20)) break;
+            __builtin_amdgcn_s_sleep(64);
+        }
+        if (waiting) atomicSub(&P.page_ctl[2], 1u);
+        if (pg != 0xFFFFFFFFu) {
+            if (n_pg == 0u) atomicAdd(&P.page_ctl[3], 1u);
+            my_pages[n_pg++] = pg;
+        }
         return pg;
     };
     auto page_free_all = [&]() {
         if (n_pg == 0u) return;
         if (page_lock()) {
             uint32_t nf = ald(&P.page_ctl[1]);
-            for (uint32_t i = 0; i < n_pg; i++) ast(&P.page_ctl[2u + nf++], my_pages[i]);
+            for (uint32_t i = 0; i < n_pg; i++) ast(&P.page_ctl[4u + nf++], my_pages[i]);
             ast(&P.page_ctl[1], nf);
             page_unlock();
         }  // (a lock that cannot be had: the pages stay out of the pool for the rest of the launch -- slower, never wrong)
+        atomicSub(&P.page_ctl[3], 1u);
         n_pg = 0u;
     };
     for (;;) {
