@@ -169,12 +169,13 @@ int  wfahip_align_batch_device(wfahip_ctx *ctx, const wfahip_params *p, const vo
 /* Pre-packed input: the sequences arrive 2-bit packed, 16 bases per uint32 (base i of a
  * sequence in bits 2(i%16).. of word i/16, code = (ascii >> 1) & 3: A 0, C 1, T 2, G 3), every sequence starting at a
  * word boundary and followed by one pad word; pair i is packed[q_woff[i] ..] (q_len[i] bases) vs packed[t_woff[i] ..].
- * A quarter of the bytes cross PCIe.  On the device the words are expanded into the byte blob every kernel of the ladder can
- * read (wfa_unpack_kernel), and the first pass of a large batch then packs its chunk again into the fixed-stride slots
- * {n, m, status, -, q words, t words} it fetches from (wfa_prepack_kernel): a pack -> unpack -> pack detour of ~4 GB of HBM
- * traffic and 1.3 ms per 1e6 x 1 kbp pairs, kept because the retry rungs, the byte path and the long-pair kernels all take
- * bytes (DESIGN.md section 8 says what removing it needs).  Valid only for pure uppercase ACGT input -- the reference compares
- * raw bytes (wfa.go:408-454), so anything else must use wfahip_align_batch.  wfahip_pack_pairs is the host-side packer (n_threads host threads; returns
+ * A quarter of the bytes cross PCIe, and they stay words on the device: a pass that fetches pre-packed pairs -- the first
+ * pass of a large batch of 240+ base reads, the long-read instances -- has its fixed-stride slots {n, m, status, -, q words,
+ * t words} copied from the uploaded words (wfa_prepack_words_kernel), and a pass that reads bytes (the retry rungs, the
+ * lane-per-pair kernel, the long-pair kernels) has exactly its pairs expanded first (wfa_unpack_pairs_kernel: a thousandth
+ * of a 1e6 x 1 kbp batch).  Rounds 2-3 expanded everything to bytes and packed it again (option "unpack_all" = 1).  Valid
+ * only for pure uppercase ACGT input -- the reference compares raw bytes (wfa.go:408-454), so anything else must use
+ * wfahip_align_batch.  wfahip_pack_pairs is the host-side packer (n_threads host threads; returns
  * WFAHIP_ERR_UNSUPPORTED if a byte outside ACGT is found); packed must hold the sum over all sequences of
  * wfahip_packed_words(len) words.  Results are identical to wfahip_align_batch on the unpacked bytes. */
 uint64_t wfahip_packed_words(uint32_t len);

@@ -103,6 +103,8 @@ struct wfahip_ctx {
     uint32_t     *pack_pin   = nullptr;      // host entry: page-locked home of the 2-bit words it packs itself, slice by slice
     size_t        pack_pin_bytes = 0;
     int64_t       opt_autopack             = 1;   // 1: wfahip_align_batch 2-bit packs large pure-ACGT batches on host threads while earlier slices upload
+    const uint32_t *pk_words = nullptr;      // host entries with packed input, while they call the alignment: the uploaded 2-bit words (device); the byte
+                                             // blob they stand for is filled in only for the pairs a pass reads as bytes (wfa_unpack_pairs_kernel)
     bool          one_ctl_clean = false;     // ... whose control words the last call's kernel left zeroed
     DevBuf        one_ctl;                   // ... and its control words: queue head / redo count / ops cursor, then the done queue of the streamed backtrace
     int64_t       opt_arena_budget_pct     = 60;  // long-pair ladder: percent of device memory its arenas may take (80 / 85 / 90: five or six slots
@@ -140,6 +142,7 @@ struct wfahip_ctx {
     int64_t       opt_team_solo_max        = TEAM_SOLO_MAX;  // rows up to this width are done by one workgroup
     int64_t       opt_team_wave            = 1;              // rows up to 64 diagonals are done by one wave (LDS ring)
     int64_t       opt_team_strict          = 1;              // agent-scope release in every team barrier (0: see wfa_team.hpp)
+    int64_t       opt_unpack_all           = 0;              // 1: host entries with packed input expand ALL of it to bytes on the device first (rounds 2-3)
     int64_t       opt_team_paged           = 1;              // 1: the teams share one pool of arena pages (a pair holds what it needs) instead of a slot each
     DevBuf        page_ctl;                                  // ... its free-page stack and the page lists of the teams
     int64_t       opt_team_xcd             = 2;              // 1: teams of one XCD's CUs (blockIdx % 8); 2 (default): ... and a team that finds itself on one XCD keeps
@@ -340,6 +343,64 @@ int make_cfg(wfahip_ctx *ctx, uint32_t max_len, int mode, int level, uint64_t n_
 
 }  // namespace
 
+// Pre-packed input without the detour through bytes (round 4).  The host entries used to expand the whole upload to bytes
+// (wfa_unpack_kernel) only for the first pass to pack its chunk again (wfa_prepack_kernel): 5 GB of HBM traffic and 1.3 ms per
+// 1e6 x 1 kbp pairs.  Now a pass that fetches from pre-packed slots has them COPIED from the uploaded words
+// (wfa_prepack_words_kernel: a wave per pair), and a pass that reads bytes -- the retry rungs, the byte path, the long-pair
+// kernels: a thousandth of the pairs -- has exactly its pairs expanded first (wfa_unpack_pairs_kernel).  Offsets are the
+// byte offsets of the blob the words stand for (multiples of 16: every sequence starts at a word).
+__global__ __launch_bounds__(256) void wfa_prepack_words_kernel(const KParams P, const uint32_t *__restrict__ words, uint32_t *__restrict__ out,
+                                                                uint32_t SW, uint32_t PW) {
+    const uint32_t lane = threadIdx.x & 63u, wi = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (wi >= P.chunk_n) return;
+    const uint32_t pr = P.work ? P.work[wi] : P.chunk_first + wi;
+    const uint32_t nq = P.q_len[pr], mt = P.t_len[pr];
+    uint32_t       status = ST_PENDING;
+    if (nq == 0 || mt == 0)
+        status = ST_EMPTY;  // wfa.go:204-206
+    else if (nq > 0x1FFFFFFFu || mt > 0x1FFFFFFFu)
+        status = ST_TOO_LONG;  // wfa.go:207-209
+    else if (((nq > mt ? nq : mt) + 15u) / 16u + 1u > SW)
+        status = ST_REDO_LDS;
+    uint32_t *const slot = out + (uint64_t)wi * PW;
+    if (status == ST_PENDING) {
+        const uint32_t *const qw = words + P.q_off[pr] / 16u, *const tw = words + P.t_off[pr] / 16u;
+        const uint32_t nwq = (nq + 15u) >> 4, nwt = (mt + 15u) >> 4;
+        for (uint32_t v = lane; v < 2u * SW; v += 64u) {
+            const bool     isq = v < SW;
+            const uint32_t j   = isq ? v : v - SW;
+            slot[4u + v]       = j < (isq ? nwq : nwt) ? (isq ? qw : tw)[j] : 0u;
+        }
+    }
+    if (lane == 0u) slot[0] = nq, slot[1] = mt, slot[2] = status, slot[3] = 0u;
+}
+
+__global__ __launch_bounds__(256) void wfa_unpack_pairs_kernel(const KParams P, const uint32_t *__restrict__ words, uint8_t *__restrict__ blob) {
+    const uint32_t lane = threadIdx.x & 63u, wi = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (wi >= P.chunk_n) return;
+    const uint32_t pr = P.work ? P.work[wi] : P.chunk_first + wi;
+    const uint32_t len[2] = {P.q_len[pr], P.t_len[pr]};
+    const uint64_t off[2] = {P.q_off[pr], P.t_off[pr]};
+    if (len[0] == 0u || len[1] == 0u || len[0] > 0x1FFFFFFFu || len[1] > 0x1FFFFFFFu) return;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const uint32_t nw = (len[q] + 15u) >> 4;
+        for (uint32_t j = lane; j < nw; j += 64u) {
+            const uint32_t w = words[off[q] / 16u + j];
+            uint32_t       o[4];
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                uint32_t v = 0;
+#pragma unroll
+                for (int b = 0; b < 4; b++) v |= ((0x47544341u >> (8u * ((w >> (2 * (4 * d + b))) & 3u))) & 0xFFu) << (8 * b);  // "ACTG"[code]
+                o[d] = v;
+            }
+            *reinterpret_cast<uint4 *>(blob + off[q] + 16ull * j) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
+
 // ------------------------------------------------------------------------------------------ C-ABI
 extern "C" int wfahip_version(void) { return WFAHIP_VERSION; }
 
@@ -480,6 +541,8 @@ static int set_option_impl(wfahip_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_team_strict = value;
     else if (k == "team_xcd")
         ctx->opt_team_xcd = value;
+    else if (k == "unpack_all")
+        ctx->opt_unpack_all = value;
     else if (k == "team_paged")
         ctx->opt_team_paged = value;
     else if (k == "arena_poison")
@@ -895,10 +958,18 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                 if ((kind == 3 && !blk_batch && !list && ctx->opt_prepack != 0) || kind == 8 || (kind == 10 && ctx->opt_lane_pack == 0) || is_long) {
                     const uint32_t pw = 4u + 2u * P.lds_seq_words;
                     if ((rc2 = ensure(ctx, ctx->prepack, (size_t)chunk * pw * 4))) return rc2;
-                    hipLaunchKernelGGL(wfa_prepack_kernel, dim3((uint32_t)((cn + 4 * PREPACK_PAIRS - 1) / (4 * PREPACK_PAIRS))), dim3(256), 0, st, P,
-                                       static_cast<uint32_t *>(ctx->prepack.p), P.lds_seq_words, pw);
+                    if (ctx->pk_words)  // (packed input: the slots are copied from the uploaded words, no bytes in between)
+                        hipLaunchKernelGGL(wfa_prepack_words_kernel, dim3((uint32_t)((cn + 3) / 4)), dim3(256), 0, st, P, ctx->pk_words,
+                                           static_cast<uint32_t *>(ctx->prepack.p), P.lds_seq_words, pw);
+                    else
+                        hipLaunchKernelGGL(wfa_prepack_kernel, dim3((uint32_t)((cn + 4 * PREPACK_PAIRS - 1) / (4 * PREPACK_PAIRS))), dim3(256), 0, st, P,
+                                           static_cast<uint32_t *>(ctx->prepack.p), P.lds_seq_words, pw);
                     HIP_TRY(hipGetLastError());
                     P.prepack = static_cast<const uint32_t *>(ctx->prepack.p), P.prepack_words = pw;
+                } else if (ctx->pk_words) {  // (packed input, a pass that reads bytes: exactly its pairs are expanded first)
+                    hipLaunchKernelGGL(wfa_unpack_pairs_kernel, dim3((uint32_t)((cn + 3) / 4)), dim3(256), 0, st, P, ctx->pk_words,
+                                       const_cast<uint8_t *>(P.blob));
+                    HIP_TRY(hipGetLastError());
                 }
                 if (is_long) P.lds_seq_words = long_cw;  // (the forward kernel's sequence windows; the slots hold long_sw words per sequence)
                 if (n_buf == 2 && c >= 2) HIP_TRY(hipStreamWaitEvent(st, ctx->evpool[4 * (c - 2) + 3], 0));  // buffer free
@@ -1452,6 +1523,11 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             P.work = static_cast<const uint32_t *>(ctx->work.p);
         }
         HIP_TRY(hipMemsetAsync(d_ctrl, 0, 8, st));  // queue_head, redo_count
+        if (ctx->pk_words) {  // (packed input: the long-pair kernels read bytes -- this job's pairs are expanded first)
+            P.chunk_first = 0, P.chunk_n = (uint32_t)n_work;
+            hipLaunchKernelGGL(wfa_unpack_pairs_kernel, dim3((uint32_t)((n_work + 3) / 4)), dim3(256), 0, st, P, ctx->pk_words, const_cast<uint8_t *>(P.blob));
+            HIP_TRY(hipGetLastError());
+        }
         // (tests: what an earlier launch left in the arena must never be read -- with the same batch run twice a stale
         // read returns the right value and hides itself)
         if (ctx->opt_arena_poison)
@@ -1810,13 +1886,19 @@ __global__ __launch_bounds__(256) void wfa_scale_offsets_kernel(uint64_t *q_off,
     if (i < n) q_off[i] *= 16, t_off[i] *= 16;
 }
 
+struct PackedFacts {
+    uint32_t max_len;
+    uint64_t sum_len;
+};
 // packed != nullptr: the sequences arrive 2-bit packed (word i of `packed` = bytes [16 i, 16 i + 16) of the blob the
 // offsets refer to); seq_blob is not read.
 static int align_batch_impl(wfahip_ctx *ctx, const wfahip_params *p, const uint8_t *seq_blob,
                             uint64_t blob_bytes, const uint64_t *q_off, const uint32_t *q_len,
                             const uint64_t *t_off, const uint32_t *t_len, uint64_t n_pairs,
                             wfahip_results *out, const uint32_t *packed = nullptr,
-                            const std::function<int(uint64_t, uint64_t)> *lazy_pack = nullptr) {
+                            const std::function<int(uint64_t, uint64_t)> *lazy_pack = nullptr, const PackedFacts *facts = nullptr) {
+    // (facts: the caller is the library itself -- it laid the packed words out pair after pair and has already validated the
+    // caller's offsets and summed the lengths: the three passes over a million pairs this function would make are 3 ms of a 38 ms call)
     // (lazy_pack: `packed` is the library's own buffer and is only filled as the pipeline gets to a range of pairs --
     // lazy_pack(first, last) packs pairs [first, last) and returns 0, or 2 when it meets a byte outside ACGT)
     if (!ctx || !out) return WFAHIP_ERR_BAD_ARG;
@@ -1833,17 +1915,24 @@ static int align_batch_impl(wfahip_ctx *ctx, const wfahip_params *p, const uint8
     const auto upload_range = [&](uint64_t lo, uint64_t hi, hipStream_t s) -> hipError_t {
         if (hi <= lo) return hipSuccess;
         if (!packed) return hipMemcpyAsync(static_cast<char *>(ctx->in_blob.p) + lo, seq_blob + lo, hi - lo, hipMemcpyHostToDevice, s);
+        // (the words stay words: the alignment copies them into the first pass's slots and expands only the pairs a pass reads
+        // as bytes -- ctx->pk_words below; wfa_unpack_kernel, which expanded everything, is kept for option "unpack_all")
         const uint64_t w0 = lo / 16, w1 = (hi + 15) / 16;
         hipError_t     e  = hipMemcpyAsync(static_cast<uint32_t *>(ctx->in_packed.p) + w0, packed + w0, (w1 - w0) * 4, hipMemcpyHostToDevice, s);
-        if (e != hipSuccess) return e;
+        if (e != hipSuccess || ctx->opt_unpack_all == 0) return e;
         hipLaunchKernelGGL(wfa_unpack_kernel, dim3((uint32_t)((w1 - w0 + 255) / 256)), dim3(256), 0, s,
                            static_cast<const uint32_t *>(ctx->in_packed.p), static_cast<uint4 *>(ctx->in_blob.p), w0, w1);
         return hipGetLastError();
     };
+    struct PkGuard {  // the packed words are the alignment's input for the duration of this call only
+        wfahip_ctx *c;
+        ~PkGuard() { c->pk_words = nullptr; }
+    } pk_guard{ctx};
+    // (ctx->pk_words is set once in_packed is allocated, below)
 
-    uint32_t max_len = 1;
-    uint64_t sum_len = 0;
-    for (uint64_t i = 0; i < n_pairs; i++) {
+    uint32_t max_len = facts ? std::max(1u, facts->max_len) : 1;
+    uint64_t sum_len = facts ? facts->sum_len : 0;
+    for (uint64_t i = 0; i < n_pairs && !facts; i++) {
         if (q_len[i] <= WFAHIP_MAX_SEQ_LEN && t_len[i] <= WFAHIP_MAX_SEQ_LEN && q_len[i] && t_len[i]) {
             // (written so that a hostile 64-bit offset cannot wrap the sum around)
             if (q_off[i] > blob_bytes / osc || q_len[i] > blob_bytes - q_off[i] * osc || t_off[i] > blob_bytes / osc ||
@@ -1857,6 +1946,7 @@ static int align_batch_impl(wfahip_ctx *ctx, const wfahip_params *p, const uint8
     // device staging (+16 bytes so aligned dword loads at the tail stay inside the allocation)
     if ((rc = ensure(ctx, ctx->in_blob, blob_bytes + 32))) return rc;
     if (packed && (rc = ensure(ctx, ctx->in_packed, (blob_bytes + 15) / 16 * 4 + 16))) return rc;
+    if (packed && ctx->opt_unpack_all == 0) ctx->pk_words = static_cast<const uint32_t *>(ctx->in_packed.p);
     if ((rc = ensure(ctx, ctx->in_qoff, n_pairs * 8))) return rc;
     if ((rc = ensure(ctx, ctx->in_toff, n_pairs * 8))) return rc;
     if ((rc = ensure(ctx, ctx->in_qlen, n_pairs * 4))) return rc;
@@ -1871,19 +1961,31 @@ static int align_batch_impl(wfahip_ctx *ctx, const wfahip_params *p, const uint8
     // Large batches: the pairs are aligned in a few slices, each as soon as the part of the blob it refers to has
     // arrived (an uploader thread feeds a copy stream), so most of the alignment time hides behind the upload.
     // Needs the blob ranges of consecutive slices to be disjoint enough (pairs laid out in order, the usual case).
-    constexpr int     UP_SLICES = 4;  // (at most; packed input -- a quarter of the bytes -- is cut into three: a slice costs ~2 ms of its own)
-    int               n_sl = (packed && !lazy_pack) ? 3 : UP_SLICES;
+    constexpr int     UP_SLICES = 6;  // (at most; packed input -- a quarter of the bytes -- is cut into three: a slice costs ~2 ms of its own)
+    // (measured, 1e6 x 1 kbp packed on the fly: 4 slices 35.8 ms, 5 slices 34.8, 3 slices 39; six fall under the pair count at
+    // which the variable-lanes kernel takes a pass: 46)
+    int               n_sl = (packed && !lazy_pack) ? 3 : (lazy_pack && n_pairs >= 900000 ? 5 : 4);
     if (const char *e = std::getenv("WFAHIP_SLICES")) n_sl = std::max(1, std::min(UP_SLICES, std::atoi(e)));
     uint64_t          sl_first[UP_SLICES + 1], sl_lo[UP_SLICES], sl_hi[UP_SLICES];
     bool              sliced = n_pairs >= 200000 && blob_bytes >= (packed ? (256u << 20) : (64u << 20)) && !std::getenv("WFAHIP_NO_UPLOAD_OVERLAP");
     if (sliced) {
         uint64_t covered = 0;
         for (int k = 0; k <= UP_SLICES; k++) sl_first[k] = k <= n_sl ? n_pairs * k / n_sl : n_pairs;
-        // (packing on the fly: nothing can be uploaded before the first slice is packed, so the first slice is a small one)
-        if (lazy_pack && n_sl == 4) sl_first[1] = n_pairs * 12 / 100, sl_first[2] = n_pairs * 40 / 100, sl_first[3] = n_pairs * 70 / 100;
+        // (packing on the fly: nothing can be uploaded before the first slice is packed, so the first slice is a small one; and
+        // the last one too: its results are downloaded with nothing left to hide them behind)
+        if (lazy_pack && n_sl == 4) sl_first[1] = n_pairs * 12 / 100, sl_first[2] = n_pairs * 46 / 100, sl_first[3] = n_pairs * 80 / 100;
+        if (lazy_pack && n_sl == 3) sl_first[1] = n_pairs * 14 / 100, sl_first[2] = n_pairs * 62 / 100;
+        if (lazy_pack && n_sl >= 5) {  // a small first slice, a smaller last one, equal ones between
+            sl_first[1] = n_pairs * 10 / 100;
+            for (int k = 2; k < n_sl; k++) sl_first[k] = n_pairs * (10 + (k - 1) * 74 / (n_sl - 2)) / 100;
+        }
         for (int k = 0; k < n_sl && sliced; k++) {
             uint64_t lo = blob_bytes, hi = 0;
-            for (uint64_t i = sl_first[k]; i < sl_first[k + 1]; i++) {
+            if (facts && sl_first[k + 1] > sl_first[k]) {  // (pair after pair: a slice's words are one range, query of its first pair .. target of its last)
+                const uint64_t a = sl_first[k], b = sl_first[k + 1] - 1;
+                lo = q_off[a] * osc, hi = (t_off[b] + wfahip_packed_words(t_len[b] <= WFAHIP_MAX_SEQ_LEN && q_len[b] && t_len[b] && q_len[b] <= WFAHIP_MAX_SEQ_LEN ? t_len[b] : 0)) * osc;
+            }
+            for (uint64_t i = sl_first[k]; i < sl_first[k + 1] && !facts; i++) {
                 if (!(q_len[i] <= WFAHIP_MAX_SEQ_LEN && t_len[i] <= WFAHIP_MAX_SEQ_LEN && q_len[i] && t_len[i])) continue;
                 lo = std::min(lo, std::min(q_off[i], t_off[i]) * osc);
                 hi = std::max(hi, std::max(q_off[i] * osc + q_len[i], t_off[i] * osc + t_len[i]));
@@ -2299,12 +2401,14 @@ static int align_batch_autopack(wfahip_ctx *ctx, const wfahip_params *p, const u
     if (!ctx || !out || !q_off || !q_len || !t_off || !t_len || !seq_blob) return WFAHIP_ERR_BAD_ARG;
     std::vector<uint64_t> &q_woff = ctx->pack_qw, &t_woff = ctx->pack_tw;  // (kept between calls: fresh pages cost more than the sums)
     q_woff.resize(n_pairs), t_woff.resize(n_pairs);
-    uint64_t pos = 0;
+    uint64_t    pos = 0;
+    PackedFacts facts{1u, 0ull};
     for (uint64_t i = 0; i < n_pairs; i++) {
         // (a pair the alignment rejects -- too long, or empty -- is not validated and packs as nothing: exactly the byte entry's rule)
         const bool v = q_len[i] <= WFAHIP_MAX_SEQ_LEN && t_len[i] <= WFAHIP_MAX_SEQ_LEN && q_len[i] && t_len[i];
         if (v && (q_off[i] > blob_bytes || q_len[i] > blob_bytes - q_off[i] || t_off[i] > blob_bytes || t_len[i] > blob_bytes - t_off[i]))
             return WFAHIP_ERR_BAD_ARG;
+        if (v) facts.max_len = std::max(facts.max_len, std::max(q_len[i], t_len[i])), facts.sum_len += (uint64_t)q_len[i] + t_len[i];
         q_woff[i] = pos, pos += wfahip_packed_words(v ? q_len[i] : 0);
         t_woff[i] = pos, pos += wfahip_packed_words(v ? t_len[i] : 0);
     }
@@ -2359,7 +2463,7 @@ static int align_batch_autopack(wfahip_ctx *ctx, const wfahip_params *p, const u
         for (auto &t : th) t.join();
         return bad ? 2 : 0;
     };
-    return align_batch_impl(ctx, p, nullptr, pos * 16, q_woff.data(), q_len, t_woff.data(), t_len, n_pairs, out, packed, &lazy);
+    return align_batch_impl(ctx, p, nullptr, pos * 16, q_woff.data(), q_len, t_woff.data(), t_len, n_pairs, out, packed, &lazy, &facts);
 }
 
 static int align_batch_entry(wfahip_ctx *ctx, const wfahip_params *p, const uint8_t *seq_blob, uint64_t blob_bytes,
