@@ -392,7 +392,10 @@ def run_rank(args):
                "packed_pairs": int(timing.n_packed_pairs),
                "retried_pairs": int(timing.n_retried_pairs), "arena_gib": timing.arena_bytes / 2 ** 30,
                "wf_cells_per_pair": cells / max(n, 1), "cigar_ops_per_pair": n_ops_total / max(n, 1),
-               "timed_region_s": elapsed}
+               "timed_region_s": elapsed,
+               "steady_state": f"the timed steps re-align the resident batch after {args.warmup + setup_steps} untimed call(s) of the same workload class: "
+                               "what the context learns per class (rows per pair, first window, arena level) is in place; a first call "
+                               "of a class also allocates its arenas (seconds, include/wfa_hip.h)"}
         if dry:
             cfg["dry"] = True
         metric = METRIC if args.config in ("c3", "c4") else (

@@ -728,18 +728,20 @@ def test_generic_kernel_wavefronts_word_for_word(built, penalties):
 
 @pytest.mark.timeout(1500)
 def test_config5_full_length_pair(built):
-    """BASELINE configs[4] at its stated length: 100 kbp pairs @10 %, semi-global + wf-adaptive 10/50/1 (seed 5, the
-    bench's --config c5s dataset), every record and every CIGAR op against the oracle (minutes of one host core per
-    pair)."""
+    """BASELINE configs[4] at its stated length: the EIGHT 100 kbp pairs @10 % of the bench's --config c5s sample (seed 5),
+    semi-global + wf-adaptive 10/50/1 -- eight teams on the paged arena, four of the pairs with 1e5-diagonal wavefronts up to
+    score 65 000 -- every record and every CIGAR op against the oracle (a minute and a half of one host core per pair, 30 GB of
+    wavefronts for a hard one), twice over a poisoned pool."""
     import wfa_amd as w
     from oracle import oracle as O
-    data = w.generate_pairs(seed=5, n_pairs=2, length=100_000, error_rate=0.10)
+    data = w.generate_pairs(seed=5, n_pairs=8, length=100_000, error_rate=0.10)
     al = _aligner(False, (10, 50, 1))
     al.set_option("arena_poison", 1)  # no word an earlier launch left in the arena may be read
     got = al.align_arrays(*data)
-    want = O.align_batch(_oracle_params(False), *data, n_threads=2)
+    want = O.align_batch(_oracle_params(False), *data, n_threads=8)
     assert_batch_equal(got, want, "C5 full length")
     assert (got.status == 0).all() and got.score.min() > 10_000
+    assert_batch_equal(al.align_arrays(*data), want, "C5 full length, second call")
     al.close()
 
 
