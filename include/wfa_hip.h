@@ -273,7 +273,7 @@ int  wfahip_last_timing(const wfahip_ctx *ctx, wfahip_timing *out);
  *                                 sub-wave kernels with sliding 2-bit sequence windows in LDS (any read length); 0: as in round 3
  *   "long_first"  0|11..15        which of those instances a batch starts on: 0 = by batch size (<= 1 024 pairs: a wave per pair with
  *                                 two diagonals per lane; <= 4 096: two pairs per wave, 128 diagonals; else four pairs per wave)
- *   "long_window_words"           packed words of each sequence a pair keeps in LDS (default 256 = 4 096 bases; 64..4096)
+ *   "long_window_words"           packed words of each sequence a pair keeps in LDS (default 240 = 3 840 bases; 64..4096)
  *   "long_wave_bt"  0|1|2         backtrace of those pairs by a wave per pair (1: for chunks of at most 2 048 pairs; 2: always; 0: never)
  *   "pair_fast"  0|1|2|3          wfahip_align_pair: 1 (default) one launch of the lone-pair instance (the wave walks its own
  *                                 backtrace); 3 / 2: round 3's one- / two-launch paths; 0: the batch entry */

@@ -300,8 +300,8 @@ WFA_DEV void blk_push_not_ok(const KParams &P, uint32_t pidx) {
 // (23.3 vs 24.3 ms per 1e6 x 1 kbp pairs): off unless the context's option "census" asks for it.
 //
 // LONG (round 4): reads of any length.  The plain instances keep BOTH whole sequences of a pair in LDS, which stops them at
-// ~10 kbp (and at two waves per SIMD well before that); here a pair keeps a WINDOW of P.lds_seq_words packed words (4 096
-// bases at 256 words) of each sequence around the band -- the band only moves forward, and under wf-adaptive the cells of a
+// ~10 kbp (and at two waves per SIMD well before that); here a pair keeps a WINDOW of P.lds_seq_words packed words (3 840
+// bases at the default 240 words) of each sequence around the band -- the band only moves forward, and under wf-adaptive the cells of a
 // row lie within ~120 bases of each other -- and refills it from the pair's pre-packed slot (wfa_prepack_kernel) as the
 // band advances.  Window word i of the query holds packed word qb + i, of the target word tb + i, the two bases tied
 // together by the window's diagonal centre (qb16 = tb16 - kc16), so that ONE test on a cell's offset h (lo <= h <= hi) says
@@ -311,7 +311,7 @@ WFA_DEV void blk_push_not_ok(const KParams &P, uint32_t pidx) {
 // until no cell is pending.  It always makes progress, so nothing is ever handed on for its length; results are those of
 // the plain instances because WF_EXTEND computes the same full LCP either way.
 template <int G, int BATCH, bool STREAM = false, int PPT = 0, bool CENSUS = true, bool LONG = false>
-__global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16 && BATCH == 1 && !CENSUS && !LONG && (!STREAM || WFA_BLK_STREAM_WAVES5) ? WFA_BLK_WAVES : 4))) void wfa_blk_kernel(const KParams P) {
+__global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16 && BATCH == 1 && !CENSUS && (!STREAM || WFA_BLK_STREAM_WAVES5) ? WFA_BLK_WAVES : 4))) void wfa_blk_kernel(const KParams P) {
     static_assert(!STREAM || (G == 16 && BATCH == 1), "streamed backtrace: 16 lanes per pair, unbatched refill");
     static_assert(PPT == 0 || (G == 8 && PPT == 4) || (G == 64 && (PPT == 1 || PPT == 2)),
                   "diagonals per lane can only be overridden for the 8-lane narrow instance and the lone-pair instances");
@@ -438,10 +438,14 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
                 const uint32_t *const slot = P.prepack + (uint64_t)pidx * P.prepack_words + 4u;
                 uint32_t *const dq = lds + grp * GW, *const dt = dq + CW;
                 for (int i = 4 * j; i < CW; i += 4 * G) {
+                    // (always a load from inside the slot, the words outside it zeroed afterwards: a select between "the slot" and
+                    // "a zero vector" makes the compiler park that vector in scratch memory and load through a flat pointer)
                     const int  wq = qbw + i, wt = tbw + i;
-                    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-                    const uint4 a = (wq >= 0 && wq < SWp) ? *reinterpret_cast<const uint4 *>(slot + wq) : z;
-                    const uint4 b = (wt >= 0 && wt < SWp) ? *reinterpret_cast<const uint4 *>(slot + SWp + wt) : z;
+                    const bool oq = wq >= 0 && wq < SWp, ot = wt >= 0 && wt < SWp;
+                    uint4 a = *reinterpret_cast<const uint4 *>(slot + (oq ? wq : 0));
+                    uint4 b = *reinterpret_cast<const uint4 *>(slot + SWp + (ot ? wt : 0));
+                    a.x = oq ? a.x : 0u, a.y = oq ? a.y : 0u, a.z = oq ? a.z : 0u, a.w = oq ? a.w : 0u;
+                    b.x = ot ? b.x : 0u, b.y = ot ? b.y : 0u, b.z = ot ? b.z : 0u, b.w = ot ? b.w : 0u;
                     *reinterpret_cast<uint4 *>(dq + i) = a;
                     *reinterpret_cast<uint4 *>(dt + i) = b;
                 }

@@ -178,7 +178,8 @@ struct wfahip_ctx {
     int64_t       opt_long                 = 1;   // 1: global pairs longer than opt_long_min_len (penalties shaped 2:4:1) take the sub-wave kernels with sliding
                                                   // sequence windows (wfa_blk_kernel<.., LONG>): four pairs per wave at any read length
     int64_t       opt_long_min_len         = 4000;   // (below it both whole sequences of a pair fit the plain instances' LDS at full occupancy)
-    int64_t       opt_long_window_words    = 256; // packed words per sequence window: 4 096 bases
+    int64_t       opt_long_window_words    = 240; // packed words per sequence window: 3 840 bases, 7.5 KB of LDS per wave of four pairs -- twenty waves per CU
+                                                  // (256 words: nineteen fit, and 2e4 x 50 kbp pairs -- 5 000 waves -- ran a second round: forward 31.5 against 28.0 ms)
     int64_t       opt_long_first           = 0;   // 0: by batch size; 11 / 12 / 13: long reads start on the 64- / 128- / 256-diagonal instance
     int64_t       opt_long_wave_bt         = 1;   // 1: the backtrace of those pairs is walked by a wave per pair (0: a lane per pair, like short pairs)
     int64_t       opt_census               = 0;   // 1: the sub-wave forward kernels count the wavefront words they store (REC_CELLS, timing.cells_stored)
@@ -564,7 +565,7 @@ static int set_option_impl(wfahip_ctx *ctx, const char *key, int64_t value) {
     else if (k == "long_min_len")
         ctx->opt_long_min_len = value;
     else if (k == "long_window_words")
-        ctx->opt_long_window_words = (value >= 64 && value <= 4096 && value % 4 == 0) ? value : 256;  // (64 words: a window every ~500 bases -- tests)
+        ctx->opt_long_window_words = (value >= 64 && value <= 4096 && value % 4 == 0) ? value : 240;  // (64 words: a window every ~500 bases -- tests)
     else if (k == "duo")
         ctx->opt_duo = value;
     else if (k == "duo_min_pairs")
@@ -870,7 +871,7 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             P.arena_words = words, P.compact_fmt = kind == 10 ? 8u : kind == 8 ? 7u : kind == 6 ? 5u : bkind == 5 ? 4u : bkind == 9 ? 6u : (kind >= 3 ? (WFA_BLK_TILED ? 3u : 1u) : 0u);
             const uint32_t waves_lds    = (uint32_t)std::min<size_t>(32, LDS_MAX_BYTES / lds_bytes);
             const bool     overlap      = ctx->opt_overlap != 0;
-            uint32_t       waves_per_cu = is_long ? std::min<uint32_t>(waves_lds, 16)
+            uint32_t       waves_per_cu = is_long ? std::min<uint32_t>(waves_lds, (kind == 11 && !P.census) ? 4 * WFA_BLK_WAVES : 16)
                                           : kind == 10 ? std::min<uint32_t>(waves_lds, 8)
                                           : kind == 8 ? std::min<uint32_t>(waves_lds, 4 * WFA_DUO_WAVES)
                                           : kind == 4 ? std::min<uint32_t>(waves_lds, 12)
