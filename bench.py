@@ -173,7 +173,7 @@ def run_rank(args):
     # the host, because two RCCL ranks cannot sit on one device)
     cdev = dev if backend == "nccl" else torch.device("cpu")
     # collectives run with more than one rank -- or with ONE when --force-collective asks for the process group anyway
-    coll = world > 1 or (bool(args.force_collective) and not dry)
+    coll = world > 1 or bool(args.force_collective)
     if coll:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if world == 1:
@@ -454,8 +454,8 @@ def run_rank(args):
 
 KNAMES = ["wfa_generic_kernel", "wfa_packed_kernel", "wfa_reg_kernel<2, 4, 1>", "wfa_blk_kernel<16",
           "wfa_blk_kernel<8", "wfa_blk_kernel<64", "wfa_blk_kernel<8, 8, false, 4", "wfa_team_kernel", "wfa_duo_kernel", "wfa_blk_kernel<32", "wfa_lane_kernel",
-          "wfa_blk_kernel<16, 1, false, 0, false, true>", "wfa_blk_kernel<32, 1, false, 0, true, true>", "wfa_blk_kernel<64, 1, false, 0, true, true>",
-          "wfa_blk_kernel<64, 1, false, 1, true, true>", "wfa_blk_kernel<64, 1, false, 2, true, true>"]
+          "wfa_blk_kernel<16, 1, false, 0, false, true>", "wfa_blk_kernel<32, 1, false, 0, true, true>", "wfa_blk_kernel<64, 1, false, 0, false, true>",
+          "wfa_blk_kernel<64, 1, false, 1, false, true>", "wfa_blk_kernel<64, 1, false, 2, false, true>"]
 # legs of config.other_configs: (config, timed steps, warm-up steps)
 OTHER_LEGS = [("c2", 300, 5), ("k10", 30, 4), ("l5", 12, 3), ("c5s", 2, 1)]
 

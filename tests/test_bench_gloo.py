@@ -48,6 +48,17 @@ def test_single_rank_dry_line(built):
     assert out["n_gpus"] == 1 and out["config"]["pairs_per_rank"] == [500] and out["config"]["dry"] is True
 
 
+@pytest.mark.timeout(300)
+def test_force_collective_with_one_rank(built):
+    """`--gpus 1 --force-collective`: the process group exists with ONE rank and every collective of the multi-rank path runs
+    (here over gloo; on the GPU box the same flag runs them over RCCL: tests/test_scale_gpu.py)."""
+    out = _run(["--gpus", "1", "--force-collective", "--pairs", "700"])
+    c = out["config"]
+    assert out["n_gpus"] == 1 and c["backend"] == "gloo" and c["collective_forced"] is True
+    assert c["pairs_per_rank"] == [700] and c["gathered_records_complete"] is True and c["gather_ms_standalone"] > 0
+    assert c["gather_bytes_per_rank_step"] == 700 * 11 * 4
+
+
 def test_configs_name_the_baseline_workloads():
     sys.path.insert(0, ROOT)
     import bench
@@ -59,3 +70,9 @@ def test_configs_name_the_baseline_workloads():
     assert (a.total_pairs, a.length, a.seed) == (10_000_000, 1000, 4)
     a = bench.parse_args(["--config", "c5s"])
     assert (a.pairs, a.length, a.error, a.semi_global, a.no_adaptive) == (8, 100_000, 0.10, True, False)
+    # the default run also measures short legs of the other configurations (config.other_configs); any other run does not
+    assert bench.parse_args([]).other_configs == 1 and bench.parse_args(["--config", "c2"]).other_configs == 0
+    assert bench.parse_args(["--pairs", "1000"]).other_configs == 0 and bench.parse_args(["--gpus", "2"]).other_configs == 0
+    assert [name for name, _, _ in bench.OTHER_LEGS] == ["c2", "k10", "l5", "c5s"]
+    for name in ("c2m", "L5", "k10", "k20", "l5", "l10", "l20"):
+        assert name in bench.CONFIGS and name in bench.DEFAULT_STEPS

@@ -984,14 +984,22 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                     hipLaunchKernelGGL((wfa_blk_kernel<16, 1, false, 0, true, true>), dim3(grid), dim3(64), lds_bytes, st, P);
                 else if (kind == 11)
                     hipLaunchKernelGGL((wfa_blk_kernel<16, 1, false, 0, false, true>), dim3(grid), dim3(64), lds_bytes, st, P);
+                // (the lone-wave instances that are first passes of small batches -- a wave per pair, one / two / four diagonals per
+                // lane -- also exist without the census of stored words: 4 % of a step that is all latency)
                 else if (kind == 12)
                     hipLaunchKernelGGL((wfa_blk_kernel<32, 1, false, 0, true, true>), dim3(grid), dim3(64), lds_bytes, st, P);
-                else if (kind == 13)
+                else if (kind == 13 && P.census)
                     hipLaunchKernelGGL((wfa_blk_kernel<64, 1, false, 0, true, true>), dim3(grid), dim3(64), lds_bytes, st, P);
-                else if (kind == 14)
+                else if (kind == 13)
+                    hipLaunchKernelGGL((wfa_blk_kernel<64, 1, false, 0, false, true>), dim3(grid), dim3(64), lds_bytes, st, P);
+                else if (kind == 14 && P.census)
                     hipLaunchKernelGGL((wfa_blk_kernel<64, 1, false, 1, true, true>), dim3(grid), dim3(64), lds_bytes, st, P);
-                else if (kind == 15)
+                else if (kind == 14)
+                    hipLaunchKernelGGL((wfa_blk_kernel<64, 1, false, 1, false, true>), dim3(grid), dim3(64), lds_bytes, st, P);
+                else if (kind == 15 && P.census)
                     hipLaunchKernelGGL((wfa_blk_kernel<64, 1, false, 2, true, true>), dim3(grid), dim3(64), lds_bytes, st, P);
+                else if (kind == 15)
+                    hipLaunchKernelGGL((wfa_blk_kernel<64, 1, false, 2, false, true>), dim3(grid), dim3(64), lds_bytes, st, P);
                 else if (kind == 10 && P.census && P.adaptive)
                     hipLaunchKernelGGL((wfa_lane_kernel<true, true>), dim3(grid), dim3(64), lds_bytes, st, P);
                 else if (kind == 10 && P.census)
