@@ -424,9 +424,12 @@ def run_rank(args):
                 peak = 256 * 4 * 2.4e9 / 2 / 1e9
                 ach = pm["valu_insts"] / (main_k_ms * 1e-3) / 1e9
                 # (wfa_lane_kernel: LDS allows two waves per SIMD -- 1.799 ns, the same row of the probe at that occupancy)
-                waves = 2 if "lane" in kname else 4 if "duo" in kname else (5 if kname.startswith("wfa_blk_kernel<16") else 4)
-                ns_per = {2: 1.799, 4: 1.333, 5: 1.079, 8: 1.080}[waves]
-                attainable = 256 * 4 / ns_per
+                # (the wave-per-pair instances of small long-read batches, wfa_blk_kernel<64, ..>: ONE wave on each SIMD they use -- 1.976 ns
+                # per instruction, the probe's lone-wave row -- and as many SIMDs as there are pairs)
+                lone = kname.startswith("wfa_blk_kernel<64")
+                waves = 1 if lone else 2 if "lane" in kname else 4 if "duo" in kname else (5 if kname.startswith("wfa_blk_kernel<16") else 4)
+                ns_per = {1: 1.976, 2: 1.799, 4: 1.333, 5: 1.079, 8: 1.080}[waves]
+                attainable = (min(n, 256 * 4) if lone else 256 * 4) / ns_per
                 roof["secondary"] = {"bound": "valu-issue", "achieved": ach, "peak": peak, "unit": "G wave-instr/s",
                                      "frac": ach / peak, "valu_wave_insts_per_launch": pm["valu_insts"],
                                      "waves_per_simd": waves, "attainable_at_this_occupancy": attainable,
