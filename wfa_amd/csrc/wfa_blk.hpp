@@ -371,7 +371,7 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
     // LONG: the pair's sequence windows.  lqo / lto: LDS index of packed word 0 of the query / target (window base minus the
     // window's first word: lds[lqo + w] is packed word w while it is resident); [lo16, hi16]: offsets h whose two 16-base
     // windows are resident on every diagonal of the diagonal window; kc16: the diagonal the two bases are tied by
-    int        lqo = 0, lto = 0, lo16 = 1, hi16 = 0, kc16 = 0;
+    int        lqo = 0, lto = 0, lo16 = INT32_MIN, hi16 = INT32_MIN, kc16 = 0;  // (lo16 = hi16 = INT32_MIN: no window yet -- no offset is inside)
     const int  CW  = (int)P.lds_seq_words;                       // LONG: words per sequence window (a multiple of 4 G)
     const int  SWp = LONG ? (int)((P.prepack_words - 4u) / 2u) : 0;  // LONG: words per sequence in a pre-packed slot (a multiple of 4)
     constexpr int LDM = (G * (PPT ? PPT : (G >= 32 ? 4 : 64 / G))) / 2 + 128;  // LONG: half the diagonal window + the drift of its centre a window tolerates
@@ -794,6 +794,23 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
                     if (want && k0 + p == 0 && nM[p] == 0u)
                         nM[p] = 1u, wd[p] = first_eq ? BLK_SEED_MATCH : BLK_SEED_MISMATCH, cc[p] = CENSUS ? 1u : 0u;
             }
+            // The lone-wave instances (one / two diagonals per lane) issue the LDS reads of WF_EXTEND's first windows HERE, ahead of
+            // the store of the row: a wave that is alone on its SIMD has nobody to hide that round trip behind but its own
+            // address arithmetic and the store's.
+            constexpr bool EARLY = G == 64 && PP <= 2;
+            uint32_t       ew[PP][4];
+            if constexpr (EARLY) {
+#pragma unroll
+                for (int p = 0; p < PP; p++) {
+                    const int h = (int)nM[p], v = h - (k0 + p);
+                    if constexpr (LONG) {
+                        const int iq = lqo + (v >> 4), it = lto + (h >> 4);
+                        ew[p][0] = lds[iq], ew[p][1] = lds[iq + 1], ew[p][2] = lds[it], ew[p][3] = lds[it + 1];
+                    } else {
+                        ew[p][0] = lq[v >> 4], ew[p][1] = lq[(v >> 4) + 1], ew[p][2] = lt[h >> 4], ew[p][3] = lt[(h >> 4) + 1];
+                    }
+                }
+            }
             // ------------------------------------------------------------ store the row's words
             // Right away: the words are complete (they hold PRE-extension offsets), and their registers are free for the
             // rest of the step.  A lane stores when one of its cells exists -- 3/4 of the lanes have none, their lines stay
@@ -840,7 +857,8 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
 #pragma unroll
                 for (int p = 0; p < PP; p++) {
                     const int h = (int)nM[p];
-                    oob |= h != 0 && lim[p] - h > 0 && (h < lo16 || h > hi16);
+                    // (lo16 <= h <= hi16 as ONE unsigned compare; h > 0 and room left: lim > h)
+                    oob |= h != 0 && lim[p] > h && (uint32_t)(h - lo16) > (uint32_t)(hi16 - lo16);
                 }
                 lslow = __ballot(run && oob) != 0ull;
             }
@@ -851,7 +869,11 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
                 const int      rem  = lim[p] - h;  // bases left on this diagonal; <= 0: at / past an end (wfa.go:404)
                 const uint32_t room = h ? (uint32_t)imax2(rem, 0) : 0u;  // (nothing for an absent cell)
                 const int      v    = h - (k0 + p);  // absent cells read a harmless word (LDS reads cannot fault)
-                const uint32_t xr   = winq(v) ^ wint(h);
+                uint32_t       xr;
+                if constexpr (EARLY)
+                    xr = __funnelshift_r(ew[p][0], ew[p][1], (uint32_t)(v & 15) * 2u) ^ __funnelshift_r(ew[p][2], ew[p][3], (uint32_t)(h & 15) * 2u);
+                else
+                    xr = winq(v) ^ wint(h);
                 // (v_ffbl_b32 of 0 is 0xFFFFFFFF: a window that matched completely runs to the end of the room)
                 const uint32_t run  = umin2(ffbl_raw(xr) >> 1, room);
                 nM[p] += umin2(run, 16u);
@@ -1162,7 +1184,7 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
                         // the sequence windows are tied together at diagonal kc16: once the diagonal window has drifted further
                         // from it than [lo16, hi16] allows for, they count as empty and the next WF_EXTEND positions them anew
                         const int dk = kb + W / 2 - kc16;
-                        if (dk < -128 || dk > 128) lo16 = 1, hi16 = 0;
+                        if (dk < -128 || dk > 128) lo16 = INT32_MIN, hi16 = INT32_MIN;
                     }
                     if (__ballot(wide) != 0ull) {  // the band does not fit the window: hand the pair on
                         if (wide && j == 0) {

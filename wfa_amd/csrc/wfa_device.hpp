@@ -494,19 +494,16 @@ struct OpsWriterRev {
             overflow = true;
         }
         n++;
+        // (selects, no branches: the lanes of a wave flush different letters; committed values are all zero before the first M)
         const uint32_t letter = (uint32_t)(cur >> 32), cnt = (uint32_t)cur;
-        if (letter == 'M') {
-            if (!seenM) {
-                seenM = true;
-                alen = cnt, matches = cnt;
-            } else {
-                alen += p_len + cnt, matches += cnt, gaps += p_gaps, regions += p_regions;
-            }
-            p_len = p_gaps = p_regions = 0;
-        } else {
-            p_len += cnt;
-            if (letter == 'I' || letter == 'D') p_gaps += cnt, p_regions++;
-        }
+        const bool     isM = letter == 'M', isG = letter == 'I' || letter == 'D';
+        const bool     join = isM && seenM;  // what was pending lies between two Ms: it counts
+        alen += (join ? p_len : 0u) + (isM ? cnt : 0u), matches += isM ? cnt : 0u;
+        gaps += join ? p_gaps : 0u, regions += join ? p_regions : 0u;
+        p_len     = isM ? 0u : p_len + cnt;
+        p_gaps    = isM ? 0u : p_gaps + (isG ? cnt : 0u);
+        p_regions = isM ? 0u : p_regions + (isG ? 1u : 0u);
+        seenM     = seenM || isM;
         if (grouped) {
 #pragma unroll
             for (uint32_t i = GROUP > 1 ? GROUP - 2 : 0; i > 0; i--) hist[i] = hist[i - 1];
@@ -588,16 +585,21 @@ struct CompactView {
 };
 
 // The blocked kernels' arenas seen by a whole WAVE that walks one pair together (every lane runs the same walk on the same
-// values): a region of 32 score indices x 32 diagonals (4 KB) lives in LDS, loaded by the 64 lanes in one round of 16-byte
-// loads -- whole 128-byte lines of the tiled layout -- whenever the walk asks for a cell outside it.  A step of the walk
-// descends 1, 2 or 4 score indices and moves at most one diagonal, so a region lasts ~10 CIGAR ops: one DRAM round trip
+// values): a region of ROWS score indices x 32 diagonals (4 KB at 32 rows; 64 rows measured the same) lives in LDS, loaded by the 64 lanes in one round
+// of 16-byte loads -- whole 128-byte lines of the tiled layout -- whenever the walk asks for a cell outside it.  A step of the
+// walk descends 1, 2 or 4 score indices and moves at most one diagonal, so a region lasts ~10 CIGAR ops: one DRAM round trip
 // per ~10 ops instead of one per op (the lane-per-pair walk of a 50 kbp pair is a chain of ~5 000 dependent misses).
+#ifndef WFA_BTW_ROWS
+#define WFA_BTW_ROWS 32
+#endif
 struct CompactViewWave {
     const uint32_t *A;
     uint64_t        cap;
     uint32_t        g, n_ent, fmt;
-    uint32_t       *reg;          // LDS, 1 024 words: [score index - r0][diagonal - d0]
-    mutable int     r0 = -64, d0 = 0;  // the region holds score indices [r0, r0 + 32) x diagonals [d0, d0 + 32)
+    static constexpr int ROWS = WFA_BTW_ROWS;  // score indices the region holds (a multiple of 8)
+    static constexpr int WORDS = ROWS * 32;
+    uint32_t       *reg;          // LDS, WORDS words: [score index - r0][diagonal - d0]
+    mutable int     r0 = -2 * ROWS, d0 = 0;  // the region holds score indices [r0, r0 + ROWS) x diagonals [d0, d0 + 32)
     WFA_DEV uint64_t widx(uint32_t idx, int k) const {  // word index of (score index, diagonal), CompactView's layouts
         if (fmt == 3u) return 512ull * (idx >> 3) + (((uint32_t)k & 60u) << 3) + ((idx & 7u) << 2) + ((uint32_t)k & 3u);
         if (fmt == 1u) return 64ull * idx + ((uint32_t)k & 63u);
@@ -605,18 +607,19 @@ struct CompactViewWave {
         return 128ull * idx + ((uint32_t)k & 127u);  // fmt 6
     }
     WFA_DEV void refill(uint32_t idx, int k) const {
-        r0 = (int)(idx & ~7u) - 24;  // the cell's tile row on top: 25-32 rows to descend through
+        r0 = (int)(idx & ~7u) - (ROWS - 8);  // the cell's tile row on top: ROWS-7 .. ROWS rows to descend through
         d0 = (k - 16) & ~3;
         const int lane = threadIdx.x & 63;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // the four 16-byte loads of a lane in flight TOGETHER: no branch between them (a row outside the arena loads row 0 and
-        // stores zeros), the layout decided once -- one round trip per refill, not four
-        uint4 v[4];
-        bool  ok[4];
+        // the 16-byte loads of a lane in flight TOGETHER: no branch between them (a row outside the arena loads row 0 and
+        // stores zeros), the layout decided once -- one round trip per refill
+        constexpr int NL = WORDS / 256;
+        uint4 v[NL];
+        bool  ok[NL];
         if (fmt == 3u) {
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
+            for (int r = 0; r < NL; r++) {
                 const int q = lane + 64 * r, si = r0 + (q >> 3), kk = d0 + 4 * (q & 7);
                 ok[r] = si >= 0 && (uint32_t)si < n_ent;
                 const uint32_t su = ok[r] ? (uint32_t)si : 0u;
@@ -625,7 +628,7 @@ struct CompactViewWave {
         } else {
             const uint32_t Wd = fmt == 1u ? 64u : (fmt == 4u ? 256u : 128u);
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
+            for (int r = 0; r < NL; r++) {
                 const int q = lane + 64 * r, si = r0 + (q >> 3), kk = d0 + 4 * (q & 7);
                 ok[r] = si >= 0 && (uint32_t)si < n_ent;
                 const uint32_t su = ok[r] ? (uint32_t)si : 0u;
@@ -633,14 +636,14 @@ struct CompactViewWave {
             }
         }
 #pragma unroll
-        for (int r = 0; r < 4; r++) *reinterpret_cast<uint4 *>(reg + 4 * (lane + 64 * r)) = ok[r] ? v[r] : make_uint4(0u, 0u, 0u, 0u);
+        for (int r = 0; r < NL; r++) *reinterpret_cast<uint4 *>(reg + 4 * (lane + 64 * r)) = ok[r] ? v[r] : make_uint4(0u, 0u, 0u, 0u);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
     WFA_DEV uint32_t word(uint32_t idx, int k) const {
         if (idx >= n_ent) return 0u;
-        if ((uint32_t)((int)idx - r0) >= 32u || (uint32_t)(k - d0) >= 32u) refill(idx, k);
-        return reg[((int)idx - r0) * 32 + (k - d0)];
+        if ((uint32_t)((int)idx - r0) >= (uint32_t)ROWS || (uint32_t)(k - d0) >= 32u) refill(idx, k);
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)reg[((int)idx - r0) * 32 + (k - d0)]);  // (uniform: see backtrace_wave_one)
     }
     WFA_DEV uint32_t tag(int comp, uint32_t idx, int k, uint32_t &off0) const { return blk_tag(word(idx, k), comp, off0); }
 };

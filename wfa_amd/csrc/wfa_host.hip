@@ -2659,7 +2659,7 @@ static int align_pair_impl(wfahip_ctx *ctx, const wfahip_params *p, const uint8_
             // stream), and the same wave walks the backtrace from an LDS region of the arena when the forward pass is done.
             P.fuse_bt = 1;
             hipLaunchKernelGGL((wfa_blk_kernel<64, 1, false, 1, false, false>), dim3(1), dim3(64),
-                               std::max<size_t>((size_t)seq_words * 2 * 4 + 16, 4096 + 16), st, P);
+                               std::max<size_t>((size_t)seq_words * 2 * 4 + 16, (size_t)CompactViewWave::WORDS * 4 + 16), st, P);
         } else {
             // ONE launch: the streaming instance of the forward kernel -- the wave pushes its finished pair to the done
             // queue and, once the pair queue is empty, walks it itself (stream_backtrace at the end of the kernel): one

@@ -340,11 +340,16 @@ WFA_DEV void backtrace_one(const KParams &P, uint32_t idx, uint32_t s_final, uin
 // The ops regions of a workgroup's pairs are carved with ONE atomic: every wave adding its own total to the one cursor
 // serialized 1 563 waves of 1e5 short pairs at the L2 -- 20 of the kernel's 41 us went to waiting for that atomic's return.
 constexpr int BT_THREADS = 512;
-// One finished pair walked by the 64 lanes of a wave together (idx: its index in the chunk; region: 1 024 words of LDS).
-WFA_DEV void backtrace_wave_one(const KParams &P, uint32_t idx, uint32_t *region) {
+// One finished pair walked by the 64 lanes of a wave together (idx: its index in the chunk; region: CompactViewWave::WORDS words of LDS).
+// The walk is the same in all 64 lanes: its inputs pass through v_readfirstlane here, and so does every word the view
+// returns, so that the compiler keeps the walk's state in scalar registers and branches on SCC instead of masking EXEC.
+WFA_DEV void backtrace_wave_one(const KParams &P, uint32_t idx_, uint32_t *region) {
+    const auto     rfl  = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); };
     const uint32_t lane = threadIdx.x & 63u;
-    const uint4    meta = P.pair_meta[idx];
-    const uint32_t pair = P.work ? P.work[idx] : P.chunk_first + idx;
+    const uint32_t idx  = rfl(idx_);
+    uint4          meta = P.pair_meta[idx];
+    meta = make_uint4(rfl(meta.x), rfl(meta.y), rfl(meta.z), rfl(meta.w));
+    const uint32_t pair = rfl(P.work ? P.work[idx] : P.chunk_first + idx);
     uint4 *const   r4   = reinterpret_cast<uint4 *>(P.rec + (uint64_t)pair * REC_WORDS);
     if (meta.x != ST_OK) {
         if (meta.x < ST_REDO_BYTES && lane == 0u) {  // (a pair that was handed on gets its record from the pass that finishes it)
@@ -354,7 +359,7 @@ WFA_DEV void backtrace_wave_one(const KParams &P, uint32_t idx, uint32_t *region
         return;
     }
     const uint32_t s_final = meta.y, h_end = meta.z, cells = meta.w;
-    const int      n = (int)P.q_len[pair], m = (int)P.t_len[pair];
+    const int      n = (int)rfl(P.q_len[pair]), m = (int)rfl(P.t_len[pair]);
     const uint32_t bound = ops_bound(P, s_final);
     unsigned long long off = 0ull;
     if (lane == 0u) off = atomicAdd(P.ops_cursor, (unsigned long long)bound);
@@ -431,7 +436,7 @@ __global__ __launch_bounds__(BT_THREADS) void wfa_backtrace_kernel(const KParams
 // ~4 500 ops each.
 constexpr int BTW_WAVES = 4;
 __global__ __launch_bounds__(64 * BTW_WAVES) void wfa_backtrace_wave_kernel(const KParams P) {
-    __shared__ __attribute__((aligned(16))) uint32_t region[BTW_WAVES][1024];
+    __shared__ __attribute__((aligned(16))) uint32_t region[BTW_WAVES][CompactViewWave::WORDS];
     const uint32_t wv  = threadIdx.x >> 6;
     const uint32_t idx = blockIdx.x * (uint32_t)BTW_WAVES + wv;
     if (idx >= P.chunk_n) return;
