@@ -33,6 +33,11 @@
 #include "wfa_packed.hpp"
 #include <type_traits>
 
+// wave-uniform branches that are almost never / almost always taken: the hint moves the cold block out of the fall-through path
+// (a lone wave pays a fetch restart for every taken branch)
+#define WFA_RARE(x) __builtin_expect(!!(x), 0)
+#define WFA_OFTEN(x) __builtin_expect(!!(x), 1)
+
 namespace wfa {
 
 #ifndef WFA_BLK_TILED
@@ -477,7 +482,7 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
             // pairs one group after the other with all 64 lanes (coalesced dword loads).
             const unsigned long long need = __ballot(st == 0);
             if constexpr (BATCH > 1) {
-                if (need != 0ull) {
+                if (WFA_RARE(need != 0ull)) {
                     uint32_t *const gbase = lds + grp * GW;
                     uint32_t *const gmeta = gbase + BATCH * 2 * SW;
                     // ---- groups whose batch is used up take BATCH queue entries each (one atomic for all of them)
@@ -610,7 +615,7 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
                         bslot += 1;
                     }
                 }
-            } else if (need != 0ull) {
+            } else if (WFA_RARE(need != 0ull)) {
                 uint32_t gbits = 0u;  // bit r: group r needs a pair (wave-uniform)
 #pragma unroll
                 for (int r = 0; r < NG; r++) gbits |= (uint32_t)((need >> (G * r)) & 1ull) << r;
@@ -736,7 +741,7 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
             const uint32_t c_edge = Ops::up1(Mo[0], j), d_edge = Ops::up1(D[0], j);
             const bool     slow_any = __ballot(run && slow) != 0ull;
             WFA_EVT(0, 1), WFA_EVT(1, slow_any ? 1 : 0), WFA_EVT(7, __builtin_popcountll(__ballot(run)) / G);
-            if (!slow_any) {
+            if (WFA_OFTEN(!slow_any)) {
 #pragma unroll
                 for (int p = 0; p < PP; p++) {
                     const uint32_t a = p ? Mo[p - 1] : a_edge, b = p ? I[p - 1] : b_edge;
@@ -787,7 +792,7 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
                 }
             }
             // seeds of initComponents (wfa.go:155-160): M[0][0] = 1/Match or M[x][0] = 1/Mismatch
-            if (__ballot(run && (si == 0u || si == seed_si)) != 0ull) {
+            if (WFA_RARE(__ballot((bool)((int)run & ((int)(si == 0u) | (int)(si == seed_si)))) != 0ull)) {  // (no short circuit: no divergent branch)
                 const bool want = run && ((si == 0u && first_eq) || (si == seed_si && !first_eq));
 #pragma unroll
                 for (int p = 0; p < PP; p++)
@@ -862,7 +867,7 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
                 }
                 lslow = __ballot(run && oob) != 0ull;
             }
-            if (!lslow) {
+            if (WFA_OFTEN(!lslow)) {
 #pragma unroll
             for (int p = 0; p < PP; p++) {
                 const int      h    = (int)nM[p];
@@ -881,7 +886,7 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
             }
             // the few cells (normally the one on the alignment path) that matched a whole window: each lane takes its
             // candidates one at a time and keeps comparing 16-base windows until a mismatch or a sequence end
-            while (__ballot(cmask != 0u) != 0ull) {
+            if (WFA_RARE(__ballot(cmask != 0u) != 0ull)) do {  // (out of line: the step without a candidate falls straight through)
                 const int psel = (int)ffbl_raw(cmask);  // -1 in lanes without a candidate
                 int       h = 0, lm = 0;
 #pragma unroll
@@ -907,10 +912,10 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
                 for (int p = 0; p < PP; p++)
                     if (psel == p) nM[p] = (uint32_t)h;
                 cmask &= cmask - 1u;
-            }
+            } while (__ballot(cmask != 0u) != 0ull);
             }
             if constexpr (LONG) {
-                if (lslow) {  // nothing has been extended yet: every cell with room is pending
+                if (WFA_RARE(lslow)) {  // nothing has been extended yet: every cell with room is pending
 #pragma unroll
                     for (int p = 0; p < PP; p++)
                         if (run && nM[p] != 0u && lim[p] - (int)nM[p] > 0) lpend |= 1u << p;
@@ -920,7 +925,7 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
                 // mismatch, the end of its room (done) or the end of the window (still pending).  The lowest pending
                 // cell of a pair always moves on or finishes, so the loop ends; which pairs share the wave changes
                 // nothing but the number of rounds.
-                while (__ballot(lpend != 0u) != 0ull) {
+                if (WFA_RARE(__ballot(lpend != 0u) != 0ull)) do {
                     int hm = BK_BIG;
 #pragma unroll
                     for (int p = 0; p < PP; p++) hm = ((lpend >> p) & 1u) ? imin2(hm, (int)nM[p]) : hm;
@@ -944,7 +949,7 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
                         nM[p] = (uint32_t)h;
                         if (fin) lpend &= ~(1u << p);
                     }
-                }
+                } while (__ballot(lpend != 0u) != 0ull);
             }
             WFA_STAMP(2); WFA_MARK(2);  // extend
 
@@ -956,7 +961,7 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
             const bool hit_any = __ballot(hitl) != 0ull;
             bool       ghit    = false;  // this pair has a cell at a sequence end in this step
             WFA_EVT(2, hit_any ? 1 : 0);
-            if (hit_any) {
+            if (WFA_RARE(hit_any)) {
                 bool tl = false;
 #pragma unroll
                 for (int p = 0; p < PP; p++) tl |= (k0 + p == m - n && nz[p] && (int)nM[p] >= m);
@@ -972,7 +977,7 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
             bool     anyM = false;
             uint32_t csum = 0u;
             if constexpr (G == 64 && PP <= 2) {
-              if (!hit_any) {
+              if (WFA_OFTEN(!hit_any)) {
                 // One or two diagonals per lane, lanes in diagonal order: the row's range and the band wf-adaptive keeps are the
                 // first / last set bits of ballots (scalar code); the minimum distance is the one real reduction of the step
                 int d[PP], dmin = BK_BIG;
@@ -1003,7 +1008,7 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
                 }
               }
             }
-            if (!hit_any && !(G == 64 && PP <= 2)) {
+            if (WFA_OFTEN(!hit_any) && !(G == 64 && PP <= 2)) {
                 // No cell of the wave sits at a sequence end (97 % of the steps): every M cell is usable, so the
                 // tight range of M (M.Lo/M.Hi, the wf-adaptive trigger of wfa.go:242) is [first, last usable entry],
                 // and with the threshold at +infinity when wf-adaptive does not run, [first_ok, last_ok] IS the
@@ -1037,7 +1042,7 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
                     nM[p] = keep ? nM[p] : 0u, nI[p] = keep ? nI[p] : 0u, nD[p] = keep ? nD[p] : 0u;
                     csum += keep ? cc[p] : 0u;  // (the words of deleted cells stay as they are: nothing ever reads them)
                 }
-            } else if (hit_any) {
+            } else if (WFA_RARE(hit_any)) {
                 // ------------------------------------------------------------ tight range of the M cells = M.Lo/M.Hi
                 int glo = BK_BIG, ghi = -BK_BIG;  // window-relative index of the lane's first / last M cell
 #pragma unroll
@@ -1125,7 +1130,7 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
 
             // ------------------------------------------------------------ finish / next score
             bool fin = run && (term || no_room);
-            if (__ballot(fin) != 0ull) {
+            if (WFA_RARE(__ballot(fin) != 0ull)) {
                 int ctot = (CENSUS && P.census) ? (int)cells : 0;
                 int hf   = 0;  // extended offset of the end cell M[s][Ak]: where the backtrace starts
 #pragma unroll
@@ -1159,7 +1164,7 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
                 const bool live    = keepl && !fin;
                 const bool need_dn = live && ilo <= 0;
                 const bool need_up = live && ihi >= W - 1;
-                if (__ballot(need_dn || need_up) != 0ull) {
+                if (WFA_RARE(__ballot(need_dn || need_up) != 0ull)) {
                     const int  ulo  = imin2(imin2(rlo[0], rlo[1]), imin2(rlo[2], rlo[3]));
                     const int  uhi  = imax2(imax2(rhi[0], rhi[1]), imax2(rhi[2], rhi[3]));
                     const bool wide = (need_dn && (need_up || uhi >= kb - SHD + W - 1)) || (need_up && ulo <= kb + SHD);
@@ -1186,7 +1191,7 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
                         const int dk = kb + W / 2 - kc16;
                         if (dk < -128 || dk > 128) lo16 = INT32_MIN, hi16 = INT32_MIN;
                     }
-                    if (__ballot(wide) != 0ull) {  // the band does not fit the window: hand the pair on
+                    if (WFA_RARE(__ballot(wide) != 0ull)) {  // the band does not fit the window: hand the pair on
                         if (wide && j == 0) {
                             P.pair_meta[pidx] = make_uint4(ST_REDO_BAND, 0u, 0u, 0u);
                             push_redo(P, pair_of(pidx), ST_REDO_BAND);
@@ -1204,20 +1209,20 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
     };
 #ifndef WFA_BLK_SHARED_REFILL
     for (;;) {  // four copies of refill + step: 68 KB of code, but measured 6 % faster than the switch below
-        if (refill()) break;
+        if (WFA_RARE(refill())) break;
         step(std::integral_constant<int, 0>{});
-        if (refill()) break;
+        if (WFA_RARE(refill())) break;
         step(std::integral_constant<int, 1>{});
-        if (refill()) break;
+        if (WFA_RARE(refill())) break;
         step(std::integral_constant<int, 2>{});
-        if (refill()) break;
+        if (WFA_RARE(refill())) break;
         step(std::integral_constant<int, 3>{});
     }
 #else
     // experiment: one copy of the refill code, the four ring phases of the step selected by a wave-uniform switch
     // (40 KB of code; slower: the merge after the switch costs register moves)
     for (int ph = 0;; ph = (ph + 1) & 3) {
-        if (refill()) break;
+        if (WFA_RARE(refill())) break;
         switch (ph) {
         case 0: step(std::integral_constant<int, 0>{}); break;
         case 1: step(std::integral_constant<int, 1>{}); break;
