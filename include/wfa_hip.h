@@ -274,9 +274,15 @@ int  wfahip_last_timing(const wfahip_ctx *ctx, wfahip_timing *out);
  *   "long_first"  0|11..15        which of those instances a batch starts on: 0 = by batch size (<= 1 024 pairs: a wave per pair with
  *                                 two diagonals per lane; <= 4 096: two pairs per wave, 128 diagonals; else four pairs per wave)
  *   "long_window_words"           packed words of each sequence a pair keeps in LDS (default 240 = 3 840 bases; 64..4096)
- *   "long_wave_bt"  0|1|2         backtrace of those pairs by a wave per pair (1: for chunks of at most 2 048 pairs; 2: always; 0: never)
+ *   "long_wave_bt"  0|1|2         backtrace of those pairs by a wave per pair (1: for chunks of at most "long_wave_bt_pairs" pairs --
+ *                                 default twenty per CU, 5 120; 2: always; 0: never)
+ *   "long_mid_lone"  0|1          1 (default): long pairs handed on for their band, when they are at most six per SIMD, go to the
+ *                                 wave-per-pair instance with two diagonals per lane (128 diagonals); 0: two pairs per wave
  *   "pair_fast"  0|1|2|3          wfahip_align_pair: 1 (default) one launch of the lone-pair instance (the wave walks its own
- *                                 backtrace); 3 / 2: round 3's one- / two-launch paths; 0: the batch entry */
+ *                                 backtrace); 3 / 2: round 3's one- / two-launch paths; 0: the batch entry
+ *   "pair_lds"  0|1               1 (default): that instance keeps the pair's arena rows in LDS (160 KB: scores up to ~1 240 at
+ *                                 penalties 4/6/2; a pair that needs more is re-run with the rows in global memory, and the next 64
+ *                                 calls start there); 0: rows in global memory */
 int  wfahip_set_option(wfahip_ctx *ctx, const char *key, int64_t value);
 
 /* Debug / parity aid: align ONE pair and return every stored wavefront row.  rows[] receives

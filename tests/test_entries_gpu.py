@@ -125,6 +125,46 @@ def test_device_generator_writes_the_host_generator_s_dataset(built, n, length, 
     al.close()
 
 
+def test_align_pair_lds_arena(built):
+    """The lone-pair instance with its arena rows in LDS (option pair_lds, the default): same results as the oracle and as the
+    global-memory instance; a pair whose score needs more rows than 160 KB of LDS hold is finished by the global-memory
+    instance in a second launch, and the calls after it start there."""
+    import wfa_amd as w
+    from oracle import oracle as O
+    oa = O.Aligner(_oracle_params(True, (10, 50, 1), (4, 6, 2)))
+    sets = {}
+    for name, length, err, n in (("near", 1000, 0.05, 40), ("far", 3000, 0.30, 3), ("short", 60, 0.1, 20)):
+        blob, q_off, q_len, t_off, t_len = w.generate_pairs(seed=length + 3, n_pairs=n, length=length, error_rate=err)
+        sets[name] = [(bytes(blob[int(q_off[i]):int(q_off[i]) + int(q_len[i])]), bytes(blob[int(t_off[i]):int(t_off[i]) + int(t_len[i])]))
+                      for i in range(n)]
+    key = lambda r: (r.Score, r.CIGAR(False), r.QBegin, r.QEnd, r.TBegin, r.TEnd, r.AlignLen, r.Matches, r.Gaps, r.GapRegions)
+    okey = lambda x: (x.score, x.cigar, x.qbegin, x.qend, x.tbegin, x.tend, x.align_len, x.matches, x.gaps, x.gap_regions)
+    al = _aligner(True, (10, 50, 1), (4, 6, 2))
+    for q, t in sets["near"] + sets["short"]:
+        assert key(al.Align(q, t)) == okey(oa.align(q, t))
+        tm = al.last_timing()
+        assert tm.n_launches == 1 and tm.main_kernel_kind == 16
+    # a pair that outgrows the rows in LDS (score > 1 240): two launches, then the global-memory instance first for a while
+    q, t = sets["far"][0]
+    want = oa.align(q, t)
+    assert want.score > 1300
+    al.set_option("pair_lds", 1)  # (also clears the skip count)
+    assert key(al.Align(q, t)) == okey(want)
+    first = al.last_timing().n_launches
+    assert key(al.Align(q, t)) == okey(want)
+    second = al.last_timing().n_launches
+    # (first call: the LDS instance, then the global-memory instance -- and the batch entry behind it when the band outgrows the
+    # 64-diagonal window too; second call: the LDS instance is skipped)
+    assert first >= 2 and second <= first, (first, second)
+    for q, t in sets["far"][1:] + sets["near"][:5]:
+        assert key(al.Align(q, t)) == okey(oa.align(q, t))
+    # the global-memory instance alone
+    al.set_option("pair_lds", 0)
+    for q, t in sets["near"][:10] + sets["far"][:1]:
+        assert key(al.Align(q, t)) == okey(oa.align(q, t))
+    al.close()
+
+
 def test_align_pair_entry(built):
     """wfahip_align_pair (Aligner.Align): the two-launch path through the mapped pinned block for pairs shaped like the
     reference's defaults, the batch entry behind it for everything else -- semi-global, other penalties, bytes outside ACGT,

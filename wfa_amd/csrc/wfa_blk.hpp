@@ -33,11 +33,6 @@
 #include "wfa_packed.hpp"
 #include <type_traits>
 
-// wave-uniform branches that are almost never / almost always taken: the hint moves the cold block out of the fall-through path
-// (a lone wave pays a fetch restart for every taken branch)
-#define WFA_RARE(x) __builtin_expect(!!(x), 0)
-#define WFA_OFTEN(x) __builtin_expect(!!(x), 1)
-
 namespace wfa {
 
 #ifndef WFA_BLK_TILED
@@ -315,12 +310,18 @@ WFA_DEV void blk_push_not_ok(const KParams &P, uint32_t pidx) {
 // pending cell (all G lanes of the pair load the two windows in one round of 16-byte loads), extend what is inside, repeat
 // until no cell is pending.  It always makes progress, so nothing is ever handed on for its length; results are those of
 // the plain instances because WF_EXTEND computes the same full LCP either way.
-template <int G, int BATCH, bool STREAM = false, int PPT = 0, bool CENSUS = true, bool LONG = false>
+// LDSA (round 4, wfahip_align_pair only): the rows of the pair's arena live in LDS behind the sequences (P.lds_arena_off words
+// in, P.arena_words of them) instead of global memory -- the wave that walks the backtrace afterwards reads them where they
+// are: no region refills, no global traffic at all between the sequences coming in and the record going out.  160 KB of LDS
+// hold 620 score indices (scores up to 1 240 at g = 2); a pair that needs more reports ST_REDO_ARENA and the host runs the
+// global-memory instance.
+template <int G, int BATCH, bool STREAM = false, int PPT = 0, bool CENSUS = true, bool LONG = false, bool LDSA = false>
 __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16 && BATCH == 1 && !CENSUS && (!STREAM || WFA_BLK_STREAM_WAVES5) ? WFA_BLK_WAVES : 4))) void wfa_blk_kernel(const KParams P) {
     static_assert(!STREAM || (G == 16 && BATCH == 1), "streamed backtrace: 16 lanes per pair, unbatched refill");
     static_assert(PPT == 0 || (G == 8 && PPT == 4) || (G == 64 && (PPT == 1 || PPT == 2)),
                   "diagonals per lane can only be overridden for the 8-lane narrow instance and the lone-pair instances");
     static_assert(!LONG || (BATCH == 1 && !STREAM && (PPT == 0 || G == 64) && G >= 16), "sliding sequence windows: unbatched, pre-packed input");
+    static_assert(!LDSA || (G == 64 && PPT == 1 && BATCH == 1 && !STREAM && !LONG && !CENSUS), "LDS-resident arena: the lone-pair instance");
     constexpr int PP  = PPT ? PPT : (G >= 32 ? 4 : 64 / G);  // diagonals per lane
     constexpr int NG  = 64 / G;                // pairs per wave
 #ifdef WFA_BLK_W
@@ -709,7 +710,8 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
                     const int Ak = m - n;
                     si = 0, cells = 0, slow = false;
                     kb   = -(W / 2) + PP * imax2(-(3 * W / 8) / PP, imin2((3 * W / 8) / PP, Ak / (2 * PP)));  // k = 0 (the seed) inside, biased towards Ak
-                    rowp = P.arena + (uint64_t)pidx * cap;
+                    if constexpr (LDSA) rowp = lds + P.lds_arena_off;
+                    else rowp = P.arena + (uint64_t)pidx * cap;
                     if constexpr (LONG) first_eq = ((slot[4] ^ slot[4 + SWp]) & 3u) == 0u;
                     else first_eq = ((lq[0] ^ lt[0]) & 3u) == 0u;  // q[0] == t[0] (wfa.go:155)
                     set_window();
@@ -792,7 +794,7 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
                 }
             }
             // seeds of initComponents (wfa.go:155-160): M[0][0] = 1/Match or M[x][0] = 1/Mismatch
-            if (WFA_RARE(__ballot((bool)((int)run & ((int)(si == 0u) | (int)(si == seed_si)))) != 0ull)) {  // (no short circuit: no divergent branch)
+            if (WFA_RARE(__ballot(si <= seed_si) != 0ull)) {  // (ONE compare on the step's path; `want` below is the exact test)
                 const bool want = run && ((si == 0u && first_eq) || (si == seed_si && !first_eq));
 #pragma unroll
                 for (int p = 0; p < PP; p++)
@@ -1249,7 +1251,9 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
         // rows were stored by this very wave; the release / acquire pair makes them its loads' too.
         if (P.fuse_bt) {
             __threadfence();
-            for (uint32_t idx = blockIdx.x; idx < P.chunk_n; idx += gridDim.x) backtrace_wave_one(P, idx, lds);
+            if constexpr (LDSA) backtrace_wave_one<true>(P, blockIdx.x, lds + P.lds_arena_off);  // (one pair: the rows are still where they were written)
+            else
+                for (uint32_t idx = blockIdx.x; idx < P.chunk_n; idx += gridDim.x) backtrace_wave_one(P, idx, lds);
             // (one wave, one pair: the control words go back to zero here, so the next Align starts without a memset of its own)
             if (lane == 0 && gridDim.x == 1u) *P.queue_head = 0u, *P.redo_count = 0u, *P.ops_cursor = 0ull;
         }

@@ -642,8 +642,19 @@ struct CompactViewWave {
     }
     WFA_DEV uint32_t word(uint32_t idx, int k) const {
         if (idx >= n_ent) return 0u;
-        if ((uint32_t)((int)idx - r0) >= (uint32_t)ROWS || (uint32_t)(k - d0) >= 32u) refill(idx, k);
+        if (WFA_RARE((uint32_t)((int)idx - r0) >= (uint32_t)ROWS || (uint32_t)(k - d0) >= 32u)) refill(idx, k);
         return (uint32_t)__builtin_amdgcn_readfirstlane((int)reg[((int)idx - r0) * 32 + (k - d0)]);  // (uniform: see backtrace_wave_one)
+    }
+    WFA_DEV uint32_t tag(int comp, uint32_t idx, int k, uint32_t &off0) const { return blk_tag(word(idx, k), comp, off0); }
+};
+
+// The lone pair's rows where the forward pass wrote them: in LDS, tiled (fmt 3).  Uniform like CompactViewWave's words.
+struct CompactViewLds {
+    const uint32_t *A;  // LDS
+    uint32_t        g, n_ent;
+    WFA_DEV uint32_t word(uint32_t idx, int k) const {
+        if (idx >= n_ent) return 0u;
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)A[512u * (idx >> 3) + (((uint32_t)k & 60u) << 3) + ((idx & 7u) << 2) + ((uint32_t)k & 3u)]);
     }
     WFA_DEV uint32_t tag(int comp, uint32_t idx, int k, uint32_t &off0) const { return blk_tag(word(idx, k), comp, off0); }
 };

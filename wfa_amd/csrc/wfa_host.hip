@@ -110,6 +110,12 @@ struct wfahip_ctx {
     int64_t       opt_arena_budget_pct     = 60;  // long-pair ladder: percent of device memory its arenas may take (80 / 85 / 90: five or six slots
                                                   // instead of four for the configs[4] pairs -- the main launch of 32 pairs 2 875 -> 1 949 / 2 074 / 1 744 ms --
                                                   // but 2 / 1 / 3 of them then outgrow the smaller slots and their re-run takes 1.1 s: no gain, measured)
+    int64_t       opt_long_wave_bt_pairs   = 0;   // chunks of at most this many long pairs are walked by a wave per pair (0: twenty per CU -- the walk keeps its state in scalar registers since round 4: 2e4 x 50 kbp, the 4 186 leftovers: 6.2 -> 5.3 ms; all 2e4 that way: +13 ms)
+    int64_t       opt_long_mid_lone        = 1;   // long reads handed on for their band, when they are few (<= 6 per SIMD): the lone-wave 128-diagonal instance takes them
+    int64_t       opt_pair_lds             = 1;   // wfahip_align_pair's lone-pair instance keeps the pair's arena rows in LDS (0: in global memory); a pair that needs more
+                                                 // rows than 160 KB hold is re-run by the global-memory instance, and the next calls start there
+    uint32_t      one_lds_skip             = 0;   // calls left that skip the LDS instance (after a pair that did not fit it)
+    bool          one_lds_attr             = false;  // the LDS instance's dynamic-LDS limit has been raised
     int64_t       opt_pair_fast            = 1;   // wfahip_align_pair, when the pair allows it: 1 = one launch of the lone-pair instance (a lane per diagonal, the wave walks its
                                                   // own backtrace); 3 = round 3's one launch of the four-pairs-per-wave streaming instance; 2 = that kernel + the backtrace kernel; 0 = the batch entry
     DevBuf        in_packed;                 // host entry with pre-packed input: the 2-bit words as uploaded (unpacked into in_blob on the device)
@@ -560,6 +566,12 @@ static int set_option_impl(wfahip_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_long = value;
     else if (k == "long_first")
         ctx->opt_long_first = value;
+    else if (k == "long_wave_bt_pairs")
+        ctx->opt_long_wave_bt_pairs = value;
+    else if (k == "long_mid_lone")
+        ctx->opt_long_mid_lone = value;
+    else if (k == "pair_lds")
+        ctx->opt_pair_lds = value, ctx->one_lds_skip = 0;
     else if (k == "long_wave_bt")
         ctx->opt_long_wave_bt = value;
     else if (k == "long_min_len")
@@ -1049,7 +1061,7 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                 // long pairs, up to two waves per SIMD of them: a wave per pair walks an LDS region of the arena (3.2 against 5.7 ms
                 // for 500 x 50 kbp).  Beyond that the lane-per-pair kernel wins: the walk is bound by instructions, and there one
                 // instruction serves 64 pairs (2e4 x 50 kbp: 15 against 47 ms)
-                if (is_long && (ctx->opt_long_wave_bt >= 2 || (ctx->opt_long_wave_bt == 1 && cn <= (uint64_t)ctx->num_cus * 8)))
+                if (is_long && (ctx->opt_long_wave_bt >= 2 || (ctx->opt_long_wave_bt == 1 && cn <= (ctx->opt_long_wave_bt_pairs ? (uint64_t)ctx->opt_long_wave_bt_pairs : (uint64_t)ctx->num_cus * 20))))
                     hipLaunchKernelGGL(wfa_backtrace_wave_kernel, dim3((uint32_t)((cn + BTW_WAVES - 1) / BTW_WAVES)), dim3(64 * BTW_WAVES), 0, st_bt, P);
                 else
                     hipLaunchKernelGGL(wfa_backtrace_kernel, dim3((uint32_t)((cn + BT_THREADS - 1) / BT_THREADS)), dim3(BT_THREADS), 0, st_bt, P);
@@ -1120,7 +1132,10 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                 const size_t n_in = lst.size();
                 std::vector<uint64_t> r2;
                 if (!from_mid && ctx->opt_blk_mid != 0) {
-                    const int rcm = forward_pass(kind_mid, &lst, 0, lst.size(), r2, false);
+                    // (long reads, leftovers that are a few waves per SIMD anyway: a wave per pair with two diagonals per lane steps
+                    // in half the instructions of two pairs per wave with four -- 2e4 x 50 kbp: 53.1 -> 47.4 ms per step, the 4 186 leftovers' pass 20.6 -> ~15 ms)
+                    const int km = (long_first && ctx->opt_long_mid_lone != 0 && lst.size() <= 6ull * (uint64_t)ctx->num_cus * 4ull) ? 15 : kind_mid;
+                    const int rcm = forward_pass(km, &lst, 0, lst.size(), r2, false);
                     if (rcm) return rcm;
                     ctx->timing.n_packed_pairs += (uint32_t)(lst.size() - r2.size());
                     mid_in += lst.size();
@@ -2647,34 +2662,65 @@ static int align_pair_impl(wfahip_ctx *ctx, const wfahip_params *p, const uint8_
         P.pair_meta = static_cast<uint4 *>(ctx->meta.p);
         P.dx = 2, P.doe = 4, P.de = 1, P.dm = 5, P.di = 2, P.min_xe = min_xe;
         P.lds_seq_words = seq_words, P.chunk_first = 0, P.chunk_n = 1, P.n_work = 1;
-        // (the lone-pair instance leaves its control words zeroed: only the first call, or one after another path, clears them)
-        if (!(ctx->opt_pair_fast == 1 && ctx->one_ctl_clean)) HIP_TRY(hipMemsetAsync(d_ctrl, 0, 1024, st));
-        ctx->one_ctl_clean = false;
-        if (ctx->opt_pair_fast == 2) {  // forward kernel, then the backtrace kernel (kept for comparison: 305 us per 1 kbp pair)
-            hipLaunchKernelGGL((wfa_blk_kernel<16, 1, false, 0, false>), dim3(1), dim3(64), (size_t)seq_words * 2 * 4 * 4 + 16, st, P);
-            hipLaunchKernelGGL(wfa_backtrace_kernel, dim3(1), dim3(256), 0, st, P);
-        } else if (ctx->opt_pair_fast == 1) {
-            // Round 4, ONE launch of the lone-pair instance: the whole wave on the pair, a lane per diagonal (a quarter of the
-            // instructions of a step of the four-pairs-per-wave kernel -- a lone wave's step is the latency of its own instruction
-            // stream), and the same wave walks the backtrace from an LDS region of the arena when the forward pass is done.
-            P.fuse_bt = 1;
-            hipLaunchKernelGGL((wfa_blk_kernel<64, 1, false, 1, false, false>), dim3(1), dim3(64),
-                               std::max<size_t>((size_t)seq_words * 2 * 4 + 16, (size_t)CompactViewWave::WORDS * 4 + 16), st, P);
-        } else {
-            // ONE launch: the streaming instance of the forward kernel -- the wave pushes its finished pair to the done
-            // queue and, once the pair queue is empty, walks it itself (stream_backtrace at the end of the kernel): one
-            // launch and its gap less than forward kernel + backtrace kernel (298 against 304 us for a 1 kbp pair).  The walk
-            // itself is 66-77 us either way: one lane, ~250 instructions per CIGAR op -- not its reads (walking a copy of the
-            // rows in LDS took as long).
-            P.done_ctl = d_ctrl + 64, P.done_q = reinterpret_cast<uint4 *>(d_ctrl + 128), P.n_stream_wgs = 0;
-            P.stream_wait = 2000000;  // 20 ms of the 100 MHz clock
-            hipLaunchKernelGGL((wfa_blk_kernel<16, 1, true, 0, false>), dim3(1), dim3(64), (size_t)seq_words * 2 * 4 * 4 + 16, st, P);
+        // Round 4, the lone-pair instance with the arena rows in LDS first (pair_lds): rows behind the sequences, as many as the
+        // worst-case score needs or 160 KB hold; a pair that runs out of them (ST_REDO_ARENA in its record) is run again by the
+        // global-memory instance, and the next calls start there (one_lds_skip).
+        const uint32_t lds_off   = ((uint32_t)seq_words * 2u + 4u + 31u) & ~31u;  // words; tiles want their 128-byte lines
+        const uint64_t lds_rows  = std::min<uint64_t>((worst / g + 16 + 7) & ~7ull, ((160u * 1024u - lds_off * 4u) / 256u) & ~7u);
+        bool           use_lds   = ctx->opt_pair_fast == 1 && ctx->opt_pair_lds != 0 && ctx->one_lds_skip == 0 && lds_rows >= 64;
+        if (ctx->one_lds_skip) ctx->one_lds_skip--;
+        uint32_t launches = 0;
+        for (;;) {
+            hrec[REC_STATUS] = ST_PENDING;
+            // (the lone-pair instance leaves its control words zeroed: only the first call, or one after another path, clears them)
+            if (!(ctx->opt_pair_fast == 1 && ctx->one_ctl_clean)) HIP_TRY(hipMemsetAsync(d_ctrl, 0, 1024, st));
+            ctx->one_ctl_clean = false;
+            if (ctx->opt_pair_fast == 2) {  // forward kernel, then the backtrace kernel (kept for comparison: 305 us per 1 kbp pair)
+                hipLaunchKernelGGL((wfa_blk_kernel<16, 1, false, 0, false>), dim3(1), dim3(64), (size_t)seq_words * 2 * 4 * 4 + 16, st, P);
+                hipLaunchKernelGGL(wfa_backtrace_kernel, dim3(1), dim3(256), 0, st, P);
+                launches += 2;
+            } else if (ctx->opt_pair_fast == 1) {
+                // ONE launch of the lone-pair instance: the whole wave on the pair, a lane per diagonal (a quarter of the
+                // instructions of a step of the four-pairs-per-wave kernel -- a lone wave's step is the latency of its own instruction
+                // stream), and the same wave walks the backtrace when the forward pass is done -- from the rows in LDS, or from an
+                // LDS region of the global arena.
+                P.fuse_bt = 1;
+                if (use_lds) {
+                    const auto kern = wfa_blk_kernel<64, 1, false, 1, false, false, true>;
+                    if (!ctx->one_lds_attr) {
+                        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                        ctx->one_lds_attr = true;
+                    }
+                    KParams PL = P;
+                    PL.arena_words = lds_rows * 64, PL.lds_arena_off = lds_off;
+                    hipLaunchKernelGGL(kern, dim3(1), dim3(64), (size_t)lds_off * 4 + (size_t)lds_rows * 256, st, PL);
+                } else {
+                    hipLaunchKernelGGL((wfa_blk_kernel<64, 1, false, 1, false, false>), dim3(1), dim3(64),
+                                       std::max<size_t>((size_t)seq_words * 2 * 4 + 16, (size_t)CompactViewWave::WORDS * 4 + 16), st, P);
+                }
+                launches++;
+            } else {
+                // ONE launch: the streaming instance of the forward kernel -- the wave pushes its finished pair to the done
+                // queue and, once the pair queue is empty, walks it itself (stream_backtrace at the end of the kernel): one
+                // launch and its gap less than forward kernel + backtrace kernel (298 against 304 us for a 1 kbp pair).  The walk
+                // itself is 66-77 us either way: one lane, ~250 instructions per CIGAR op -- not its reads (walking a copy of the
+                // rows in LDS took as long).
+                P.done_ctl = d_ctrl + 64, P.done_q = reinterpret_cast<uint4 *>(d_ctrl + 128), P.n_stream_wgs = 0;
+                P.stream_wait = 2000000;  // 20 ms of the 100 MHz clock
+                hipLaunchKernelGGL((wfa_blk_kernel<16, 1, true, 0, false>), dim3(1), dim3(64), (size_t)seq_words * 2 * 4 * 4 + 16, st, P);
+                launches++;
+            }
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(st));
+            ctx->one_ctl_clean = ctx->opt_pair_fast == 1;
+            if (use_lds && hrec[REC_STATUS] == ST_REDO_ARENA) {  // more rows than LDS holds: the global-memory instance
+                use_lds = false, ctx->one_lds_skip = 64;
+                continue;
+            }
+            break;
         }
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(st));
-        ctx->one_ctl_clean = ctx->opt_pair_fast == 1;
         ctx->timing = wfahip_timing{};
-        ctx->timing.n_launches = ctx->opt_pair_fast == 2 ? 2 : 1, ctx->timing.main_kernel_kind = ctx->opt_pair_fast == 1 ? 16 : 3;  // (the batch entry never makes fewer than two launches)
+        ctx->timing.n_launches = launches, ctx->timing.main_kernel_kind = ctx->opt_pair_fast == 1 ? 16 : 3;  // (the batch entry never makes fewer than two launches)
         if (hrec[REC_STATUS] == ST_OK) {
             const uint64_t off = (uint64_t)hrec[REC_OPS_OFF_LO] | ((uint64_t)hrec[REC_OPS_OFF_HI] << 32);
             const uint32_t len = hrec[REC_OPS_LEN];

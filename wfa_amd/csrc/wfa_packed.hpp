@@ -17,6 +17,7 @@
 // Both halves of a wave run the same instruction stream with their own score counter; a half that
 // finishes its pair pulls the next one from the device queue while the other keeps stepping.
 #pragma once
+#include <type_traits>
 #include "wfa_device.hpp"
 
 namespace wfa {
@@ -343,6 +344,8 @@ constexpr int BT_THREADS = 512;
 // One finished pair walked by the 64 lanes of a wave together (idx: its index in the chunk; region: CompactViewWave::WORDS words of LDS).
 // The walk is the same in all 64 lanes: its inputs pass through v_readfirstlane here, and so does every word the view
 // returns, so that the compiler keeps the walk's state in scalar registers and branches on SCC instead of masking EXEC.
+// LDSV: `region` IS the pair's arena (CompactViewLds; wfa_blk_kernel<.., LDSA = true>).
+template <bool LDSV = false>
 WFA_DEV void backtrace_wave_one(const KParams &P, uint32_t idx_, uint32_t *region) {
     const auto     rfl  = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); };
     const uint32_t lane = threadIdx.x & 63u;
@@ -352,7 +355,9 @@ WFA_DEV void backtrace_wave_one(const KParams &P, uint32_t idx_, uint32_t *regio
     const uint32_t pair = rfl(P.work ? P.work[idx] : P.chunk_first + idx);
     uint4 *const   r4   = reinterpret_cast<uint4 *>(P.rec + (uint64_t)pair * REC_WORDS);
     if (meta.x != ST_OK) {
-        if (meta.x < ST_REDO_BYTES && lane == 0u) {  // (a pair that was handed on gets its record from the pass that finishes it)
+        // (a pair that was handed on gets its record from the pass that finishes it; wfahip_align_pair's LDS instance reports it:
+        // the host decides what runs next)
+        if ((LDSV || meta.x < ST_REDO_BYTES) && lane == 0u) {
             const uint4 z = make_uint4(0u, 0u, 0u, 0u);
             r4[0] = make_uint4(meta.x, 0u, 0u, 0u), r4[1] = z, r4[2] = z, r4[3] = z;
         }
@@ -365,9 +370,13 @@ WFA_DEV void backtrace_wave_one(const KParams &P, uint32_t idx_, uint32_t *regio
     if (lane == 0u) off = atomicAdd(P.ops_cursor, (unsigned long long)bound);
     off = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(off >> 32)) << 32) |
           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)off);
-    CompactViewWave cv;
-    cv.A = P.arena + (uint64_t)idx * P.arena_words, cv.cap = P.arena_words, cv.g = P.g, cv.n_ent = s_final / P.g + 1u;
-    cv.fmt = P.compact_fmt, cv.reg = region;
+    typename std::conditional<LDSV, CompactViewLds, CompactViewWave>::type cv;
+    if constexpr (LDSV) {
+        cv.A = region, cv.g = P.g, cv.n_ent = s_final / P.g + 1u;
+    } else {
+        cv.A = P.arena + (uint64_t)idx * P.arena_words, cv.cap = P.arena_words, cv.g = P.g, cv.n_ent = s_final / P.g + 1u;
+        cv.fmt = P.compact_fmt, cv.reg = region;
+    }
     OpsWriterRev ow;
     const bool   fits = off + bound <= P.ops_cap;
     ow.combine = false;

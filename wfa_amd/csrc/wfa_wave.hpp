@@ -89,16 +89,16 @@ WFA_DEV uint32_t wave_mode_steps(const KParams &P, const SeqView<MODE> &sv, uint
         if (su == 0u) wlo = INT32_MAX, whi = INT32_MIN;
         if (wseed) wlo = imin2(wlo, seed_lo), whi = imax2(whi, seed_hi);
         const int64_t WW = (whi >= wlo) ? ((int64_t)whi - wlo + 1) : 0;
-        if (dir_entries == 0u ? utop + 3ull * (uint64_t)WW + (uint64_t)DIR_WORDS * (sj + 2) > cap
-                              : (utop + 3ull * (uint64_t)WW > row_end || sj + 2u > dir_entries)) {
+        if (WFA_RARE(dir_entries == 0u ? utop + 3ull * (uint64_t)WW + (uint64_t)DIR_WORDS * (sj + 2) > cap
+                                       : (utop + 3ull * (uint64_t)WW > row_end || sj + 2u > dir_entries))) {
             wflags = WAVE_OVERFLOW;
             break;
         }
-        if (WW > 64) {
+        if (WFA_RARE(WW > 64)) {
             wflags = WAVE_WIDE;
             break;
         }
-        if (WW == 0) {
+        if (WFA_RARE(WW == 0)) {
             put_ent(sj, 0ull, 0, 0, 0u);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -129,13 +129,13 @@ WFA_DEV uint32_t wave_mode_steps(const KParams &P, const SeqView<MODE> &sv, uint
         utop += 3ull * (uint64_t)WW;
         // lanes are ordered by diagonal: first / last lane of a ballot = lowest / highest diagonal
         const unsigned long long bM = __ballot(c.M != 0u);
-        if (bM == 0ull) {  // no M cell: nothing to reduce, the entry is empty (mlo > mhi)
+        if (WFA_RARE(bM == 0ull)) {  // no M cell: nothing to reduce, the entry is empty (mlo > mhi)
             put_ent(sj, 0ull, 0, 0, 0u);
         } else {
             const int  wmlo = wlo + (int)__builtin_ctzll(bM), wmhi = wlo + 63 - (int)__builtin_clzll(bM);
             const int  dd   = reduce_dist(c.M, k, n, m);
             const bool hit  = c.M != 0u && k == Ak && (int)(c.M >> TAG_BITS) >= m;
-            if (__ballot(hit) != 0ull) {
+            if (WFA_RARE(__ballot(hit) != 0ull)) {
                 put_ent(sj, wbase, wlo, (int)WW, (uint32_t)WW);
                 wflags = WAVE_DONE;
                 break;
