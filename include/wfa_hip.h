@@ -271,8 +271,8 @@ int  wfahip_last_timing(const wfahip_ctx *ctx, wfahip_timing *out);
  *                                 XCD keeps its rows in that XCD's L2 (checked at run time; any other placement: the memory-side protocol)
  *   "long"  0|1                   1 (default): global pairs longer than "long_min_len" (4 000) bases, penalties shaped 4/6/2, take the
  *                                 sub-wave kernels with sliding 2-bit sequence windows in LDS (any read length); 0: as in round 3
- *   "long_first"  0|11..15        which of those instances a batch starts on: 0 = by batch size (<= 1 024 pairs: a wave per pair with
- *                                 two diagonals per lane; <= 4 096: two pairs per wave, 128 diagonals; else four pairs per wave)
+ *   "long_first"  0|11..15        which of those instances a batch starts on: 0 = by batch size (up to six pairs per SIMD, 6 144: a
+ *                                 wave per pair with two diagonals per lane; else four pairs per wave)
  *   "long_window_words"           packed words of each sequence a pair keeps in LDS (default 240 = 3 840 bases; 64..4096)
  *   "long_wave_bt"  0|1|2         backtrace of those pairs by a wave per pair (1: for chunks of at most "long_wave_bt_pairs" pairs --
  *                                 default twenty per CU, 5 120; 2: always; 0: never)

@@ -1476,6 +1476,9 @@ def test_long_window_kernel_batch(built):
     al.set_option("long_wave_bt", 2)  # ... and the wave-per-pair one whatever the batch size
     assert_batch_equal(al.align_arrays(*data), want, "wave-per-pair backtrace")
     al.set_option("long_wave_bt", 1)
+    al.set_option("long_mid_lone", 0)  # ... and the leftovers of the 64-diagonal pass on two pairs per wave instead of a wave per pair
+    assert_batch_equal(al.align_arrays(*data), want, "leftovers on two pairs per wave")
+    al.set_option("long_mid_lone", 1)
     # the same pairs on the plain whole-sequence path (option long = 0): the two paths agree with each other too
     al.set_option("long", 0)
     plain = al.align_arrays(*data)

@@ -1181,8 +1181,10 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             if (long_first && done_pairs == 0 && kind_rest == 11 && wide_ok) {
                 const uint64_t simds = (uint64_t)ctx->num_cus * 4;
                 if (ctx->opt_long_first >= 11 && ctx->opt_long_first <= 15) kind_rest = (int)ctx->opt_long_first;
-                else if (n_pairs <= simds) kind_rest = 15;  // (a wave per pair, two diagonals per lane: 128 diagonals at half the instructions of a step)
-                else if (n_pairs <= 4 * simds) kind_rest = 12;
+                // (a wave per pair, two diagonals per lane: 128 diagonals at half the instructions of a step.  3 000 / 6 000 pairs of
+                // 50 kbp: 14.2 / 23.1 ms against 18.1 / 25.3 with two pairs per wave and 26.6 with four; 2e4 pairs are issue-bound and
+                // four pairs per wave share a step's instructions)
+                else if (n_pairs <= 6 * simds) kind_rest = 15;
             }
             if (!skip_rest) {
                 std::vector<uint64_t> more;
