@@ -457,8 +457,9 @@ def run_rank(args):
 
 KNAMES = ["wfa_generic_kernel", "wfa_packed_kernel", "wfa_reg_kernel<2, 4, 1>", "wfa_blk_kernel<16",
           "wfa_blk_kernel<8", "wfa_blk_kernel<64", "wfa_blk_kernel<8, 8, false, 4", "wfa_team_kernel", "wfa_duo_kernel", "wfa_blk_kernel<32", "wfa_lane_kernel",
-          "wfa_blk_kernel<16, 1, false, 0, false, true>", "wfa_blk_kernel<32, 1, false, 0, true, true>", "wfa_blk_kernel<64, 1, false, 0, false, true>",
-          "wfa_blk_kernel<64, 1, false, 1, false, true>", "wfa_blk_kernel<64, 1, false, 2, false, true>"]
+          "wfa_blk_kernel<16, 1, false, 0, false, true, false>", "wfa_blk_kernel<32, 1, false, 0, true, true, false>",
+          "wfa_blk_kernel<64, 1, false, 0, false, true, false>", "wfa_blk_kernel<64, 1, false, 1, false, true, false>",
+          "wfa_blk_kernel<64, 1, false, 2, false, true, false>"]
 # legs of config.other_configs: (config, timed steps, warm-up steps)
 OTHER_LEGS = [("c2", 300, 5), ("k10", 30, 4), ("l5", 12, 3), ("c5s", 2, 1)]
 
@@ -551,9 +552,13 @@ def find_profile(config, kname):
             pm = doc["kernels"]
         except Exception:
             continue
-        # (the blocked kernel has two instances: the timed steps run the one without the census, "..., false>")
-        for name, grids in sorted(pm.items(), key=lambda kv: 0 if "false>" in kv[0] else 1):
-            if kname in name:
+        # (the blocked kernel has two instances: the timed steps run the one without the census -- its fifth template argument)
+        import re
+        no_census = lambda nm: 0 if re.search(r"wfa_blk_kernel<\d+, \d+, \w+, \d+, false", nm) else 1
+        # (names of before the seventh template argument, LDSA, are prefixes of today's up to the closing bracket)
+        kpre = kname[:-1] if kname.endswith(">") else kname
+        for name, grids in sorted(pm.items(), key=lambda kv: no_census(kv[0])):
+            if kname in name or (kpre + ", ") in name:
                 g0 = max(grids.values(), key=lambda d: d.get("WRITE_SIZE_KB", 0))
                 if "FETCH_SIZE_KB" in g0 and "WRITE_SIZE_KB" in g0:
                     return {"traffic": (2.0 * g0["FETCH_SIZE_KB"] + g0["WRITE_SIZE_KB"]) * 1024.0,
