@@ -1319,7 +1319,9 @@ WFA_DEV uint32_t prepack_word(const uint8_t *blob, uint64_t off, uint32_t len, u
 // workgroups -- 1.01 ms for 2.5 GB of traffic)
 constexpr int PREPACK_PAIRS = 4;
 #ifndef WFA_NO_AUX_KERNELS
-__global__ __launch_bounds__(256) void wfa_prepack_kernel(const KParams P, uint32_t *out, uint32_t SW, uint32_t PW) {
+// ppw: pairs a wave packs one after the other -- PREPACK_PAIRS, or 1 for a few long pairs (500 x 50 kbp: 125 waves of four pairs
+// were 0.32 ms of latency; 500 waves: 0.08).
+__global__ __launch_bounds__(256) void wfa_prepack_kernel(const KParams P, uint32_t *out, uint32_t SW, uint32_t PW, uint32_t ppw) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv   = blockIdx.x * 4u + (threadIdx.x >> 6);
     // short reads (a slot of at most 32 words): two pairs side by side, 32 lanes each
@@ -1328,18 +1330,18 @@ __global__ __launch_bounds__(256) void wfa_prepack_kernel(const KParams P, uint3
     // in flight: the kernel was half the time waiting for a round trip with nothing else under way -- 3.2 TB/s)
     struct Hd { uint32_t nq, mt; uint64_t qo, to; };
     const auto load_hd = [&](uint32_t k) -> Hd {
-        const uint32_t wi = wv * (uint32_t)PREPACK_PAIRS + k + side;
+        const uint32_t wi = wv * ppw + k + side;
         Hd h = {0u, 0u, 0ull, 0ull};
-        if (k < (uint32_t)PREPACK_PAIRS && wi < P.chunk_n) {
+        if (k < ppw && wi < P.chunk_n) {
             const uint32_t pr = P.work ? P.work[wi] : P.chunk_first + wi;
             h.nq = P.q_len[pr], h.mt = P.t_len[pr], h.qo = P.q_off[pr], h.to = P.t_off[pr];
         }
         return h;
     };
     Hd nxt = load_hd(0);
-    for (uint32_t k = 0; k < (uint32_t)PREPACK_PAIRS; k += n_side) {
-        const uint32_t wi = wv * (uint32_t)PREPACK_PAIRS + k + side;
-        if (wv * (uint32_t)PREPACK_PAIRS + k >= P.chunk_n) return;
+    for (uint32_t k = 0; k < ppw; k += n_side) {
+        const uint32_t wi = wv * ppw + k + side;
+        if (wv * ppw + k >= P.chunk_n) return;
         const bool     have = wi < P.chunk_n;
         const Hd       cur  = nxt;
         nxt                 = load_hd(k + n_side);

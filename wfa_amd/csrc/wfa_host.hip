@@ -974,9 +974,13 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                     if (ctx->pk_words)  // (packed input: the slots are copied from the uploaded words, no bytes in between)
                         hipLaunchKernelGGL(wfa_prepack_words_kernel, dim3((uint32_t)((cn + 3) / 4)), dim3(256), 0, st, P, ctx->pk_words,
                                            static_cast<uint32_t *>(ctx->prepack.p), P.lds_seq_words, pw);
-                    else
-                        hipLaunchKernelGGL(wfa_prepack_kernel, dim3((uint32_t)((cn + 4 * PREPACK_PAIRS - 1) / (4 * PREPACK_PAIRS))), dim3(256), 0, st, P,
-                                           static_cast<uint32_t *>(ctx->prepack.p), P.lds_seq_words, pw);
+                    else {
+                        // (a chunk that gives fewer than four waves per SIMD at four pairs per wave: a wave per pair; short slots pack
+                        // two pairs side by side in a wave: they keep four)
+                        const uint32_t ppw = (cn <= (uint64_t)ctx->num_cus * 64 && 2u * P.lds_seq_words > 32u) ? 1u : (uint32_t)PREPACK_PAIRS;
+                        hipLaunchKernelGGL(wfa_prepack_kernel, dim3((uint32_t)((cn + 4 * ppw - 1) / (4 * ppw))), dim3(256), 0, st, P,
+                                           static_cast<uint32_t *>(ctx->prepack.p), P.lds_seq_words, pw, ppw);
+                    }
                     HIP_TRY(hipGetLastError());
                     P.prepack = static_cast<const uint32_t *>(ctx->prepack.p), P.prepack_words = pw;
                 } else if (ctx->pk_words) {  // (packed input, a pass that reads bytes: exactly its pairs are expanded first)
