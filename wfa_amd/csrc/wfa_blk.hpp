@@ -374,6 +374,10 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
     bool       pend = false;  // STREAM: the pair just finished still has to be pushed (its score index, end offset and
                               // cell count wait in si, Ak and cells, which are dead until the next pair starts)
     uint32_t  *rowp = nullptr;  // row of the current score in the pair's arena slot (64 words per score)
+    uint32_t   lone_taken = 0u;  // LDSA: the launch's one pair has been started
+    if constexpr (LDSA) {
+        if (lane == 0) lds[P.lds_arena_off - 4] = ST_PENDING;  // (the walk's start words: ST_OK once the forward pass has written them)
+    }
     // LONG: the pair's sequence windows.  lqo / lto: LDS index of packed word 0 of the query / target (window base minus the
     // window's first word: lds[lqo + w] is packed word w while it is resident); [lo16, hi16]: offsets h whose two 16-base
     // windows are resident on every diagonal of the diagonal window; kc16: the diagonal the two bases are tied by
@@ -639,6 +643,8 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
                         blk_store_sc1(P.done_q + (t0 + (uint32_t)__builtin_popcount(pbits & ((1u << grp) - 1u))), pidx + 1u,
                                       si * P.g, (uint32_t)pend_h, cells);
                     pend = false;
+                } else if constexpr (LDSA) {
+                    base = lone_taken, lone_taken = 1u;  // (one pair, one wave: no queue to ask -- two round trips to the L2 less per Align)
                 } else {
                     if (lane == 0) base = atomicAdd(P.queue_head, (uint32_t)__builtin_popcount(gbits));
                     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
@@ -658,6 +664,8 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
                         // queue atomic instead of two (lengths / offsets, then the bytes) and no packing arithmetic here
                         slot = P.prepack + (uint64_t)wi * P.prepack_words;
                         nq = slot[0], mt = slot[1], status = slot[2];
+                    } else if constexpr (LDSA) {
+                        nq = P.one_n, mt = P.one_m, qo = 0ull, to = ((uint64_t)P.one_n + 15ull) & ~15ull;
                     } else {
                         nq = P.q_len[pr], mt = P.t_len[pr], qo = P.q_off[pr], to = P.t_off[pr];
                     }
@@ -1146,6 +1154,8 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
                         if constexpr (STREAM) blk_push_not_ok(P, pidx);
                     } else if constexpr (!STREAM) {
                         P.pair_meta[pidx] = make_uint4(ST_OK, si * P.g, (uint32_t)hf, (uint32_t)ctot);
+                        // (the walk of the LDS instance reads its start from the four words in front of the rows: nothing of it waits for global memory)
+                        if constexpr (LDSA) *reinterpret_cast<uint4 *>(lds + P.lds_arena_off - 4) = make_uint4(ST_OK, si * P.g, (uint32_t)hf, (uint32_t)ctot);
                     }
                 }
                 if (fin) {
@@ -1250,9 +1260,17 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
         // The sequences in LDS are dead by now: their place is the walk's arena region (the host reserves 4 KB).  The arena
         // rows were stored by this very wave; the release / acquire pair makes them its loads' too.
         if (P.fuse_bt) {
-            __threadfence();
-            if constexpr (LDSA) backtrace_wave_one<true>(P, blockIdx.x, lds + P.lds_arena_off);  // (one pair: the rows are still where they were written)
-            else
+            if constexpr (LDSA) {
+                // (one pair: the rows are still where they were written, and so is the walk's start -- unless the pair was handed on:
+                // then the start words still hold what the kernel began with, and the record comes from pair_meta)
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                if (lds[P.lds_arena_off - 4] != ST_OK) __threadfence();
+                backtrace_wave_one<true>(P, blockIdx.x, lds + P.lds_arena_off);
+            } else {
+                __threadfence();
+            }
+            if constexpr (LDSA) {
+            } else
                 for (uint32_t idx = blockIdx.x; idx < P.chunk_n; idx += gridDim.x) backtrace_wave_one(P, idx, lds);
             // (one wave, one pair: the control words go back to zero here, so the next Align starts without a memset of its own)
             if (lane == 0 && gridDim.x == 1u) *P.queue_head = 0u, *P.redo_count = 0u, *P.ops_cursor = 0ull;

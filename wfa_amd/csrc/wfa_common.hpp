@@ -118,6 +118,8 @@ struct KParams {
     uint32_t  fuse_bt;               // wfa_blk_kernel<64, 1, false, 1> (one pair, wfahip_align_pair): 1 = the wave walks its pair's backtrace itself when
                                      // the pair queue is empty (one launch for the whole Align)
     uint32_t  lds_arena_off;         // wfa_blk_kernel<.., LDSA = true>: word offset of the pair's arena rows inside the workgroup's LDS
+    uint32_t  one_n, one_m;          // ... and the lengths of its one pair (query at blob offset 0, target at (one_n + 15) & ~15): the kernel arguments carry
+                                     // them, so that neither the refill nor the walk fetches them from the host's mapped block (a PCIe round trip each)
     uint32_t  compact_fmt;           // compact arena layout (CompactView): 0 = rows + directory; no directory: 1 = 64 words
                                      // per score, diagonal k at slot k & 63; 3 = tiles of 8 scores x 64 diagonals;
                                      // 4 = 256 words per score, slot k & 255; 5 = 32 words per score, slot k & 31

@@ -2698,7 +2698,7 @@ static int align_pair_impl(wfahip_ctx *ctx, const wfahip_params *p, const uint8_
                         ctx->one_lds_attr = true;
                     }
                     KParams PL = P;
-                    PL.arena_words = lds_rows * 64, PL.lds_arena_off = lds_off;
+                    PL.arena_words = lds_rows * 64, PL.lds_arena_off = lds_off, PL.one_n = n, PL.one_m = m;
                     hipLaunchKernelGGL(kern, dim3(1), dim3(64), (size_t)lds_off * 4 + (size_t)lds_rows * 256, st, PL);
                 } else {
                     hipLaunchKernelGGL((wfa_blk_kernel<64, 1, false, 1, false, false>), dim3(1), dim3(64),

@@ -350,7 +350,13 @@ WFA_DEV void backtrace_wave_one(const KParams &P, uint32_t idx_, uint32_t *regio
     const auto     rfl  = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); };
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t idx  = rfl(idx_);
-    uint4          meta = P.pair_meta[idx];
+    uint4          meta;
+    if constexpr (LDSV) {  // (the forward pass left the walk's start in front of the rows; a pair it handed on: pair_meta)
+        meta = *reinterpret_cast<const uint4 *>(region - 4);
+        if (rfl(meta.x) != ST_OK) meta = P.pair_meta[idx];
+    } else {
+        meta = P.pair_meta[idx];
+    }
     meta = make_uint4(rfl(meta.x), rfl(meta.y), rfl(meta.z), rfl(meta.w));
     const uint32_t pair = rfl(P.work ? P.work[idx] : P.chunk_first + idx);
     uint4 *const   r4   = reinterpret_cast<uint4 *>(P.rec + (uint64_t)pair * REC_WORDS);
@@ -364,12 +370,14 @@ WFA_DEV void backtrace_wave_one(const KParams &P, uint32_t idx_, uint32_t *regio
         return;
     }
     const uint32_t s_final = meta.y, h_end = meta.z, cells = meta.w;
-    const int      n = (int)rfl(P.q_len[pair]), m = (int)rfl(P.t_len[pair]);
+    const int      n = LDSV ? (int)P.one_n : (int)rfl(P.q_len[pair]), m = LDSV ? (int)P.one_m : (int)rfl(P.t_len[pair]);
     const uint32_t bound = ops_bound(P, s_final);
     unsigned long long off = 0ull;
-    if (lane == 0u) off = atomicAdd(P.ops_cursor, (unsigned long long)bound);
-    off = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(off >> 32)) << 32) |
-          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)off);
+    if constexpr (!LDSV) {  // (the LDS instance's launch holds ONE pair: its ops region starts at 0, no cursor to move)
+        if (lane == 0u) off = atomicAdd(P.ops_cursor, (unsigned long long)bound);
+        off = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(off >> 32)) << 32) |
+              (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)off);
+    }
     typename std::conditional<LDSV, CompactViewLds, CompactViewWave>::type cv;
     if constexpr (LDSV) {
         cv.A = region, cv.g = P.g, cv.n_ent = s_final / P.g + 1u;
