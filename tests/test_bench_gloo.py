@@ -76,3 +76,21 @@ def test_configs_name_the_baseline_workloads():
     assert [name for name, _, _ in bench.OTHER_LEGS] == ["c2", "k10", "l5", "c5s"]
     for name in ("c2m", "L5", "k10", "k20", "l5", "l10", "l20"):
         assert name in bench.CONFIGS and name in bench.DEFAULT_STEPS
+
+
+def test_committed_profiles_hold_the_kernels_the_lines_name():
+    """`roofline.traffic` comes from the committed PMC profile of a configuration: the name bench.py looks for (the library's
+    main_kernel_kind -> KNAMES) must be found in it, the instance WITHOUT the census of stored words first -- also for names
+    that were recorded before the kernel template got its latest argument."""
+    sys.path.insert(0, ROOT)
+    import bench
+    for cfg, kname, census_arg in (("c3", "wfa_duo_kernel", None), ("c2", "wfa_lane_kernel", None), ("c2m", "wfa_lane_kernel", None),
+                                   ("c5s", "wfa_team_kernel", None), ("k10", "wfa_blk_kernel<16", "false"),
+                                   ("l5", bench.KNAMES[15], "false"), ("L5", bench.KNAMES[11], "false"), ("l20", bench.KNAMES[13], "false")):
+        pm = bench.find_profile(cfg, kname)
+        assert pm is not None and pm["traffic"] > 0, (cfg, kname)
+        if census_arg is not None:  # wfa_blk_kernel<G, BATCH, STREAM, PPT, CENSUS, ...>: the timed steps run CENSUS = false
+            assert pm["kernel"].split(", ")[4].rstrip(">") == census_arg, (cfg, pm["kernel"])
+    # a six-argument name of before round 4's LDSA argument still finds today's seven-argument instance
+    old = bench.KNAMES[15].rsplit(", ", 1)[0] + ">"
+    assert bench.find_profile("l5", old)["kernel"] == bench.KNAMES[15]
