@@ -83,3 +83,47 @@ def test_python_restatement_on_the_published_vectors(known_answers):
         for f in ("score", "qbegin", "qend", "tbegin", "tend", "align_len", "matches", "gaps", "gap_regions"):
             if f in ka:
                 assert getattr(r, f) == ka[f], (ka["id"], f)
+
+
+def _gotoh_first_column(q, t, x, o, e):
+    """Minimum gap-affine cost (mismatch x, a gap of length L costs o + L e) of a global alignment whose FIRST column aligns
+    q[0] with t[0] -- what the reference's initComponents fixes (wfa.go:155-160: the seed cell consumes one base of each
+    sequence as a match at score 0 or a mismatch at score x).  Plain Gotoh dynamic programming: nothing of it comes from
+    the wavefront formulation."""
+    n, m, inf = len(q), len(t), 1 << 40
+    M = [[inf] * (m + 1) for _ in range(n + 1)]
+    I = [[inf] * (m + 1) for _ in range(n + 1)]  # the column consumes a target base only
+    D = [[inf] * (m + 1) for _ in range(n + 1)]  # ... a query base only
+    M[1][1] = 0 if q[0] == t[0] else x
+    for i in range(1, n + 1):
+        for j in range(1, m + 1):
+            if i == 1 and j == 1:
+                continue
+            if i > 1 and j > 1:
+                prev = min(M[i - 1][j - 1], I[i - 1][j - 1], D[i - 1][j - 1])
+                if prev < inf:
+                    M[i][j] = prev + (0 if q[i - 1] == t[j - 1] else x)
+            if j > 1:
+                I[i][j] = min(min(M[i][j - 1], D[i][j - 1]) + o + e, I[i][j - 1] + e)
+            if i > 1:
+                D[i][j] = min(min(M[i - 1][j], I[i - 1][j]) + o + e, D[i - 1][j] + e)
+    return min(M[n][m], I[n][m], D[n][m])
+
+
+@pytest.mark.parametrize("pen", [(4, 6, 2), (2, 3, 1), (5, 3, 2), (1, 1, 1), (6, 2, 4), (3, 7, 2)])
+def test_global_scores_are_the_gap_affine_optimum(built, pen):
+    """A pin of the oracle that owes nothing to the reference's code: without wf-adaptive, the score of a global alignment is
+    the optimum of the gap-affine model (the reference's one deviation from the textbook: the first column is a (mis)match),
+    computed here by Gotoh's dynamic programme over 300 random pairs of up to 30 bases per penalty set; and the CIGAR the
+    oracle returns costs exactly that score."""
+    import re
+    from oracle import oracle as O
+    x, o, e = pen
+    rng = random.Random(1000 + 7 * x + o)
+    al = O.Aligner(O.make_params(global_alignment=True, adaptive=None, mismatch=x, gap_open=o, gap_ext=e))
+    for _ in range(300):
+        q, t = _pair(rng, 30)
+        r = al.align(q, t)
+        assert r.score == _gotoh_first_column(q, t, x, o, e), (pen, q, t, r.cigar)
+        cost = sum((x * int(n) if op == "X" else (o + e * int(n)) if op in "ID" else 0) for n, op in re.findall(r"(\d+)([MXIDH])", r.cigar))
+        assert cost == r.score, (pen, q, t, r.cigar)
