@@ -127,3 +127,43 @@ def test_global_scores_are_the_gap_affine_optimum(built, pen):
         assert r.score == _gotoh_first_column(q, t, x, o, e), (pen, q, t, r.cigar)
         cost = sum((x * int(n) if op == "X" else (o + e * int(n)) if op in "ID" else 0) for n, op in re.findall(r"(\d+)([MXIDH])", r.cigar))
         assert cost == r.score, (pen, q, t, r.cigar)
+
+
+def _semi_global_optimum(q, t, x, o, e):
+    """The same dynamic programme for the reference's semi-global mode: an alignment may START at any cell of the first row or
+    column (initComponents seeds every diagonal, wfa.go:163-183: leading overhangs are free) and END at a cell on the last query
+    row with at least n target bases consumed, or on the last target column with at least m query bases consumed -- the hit
+    test of backtraceStartPosistion, wfa.go:319 and :354, literally `(v == n && h >= n) || (h == m && v >= m)`."""
+    n, m, inf = len(q), len(t), 1 << 40
+    M = [[inf] * (m + 1) for _ in range(n + 1)]
+    I = [[inf] * (m + 1) for _ in range(n + 1)]
+    D = [[inf] * (m + 1) for _ in range(n + 1)]
+    for i in range(1, n + 1):
+        for j in range(1, m + 1):
+            if i == 1 or j == 1:
+                M[i][j] = 0 if q[i - 1] == t[j - 1] else x
+            if i > 1 and j > 1:
+                prev = min(M[i - 1][j - 1], I[i - 1][j - 1], D[i - 1][j - 1])
+                if prev < inf:
+                    M[i][j] = min(M[i][j], prev + (0 if q[i - 1] == t[j - 1] else x))
+            if j > 1:
+                I[i][j] = min(min(M[i][j - 1], D[i][j - 1]) + o + e, I[i][j - 1] + e)
+            if i > 1:
+                D[i][j] = min(min(M[i - 1][j], I[i - 1][j]) + o + e, D[i - 1][j] + e)
+    ends = [(n, j) for j in range(n, m + 1)] + [(i, m) for i in range(m, n + 1)]
+    return min(min(M[i][j], I[i][j], D[i][j]) for i, j in ends)
+
+
+@pytest.mark.parametrize("pen", [(4, 6, 2), (2, 3, 1), (5, 3, 2), (1, 1, 1)])
+def test_semi_global_scores_are_the_optimum_under_the_reference_end_rule(built, pen):
+    """... and the semi-global score is the optimum over free starts on the first row / column and the ends the reference's
+    end-cell search accepts (with ANY cell of the last row / column as an end only a third of the pairs agree: the rule is
+    the reference's, not the textbook's)."""
+    from oracle import oracle as O
+    x, o, e = pen
+    rng = random.Random(2000 + 7 * x + o)
+    al = O.Aligner(O.make_params(global_alignment=False, adaptive=None, mismatch=x, gap_open=o, gap_ext=e))
+    for _ in range(300):
+        q, t = _pair(rng, 25)
+        r = al.align(q, t)
+        assert r.score == _semi_global_optimum(q, t, x, o, e), (pen, q, t, r.cigar)
