@@ -125,8 +125,18 @@ def test_global_scores_are_the_gap_affine_optimum(built, pen):
         q, t = _pair(rng, 30)
         r = al.align(q, t)
         assert r.score == _gotoh_first_column(q, t, x, o, e), (pen, q, t, r.cigar)
-        cost = sum((x * int(n) if op == "X" else (o + e * int(n)) if op in "ID" else 0) for n, op in re.findall(r"(\d+)([MXIDH])", r.cigar))
-        assert cost == r.score, (pen, q, t, r.cigar)
+        cig_cost = lambda c: sum((x * int(n) if op == "X" else (o + e * int(n)) if op in "ID" else 0) for n, op in re.findall(r"(\d+)([MXIDH])", c))
+        assert cig_cost(r.cigar) == r.score, (pen, q, t, r.cigar)
+        # wf-adaptive is a heuristic: the score it reports may only lose against the optimum.  (Its CIGAR is NOT held to anything
+        # here: the reference's backtrace recomputes each step from the wavefronts as reduce() left them, and on small pairs with
+        # aggressive settings it comes out on paths that neither cost the reported score nor consume exactly the two sequences --
+        # 4/6/2, adaptive 4/5/1: GGATGTTGTAGCCGTGCTC vs TCGTGATGTTGTAGCCGTGCTCTATACGG reports 58 with a CIGAR that costs 52;
+        # CCTTCAGGTGCCGAGTGTTA vs CCTTCAGGTGCAGTGT returns 11M1X1M4D1M1X1M1X, 21 query bases for a query of 20.  Both
+        # restatements of the reference agree on these, and the HIP path reproduces them: parity is with the reference as it is.)
+        for ad in ((4, 5, 1), (1, 1, 1)):
+            ra = O.Aligner(O.make_params(global_alignment=True, adaptive=ad, mismatch=x, gap_open=o, gap_ext=e)).align(q, t)
+            assert ra.score >= r.score, (pen, ad, q, t, ra.cigar)
+
 
 
 def _semi_global_optimum(q, t, x, o, e):
