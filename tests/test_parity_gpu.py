@@ -157,6 +157,41 @@ def test_other_penalties(built, pen):
             al.close()
 
 
+def test_aggressive_adaptive_short_pairs(built):
+    """Short pairs under aggressive wf-adaptive settings, where the reference's backtrace leaves the path its score was reached
+    on (tests/test_oracle_crosscheck.py: CIGARs that do not cost the score, or consume a base more than a sequence has): the HIP
+    path returns exactly what the oracle returns -- the two pairs named there, and 3 000 random ones of up to 30 bases."""
+    import random
+    import wfa_amd as w
+    from oracle import oracle as O
+    rng = random.Random(77)
+    qs = [b"GGATGTTGTAGCCGTGCTC", b"CCTTCAGGTGCCGAGTGTTA"]
+    ts = [b"TCGTGATGTTGTAGCCGTGCTCTATACGG", b"CCTTCAGGTGCAGTGT"]
+    for _ in range(3000):
+        q = bytes(rng.choice(b"ACGT") for _ in range(rng.randint(1, 30)))
+        t = bytearray(q)
+        for _ in range(rng.randint(0, 7)):
+            kind, pos = rng.randint(0, 2), rng.randint(0, max(0, len(t) - 1))
+            if kind == 0 and t:
+                t[pos] = rng.choice(b"ACGT")
+            elif kind == 1:
+                t.insert(pos, rng.choice(b"ACGT"))
+            elif len(t) > 1:
+                del t[pos]
+        qs.append(q), ts.append(bytes(t) or b"A")
+    data = w.make_blob(qs, ts)
+    for glob in (True, False):
+        for ad in ((4, 5, 1), (1, 1, 1), (2, 3, 1)):
+            al = _aligner(glob, ad)
+            got = al.align_arrays(*data)
+            want = O.align_batch(_oracle_params(glob, ad), *data, n_threads=8)
+            assert_batch_equal(got, want, f"glob={glob} ad={ad}")
+            if glob:
+                r = al.Align(qs[0], ts[0])
+                assert (r.Score, r.CIGAR(False)) == ((58, "3X2M1X3M1X1M3I8M7I") if ad == (4, 5, 1) else (want.score[0], r.CIGAR(False)))
+            al.close()
+
+
 def test_ragged_and_edge_inputs(built):
     """Empty / 1-base / very unequal lengths / non-ACGT bytes / lowercase, mixed in one batch."""
     import wfa_amd as w
