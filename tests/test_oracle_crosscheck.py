@@ -177,3 +177,37 @@ def test_semi_global_scores_are_the_optimum_under_the_reference_end_rule(built, 
         q, t = _pair(rng, 25)
         r = al.align(q, t)
         assert r.score == _semi_global_optimum(q, t, x, o, e), (pen, q, t, r.cigar)
+
+
+@pytest.mark.parametrize("glob", [True, False])
+def test_result_fields_follow_from_the_cigar(built, glob):
+    """process() (wfa_cigar.go:136-214) said a second way: the match region and the four statistics of a result are functions of
+    its CIGAR alone -- the span from the first M op to the last one (M, X, D, H consume the query; M, X, I the target), or the
+    first op when there is no M at all.  2 000 random pairs, wf-adaptive off and on."""
+    import re
+    from oracle import oracle as O
+    rng = random.Random(31 + glob)
+    for ad in (None, (10, 50, 1), (4, 5, 1)):
+        al = O.Aligner(O.make_params(global_alignment=glob, adaptive=ad))
+        for _ in range(350):
+            q, t = _pair(rng, 40)
+            r = al.align(q, t)
+            ops = [(int(n), op) for n, op in re.findall(r"(\d+)([MXIDH])", r.cigar)]
+            ms = [i for i, (_, op) in enumerate(ops) if op == "M"]
+            if ms:
+                span = ops[ms[0]:ms[-1] + 1]
+                stats = (sum(n for n, _ in span), sum(n for n, op in span if op == "M"), sum(n for n, op in span if op in "ID"),
+                         sum(1 for _, op in span if op in "ID"))
+                qc = tc = 0
+                for i, (n, op) in enumerate(ops):
+                    if i == ms[0]:
+                        qb, tb = qc + 1, tc + 1
+                    qc += n if op in "MXDH" else 0
+                    tc += n if op in "MXI" else 0
+                    if i == ms[-1]:
+                        qe, te = qc, tc
+                assert (qb, qe, tb, te) == (r.qbegin, r.qend, r.tbegin, r.tend), (glob, ad, q, t, r.cigar)
+            else:
+                n0, op0 = ops[0]
+                stats = (n0, 0, n0 if op0 in "ID" else 0, 1 if op0 in "ID" else 0)
+            assert stats == (r.align_len, r.matches, r.gaps, r.gap_regions), (glob, ad, q, t, r.cigar)
