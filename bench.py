@@ -426,7 +426,9 @@ def run_rank(args):
                 # (wfa_lane_kernel: LDS allows two waves per SIMD -- 1.799 ns, the same row of the probe at that occupancy)
                 # (the wave-per-pair instances of small long-read batches, wfa_blk_kernel<64, ..>: ONE wave on each SIMD they use -- 1.976 ns
                 # per instruction, the probe's lone-wave row -- and as many SIMDs as there are pairs)
-                lone = kname.startswith("wfa_blk_kernel<64")
+                # (by the kernel KIND, not the name: kinds 5 and 13 are wfa_blk_kernel<64, ..> too, but with four diagonals per lane and up to
+                # sixteen waves per CU on a GPU-filling pass)
+                lone = int(timing.main_kernel_kind) in (14, 15, 16)
                 waves = 1 if lone else 2 if "lane" in kname else 4 if "duo" in kname else (5 if kname.startswith("wfa_blk_kernel<16") else 4)
                 ns_per = {1: 1.976, 2: 1.799, 4: 1.333, 5: 1.079, 8: 1.080}[waves]
                 attainable = (min(n, 256 * 4) if lone else 256 * 4) / ns_per
@@ -459,7 +461,8 @@ KNAMES = ["wfa_generic_kernel", "wfa_packed_kernel", "wfa_reg_kernel<2, 4, 1>", 
           "wfa_blk_kernel<8", "wfa_blk_kernel<64", "wfa_blk_kernel<8, 8, false, 4", "wfa_team_kernel", "wfa_duo_kernel", "wfa_blk_kernel<32", "wfa_lane_kernel",
           "wfa_blk_kernel<16, 1, false, 0, false, true, false>", "wfa_blk_kernel<32, 1, false, 0, true, true, false>",
           "wfa_blk_kernel<64, 1, false, 0, false, true, false>", "wfa_blk_kernel<64, 1, false, 1, false, true, false>",
-          "wfa_blk_kernel<64, 1, false, 2, false, true, false>"]
+          "wfa_blk_kernel<64, 1, false, 2, false, true, false>",
+          "wfa_blk_kernel<64, 1, false, 1, false, false"]  # 16: the lone-pair instance of wfahip_align_pair
 # legs of config.other_configs: (config, timed steps, warm-up steps)
 OTHER_LEGS = [("c2", 300, 5), ("k10", 30, 4), ("l5", 12, 3), ("c5s", 2, 1)]
 

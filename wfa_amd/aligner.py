@@ -207,10 +207,20 @@ class Aligner:
         # (a third of the Python side of a 150 us call)
         lq, lt = len(q), len(t)
         one = self._one
-        if one is None or len(one[1]) < 2 * (lq + lt) + 64 or one[6] is not self.ad:
+        if one is None or len(one[1]) < 2 * (lq + lt) + 64:
             rec, ops, n_ops, prm = (C.c_uint32 * L.REC_WORDS)(), (C.c_uint64 * (2 * (lq + lt) + 64))(), C.c_uint64(), self._params()
-            one = self._one = (rec, ops, n_ops, C.byref(prm), C.byref(n_ops), L.lib().wfahip_align_pair, self.ad, prm)
+            one = self._one = (rec, ops, n_ops, C.byref(prm), C.byref(n_ops), L.lib().wfahip_align_pair, prm)
         rec, ops, n_ops, prm_ref, n_ref, entry = one[0], one[1], one[2], one[3], one[4], one[5]
+        # The Go aligner reads algn.p / algn.opt / algn.ad on every Align (wfa.go:79-87,134-140): penalties or options
+        # re-assigned, or an AdaptiveReductionOption mutated in place, between two calls must show in the second one -- the
+        # cached block is REFILLED every call (a few attribute stores; the by-reference wrapper stays)
+        prm, p_, ad = one[6], self.p, self.ad
+        prm.mismatch, prm.gap_open, prm.gap_ext = p_.Mismatch, p_.GapOpen, p_.GapExt
+        prm.global_alignment = 1 if self.opt.GlobalAlignment else 0
+        if ad is None:
+            prm.adaptive = 0
+        else:
+            prm.adaptive, prm.min_wf_len, prm.max_dist_diff, prm.cutoff_step = 1, ad.MinWFLen, ad.MaxDistDiff, ad.CutoffStep
         rc = entry(self._ctx, prm_ref, q, lq, t, lt, rec, ops, len(ops), n_ref)
         if rc != 0:
             L.check(rc, "wfahip_align_pair")

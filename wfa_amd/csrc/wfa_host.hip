@@ -1425,6 +1425,7 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
         // halves the teams that share it -- the launch configuration is then that of the last level whose slot fitted)
         const bool paged_capable = ctx->opt_team_paged != 0 && !debug_single && ctx->opt_team_wgs == 0 && ctx->opt_arena_bytes_per_slot <= 0 &&
                                    ctx->opt_team_min_len > 0 && max_len >= (uint64_t)ctx->opt_team_min_len && P.e != 0u;
+        const bool no_slot_fits = cr == 2;  // (if the paged launch does not happen after all, the job ends as "no memory" as it used to)
         for (int lv = job.level; cr == 2 && paged_capable && lv > 0;) cr = make_cfg(ctx, max_len, job.mode, --lv, n_work, !P.global_alignment, cfg);
         if (debug_single) cfg.slots = 1;
         // Wide wavefronts: a team of workgroups per pair (wfa_team_kernel) instead of one workgroup per pair.
@@ -1503,6 +1504,7 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                 if (ctx->opt_team_wgs == 0) team_T = std::min<uint32_t>(cus / team_n, 2 * t0);
             }
         }
+        if (no_slot_fits && !paged) cr = 2;  // (the configuration of a lower level was only borrowed for the paged launch)
         if (cr == 2 || job.level > max_level) {
             if (job.all) {
                 no_memory.resize(n_pairs);
@@ -2443,8 +2445,10 @@ static int align_batch_autopack(wfahip_ctx *ctx, const wfahip_params *p, const u
         t_woff[i] = pos, pos += wfahip_packed_words(v ? t_len[i] : 0);
     }
     // (pairs are packed one by one: a batch whose pairs SHARE sequences -- one target against many queries -- would carry every
-    // copy over PCIe; beyond a quarter more than the blob itself the byte path is the cheaper one)
-    if (pos * 16 > blob_bytes + blob_bytes / 4) return WFAHIP_ERR_UNSUPPORTED;
+    // copy over PCIe; beyond a quarter more than the blob itself the byte path is the cheaper one.  Sharing shows in the BASES
+    // the pairs name against the bytes of the blob -- not in the packed words, whose pad word and 16-base rounding per
+    // sequence alone are a quarter of a tightly laid-out batch of 100-base reads)
+    if (facts.sum_len > blob_bytes + blob_bytes / 4) return WFAHIP_ERR_UNSUPPORTED;
     const size_t need = (size_t)(pos + 4) * 4;
     if (ctx->pack_pin_bytes < need) {
         HIP_TRY(hipSetDevice(ctx->device));
