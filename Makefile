@@ -5,29 +5,26 @@ HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-functi
 # wfa_duo_kernel's translation unit: LLVM's atomic optimizer off (wfa_amd/csrc/wfa_duo_cfg.hpp says why)
 DUOFLAGS ?= -mllvm -amdgpu-atomic-optimizer-strategy=None
 LIB     := wfa_amd/lib/libwfahip.so
-SRC     := wfa_amd/csrc/wfa_host.hip wfa_amd/csrc/wfa_gen.cpp wfa_amd/csrc/wfa_multi.cpp
-DUOSRC  := wfa_amd/csrc/wfa_duo.hip
-DUOOBJ  := build/obj/wfa_duo.o
-HDR     := $(wildcard wfa_amd/csrc/*.hpp) include/wfa_hip.h
+CSRC    := wfa_amd/csrc
+HDR     := $(wildcard $(CSRC)/*.hpp) $(wildcard $(CSRC)/*.inc) include/wfa_hip.h
+OBJDIR  := build/obj
+# one translation unit per penalty shape of the sub-wave forward kernels (wfa_fwd.hpp), one for wfa_duo_kernel, one for the
+# long-pair kernels, one for the router and the C-ABI: they compile side by side (make -j)
+SHAPES  := s24 s13 s12 s23 s22 s33
+UNITS   := wfa_host wfa_long wfa_duo $(addprefix wfa_fwd_,$(SHAPES))
+OBJS    := $(addprefix $(OBJDIR)/,$(addsuffix .o,$(UNITS))) $(OBJDIR)/wfa_gen.o $(OBJDIR)/wfa_multi.o
 
 all: $(LIB) oracle
 
-OBJDIR  := build/obj
-OBJS    := $(OBJDIR)/wfa_host.o $(OBJDIR)/wfa_gen.o $(OBJDIR)/wfa_multi.o $(DUOOBJ)
-
-$(DUOOBJ): $(DUOSRC) $(HDR)
+$(OBJDIR)/wfa_duo.o: $(CSRC)/wfa_duo.hip $(HDR)
 	@mkdir -p $(OBJDIR)
-	$(HIPCC) $(HIPFLAGS) $(DUOFLAGS) -c -o $@ $(DUOSRC)
+	$(HIPCC) $(HIPFLAGS) $(DUOFLAGS) -c -o $@ $<
 
-$(OBJDIR)/wfa_host.o: wfa_amd/csrc/wfa_host.hip $(HDR)
+$(OBJDIR)/%.o: $(CSRC)/%.hip $(HDR)
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
 
-$(OBJDIR)/wfa_gen.o: wfa_amd/csrc/wfa_gen.cpp $(HDR)
-	@mkdir -p $(OBJDIR)
-	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
-
-$(OBJDIR)/wfa_multi.o: wfa_amd/csrc/wfa_multi.cpp $(HDR)
+$(OBJDIR)/%.o: $(CSRC)/%.cpp $(HDR)
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
 
@@ -38,10 +35,13 @@ $(LIB): $(OBJS)
 oracle:
 	$(MAKE) -C oracle -s
 
-asm: $(SRC) $(DUOSRC) $(HDR)
+asm: $(HDR)
 	@mkdir -p build/asm
-	$(HIPCC) $(HIPFLAGS) -save-temps=obj -c -o build/asm/wfa_host.o wfa_amd/csrc/wfa_host.hip -Rpass-analysis=kernel-resource-usage 2> build/asm/resource_usage.txt || true
-	$(HIPCC) $(HIPFLAGS) $(DUOFLAGS) -save-temps=obj -c -o build/asm/wfa_duo.o wfa_amd/csrc/wfa_duo.hip -Rpass-analysis=kernel-resource-usage 2>> build/asm/resource_usage.txt || true
+	@rm -f build/asm/resource_usage.txt
+	for u in $(UNITS); do \
+	  fl=""; [ $$u = wfa_duo ] && fl="$(DUOFLAGS)"; \
+	  $(HIPCC) $(HIPFLAGS) $$fl -save-temps=obj -c -o build/asm/$$u.o $(CSRC)/$$u.hip -Rpass-analysis=kernel-resource-usage 2>> build/asm/resource_usage.txt || true; \
+	done
 
 clean:
 	rm -rf $(LIB) build

@@ -51,9 +51,17 @@ CONFIGS = {
     "L5": dict(pairs=20_000, length=50_000, error=0.05, seed=55, semi_global=False, adaptive=True, total=0, cpu=200),
     "l10": dict(pairs=500, length=50_000, error=0.10, seed=510, semi_global=False, adaptive=True, total=0, cpu=300),
     "l20": dict(pairs=500, length=50_000, error=0.20, seed=520, semi_global=False, adaptive=True, total=0, cpu=120),
+    # round 5, off the 2 : 4 / global rails: the headline's pairs under penalties of another shape (2/4/2: x : o+e : e = 1 : 3 : 1,
+    # wfa.go:32-36 takes any), and the headline's pairs aligned semi-global (wfa-go -g, wfa-go/wfa-go.go:96: seeds on the whole
+    # first row and column, wfa.go:163-183, until wf-adaptive has collapsed the band)
+    "p242": dict(pairs=1_000_000, length=1000, error=0.05, seed=3, semi_global=False, adaptive=True, total=0, cpu=150_000, pen=(2, 4, 2)),
+    "g3": dict(pairs=1_000_000, length=1000, error=0.05, seed=3, semi_global=True, adaptive=True, total=0, cpu=20_000),
+    # configs[4] sample at 32 pairs: every team draws wide pairs
+    "c5s32": dict(pairs=32, length=100_000, error=0.10, seed=5, semi_global=True, adaptive=True, total=0, cpu=0),
 }
 # steps of the default run: timed regions of a few seconds
-DEFAULT_STEPS = {"c3": 250, "c2": 10000, "c2m": 2000, "c4": 25, "c5s": 4, "k10": 400, "k20": 150, "l5": 150, "L5": 20, "l10": 60, "l20": 25}
+DEFAULT_STEPS = {"c3": 250, "c2": 10000, "c2m": 2000, "c4": 25, "c5s": 4, "k10": 400, "k20": 150, "l5": 150, "L5": 20, "l10": 60, "l20": 25,
+                 "p242": 200, "g3": 5, "c5s32": 1}
 
 
 def parse_args(argv=None):
@@ -69,6 +77,7 @@ def parse_args(argv=None):
     ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--semi-global", action="store_true", default=None)
     ap.add_argument("--no-adaptive", action="store_true", default=None)
+    ap.add_argument("--penalties", default=None, help="mismatch,gap_open,gap_ext (default: the configuration's, 4,6,2)")
     ap.add_argument("--cpu-sample", type=int, default=None, help="pairs timed on host cores (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=None, help="threads of the cpu_baseline leg (default 1; c5s: 8, one pair each)")
     ap.add_argument("--cpu-all-cores", type=int, default=1, help="1: also time the oracle on every host core (N = 1 only)")
@@ -108,14 +117,15 @@ def parse_args(argv=None):
         args.semi_global = c["semi_global"]
     if args.no_adaptive is None:
         args.no_adaptive = not c["adaptive"]
+    args.pen = tuple(int(v) for v in args.penalties.split(",")) if args.penalties else tuple(c.get("pen", (4, 6, 2)))
     if args.cpu_sample is None:
         args.cpu_sample = c["cpu"]
     if args.cpu_threads is None:
-        args.cpu_threads = 8 if args.config == "c5s" else 1  # (a 100 kbp semi-global pair is minutes of one core)
+        args.cpu_threads = 8 if args.config in ("c5s", "c5s32") else 1  # (a 100 kbp semi-global pair is minutes of one core)
     if args.steps is None:
         args.steps = DEFAULT_STEPS[args.config]  # (timed regions of ~5 s; c5s ~3 s)
     if args.warmup is None:
-        args.warmup = 1 if args.config == "c5s" else 3
+        args.warmup = 1 if args.config in ("c5s", "c5s32", "g3") else 3
     if args.other_configs is None:
         plain = (args.config == "c3" and args.gpus == 1 and not args.dry and not args.opt and args.pairs == c["pairs"] and
                  args.total_pairs == c["total"] and args.length == c["length"] and args.error == c["error"])
@@ -228,7 +238,7 @@ def run_rank(args):
         d_toff = torch.from_numpy(t_off.view(np.int64)).to(dev)
         d_qlen = torch.from_numpy(q_len.view(np.int32)).to(dev)
         d_tlen = torch.from_numpy(t_len.view(np.int32)).to(dev)
-        al = w.New(w.DefaultPenalties, w.Options(GlobalAlignment=not args.semi_global), device=dev_index)
+        al = w.New(w.Penalties(*args.pen), w.Options(GlobalAlignment=not args.semi_global), device=dev_index)
         if not args.no_adaptive:
             assert al.AdaptiveReduction(w.DefaultAdaptiveOption) is None
         for kv in args.opt:
@@ -297,6 +307,7 @@ def run_rank(args):
     kernel_ms, main_ms = [], []
     n_ops = 0
     sync_all()
+    smi_before = gpu_telemetry(dev_index) if (rank == 0 and not dry) else None
     t0 = time.perf_counter()
     for _ in range(args.steps):
         n_ops = step()
@@ -305,6 +316,15 @@ def run_rank(args):
     drain()  # the last gather completes inside the timed region
     sync_all()
     elapsed = time.perf_counter() - t0
+    # what the run ran AT (round 5: the round-4 driver measured the unchanged headline kernel 7 % slower than the builder's box and
+    # nothing in the line could say why): rocm-smi's clocks / power / temperature right before and right after the timed region,
+    # and the shader clock under load by the library's own probe (s_memtime against the 100 MHz s_memrealtime on every SIMD)
+    smi_after = gpu_telemetry(dev_index) if (rank == 0 and not dry) else None
+    clock = None
+    if rank == 0 and not dry:
+        f0, f1, f2 = C.c_double(), C.c_double(), C.c_double()
+        if lib.wfahip_debug_clock(al._ctx, C.byref(f0), C.byref(f1), C.byref(f2)) == 0:
+            clock = {"mean": f0.value, "min": f1.value, "max": f2.value}
     tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
     if coll:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -375,7 +395,7 @@ def run_rank(args):
         total_pairs = n_all * args.steps
         value = total_pairs / elapsed
         cfg = {"workload": f"{n_all if scaling == 'strong' else n} x {args.length} bp pairs{'' if scaling == 'strong' else '/GPU'} "
-                           f"@{args.error:.0%} error, {'semi-global' if args.semi_global else 'global'} gap-affine 4/6/2, "
+                           f"@{args.error:.0%} error, {'semi-global' if args.semi_global else 'global'} gap-affine {'/'.join(str(v) for v in args.pen)}, "
                            f"wf-adaptive {'off' if args.no_adaptive else '10/50/1'}, seed {args.seed}",
                "config": args.config, "pairs_per_gpu": n, "pairs_per_rank": pairs_per_rank, "total_pairs_per_step": n_all,
                "length": args.length, "error_rate": args.error,
@@ -393,6 +413,9 @@ def run_rank(args):
                "retried_pairs": int(timing.n_retried_pairs), "arena_gib": timing.arena_bytes / 2 ** 30,
                "wf_cells_per_pair": cells / max(n, 1), "cigar_ops_per_pair": n_ops_total / max(n, 1),
                "timed_region_s": elapsed,
+               "clock_mhz_under_load": clock["mean"] if clock else None, "clock_mhz_under_load_range": [clock["min"], clock["max"]] if clock else None,
+               "clock_note": "shader MHz while the library's probe kernel keeps every SIMD issuing (s_memtime / s_memrealtime), right after the timed region",
+               "rocm_smi_before": smi_before, "rocm_smi_after": smi_after,
                "steady_state": f"the timed steps re-align the resident batch after {args.warmup + setup_steps} untimed call(s) of the same workload class: "
                                "what the context learns per class (rows per pair, first window, arena level) is in place; a first call "
                                "of a class also allocates its arenas (seconds, include/wfa_hip.h)"}
@@ -436,6 +459,9 @@ def run_rank(args):
                                      "frac": ach / peak, "valu_wave_insts_per_launch": pm["valu_insts"],
                                      "waves_per_simd": waves, "attainable_at_this_occupancy": attainable,
                                      "frac_of_attainable": ach / attainable,
+                                     # ... and in CYCLES (no wall clock in it): SIMD cycles per vector instruction at the clock this run ran at
+                                     "cycles_per_simd_inst": ((main_k_ms * 1e-3) * clock["mean"] * 1e6 * (min(n, 256 * 4) if lone else 256 * 4) / pm["valu_insts"]) if clock else None,
+                                     "attainable_cycles_per_simd_inst": {1: 4.44, 2: 4.0, 4: 3.1, 5: 2.5, 8: 2.55}[waves],
                                      "attainable_source": "profiles/r03_valu_issue_probe.txt (mix_add_max row at this occupancy)",
                                      "source": pm["source"], "stale": pm["stale"]}
             out["roofline"] = roof
@@ -464,7 +490,9 @@ KNAMES = ["wfa_generic_kernel", "wfa_packed_kernel", "wfa_reg_kernel<2, 4, 1>", 
           "wfa_blk_kernel<64, 1, false, 2, false, true, false>",
           "wfa_blk_kernel<64, 1, false, 1, false, false"]  # 16: the lone-pair instance of wfahip_align_pair
 # legs of config.other_configs: (config, timed steps, warm-up steps)
-OTHER_LEGS = [("c2", 300, 5), ("k10", 30, 4), ("l5", 12, 3), ("c5s", 2, 1)]
+# (round 5: every configuration that had a line only under profiles/ now has a driver-observed leg -- about two minutes in all)
+OTHER_LEGS = [("c2", 300, 5), ("c2m", 100, 3), ("p242", 12, 3), ("k10", 30, 4), ("k20", 12, 3), ("l5", 12, 3), ("l20", 5, 2), ("L5", 4, 2),
+              ("c4", 3, 1), ("c5s", 2, 1), ("c5s32", 1, 1)]
 
 
 def other_configs(w, L, torch, dev, dev_index):
@@ -481,25 +509,32 @@ def other_configs(w, L, torch, dev, dev_index):
         t_leg = time.perf_counter()
         al = None
         try:
-            n = c["pairs"]
-            blob, q_off, q_len, t_off, t_len = w.generate_pairs(c["seed"], n, c["length"], c["error"], n_threads=min(32, os.cpu_count() or 8))
+            n = c["pairs"] or c["total"]  # (c4: all 1e7 pairs on the one GPU)
+            pen = tuple(c.get("pen", (4, 6, 2)))
+            al = w.New(w.Penalties(*pen), w.Options(GlobalAlignment=not c["semi_global"]), device=dev_index)
+            if c["adaptive"]:
+                assert al.AdaptiveReduction(w.DefaultAdaptiveOption) is None
+            if n >= 5_000_000:  # generated in HBM, byte for byte the host generator's dataset (wfahip_generate_pairs_device): 20 GB never cross PCIe
+                d = list(w.generate_pairs_device(al, c["seed"], n, c["length"], c["error"]))
+                q_len, t_len = d[2].cpu().numpy().view(np.uint32), d[4].cpu().numpy().view(np.uint32)
+                blob_size = int(d[0].numel())
+            else:
+                blob, q_off, q_len, t_off, t_len = w.generate_pairs(c["seed"], n, c["length"], c["error"], n_threads=min(32, os.cpu_count() or 8))
+                d = [torch.from_numpy(a).to(dev) for a in (blob, q_off.view(np.int64), q_len.view(np.int32), t_off.view(np.int64), t_len.view(np.int32))]
+                blob_size = blob.size
             max_len = int(max(q_len.max(), t_len.max()))
             sum_len = int(q_len.astype(np.int64).sum() + t_len.astype(np.int64).sum())
             ops_cap = int(sum_len * max(0.25, 3.0 * c["error"])) + 8 * n + 1024
             if c["semi_global"] or c["length"] >= 20000:
                 ops_cap = sum_len + 2 * n + 1024
-            d = [torch.from_numpy(a).to(dev) for a in (blob, q_off.view(np.int64), q_len.view(np.int32), t_off.view(np.int64), t_len.view(np.int32))]
             d_rec = torch.zeros((n, L.REC_WORDS), dtype=torch.int32, device=dev)
             d_ops = torch.zeros(ops_cap, dtype=torch.int64, device=dev)
-            al = w.New(w.DefaultPenalties, w.Options(GlobalAlignment=not c["semi_global"]), device=dev_index)
-            if c["adaptive"]:
-                assert al.AdaptiveReduction(w.DefaultAdaptiveOption) is None
             prm, lib, timing = al._params(), L.lib(), L.Timing()
             stream = torch.cuda.current_stream(dev).cuda_stream
 
             def step():
                 needed = C.c_uint64()
-                L.check(lib.wfahip_align_batch_device(al._ctx, C.byref(prm), d[0].data_ptr(), blob.size, d[1].data_ptr(), d[2].data_ptr(),
+                L.check(lib.wfahip_align_batch_device(al._ctx, C.byref(prm), d[0].data_ptr(), blob_size, d[1].data_ptr(), d[2].data_ptr(),
                                                       d[3].data_ptr(), d[4].data_ptr(), n, max_len, d_rec.data_ptr(), d_ops.data_ptr(),
                                                       ops_cap, C.byref(needed), stream), f"wfahip_align_batch_device ({name})")
                 lib.wfahip_last_timing(al._ctx, C.byref(timing))
@@ -523,7 +558,7 @@ def other_configs(w, L, torch, dev, dev_index):
             n_ops = int(rec[:, L.REC_OPS_LEN].astype(np.uint64).sum())
             alg_bytes = 4 * cells + sum_len + 64 * n + 8 * n_ops
             mk = float(np.mean(main_ms))
-            res[name] = {"workload": f"{n} x {c['length']} bp @{c['error']:.0%}, {'semi-global' if c['semi_global'] else 'global'}, "
+            res[name] = {"workload": f"{n} x {c['length']} bp @{c['error']:.0%}, {'semi-global' if c['semi_global'] else 'global'} {'/'.join(str(v) for v in pen)}, "
                                      f"wf-adaptive {'10/50/1' if c['adaptive'] else 'off'}, seed {c['seed']}",
                          "value": n * steps / elapsed, "unit": "pairs/s", "steps": steps, "warmup": warmup,
                          "ms_per_step": elapsed / steps * 1e3, "kernel": KNAMES[min(kind, len(KNAMES) - 1)], "kernel_ms": mk,
@@ -540,6 +575,23 @@ def other_configs(w, L, torch, dev, dev_index):
             torch.cuda.empty_cache()
         res[name]["leg_s"] = time.perf_counter() - t_leg
     return res
+
+
+def gpu_telemetry(dev_index):
+    """rocm-smi's view of the GPU (clocks, power, temperature), or the error that kept it from being read."""
+    try:
+        r = subprocess.run(["rocm-smi", "-d", str(dev_index), "--showclocks", "--showpower", "--showtemp", "--showperflevel", "--json"],
+                           capture_output=True, text=True, timeout=20)
+        d = json.loads(r.stdout)
+        card = next(iter(d.values())) if d else {}
+        keep = {}
+        for k, v in card.items():
+            kl = k.lower()
+            if any(t in kl for t in ("sclk", "mclk", "fclk", "socclk", "power", "temperature", "performance level")):
+                keep[k] = v
+        return keep or {"raw": r.stdout[:400], "stderr": r.stderr[:200]}
+    except Exception as e:  # noqa: BLE001 -- telemetry must never take the bench line with it
+        return {"error": f"{type(e).__name__}: {e}"}
 
 
 def find_profile(config, kname):
@@ -590,7 +642,7 @@ def extras(args, out, w, L, al, blob, q_off, q_len, t_off, t_len, rec, n):
     if args.cpu_sample > 0:
         from oracle import oracle as O
         ns = min(args.cpu_sample, n)
-        p = O.make_params(global_alignment=not args.semi_global, adaptive=None if args.no_adaptive else (10, 50, 1))
+        p = O.make_params(*args.pen, global_alignment=not args.semi_global, adaptive=None if args.no_adaptive else (10, 50, 1))
         t1 = time.perf_counter()
         ref = O.align_batch(p, blob, q_off[:ns], q_len[:ns], t_off[:ns], t_len[:ns], n_threads=args.cpu_threads,
                             want_ops=False)

@@ -197,11 +197,13 @@ int      wfahip_submit(wfahip_ctx *ctx, const uint8_t *q, uint32_t n, const uint
  * ops the CIGAR ops (op<<32 | n, forward order, merged; capacity ops_cap entries), *n_ops their number.  If ops_cap is
  * too small the call returns WFAHIP_ERR_OOM with *n_ops = the capacity needed (at most n + m + 2).  Per-pair failures
  * are statuses in rec[WFAHIP_REC_STATUS] (EMPTY / TOO_LONG), like the batch entry.  A pair whose shape allows it (global,
- * penalties shaped like 4/6/2, both sequences within ~30 kbp) takes ONE kernel launch and no copy -- a wave with a lane per
+ * penalties of a shape the register-ring kernels are built for -- x : o+e : e = 2:4:1 (4/6/2), 1:3:1, 1:2:1, 2:3:1, 2:2:1 or
+ * 3:3:1 --, both sequences within ~30 kbp) takes ONE kernel launch and no copy -- a wave with a lane per
  * diagonal reads the sequences from, and writes record and CIGAR to, a page-locked block mapped into the GPU's address
- * space, and walks its own backtrace -- 0.17 ms for a 1 kbp pair (round 3: 0.29; wfahip_align_batch with n_pairs = 1: 0.45);
- * every other pair, and one whose band leaves 64 diagonals, goes through that entry.  Same results either way.
- * A caller that CAN batch should: a batch aligns ~58 million pairs a second, this call six thousand. */
+ * space, and walks its own backtrace -- 0.144 ms for a 1 kbp pair as the round-4 driver measured it (round 3: 0.29;
+ * wfahip_align_batch with n_pairs = 1: 0.45); every other pair, and one whose band leaves 64 diagonals, goes through that
+ * entry.  Same results either way.
+ * A caller that CAN batch should: a batch aligns ~55 million pairs a second, this call seven thousand. */
 int      wfahip_align_pair(wfahip_ctx *ctx, const wfahip_params *p, const uint8_t *q, uint32_t n, const uint8_t *t, uint32_t m,
                            uint32_t *rec, uint64_t *ops, uint64_t ops_cap, uint64_t *n_ops);
 uint64_t wfahip_pending(const wfahip_ctx *ctx);
@@ -324,6 +326,12 @@ int      wfahip_generate_pairs(uint64_t seed, uint64_t first_index, uint64_t n_p
  * n_pairs * wfahip_gen_stride(length, error_rate) + 16 bytes, the other arrays n_pairs entries; all device addresses
  * on the context's GPU.  stream = hipStream_t (NULL = the context's own); returns when the data is there.
  * WFAHIP_ERR_UNSUPPORTED when a pair's text does not fit the LDS it is edited in (length + edits > 160 KB). */
+/* Diagnostics for the bench (round 5): the shader clock UNDER LOAD.  Launches a short kernel that keeps every SIMD issuing
+ * dependent vector instructions (~0.3 ms) and compares s_memtime (shader cycles) with s_memrealtime (the constant 100 MHz
+ * wall clock) in every wave: *mhz = mean shader clock while the GPU was busy with it, *mhz_min / *mhz_max over the waves
+ * (either may be NULL).  A kernel-time figure can then be read in cycles as well as in nanoseconds, and two runs on
+ * two boxes compared by more than their wall clocks. */
+int      wfahip_debug_clock(wfahip_ctx *ctx, double *mhz, double *mhz_min, double *mhz_max);
 int      wfahip_generate_pairs_device(wfahip_ctx *ctx, uint64_t seed, uint64_t first_index, uint64_t n_pairs, uint32_t length,
                                       double error_rate, void *d_blob, void *d_q_off, void *d_q_len, void *d_t_off,
                                       void *d_t_len, void *stream);

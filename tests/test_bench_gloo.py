@@ -73,9 +73,16 @@ def test_configs_name_the_baseline_workloads():
     # the default run also measures short legs of the other configurations (config.other_configs); any other run does not
     assert bench.parse_args([]).other_configs == 1 and bench.parse_args(["--config", "c2"]).other_configs == 0
     assert bench.parse_args(["--pairs", "1000"]).other_configs == 0 and bench.parse_args(["--gpus", "2"]).other_configs == 0
-    assert [name for name, _, _ in bench.OTHER_LEGS] == ["c2", "k10", "l5", "c5s"]
-    for name in ("c2m", "L5", "k10", "k20", "l5", "l10", "l20"):
+    # (round 5: every configuration that used to have a line only under profiles/ is a driver-observed leg)
+    legs = [name for name, _, _ in bench.OTHER_LEGS]
+    assert len(legs) >= 10 and {"c2", "c2m", "p242", "k10", "k20", "l5", "l20", "L5", "c4", "c5s", "c5s32"} <= set(legs)
+    for name in ("c2m", "L5", "k10", "k20", "l5", "l10", "l20", "p242", "g3", "c5s32"):
         assert name in bench.CONFIGS and name in bench.DEFAULT_STEPS
+    a = bench.parse_args(["--config", "p242"])
+    assert (a.pen, a.pairs, a.length, a.seed, a.semi_global) == ((2, 4, 2), 1_000_000, 1000, 3, False)
+    a = bench.parse_args(["--config", "g3"])
+    assert (a.pen, a.pairs, a.length, a.seed, a.semi_global) == ((4, 6, 2), 1_000_000, 1000, 3, True)
+    assert bench.parse_args(["--penalties", "1,1,1"]).pen == (1, 1, 1)
 
 
 def test_committed_profiles_hold_the_kernels_the_lines_name():

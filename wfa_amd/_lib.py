@@ -24,7 +24,7 @@ EXPORTS = [
     "wfahip_generate_pairs", "wfahip_packed_words", "wfahip_pack_pairs", "wfahip_align_batch_packed", "wfahip_submit",
     "wfahip_pending", "wfahip_collect", "wfahip_create_multi", "wfahip_destroy_multi", "wfahip_multi_size",
     "wfahip_multi_ctx", "wfahip_align_batch_multi", "wfahip_debug_compact_arena",
-    "wfahip_generate_pairs_device", "wfahip_align_pair", "wfahip_last_error",
+    "wfahip_generate_pairs_device", "wfahip_align_pair", "wfahip_last_error", "wfahip_debug_clock",
 ]
 
 
@@ -103,6 +103,8 @@ def lib():
         L.wfahip_submit.restype = C.c_int
         L.wfahip_submit.argtypes = [vp, C.c_char_p, u32, C.c_char_p, u32, C.POINTER(u64)]
         L.wfahip_pending.restype = u64
+        L.wfahip_debug_clock.restype = C.c_int
+        L.wfahip_debug_clock.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.wfahip_align_pair.restype = C.c_int
         L.wfahip_align_pair.argtypes = [vp, C.POINTER(Params), C.c_char_p, u32, C.c_char_p, u32, vp, vp, u64, C.POINTER(u64)]
         L.wfahip_last_error.restype = C.c_char_p

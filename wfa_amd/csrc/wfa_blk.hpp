@@ -315,13 +315,20 @@ WFA_DEV void blk_push_not_ok(const KParams &P, uint32_t pidx) {
 // are: no region refills, no global traffic at all between the sequences coming in and the record going out.  160 KB of LDS
 // hold 620 score indices (scores up to 1 240 at g = 2); a pair that needs more reports ST_REDO_ARENA and the host runs the
 // global-memory instance.
-template <int G, int BATCH, bool STREAM = false, int PPT = 0, bool CENSUS = true, bool LONG = false, bool LDSA = false>
+// DX / DOE (round 5): the penalty shape x/g : (o+e)/g the instance is built for, with e/g == 1 (wfa.go:32-36 takes any
+// penalties; 4/6/2 and its multiples are 2 : 4, 2/4/2 is 1 : 3, 1/1/1 is 1 : 2, 4/4/2 is 2 : 3).  The M ring holds the last
+// R = max(DX, DOE) rows, indexed by (step mod R) with the step loop unrolled R times; the row of step i goes to slot
+// i mod R (the row of step i - R, which nothing reads any more), M[s-o-e] is slot (i - DOE) mod R and M[s-x] is slot
+// (i - DX) mod R (wfa.go:557-560).  The I and D rings are the one previous row (e/g == 1).
+template <int G, int BATCH, bool STREAM = false, int PPT = 0, bool CENSUS = true, bool LONG = false, bool LDSA = false, int DX = 2, int DOE = 4>
 __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16 && BATCH == 1 && !CENSUS && (!STREAM || WFA_BLK_STREAM_WAVES5) ? WFA_BLK_WAVES : 4))) void wfa_blk_kernel(const KParams P) {
     static_assert(!STREAM || (G == 16 && BATCH == 1), "streamed backtrace: 16 lanes per pair, unbatched refill");
     static_assert(PPT == 0 || (G == 8 && PPT == 4) || (G == 64 && (PPT == 1 || PPT == 2)),
                   "diagonals per lane can only be overridden for the 8-lane narrow instance and the lone-pair instances");
     static_assert(!LONG || (BATCH == 1 && !STREAM && (PPT == 0 || G == 64) && G >= 16), "sliding sequence windows: unbatched, pre-packed input");
     static_assert(!LDSA || (G == 64 && PPT == 1 && BATCH == 1 && !STREAM && !LONG && !CENSUS), "LDS-resident arena: the lone-pair instance");
+    static_assert(DX >= 1 && DOE >= 1 && DX <= 4 && DOE <= 4, "ring depths of one to four score steps");
+    constexpr int R = DX > DOE ? DX : DOE;  // rows of the M ring
     constexpr int PP  = PPT ? PPT : (G >= 32 ? 4 : 64 / G);  // diagonals per lane
     constexpr int NG  = 64 / G;                // pairs per wave
 #ifdef WFA_BLK_W
@@ -387,11 +394,11 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
     constexpr int LDM = (G * (PPT ? PPT : (G >= 32 ? 4 : 64 / G))) / 2 + 128;  // LONG: half the diagonal window + the drift of its centre a window tolerates
     constexpr int LMARGIN = 128;                                 // LONG: bases kept below the cell a window is positioned at
 
-    uint32_t M[4][PP], I[PP], D[PP];  // offsets, 0 = absent; M[i & 3] = row of step i
-    int      rlo[4], rhi[4];          // band of each kept M row (absolute k); empty = (BIG, -BIG)
+    uint32_t M[R][PP], I[PP], D[PP];  // offsets, 0 = absent; M[i mod R] = row of step i
+    int      rlo[R], rhi[R];          // band of each kept M row (absolute k); empty = (BIG, -BIG)
     int      lim[PP], lmx[PP];        // max(1, min(n + k, m)) and max(n + k, m) of the lane's diagonals
 #pragma unroll
-    for (int d = 0; d < 4; d++) {
+    for (int d = 0; d < R; d++) {
         rlo[d] = BK_BIG, rhi[d] = -BK_BIG;
 #pragma unroll
         for (int p = 0; p < PP; p++) M[d][p] = 0u;
@@ -408,7 +415,7 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
     };
     const auto clear_rings = [&]() {
 #pragma unroll
-        for (int d = 0; d < 4; d++) {
+        for (int d = 0; d < R; d++) {
             rlo[d] = BK_BIG, rhi[d] = -BK_BIG;
 #pragma unroll
             for (int p = 0; p < PP; p++) M[d][p] = 0u;
@@ -742,8 +749,9 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
             const bool run = (st == 1);
             WFA_STAMP(0); WFA_MARK(0);  // refill
 
-            uint32_t(&Mo)[PP] = M[ph];            // M[s-o-e]: read as a source, then replaced by the new row
-            uint32_t(&Mx)[PP] = M[(ph + 2) & 3];  // M[s-x]
+            uint32_t(&Mo)[PP] = M[(ph + R - DOE) % R];  // M[s-o-e]
+            uint32_t(&Mx)[PP] = M[(ph + R - DX) % R];   // M[s-x]
+            uint32_t(&Mn)[PP] = M[ph];                  // the slot of the row being computed: the oldest row (= M[s-o-e] when DOE >= DX), read before it is replaced
 
             // ------------------------------------------------------------ WF_NEXT (wfa.go:549-700)
             uint32_t nM[PP], nI[PP], nD[PP], wd[PP], cc[PP];
@@ -1134,7 +1142,7 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
 
             // ------------------------------------------------------------ the new row enters the rings
 #pragma unroll
-            for (int p = 0; p < PP; p++) Mo[p] = nM[p], I[p] = nI[p], D[p] = nD[p];
+            for (int p = 0; p < PP; p++) Mn[p] = nM[p], I[p] = nI[p], D[p] = nD[p];
             rlo[ph] = keepl ? kb + ilo : BK_BIG;
             rhi[ph] = keepl ? kb + ihi : -BK_BIG;
 
@@ -1145,7 +1153,7 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
                 int hf   = 0;  // extended offset of the end cell M[s][Ak]: where the backtrace starts
 #pragma unroll
                 for (int p = 0; p < PP; p++)
-                    if (k0 + p == m - n) hf = (int)Mo[p];
+                    if (k0 + p == m - n) hf = (int)Mn[p];
                 Red::max_add(hf, ctot);
                 if (fin && j == 0) {
                     if (no_room) {
@@ -1177,12 +1185,13 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
                 const bool need_dn = live && ilo <= 0;
                 const bool need_up = live && ihi >= W - 1;
                 if (WFA_RARE(__ballot(need_dn || need_up) != 0ull)) {
-                    const int  ulo  = imin2(imin2(rlo[0], rlo[1]), imin2(rlo[2], rlo[3]));
-                    const int  uhi  = imax2(imax2(rhi[0], rhi[1]), imax2(rhi[2], rhi[3]));
+                    int ulo = rlo[0], uhi = rhi[0];
+#pragma unroll
+                    for (int d = 1; d < R; d++) ulo = imin2(ulo, rlo[d]), uhi = imax2(uhi, rhi[d]);
                     const bool wide = (need_dn && (need_up || uhi >= kb - SHD + W - 1)) || (need_up && ulo <= kb + SHD);
                     const bool dn = need_dn && !wide, up = need_up && !wide;
 #pragma unroll
-                    for (int d = 0; d < 4; d++)
+                    for (int d = 0; d < R; d++)
 #pragma unroll
                         for (int p = 0; p < PP; p++) {
                             const uint32_t a = Ops::shr(M[d][p], j), b = Ops::shl(M[d][p], j);
@@ -1220,26 +1229,32 @@ __global__ __launch_bounds__(64, (G == 8 && PPT == 0 ? WFA_BLK8_WAVES : (G == 16
         }
     };
 #ifndef WFA_BLK_SHARED_REFILL
-    for (;;) {  // four copies of refill + step: 68 KB of code, but measured 6 % faster than the switch below
+    for (;;) {  // R copies of refill + step (four at 2 : 4: 68 KB of code, but measured 6 % faster than the switch below)
         if (WFA_RARE(refill())) break;
         step(std::integral_constant<int, 0>{});
-        if (WFA_RARE(refill())) break;
-        step(std::integral_constant<int, 1>{});
-        if (WFA_RARE(refill())) break;
-        step(std::integral_constant<int, 2>{});
-        if (WFA_RARE(refill())) break;
-        step(std::integral_constant<int, 3>{});
+        if constexpr (R > 1) {
+            if (WFA_RARE(refill())) break;
+            step(std::integral_constant<int, 1 % R>{});
+        }
+        if constexpr (R > 2) {
+            if (WFA_RARE(refill())) break;
+            step(std::integral_constant<int, 2 % R>{});
+        }
+        if constexpr (R > 3) {
+            if (WFA_RARE(refill())) break;
+            step(std::integral_constant<int, 3 % R>{});
+        }
     }
 #else
-    // experiment: one copy of the refill code, the four ring phases of the step selected by a wave-uniform switch
+    // experiment: one copy of the refill code, the ring phases of the step selected by a wave-uniform switch
     // (40 KB of code; slower: the merge after the switch costs register moves)
-    for (int ph = 0;; ph = (ph + 1) & 3) {
+    for (int ph = 0;; ph = (ph + 1) % R) {
         if (WFA_RARE(refill())) break;
         switch (ph) {
         case 0: step(std::integral_constant<int, 0>{}); break;
-        case 1: step(std::integral_constant<int, 1>{}); break;
-        case 2: step(std::integral_constant<int, 2>{}); break;
-        default: step(std::integral_constant<int, 3>{}); break;
+        case 1: step(std::integral_constant<int, 1 % R>{}); break;
+        case 2: step(std::integral_constant<int, 2 % R>{}); break;
+        default: step(std::integral_constant<int, 3 % R>{}); break;
         }
     }
 #endif

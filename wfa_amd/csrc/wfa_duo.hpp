@@ -85,9 +85,12 @@ struct DuoRed {
 #undef WFA_DUO_1
 };
 
-template <bool CENSUS>
+// DX / DOE: the penalty shape, as in wfa_blk_kernel (R = max(DX, DOE) rows in the M ring)
+template <bool CENSUS, int DX = 2, int DOE = 4>
 __global__ __launch_bounds__(64, WFA_DUO_WAVES) void wfa_duo_kernel(const KParams P) {
     constexpr int PP = 4;
+    static_assert(DX >= 1 && DOE >= 1 && DX <= 4 && DOE <= 4, "ring depths of one to four score steps");
+    constexpr int R = DX > DOE ? DX : DOE;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int  lane = threadIdx.x, l7 = lane & 7, l15 = lane & 15;
     const bool hi_half = (lane & 8) != 0;
@@ -114,11 +117,11 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) void wfa_duo_kernel(const KParam
     const uint32_t *lq = lds + 4, *lt = lds + 4;
     uint32_t       *rowp = nullptr;
 
-    uint32_t M[4][PP], I[PP], D[PP];  // offsets, 0 = absent; M[i & 3] = row of step i
-    int      rlo[4], rhi[4];          // band of each kept M row (absolute k); empty = (BIG, -BIG)
+    uint32_t M[R][PP], I[PP], D[PP];  // offsets, 0 = absent; M[i mod R] = row of step i
+    int      rlo[R], rhi[R];          // band of each kept M row (absolute k); empty = (BIG, -BIG)
     int      lim[PP], lmx[PP];
 #pragma unroll
-    for (int d = 0; d < 4; d++) {
+    for (int d = 0; d < R; d++) {
         rlo[d] = BK_BIG, rhi[d] = -BK_BIG;
 #pragma unroll
         for (int p = 0; p < PP; p++) M[d][p] = 0u;
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) void wfa_duo_kernel(const KParam
     };
     const auto clear_rings = [&]() {
 #pragma unroll
-        for (int d = 0; d < 4; d++) {
+        for (int d = 0; d < R; d++) {
             rlo[d] = BK_BIG, rhi[d] = -BK_BIG;
 #pragma unroll
             for (int p = 0; p < PP; p++) M[d][p] = 0u;
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) void wfa_duo_kernel(const KParam
     // prefetch pipeline, then -- only when something has to change -- recentre / widen / narrow / park / resume / start
     const auto refill = [&](auto ph_c) __attribute__((always_inline)) -> bool {
         constexpr int ph  = decltype(ph_c)::value;
-        constexpr int NEW = (ph + 3) & 3;  // ring slot of the newest row; M[ph] is the oldest (replaced by the next step)
+        constexpr int NEW = (ph + R - 1) % R;  // ring slot of the newest row; M[ph] is the oldest (replaced by the next step)
         // ---------------------------------------------------------------- prefetch of the next pair, one stage per call
         // (wave-uniform by construction; said so explicitly, or hipcc keeps them in vector registers)
         pf        = (uint32_t)__builtin_amdgcn_readfirstlane((int)pf);
@@ -237,8 +240,9 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) void wfa_duo_kernel(const KParam
         const bool touch = run && rhi[NEW] >= rlo[NEW] && (rlo[NEW] <= kb || rhi[NEW] >= kb + Wc - 1);
         bool       narrowable = false;
         if constexpr (ph == 0) {  // (looked at every fourth step: a wide pair that could be narrow costs a half row, nothing else)
-            const int ulo = imin2(imin2(rlo[0], rlo[1]), imin2(rlo[2], rlo[3]));
-            const int uhi = imax2(imax2(rhi[0], rhi[1]), imax2(rhi[2], rhi[3]));
+            int ulo = rlo[0], uhi = rhi[0];
+#pragma unroll
+            for (int d = 1; d < R; d++) ulo = imin2(ulo, rlo[d]), uhi = imax2(uhi, rhi[d]);
             narrowable    = run && wide && uhi - ulo + 1 <= DUO_NARROW_AT;
         }
         const unsigned long long m_ev = __ballot(touch || narrowable);
@@ -248,8 +252,9 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) void wfa_duo_kernel(const KParam
         WFA_EVT(1, 1);
         {
             // ------------------------------------------------------------ what each pair wants
-            const int ulo  = imin2(imin2(rlo[0], rlo[1]), imin2(rlo[2], rlo[3]));
-            const int uhi  = imax2(imax2(rhi[0], rhi[1]), imax2(rhi[2], rhi[3]));
+            int ulo = rlo[0], uhi = rhi[0];
+#pragma unroll
+            for (int d = 1; d < R; d++) ulo = imin2(ulo, rlo[d]), uhi = imax2(uhi, rhi[d]);
             const int span = uhi - ulo + 1;
             int act = 0;  // 1 recentre, 2 widen, 3 narrow, 4 hand on (band wider than a whole row holds)
             if (touch) act = wide ? (span > DUO_WIDE_MAX ? 4 : 1) : (span > DUO_WIDEN_AT ? 2 : 1);
@@ -284,19 +289,26 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) void wfa_duo_kernel(const KParam
                 WFA_EVT(3, 1);
                 uint32_t *const pr = park0 + rec * DUO_PARK_WORDS;
                 if (mine) {
+                    // (record row r = the r-th oldest row of the ring, M[(ph + r) mod R]; a ring of fewer than four rows leaves the rest empty)
                     uint4 *const w = reinterpret_cast<uint4 *>(pr + 12 * l7);
                     const auto pk = [](uint32_t lo, uint32_t hi) { return lo | (hi << 16); };
-                    w[0] = make_uint4(pk(M[ph][0], M[ph][1]), pk(M[ph][2], M[ph][3]), pk(M[(ph + 1) & 3][0], M[(ph + 1) & 3][1]),
-                                      pk(M[(ph + 1) & 3][2], M[(ph + 1) & 3][3]));
-                    w[1] = make_uint4(pk(M[(ph + 2) & 3][0], M[(ph + 2) & 3][1]), pk(M[(ph + 2) & 3][2], M[(ph + 2) & 3][3]),
-                                      pk(M[(ph + 3) & 3][0], M[(ph + 3) & 3][1]), pk(M[(ph + 3) & 3][2], M[(ph + 3) & 3][3]));
+                    uint32_t pw[8];
+                    int      plo[4], phi[4];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        pw[2 * r]     = r < R ? pk(M[(ph + r) % R][0], M[(ph + r) % R][1]) : 0u;
+                        pw[2 * r + 1] = r < R ? pk(M[(ph + r) % R][2], M[(ph + r) % R][3]) : 0u;
+                        plo[r] = r < R ? rlo[(ph + r) % R] : BK_BIG, phi[r] = r < R ? rhi[(ph + r) % R] : -BK_BIG;
+                    }
+                    w[0] = make_uint4(pw[0], pw[1], pw[2], pw[3]);
+                    if constexpr (R > 2) w[1] = make_uint4(pw[4], pw[5], pw[6], pw[7]);
                     w[2] = make_uint4(pk(I[0], I[1]), pk(I[2], I[3]), pk(D[0], D[1]), pk(D[2], D[3]));
                     if (l7 == 0) {
                         uint4 *const s4 = reinterpret_cast<uint4 *>(pr + 96);
                         s4[0] = make_uint4(pidx, si, cells, sbuf);
                         s4[1] = make_uint4((uint32_t)n, (uint32_t)m, (uint32_t)kb, (slow ? 1u : 0u) | (first_eq ? 2u : 0u));
-                        s4[2] = make_uint4((uint32_t)rlo[ph], (uint32_t)rlo[(ph + 1) & 3], (uint32_t)rlo[(ph + 2) & 3], (uint32_t)rlo[(ph + 3) & 3]);
-                        s4[3] = make_uint4((uint32_t)rhi[ph], (uint32_t)rhi[(ph + 1) & 3], (uint32_t)rhi[(ph + 2) & 3], (uint32_t)rhi[(ph + 3) & 3]);
+                        s4[2] = make_uint4((uint32_t)plo[0], (uint32_t)plo[1], (uint32_t)plo[2], (uint32_t)plo[3]);
+                        s4[3] = make_uint4((uint32_t)phi[0], (uint32_t)phi[1], (uint32_t)phi[2], (uint32_t)phi[3]);
                     }
                 }
             }
@@ -347,7 +359,7 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) void wfa_duo_kernel(const KParam
                 WFA_EVT(2, 1);
                 const int sl = (src < 0 ? lane : src) << 2;
 #pragma unroll
-                for (int d = 0; d < 4; d++)
+                for (int d = 0; d < R; d++)
 #pragma unroll
                     for (int p = 0; p < PP; p++) {
                         const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute(sl, (int)M[d][p]);
@@ -365,14 +377,14 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) void wfa_duo_kernel(const KParam
                     const uint32_t o_pidx = (uint32_t)other_half((int)pidx), o_si = (uint32_t)other_half((int)si);
                     const uint32_t o_cells = (uint32_t)other_half((int)cells), o_sbuf = (uint32_t)other_half((int)sbuf);
                     const int      o_fl = other_half((slow ? 1 : 0) | (first_eq ? 2 : 0));
-                    int o_rlo[4], o_rhi[4];
+                    int o_rlo[R], o_rhi[R];
 #pragma unroll
-                    for (int d = 0; d < 4; d++) o_rlo[d] = other_half(rlo[d]), o_rhi[d] = other_half(rhi[d]);
+                    for (int d = 0; d < R; d++) o_rlo[d] = other_half(rlo[d]), o_rhi[d] = other_half(rhi[d]);
                     if (join) {
                         n = o_n, m = o_m, pidx = o_pidx, si = o_si, cells = o_cells, sbuf = o_sbuf;
                         slow = (o_fl & 1) != 0, first_eq = (o_fl & 2) != 0;
 #pragma unroll
-                        for (int d = 0; d < 4; d++) rlo[d] = o_rlo[d], rhi[d] = o_rhi[d];
+                        for (int d = 0; d < R; d++) rlo[d] = o_rlo[d], rhi[d] = o_rhi[d];
                         st = 1;
                     }
                 }
@@ -383,7 +395,7 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) void wfa_duo_kernel(const KParam
                 if (freed) {
                     st = 0;
 #pragma unroll
-                    for (int d = 0; d < 4; d++) rlo[d] = BK_BIG, rhi[d] = -BK_BIG;
+                    for (int d = 0; d < R; d++) rlo[d] = BK_BIG, rhi[d] = -BK_BIG;
                 }
             }
             // ------------------------------------------------------------ free halves: parked pairs first, then the staged pair
@@ -397,20 +409,23 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) void wfa_duo_kernel(const KParam
                     WFA_EVT(4, 1);
                     const uint32_t *const pr = park0 + rec * DUO_PARK_WORDS;
                     if (mine) {
+                        // (record row r -> M[(ph + r) mod R]: the phase of the resuming wave, not of the one that parked it)
                         const uint4 *const w = reinterpret_cast<const uint4 *>(pr + 12 * l7);
-                        const uint4 v0 = w[0], v1 = w[1], v2 = w[2];
-                        M[ph][0] = v0.x & 0xFFFFu, M[ph][1] = v0.x >> 16, M[ph][2] = v0.y & 0xFFFFu, M[ph][3] = v0.y >> 16;
-                        M[(ph + 1) & 3][0] = v0.z & 0xFFFFu, M[(ph + 1) & 3][1] = v0.z >> 16, M[(ph + 1) & 3][2] = v0.w & 0xFFFFu, M[(ph + 1) & 3][3] = v0.w >> 16;
-                        M[(ph + 2) & 3][0] = v1.x & 0xFFFFu, M[(ph + 2) & 3][1] = v1.x >> 16, M[(ph + 2) & 3][2] = v1.y & 0xFFFFu, M[(ph + 2) & 3][3] = v1.y >> 16;
-                        M[(ph + 3) & 3][0] = v1.z & 0xFFFFu, M[(ph + 3) & 3][1] = v1.z >> 16, M[(ph + 3) & 3][2] = v1.w & 0xFFFFu, M[(ph + 3) & 3][3] = v1.w >> 16;
-                        I[0] = v2.x & 0xFFFFu, I[1] = v2.x >> 16, I[2] = v2.y & 0xFFFFu, I[3] = v2.y >> 16;
-                        D[0] = v2.z & 0xFFFFu, D[1] = v2.z >> 16, D[2] = v2.w & 0xFFFFu, D[3] = v2.w >> 16;
+                        const uint4 v0 = w[0], v1 = R > 2 ? w[1] : make_uint4(0u, 0u, 0u, 0u), v2 = w[2];
+                        const uint32_t pw[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
                         const uint4 *const s4 = reinterpret_cast<const uint4 *>(pr + 96);
                         const uint4 a0 = s4[0], a1 = s4[1], a2 = s4[2], a3 = s4[3];
+                        const uint32_t plo[4] = {a2.x, a2.y, a2.z, a2.w}, phi[4] = {a3.x, a3.y, a3.z, a3.w};
+#pragma unroll
+                        for (int r = 0; r < R; r++) {
+                            M[(ph + r) % R][0] = pw[2 * r] & 0xFFFFu, M[(ph + r) % R][1] = pw[2 * r] >> 16;
+                            M[(ph + r) % R][2] = pw[2 * r + 1] & 0xFFFFu, M[(ph + r) % R][3] = pw[2 * r + 1] >> 16;
+                            rlo[(ph + r) % R] = (int)plo[r], rhi[(ph + r) % R] = (int)phi[r];
+                        }
+                        I[0] = v2.x & 0xFFFFu, I[1] = v2.x >> 16, I[2] = v2.y & 0xFFFFu, I[3] = v2.y >> 16;
+                        D[0] = v2.z & 0xFFFFu, D[1] = v2.z >> 16, D[2] = v2.w & 0xFFFFu, D[3] = v2.w >> 16;
                         pidx = a0.x, si = a0.y, cells = a0.z, sbuf = a0.w;
                         n = (int)a1.x, m = (int)a1.y, kb = (int)a1.z, slow = (a1.w & 1u) != 0u, first_eq = (a1.w & 2u) != 0u;
-                        rlo[ph] = (int)a2.x, rlo[(ph + 1) & 3] = (int)a2.y, rlo[(ph + 2) & 3] = (int)a2.z, rlo[(ph + 3) & 3] = (int)a2.w;
-                        rhi[ph] = (int)a3.x, rhi[(ph + 1) & 3] = (int)a3.y, rhi[(ph + 2) & 3] = (int)a3.z, rhi[(ph + 3) & 3] = (int)a3.w;
                         st = 1, wide = false;
                     }
                     m_free &= ~(0xFFull << (8 * oct));
@@ -463,8 +478,9 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) void wfa_duo_kernel(const KParam
         const bool run = (st == 1);
         WFA_EVT(0, 1), WFA_EVT(6, __builtin_popcountll(__ballot(run)) / 8);
 
-        uint32_t(&Mo)[PP] = M[ph];            // M[s-o-e]: read as a source, then replaced by the new row
-        uint32_t(&Mx)[PP] = M[(ph + 2) & 3];  // M[s-x]
+        uint32_t(&Mo)[PP] = M[(ph + R - DOE) % R];  // M[s-o-e]
+        uint32_t(&Mx)[PP] = M[(ph + R - DX) % R];   // M[s-x]
+        uint32_t(&Mn)[PP] = M[ph];                  // the slot of the row being computed (the oldest row of the ring)
 
         // ------------------------------------------------------------ WF_NEXT (wfa.go:549-700)
         uint32_t nM[PP], nI[PP], nD[PP], wd[PP], cc[PP];
@@ -686,7 +702,7 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) void wfa_duo_kernel(const KParam
 
         // ------------------------------------------------------------ the new row enters the rings
 #pragma unroll
-        for (int p = 0; p < PP; p++) Mo[p] = nM[p], I[p] = nI[p], D[p] = nD[p];
+        for (int p = 0; p < PP; p++) Mn[p] = nM[p], I[p] = nI[p], D[p] = nD[p];
         rlo[ph] = keepl ? kb + ilo : BK_BIG;
         rhi[ph] = keepl ? kb + ihi : -BK_BIG;
 
@@ -697,7 +713,7 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) void wfa_duo_kernel(const KParam
             int hf   = 0;  // extended offset of the end cell M[s][Ak]: where the backtrace starts
 #pragma unroll
             for (int p = 0; p < PP; p++)
-                if (k0 + p == m - n) hf = (int)Mo[p];
+                if (k0 + p == m - n) hf = (int)Mn[p];
             hf = DuoRed::max1(hf, wide);
             if (fin && j == 0) {
                 if (no_room) {
@@ -720,12 +736,18 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) void wfa_duo_kernel(const KParam
     for (;;) {
         if (refill(std::integral_constant<int, 0>{})) break;
         step(std::integral_constant<int, 0>{});
-        if (refill(std::integral_constant<int, 1>{})) break;
-        step(std::integral_constant<int, 1>{});
-        if (refill(std::integral_constant<int, 2>{})) break;
-        step(std::integral_constant<int, 2>{});
-        if (refill(std::integral_constant<int, 3>{})) break;
-        step(std::integral_constant<int, 3>{});
+        if constexpr (R > 1) {
+            if (refill(std::integral_constant<int, 1 % R>{})) break;
+            step(std::integral_constant<int, 1 % R>{});
+        }
+        if constexpr (R > 2) {
+            if (refill(std::integral_constant<int, 2 % R>{})) break;
+            step(std::integral_constant<int, 2 % R>{});
+        }
+        if constexpr (R > 3) {
+            if (refill(std::integral_constant<int, 3 % R>{})) break;
+            step(std::integral_constant<int, 3 % R>{});
+        }
     }
 #ifdef WFA_STAMPS
     if (lane == 0 && P.debug_info) {

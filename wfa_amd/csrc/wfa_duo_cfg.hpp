@@ -41,7 +41,7 @@ __host__ __device__ inline uint32_t duo_lds_words(uint32_t prepack_words) {
     return duo_bufs(prepack_words) * prepack_words + (uint32_t)DUO_PARK * DUO_PARK_WORDS;
 }
 
-// launches wfa_duo_kernel<census> (wfa_duo.hip)
-hipError_t wfa_launch_duo(const KParams &P, uint32_t grid, size_t lds_bytes, hipStream_t st, bool census);
+// launches wfa_duo_kernel<census, DX, DOE> of penalty shape `shape` (wfa_duo.hip; wfa_fwd.hpp: fwd_shape())
+hipError_t wfa_launch_duo(int shape, const KParams &P, uint32_t grid, size_t lds_bytes, hipStream_t st, bool census);
 
 }  // namespace wfa

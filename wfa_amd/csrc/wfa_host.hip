@@ -4,6 +4,10 @@
 // There is NO CPU fallback here: every alignment is produced by the HIP kernels.  Without a GPU the
 // entry points return WFAHIP_ERR_NO_DEVICE.
 #include "../../include/wfa_hip.h"
+// (the kernels' headers for their constants and device functions; the forward kernels are instantiated per penalty shape in
+// wfa_fwd_s*.hip, wfa_duo_kernel in wfa_duo.hip, the long-pair kernels in wfa_long.hip: this unit keeps the router, the
+// non-template kernels of the pipeline -- packing, backtrace, result assembly, the generator -- and the two first-generation
+// forward kernels that are only selectable by option)
 #include "wfa_generic.hpp"
 #include "wfa_packed.hpp"
 #include "wfa_reg.hpp"
@@ -11,6 +15,8 @@
 #include "wfa_duo_cfg.hpp"
 #include "wfa_lane.hpp"
 #include "wfa_team.hpp"
+#include "wfa_fwd.hpp"
+#include "wfa_long.hpp"
 #include "wfa_finalize.hpp"
 #include "wfa_gen_dev.hpp"
 
@@ -32,6 +38,32 @@
 #include <vector>
 
 using namespace wfa;
+
+// the per-shape launchers behind one switch (wfa_fwd.hpp)
+namespace wfa {
+hipError_t wfa_launch_fwd(int shape, int kind, uint32_t flags, const KParams &P, uint32_t grid, size_t lds_bytes, hipStream_t st) {
+    switch (shape) {
+    case 0: return wfa_launch_fwd_s24(kind, flags, P, grid, lds_bytes, st);
+    case 1: return wfa_launch_fwd_s13(kind, flags, P, grid, lds_bytes, st);
+    case 2: return wfa_launch_fwd_s12(kind, flags, P, grid, lds_bytes, st);
+    case 3: return wfa_launch_fwd_s23(kind, flags, P, grid, lds_bytes, st);
+    case 4: return wfa_launch_fwd_s22(kind, flags, P, grid, lds_bytes, st);
+    case 5: return wfa_launch_fwd_s33(kind, flags, P, grid, lds_bytes, st);
+    }
+    return hipErrorInvalidValue;
+}
+hipError_t wfa_launch_pair(int shape, bool lds_arena, const KParams &P, size_t lds_bytes, hipStream_t st) {
+    switch (shape) {
+    case 0: return wfa_launch_pair_s24(lds_arena, P, lds_bytes, st);
+    case 1: return wfa_launch_pair_s13(lds_arena, P, lds_bytes, st);
+    case 2: return wfa_launch_pair_s12(lds_arena, P, lds_bytes, st);
+    case 3: return wfa_launch_pair_s23(lds_arena, P, lds_bytes, st);
+    case 4: return wfa_launch_pair_s22(lds_arena, P, lds_bytes, st);
+    case 5: return wfa_launch_pair_s33(lds_arena, P, lds_bytes, st);
+    }
+    return hipErrorInvalidValue;
+}
+}  // namespace wfa
 
 #define HIP_TRY(expr)                                                                                  \
     do {                                                                                               \
@@ -115,7 +147,6 @@ struct wfahip_ctx {
     int64_t       opt_pair_lds             = 1;   // wfahip_align_pair's lone-pair instance keeps the pair's arena rows in LDS (0: in global memory); a pair that needs more
                                                  // rows than 160 KB hold is re-run by the global-memory instance, and the next calls start there
     uint32_t      one_lds_skip             = 0;   // calls left that skip the LDS instance (after a pair that did not fit it)
-    bool          one_lds_attr             = false;  // the LDS instance's dynamic-LDS limit has been raised
     int64_t       opt_pair_fast            = 1;   // wfahip_align_pair, when the pair allows it: 1 = one launch of the lone-pair instance (a lane per diagonal, the wave walks its
                                                   // own backtrace); 3 = round 3's one launch of the four-pairs-per-wave streaming instance; 2 = that kernel + the backtrace kernel; 0 = the batch entry
     DevBuf        in_packed;                 // host entry with pre-packed input: the 2-bit words as uploaded (unpacked into in_blob on the device)
@@ -260,29 +291,7 @@ struct LaunchCfg {
     uint32_t slots;
 };
 
-template <int WAVES, int MODE>
-hipError_t launch_one(const KParams &P, const LaunchCfg &c, hipStream_t st) {
-    auto kfn = wfa_generic_kernel<WAVES, MODE>;
-    if (c.lds_bytes > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds_bytes);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(kfn, dim3(c.slots), dim3(64 * WAVES), c.lds_bytes, st, P);
-    return hipGetLastError();
-}
-
-hipError_t launch_generic(const KParams &P, const LaunchCfg &c, hipStream_t st) {
-    switch (c.waves * 2 + c.mode) {
-    case 1 * 2 + 0: return launch_one<1, 0>(P, c, st);
-    case 1 * 2 + 1: return launch_one<1, 1>(P, c, st);
-    case 4 * 2 + 0: return launch_one<4, 0>(P, c, st);
-    case 4 * 2 + 1: return launch_one<4, 1>(P, c, st);
-    case 16 * 2 + 0: return launch_one<16, 0>(P, c, st);
-    case 16 * 2 + 1: return launch_one<16, 1>(P, c, st);
-    }
-    return hipErrorInvalidValue;
-}
+hipError_t launch_generic(const KParams &P, const LaunchCfg &c, hipStream_t st) { return wfa_launch_generic(P, c.waves, c.mode, c.slots, c.lds_bytes, st); }
 
 struct Job {
     int                   mode;
@@ -773,7 +782,9 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
         constexpr uint32_t SUB_LEN_LIMIT = 10200;
         uint32_t           sub_len       = max_len;
         // long reads: the blocked kernels with sliding sequence windows (kinds 11 / 12 / 13 = 64 / 128 / 256 diagonals)
-        const bool can_long = ctx->opt_long != 0 && ctx->opt_blk == 16 && dx == 2 && doe == 4 && de == 1 && (int64_t)max_len > ctx->opt_long_min_len;
+        // the penalty shape the register-ring kernels are instantiated for (wfa_fwd.hpp); -1: none, the LDS-ring kernel takes the batch
+        const int  shape    = fwd_shape(dx, doe, de);
+        const bool can_long = ctx->opt_long != 0 && ctx->opt_blk == 16 && shape >= 0 && (int64_t)max_len > ctx->opt_long_min_len;
         // (a batch of mostly short pairs with a few long ones keeps the short pairs' pipeline -- slots, arenas and windows of the
         // long instances are sized by the longest pair -- and the long ones get a pass of their own behind it: long_first below)
         if (max_len > SUB_LEN_LIMIT && n_pairs >= 256) {
@@ -804,7 +815,7 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
         const size_t   lds_d     = (size_t)seq_words * 2 * 4 * (ctx->opt_blk == 8 ? 8 : 4) + 16;  // blocked kernel
         const bool     can_b     = lds_b <= 20 * 1024;
         const bool     can_c     = ctx->opt_reg && dx == 2 && doe == 4 && de == 1 && lds_c <= 20 * 1024;
-        const bool     can_d     = long_first || (ctx->opt_blk && dx == 2 && doe == 4 && de == 1 && sub_len < 32768 &&
+        const bool     can_d     = long_first || (ctx->opt_blk && shape >= 0 && (shape == 0 || ctx->opt_blk == 16) && sub_len < 32768 &&
                                                 lds_d <= (ctx->opt_blk == 8 ? 40 : 20) * 1024);
         const auto words_dir_of = [&](uint32_t len) {
             uint64_t wd = std::max<uint64_t>(1024, 8ull * len);  // compact rows: 1 word per diagonal
@@ -921,7 +932,7 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             // (off unless asked for since round 2: with the forward pass at 20 ms per 1e6 pairs the write-through row
             // stores of the streaming instance cost more than the backtrace kernel they save -- 3e6 x 1 kbp pairs in two
             // chunks: 65.2 ms with a backtrace kernel per chunk, 70.5 ms streamed)
-            const bool stream_bt = kind == 3 && !blk_batch && n_buf == 1 && ctx->opt_bt_stream > 0 && (int64_t)chunk >= ctx->opt_bt_stream_min &&
+            const bool stream_bt = kind == 3 && shape == 0 && !blk_batch && n_buf == 1 && ctx->opt_bt_stream > 0 && (int64_t)chunk >= ctx->opt_bt_stream_min &&
                                    ctx->opt_bt_stream_single != 0;
             P.done_q = nullptr, P.done_ctl = nullptr, P.n_stream_wgs = 0;
             if (stream_bt) {
@@ -994,67 +1005,23 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                 // (tests: the sub-wave kernels zero nothing -- no word the backtrace reads may be one they did not write)
                 if (ctx->opt_arena_poison) HIP_TRY(hipMemsetAsync(P.arena, 0xA5, (size_t)(words * 4ull * cn), st));
                 HIP_TRY(hipEventRecord(evFa, st));
-                if (kind == 8)
-                    HIP_TRY(wfa_launch_duo(P, grid, lds_bytes, st, P.census != 0));
-                else if (kind == 11 && P.census)
-                    hipLaunchKernelGGL((wfa_blk_kernel<16, 1, false, 0, true, true>), dim3(grid), dim3(64), lds_bytes, st, P);
-                else if (kind == 11)
-                    hipLaunchKernelGGL((wfa_blk_kernel<16, 1, false, 0, false, true>), dim3(grid), dim3(64), lds_bytes, st, P);
-                // (the lone-wave instances that are first passes of small batches -- a wave per pair, one / two / four diagonals per
-                // lane -- also exist without the census of stored words: 4 % of a step that is all latency)
-                else if (kind == 12)
-                    hipLaunchKernelGGL((wfa_blk_kernel<32, 1, false, 0, true, true>), dim3(grid), dim3(64), lds_bytes, st, P);
-                else if (kind == 13 && P.census)
-                    hipLaunchKernelGGL((wfa_blk_kernel<64, 1, false, 0, true, true>), dim3(grid), dim3(64), lds_bytes, st, P);
-                else if (kind == 13)
-                    hipLaunchKernelGGL((wfa_blk_kernel<64, 1, false, 0, false, true>), dim3(grid), dim3(64), lds_bytes, st, P);
-                else if (kind == 14 && P.census)
-                    hipLaunchKernelGGL((wfa_blk_kernel<64, 1, false, 1, true, true>), dim3(grid), dim3(64), lds_bytes, st, P);
-                else if (kind == 14)
-                    hipLaunchKernelGGL((wfa_blk_kernel<64, 1, false, 1, false, true>), dim3(grid), dim3(64), lds_bytes, st, P);
-                else if (kind == 15 && P.census)
-                    hipLaunchKernelGGL((wfa_blk_kernel<64, 1, false, 2, true, true>), dim3(grid), dim3(64), lds_bytes, st, P);
-                else if (kind == 15)
-                    hipLaunchKernelGGL((wfa_blk_kernel<64, 1, false, 2, false, true>), dim3(grid), dim3(64), lds_bytes, st, P);
-                else if (kind == 10 && P.census && P.adaptive)
-                    hipLaunchKernelGGL((wfa_lane_kernel<true, true>), dim3(grid), dim3(64), lds_bytes, st, P);
-                else if (kind == 10 && P.census)
-                    hipLaunchKernelGGL((wfa_lane_kernel<true, false>), dim3(grid), dim3(64), lds_bytes, st, P);
-                else if (kind == 10 && P.adaptive)
-                    hipLaunchKernelGGL((wfa_lane_kernel<false, true>), dim3(grid), dim3(64), lds_bytes, st, P);
-                else if (kind == 10)
-                    hipLaunchKernelGGL((wfa_lane_kernel<false, false>), dim3(grid), dim3(64), lds_bytes, st, P);
-                else if (kind == 5)
-                    hipLaunchKernelGGL((wfa_blk_kernel<64, 1>), dim3(grid), dim3(64), lds_bytes, st, P);
-                else if (kind == 9)
-                    hipLaunchKernelGGL((wfa_blk_kernel<32, 1>), dim3(grid), dim3(64), lds_bytes, st, P);
-                else if (kind == 4)
-                    hipLaunchKernelGGL((wfa_blk_kernel<8, 1>), dim3(grid), dim3(64), lds_bytes, st, P);
-                else if (blk_batch) {
-                    // entries per grab: the chunk's share of one resident group, cut into the fewest rounds of <= 8
-                    const uint64_t groups = (uint64_t)ctx->num_cus * 16 * pairs_wave;  // 4 waves per SIMD x 4 (8) pairs
-                    const uint64_t share  = (cn + groups - 1) / groups;
-                    const uint64_t rounds = (share + BLK_BATCH - 1) / BLK_BATCH;
-                    P.blk_batch_n = (uint32_t)std::min<uint64_t>(BLK_BATCH, std::max<uint64_t>(1, (share + rounds - 1) / std::max<uint64_t>(1, rounds)));
-                    if (ctx->opt_blk_batch > 1) P.blk_batch_n = (uint32_t)std::min<int64_t>(BLK_BATCH, ctx->opt_blk_batch);
-                    if (kind == 6 && !P.census)
-                        hipLaunchKernelGGL((wfa_blk_kernel<8, BLK_BATCH, false, 4, false>), dim3(grid), dim3(64), lds_bytes, st, P);
-                    else if (kind == 6)
-                        hipLaunchKernelGGL((wfa_blk_kernel<8, BLK_BATCH, false, 4>), dim3(grid), dim3(64), lds_bytes, st, P);
-                    else
-                        hipLaunchKernelGGL((wfa_blk_kernel<16, BLK_BATCH>), dim3(grid), dim3(64), lds_bytes, st, P);
-                }
-                else if (kind == 6)
-                    hipLaunchKernelGGL((wfa_blk_kernel<8, 1, false, 4>), dim3(grid), dim3(64), lds_bytes, st, P);
-                else if (kind == 3 && stream_bt && P.census)
-                    hipLaunchKernelGGL((wfa_blk_kernel<16, 1, true>), dim3(grid), dim3(64), lds_bytes, st, P);
-                else if (kind == 3 && stream_bt)
-                    hipLaunchKernelGGL((wfa_blk_kernel<16, 1, true, 0, false>), dim3(grid), dim3(64), lds_bytes, st, P);
-                else if (kind == 3 && P.census)
-                    hipLaunchKernelGGL((wfa_blk_kernel<16, 1>), dim3(grid), dim3(64), lds_bytes, st, P);
-                else if (kind == 3)
-                    hipLaunchKernelGGL((wfa_blk_kernel<16, 1, false, 0, false>), dim3(grid), dim3(64), lds_bytes, st, P);
-                else if (kind == 2)
+                if (kind == 8) {
+                    HIP_TRY(wfa_launch_duo(shape, P, grid, lds_bytes, st, P.census != 0));
+                } else if (kind >= 3) {
+                    uint32_t fl = (P.census ? (uint32_t)FWD_CENSUS : 0u) | (P.adaptive ? (uint32_t)FWD_ADAPTIVE : 0u);
+                    if (kind == 3 && stream_bt) fl |= FWD_STREAM;
+                    if (blk_batch) {
+                        // entries per grab: the chunk's share of one resident group, cut into the fewest rounds of <= 8
+                        const uint64_t groups = (uint64_t)ctx->num_cus * 16 * pairs_wave;  // 4 waves per SIMD x 4 (8) pairs
+                        const uint64_t share  = (cn + groups - 1) / groups;
+                        const uint64_t rounds = (share + BLK_BATCH - 1) / BLK_BATCH;
+                        P.blk_batch_n = (uint32_t)std::min<uint64_t>(BLK_BATCH, std::max<uint64_t>(1, (share + rounds - 1) / std::max<uint64_t>(1, rounds)));
+                        if (ctx->opt_blk_batch > 1) P.blk_batch_n = (uint32_t)std::min<int64_t>(BLK_BATCH, ctx->opt_blk_batch);
+                        fl |= FWD_BATCH;
+                    }
+                    // (instances without the census of stored words exist where a first pass runs them: the others count always)
+                    HIP_TRY(wfa_launch_fwd(shape, kind, fl, P, grid, lds_bytes, st));
+                } else if (kind == 2)
                     hipLaunchKernelGGL((wfa_reg_kernel<2, 4, 1>), dim3(grid), dim3(64), lds_bytes, st, P);
                 else
                     hipLaunchKernelGGL(wfa_packed_kernel, dim3(grid), dim3(64), lds_bytes, st, P);
@@ -1100,7 +1067,7 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             // them retries on the 16-lane instance below
             const bool narrow1 = can_d && ctx->opt_blk == 16 && ctx->opt_blk_narrow != 0 &&
                                  ((ctx->opt_blk_batch != 0 && max_len < 200 && seq_words <= 16) ||
-                                  (ctx->opt_narrow_long != 0 && (size_t)seq_words * 2 * 4 * 8 + 16 <= 8 * 1024));
+                                  (ctx->opt_narrow_long != 0 && shape == 0 && (size_t)seq_words * 2 * 4 * 8 + 16 <= 8 * 1024));
             // reads of 240+ bases: the variable-lanes kernel (its slots hold at most 126 packed words per sequence)
             const bool duo_long  = !narrow1 && seq_words > 16 &&
                                    (ctx->opt_duo >= 2 || (ctx->opt_duo == 1 && (int64_t)n_pairs >= ctx->opt_duo_min_pairs));
@@ -1568,18 +1535,13 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
         if (team_T > 0) {
             if ((rc = ensure(ctx, ctx->team_ctl, (size_t)team_n * TEAM_CTL_WORDS * 4))) return rc;
             HIP_TRY(hipMemsetAsync(ctx->team_ctl.p, 0, (size_t)team_n * TEAM_CTL_WORDS * 4, st));
-            auto kfn = job.mode == 0 ? wfa_team_kernel<0> : wfa_team_kernel<1>;
-            if (cfg.lds_bytes > 48 * 1024)
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            (int)cfg.lds_bytes));
             // teams of one XCD's CUs (team = blockIdx % 8) when at most eight teams run and the CUs divide by eight
             const bool     xmap   = ctx->opt_team_xcd != 0 && ctx->opt_team_wgs == 0 && team_n <= 8 && ctx->num_cus % 8 == 0 && ctx->num_cus >= 16;
             const uint32_t grid_t = xmap ? (uint32_t)ctx->num_cus : team_n * team_T;
             if (xmap) team_T = (uint32_t)ctx->num_cus / 8u;
-            hipLaunchKernelGGL(kfn, dim3(grid_t), dim3(TEAM_THREADS), cfg.lds_bytes, st, P,
-                               static_cast<uint32_t *>(ctx->team_ctl.p), team_T, (uint32_t)std::max<int64_t>(0, ctx->opt_team_solo_max),
-                               team_wave_rows, (uint32_t)(ctx->opt_team_strict != 0) | (xmap ? 2u : 0u) | (xmap && ctx->opt_team_xcd >= 2 ? 4u : 0u) | (team_n << 16));
-            HIP_TRY(hipGetLastError());
+            HIP_TRY(wfa_launch_team(P, job.mode, grid_t, cfg.lds_bytes, st, static_cast<uint32_t *>(ctx->team_ctl.p), team_T,
+                                    (uint32_t)std::max<int64_t>(0, ctx->opt_team_solo_max), team_wave_rows,
+                                    (uint32_t)(ctx->opt_team_strict != 0) | (xmap ? 2u : 0u) | (xmap && ctx->opt_team_xcd >= 2 ? 4u : 0u) | (team_n << 16)));
         } else {
             // wave mode of the generic kernel: directory ring + ring of the last rows in LDS, if they fit
             P.wave_rows = 0, P.wave_bt = 0;
@@ -2626,8 +2588,10 @@ static int align_pair_impl(wfahip_ctx *ctx, const wfahip_params *p, const uint8_
     const uint64_t worst = (uint64_t)p->mismatch * min_len + 2ull * (p->gap_open + p->gap_ext) + (uint64_t)p->gap_ext * (max_len - min_len + 2);
     const uint32_t min_xe = std::min(p->mismatch, p->gap_ext ? p->gap_ext : p->mismatch);
     const uint64_t ops_bound = 2 * (worst / std::max(1u, min_xe)) + 64;
+    // (the lone-pair instance exists for every penalty shape of wfa_fwd.hpp; round 3's paths, pair_fast = 2 / 3, for the default one)
+    const int  shape = p->gap_ext != 0 ? fwd_shape(p->mismatch / g, (p->gap_open + p->gap_ext) / g, p->gap_ext / g) : -1;
     const bool fast = ctx->opt_pair_fast != 0 && ctx->opt_packed != 0 && ctx->opt_blk == 16 && ctx->force_mode < 0 && p->global_alignment &&
-                      p->gap_ext != 0 && p->mismatch / g == 2 && (p->gap_open + p->gap_ext) / g == 4 && p->gap_ext / g == 1 &&
+                      shape >= 0 && (shape == 0 || ctx->opt_pair_fast == 1) &&
                       (size_t)seq_words * 2 * 4 * (ctx->opt_pair_fast == 1 ? 1 : 4) + 16 <= (ctx->opt_pair_fast == 1 ? 64 : 20) * 1024 && img <= ONE_IMG_MAX &&
                       ONE_OPS_OFF + ops_bound * 8 <= ONE_PIN_BYTES;
     if (fast) {
@@ -2670,7 +2634,7 @@ static int align_pair_impl(wfahip_ctx *ctx, const wfahip_params *p, const uint8_
         P.ops = reinterpret_cast<uint64_t *>(d + ONE_OPS_OFF), P.ops_cap = (ONE_PIN_BYTES - ONE_OPS_OFF) / 8;
         P.arena = static_cast<uint32_t *>(ctx->arena.p), P.arena_words = words, P.compact_fmt = WFA_BLK_TILED ? 3u : 1u;
         P.pair_meta = static_cast<uint4 *>(ctx->meta.p);
-        P.dx = 2, P.doe = 4, P.de = 1, P.dm = 5, P.di = 2, P.min_xe = min_xe;
+        P.dx = P.x / g, P.doe = P.oe / g, P.de = 1, P.dm = std::max(P.dx, P.doe) + 1, P.di = 2, P.min_xe = min_xe;
         P.lds_seq_words = seq_words, P.chunk_first = 0, P.chunk_n = 1, P.n_work = 1;
         // Round 4, the lone-pair instance with the arena rows in LDS first (pair_lds): rows behind the sequences, as many as the
         // worst-case score needs or 160 KB hold; a pair that runs out of them (ST_REDO_ARENA in its record) is run again by the
@@ -2686,7 +2650,7 @@ static int align_pair_impl(wfahip_ctx *ctx, const wfahip_params *p, const uint8_
             if (!(ctx->opt_pair_fast == 1 && ctx->one_ctl_clean)) HIP_TRY(hipMemsetAsync(d_ctrl, 0, 1024, st));
             ctx->one_ctl_clean = false;
             if (ctx->opt_pair_fast == 2) {  // forward kernel, then the backtrace kernel (kept for comparison: 305 us per 1 kbp pair)
-                hipLaunchKernelGGL((wfa_blk_kernel<16, 1, false, 0, false>), dim3(1), dim3(64), (size_t)seq_words * 2 * 4 * 4 + 16, st, P);
+                HIP_TRY(wfa_launch_fwd(0, 3, 0u, P, 1u, (size_t)seq_words * 2 * 4 * 4 + 16, st));
                 hipLaunchKernelGGL(wfa_backtrace_kernel, dim3(1), dim3(256), 0, st, P);
                 launches += 2;
             } else if (ctx->opt_pair_fast == 1) {
@@ -2696,17 +2660,11 @@ static int align_pair_impl(wfahip_ctx *ctx, const wfahip_params *p, const uint8_
                 // LDS region of the global arena.
                 P.fuse_bt = 1;
                 if (use_lds) {
-                    const auto kern = wfa_blk_kernel<64, 1, false, 1, false, false, true>;
-                    if (!ctx->one_lds_attr) {
-                        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                        ctx->one_lds_attr = true;
-                    }
                     KParams PL = P;
                     PL.arena_words = lds_rows * 64, PL.lds_arena_off = lds_off, PL.one_n = n, PL.one_m = m;
-                    hipLaunchKernelGGL(kern, dim3(1), dim3(64), (size_t)lds_off * 4 + (size_t)lds_rows * 256, st, PL);
+                    HIP_TRY(wfa_launch_pair(shape, true, PL, (size_t)lds_off * 4 + (size_t)lds_rows * 256, st));
                 } else {
-                    hipLaunchKernelGGL((wfa_blk_kernel<64, 1, false, 1, false, false>), dim3(1), dim3(64),
-                                       std::max<size_t>((size_t)seq_words * 2 * 4 + 16, (size_t)CompactViewWave::WORDS * 4 + 16), st, P);
+                    HIP_TRY(wfa_launch_pair(shape, false, P, std::max<size_t>((size_t)seq_words * 2 * 4 + 16, (size_t)CompactViewWave::WORDS * 4 + 16), st));
                 }
                 launches++;
             } else {
@@ -2717,7 +2675,7 @@ static int align_pair_impl(wfahip_ctx *ctx, const wfahip_params *p, const uint8_
                 // rows in LDS took as long).
                 P.done_ctl = d_ctrl + 64, P.done_q = reinterpret_cast<uint4 *>(d_ctrl + 128), P.n_stream_wgs = 0;
                 P.stream_wait = 2000000;  // 20 ms of the 100 MHz clock
-                hipLaunchKernelGGL((wfa_blk_kernel<16, 1, true, 0, false>), dim3(1), dim3(64), (size_t)seq_words * 2 * 4 * 4 + 16, st, P);
+                HIP_TRY(wfa_launch_fwd(0, 3, (uint32_t)FWD_STREAM, P, 1u, (size_t)seq_words * 2 * 4 * 4 + 16, st));
                 launches++;
             }
             HIP_TRY(hipGetLastError());
@@ -2847,6 +2805,58 @@ extern "C" int wfahip_generate_pairs_device(wfahip_ctx *ctx, uint64_t seed, uint
     HIP_TRY(hipStreamSynchronize(st));
     return WFAHIP_OK;
 }
+
+// ---------------------------------------------------------------------------------------------- clock probe (bench)
+// Every wave runs a chain of dependent integer max / add instructions (the forward kernels' mix) and reads both clocks
+// around it: s_memtime counts shader cycles, s_memrealtime the constant 100 MHz reference.
+__global__ __launch_bounds__(256) void wfa_clock_probe_kernel(unsigned long long *out, uint32_t iters) {
+    unsigned long long t0, t1, r0, r1;
+    uint32_t           a = threadIdx.x, b = blockIdx.x | 1u;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0)::"memory");
+    for (uint32_t i = 0; i < iters; i++) {
+#pragma unroll
+        for (int u = 0; u < 16; u++) a = (a > b ? a : b) + (uint32_t)u, b = (b > a ? b : a) ^ a;
+    }
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1) : "v"(a), "v"(b) : "memory");
+    if ((threadIdx.x & 63u) == 0u) {
+        const uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6);
+        out[2 * w] = t1 - t0, out[2 * w + 1] = r1 - r0;
+    }
+}
+
+static int debug_clock_impl(wfahip_ctx *ctx, double *mhz, double *mhz_min, double *mhz_max) {
+    if (!ctx || !mhz) return WFAHIP_ERR_BAD_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const uint32_t wgs = (uint32_t)ctx->num_cus * 4u, waves = wgs * 4u;  // four waves per SIMD
+    DevBuf buf;
+    int rc = ensure(ctx, buf, (size_t)waves * 16);
+    if (rc) return rc;
+    std::vector<unsigned long long> h((size_t)waves * 2);
+    for (int pass = 0; pass < 2; pass++) {  // (the first pass brings the clock up; the second one is read)
+        hipLaunchKernelGGL(wfa_clock_probe_kernel, dim3(wgs), dim3(256), 0, ctx->stream, static_cast<unsigned long long *>(buf.p), 6000u);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            release(buf);
+            return WFAHIP_ERR_HIP;
+        }
+    }
+    const hipError_t e = hipMemcpy(h.data(), buf.p, h.size() * 8, hipMemcpyDeviceToHost);
+    release(buf);
+    if (e != hipSuccess) return WFAHIP_ERR_HIP;
+    double sum = 0, lo = 1e30, hi = 0;
+    uint32_t cnt = 0;
+    for (uint32_t w = 0; w < waves; w++) {
+        if (h[2 * w + 1] == 0) continue;
+        const double f = (double)h[2 * w] / (double)h[2 * w + 1] * 100.0;  // cycles per tick of the 100 MHz clock -> MHz
+        sum += f, lo = std::min(lo, f), hi = std::max(hi, f), cnt++;
+    }
+    if (cnt == 0) return WFAHIP_ERR_INTERNAL;
+    *mhz = sum / cnt;
+    if (mhz_min) *mhz_min = lo;
+    if (mhz_max) *mhz_max = hi;
+    return WFAHIP_OK;
+}
+
+extern "C" int wfahip_debug_clock(wfahip_ctx *ctx, double *mhz, double *mhz_min, double *mhz_max) { WFAHIP_GUARD(debug_clock_impl(ctx, mhz, mhz_min, mhz_max)) }
 
 static int debug_wavefronts_impl(wfahip_ctx *ctx, const wfahip_params *p, const uint8_t *q, uint32_t n,
                                  const uint8_t *t, uint32_t m, wfahip_row **rows, uint64_t *n_rows,

@@ -90,8 +90,12 @@ WFA_DEV bool lane_pack_seq(const uint8_t *src, uint32_t len, uint32_t *dst, uint
     return bad != 0u;
 }
 
-template <bool CENSUS, bool ADAPTIVE>
+// DX / DOE (round 5): the penalty shape x/g : (o+e)/g with e/g == 1 and DX <= DOE <= 4.  The M ring holds DOE rows (slot =
+// step mod DOE): the row of step i replaces M[i - DOE] = M[s-o-e] in place, which is what the in-place trick above needs;
+// M[s-x] is slot (i - DX) mod DOE (with DX == DOE the very row being replaced: its cell at k is read before it is stored).
+template <bool CENSUS, bool ADAPTIVE, int DX = 2, int DOE = 4>
 __global__ __launch_bounds__(64) void wfa_lane_kernel(const KParams P) {
+    static_assert(DX >= 1 && DX <= DOE && DOE <= 4, "the in-place ring replaces M[s-o-e]: x <= o+e, at most four rows");
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int lane = threadIdx.x;
     const uint32_t        SW   = P.lds_seq_words;  // (even: a slot is a whole number of 16-byte units)
@@ -180,16 +184,19 @@ __global__ __launch_bounds__(64) void wfa_lane_kernel(const KParams P) {
         SeqView<0>  sv;
         sv.q = lq, sv.t = lt, sv.n = n, sv.m = m;
         uint16_t *const A16 = reinterpret_cast<uint16_t *>(P.arena + (uint64_t)wi * cap);
-        // kept bands of the M rows of the last four score steps (lo1 / hi1: the newest, which is also the I and D rows' band)
-        int      lo1 = BIG, hi1 = -BIG, lo2 = BIG, hi2 = -BIG, lo3 = BIG, hi3 = -BIG, lo4 = BIG, hi4 = -BIG;
+        // kept bands of the M rows of the last DOE score steps (blo[0] / bhi[0]: the newest, which is also the I and D rows' band)
+        int blo[DOE], bhi[DOE];
+#pragma unroll
+        for (int d = 0; d < DOE; d++) blo[d] = BIG, bhi[d] = -BIG;
         uint32_t fail = 0u;          // ST_REDO_* of a pair this kernel hands on
         uint32_t si = 0, cells = 0;  // (si: the same for every lane of the wave that is still running -- a generation starts together)
+        int      r0 = 0;             // si mod DOE: ring slot of M[s-o-e] (replaced by this step's row)
 
         // ------------------------------------------------------------ score steps
         while (__ballot(active) != 0ull) {
-            const int R0 = (int)(si & 3u), R2 = (int)((si + 2u) & 3u);  // ring slots of M[s-o-e] (replaced by this step's row) and M[s-x]
+            const int R0 = r0, R2 = r0 + (DOE - DX) >= DOE ? r0 - DX : r0 + (DOE - DX);  // ring slots of M[s-o-e] (replaced by this step's row) and M[s-x]
             // range of next() (wfa.go:557-563): sources' ranges +-1, clamped to the matrix
-            int lo = imin2(imin2(lo4, lo2), lo1), hi = imax2(imax2(hi4, hi2), hi1);
+            int lo = imin2(imin2(blo[DOE - 1], blo[DX - 1]), blo[0]), hi = imax2(imax2(bhi[DOE - 1], bhi[DX - 1]), bhi[0]);
             const bool want_seed = active && ((si == 0u && first_eq) || (si == seed_si && !first_eq));
             bool       any_src = hi >= lo;
             lo = any_src ? lo - 1 : 0, hi = any_src ? hi + 1 : 0;
@@ -353,14 +360,16 @@ __global__ __launch_bounds__(64) void wfa_lane_kernel(const KParams P) {
             }
             // (the I / D rows exist where wf-adaptive kept the M row: Delete of wfa.go:526-535; an I or D cell never exists
             // without the M cell of its diagonal -- M[s][k] >= I[s][k], D[s][k])
-            lo4 = lo3, hi4 = hi3, lo3 = lo2, hi3 = hi2, lo2 = lo1, hi2 = hi1;
-            lo1 = keepl ? ilo : BIG, hi1 = keepl ? ihi : -BIG;
+#pragma unroll
+            for (int d = DOE - 1; d > 0; d--) blo[d] = blo[d - 1], bhi[d] = bhi[d - 1];
+            blo[0] = keepl ? ilo : BIG, bhi[0] = keepl ? ihi : -BIG;
             if (active && term) {
                 const uint32_t hf = Mo[Ak & 31];
                 P.pair_meta[wi]   = make_uint4(ST_OK, si * P.g, hf, (CENSUS && P.census) ? cells : 0u);
                 active            = false;
             }
             si += 1u;
+            r0 = r0 + 1 == DOE ? 0 : r0 + 1;
         }
         if (fail != 0u) {
             P.pair_meta[wi] = make_uint4(fail, 0u, 0u, 0u);
