@@ -737,6 +737,45 @@ def test_team_kernel_wavefronts_word_for_word(built, penalties):
         oa.close()
 
 
+@pytest.mark.parametrize("stripe", [0, 1, 3])
+def test_team_kernel_stripe_mode(built, stripe):
+    """Stripe mode of the team kernel (round 5: contiguous stripes per workgroup, the rows the next steps source in LDS, the
+    k +- 1 sources of a stripe's edge cells from the arena) against the classic step (stripe = 0) and the oracle: every stored
+    word of pairs whose rows span several stripes and cross their edges (semi-global seeds: n + m - 1 diagonals; wf-adaptive off:
+    bands that grow until the axis has to move), with the axis positioned with 3 diagonals of slack (stripe = 3: it moves every few
+    steps), team and solo mode and the switches to wave mode and back, a penalty set with a deeper ring; then results of a
+    batch of 9 kbp pairs through three and five workgroups per team."""
+    import wfa_amd as w
+    from oracle import oracle as O
+    blob, qo, ql, to, tl = w.generate_pairs(seed=41, n_pairs=2, length=2600, error_rate=0.08)
+    for pen in ((4, 6, 2), (2, 4, 2)):
+        for glob, ad in ((False, (10, 50, 1)), (True, None), (False, None)):
+            oa = O.Aligner(_oracle_params(glob, ad, pen))
+            for solo_max in (64, 4096):
+                al = _aligner(glob, ad, pen)
+                for k, v in (("packed", 0), ("team_min_len", 1), ("team_wgs", 2), ("team_solo_max", solo_max), ("team_stripe", stripe), ("arena_poison", 1)):
+                    al.set_option(k, v)
+                for i in range(len(ql)):
+                    q, t = bytes(blob[qo[i]:qo[i] + ql[i]]), bytes(blob[to[i]:to[i] + tl[i]])
+                    r = oa.align(q, t)
+                    want = {c: {sc: {lo + j: v for j, v in enumerate(raw) if v} for sc, (lo, hi, raw) in d.items()}
+                            for c, d in oa.dump().items()}
+                    wf, res = al.debug_wavefronts(q, t)
+                    assert res.Score == r.score and res.CIGAR(False) == r.cigar
+                    for c in "MID":
+                        assert wf[c] == {sc: row for sc, row in want[c].items() if row}, (pen, glob, ad, solo_max, i, c)
+                al.close()
+            oa.close()
+    data = w.generate_pairs(seed=42, n_pairs=6, length=9000, error_rate=0.06)
+    want = O.align_batch(_oracle_params(False, (10, 50, 1)), *data, n_threads=6)
+    for wgs in (3, 5):
+        al = _aligner(False, (10, 50, 1))
+        for k, v in (("packed", 0), ("team_min_len", 1), ("team_wgs", wgs), ("team_stripe", stripe), ("arena_poison", 1)):
+            al.set_option(k, v)
+        assert_batch_equal(al.align_arrays(*data), want, f"9 kbp semi-global, {wgs} workgroups per team, stripe={stripe}")
+        al.close()
+
+
 @pytest.mark.parametrize("penalties", [(4, 6, 2), (5, 20, 3)])
 def test_generic_kernel_wavefronts_word_for_word(built, penalties):
     """The one-workgroup-per-pair kernel, with its wave mode (rows of <= 64 diagonals stepped by one wave,
@@ -1025,7 +1064,7 @@ def test_lane_kernel_arena_word_for_word(built, length, err, pen, ad, census):
     _arena_word_check(length, err, pen, ad, 8, census, 0, 1)
 
 
-def _arena_word_check(length, err, pen, ad, fmt, census, duo, lane):
+def _arena_word_check(length, err, pen, ad, fmt, census, duo, lane, min_pairs=None):
     """The dominant kernel's stored state, not only its results: every compact backtrace word wfa_blk_kernel leaves in
     HBM (M tag, I and D tag bits, pre-extension offset) against what the oracle's wavefronts imply -- visited by the
     backtrace or not.  Covers wf-adaptive pruning (deleted cells must not be there with a source role), ragged lengths
@@ -1075,7 +1114,7 @@ def _arena_word_check(length, err, pen, ad, fmt, census, duo, lane):
         pairs += 1
     # (the others were handed on: band or arena.  The lane-per-pair kernel hands on rows wider than 30 diagonals, and its
     # short pairs have fewer cells)
-    assert pairs >= (n // 3 if lane else n // 2) and checked > (20 if lane else 50) * pairs, (pairs, checked)
+    assert pairs >= (min_pairs if min_pairs is not None else (n // 3 if lane else n // 2)) and checked > (20 if lane else 50) * pairs, (pairs, checked)
     al.close()
 
 
@@ -1394,7 +1433,10 @@ def test_fuzz_short_reads(built, seed):
         for rep in range(2):
             got = al.align_arrays(*data)
             assert_batch_equal(got, want, f"fuzz short seed={seed} pen={pen} ad={ad} n={n} max_l={max_l} unaligned={unaligned} opts={opts} rep={rep}")
-        shaped = pen[0] * 2 == pen[1] + pen[2] and pen[2] * 2 == pen[0]
+        # (the penalty shapes the register-ring kernels are instantiated for, wfa_amd/csrc/wfa_fwd.hpp: e/g == 1 and
+        # x/g : (o+e)/g one of 2:4, 1:3, 1:2, 2:3, 2:2, 3:3 -- here 4/6/2, 2/3/1, 8/12/4, 6/9/3 and, since round 5, 1/1/1; not 3/5/2)
+        g = int(np.gcd.reduce([pen[0], pen[1] + pen[2], pen[2]]))
+        shaped = pen[2] == g and (pen[0] // g, (pen[1] + pen[2]) // g) in ((2, 4), (1, 3), (1, 2), (2, 3), (2, 2), (3, 3))
         assert (al.last_timing().main_kernel_kind == 10) == shaped, (pen, al.last_timing().main_kernel_kind)
         al.close()
 

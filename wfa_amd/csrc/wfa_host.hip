@@ -180,6 +180,8 @@ struct wfahip_ctx {
     int64_t       opt_team_wave            = 1;              // rows up to 64 diagonals are done by one wave (LDS ring)
     int64_t       opt_team_strict          = 1;              // agent-scope release in every team barrier (0: see wfa_team.hpp)
     int64_t       opt_unpack_all           = 0;              // 1: host entries with packed input expand ALL of it to bytes on the device first (rounds 2-3)
+    int64_t       opt_team_stripe          = 1;              // 1: stripe mode of the team kernel (contiguous stripes per workgroup, the last rows in LDS: wfa_team.hpp);
+                                                             // n > 1: the same with at most n diagonals of slack when the axis is positioned (tests: it then moves every few steps)
     int64_t       opt_team_paged           = 1;              // 1: the teams share one pool of arena pages (a pair holds what it needs) instead of a slot each
     DevBuf        page_ctl;                                  // ... its free-page stack and the page lists of the teams
     int64_t       opt_team_xcd             = 2;              // 1: teams of one XCD's CUs (blockIdx % 8); 2 (default): ... and a team that finds itself on one XCD keeps
@@ -561,6 +563,8 @@ static int set_option_impl(wfahip_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_unpack_all = value;
     else if (k == "team_paged")
         ctx->opt_team_paged = value;
+    else if (k == "team_stripe")
+        ctx->opt_team_stripe = value;
     else if (k == "arena_poison")
         ctx->opt_arena_poison = value;
     else if (k == "fail_pass")
@@ -1539,9 +1543,16 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             const bool     xmap   = ctx->opt_team_xcd != 0 && ctx->opt_team_wgs == 0 && team_n <= 8 && ctx->num_cus % 8 == 0 && ctx->num_cus >= 16;
             const uint32_t grid_t = xmap ? (uint32_t)ctx->num_cus : team_n * team_T;
             if (xmap) team_T = (uint32_t)ctx->num_cus / 8u;
+            // stripe mode (round 5): the rows the next steps source -- max(x, o+e)/g of M, e/g of I and of D -- of a workgroup's 4 096
+            // diagonals in LDS, when they fit beside the sequences (default penalties: six rows, 96 KB; a 100 kbp pair's packed
+            // sequences: 50 KB)
+            const size_t lr_bytes = (size_t)(std::max(P.x, P.oe) / P.g + 2u * (P.e / P.g)) * TEAM_STRIPE * 4u;
+            const bool   lring    = ctx->opt_team_stripe != 0 && cfg.lds_bytes + lr_bytes <= LDS_MAX_BYTES;
+            if (lring) cfg.lds_bytes += lr_bytes;
             HIP_TRY(wfa_launch_team(P, job.mode, grid_t, cfg.lds_bytes, st, static_cast<uint32_t *>(ctx->team_ctl.p), team_T,
                                     (uint32_t)std::max<int64_t>(0, ctx->opt_team_solo_max), team_wave_rows,
-                                    (uint32_t)(ctx->opt_team_strict != 0) | (xmap ? 2u : 0u) | (xmap && ctx->opt_team_xcd >= 2 ? 4u : 0u) | (team_n << 16)));
+                                    (uint32_t)(ctx->opt_team_strict != 0) | (xmap ? 2u : 0u) | (xmap && ctx->opt_team_xcd >= 2 ? 4u : 0u) | (team_n << 16),
+                                    lring ? (uint32_t)std::min<int64_t>(ctx->opt_team_stripe == 1 ? 1024 : ctx->opt_team_stripe, 1 << 20) : 0u));
         } else {
             // wave mode of the generic kernel: directory ring + ring of the last rows in LDS, if they fit
             P.wave_rows = 0, P.wave_bt = 0;
