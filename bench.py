@@ -99,6 +99,11 @@ def parse_args(argv=None):
     ap.add_argument("--other-configs", type=int, default=None,
                     help="1: after the timed region of the default (c3, N = 1) run, short legs of c2, k10, l5 and c5s on the same "
                          "GPU, reported under config.other_configs (default: 1 for the default run, else 0)")
+    ap.add_argument("--plan", action="store_true",
+                    help="no GPU, no processes: print ONE JSON line with what each of the --gpus ranks would hold in HBM for this "
+                         "configuration (input blob, records, CIGAR ops, wavefront arenas per chunk) -- an out-of-memory condition shows "
+                         "before a multi-GPU run is launched")
+    ap.add_argument("--hbm-gib", type=float, default=288.0, help="--plan: HBM per GPU (MI355X: 288)")
     ap.add_argument("--dump-records", default=None,
                     help="rank 0 writes the records gathered in the last timed step (all ranks, pair order) to this .npy file")
     args = ap.parse_args(argv)
@@ -151,9 +156,53 @@ def spawn_ranks(args, argv):
     return subprocess.call(cmd, env=env)
 
 
+def plan(args):
+    """What every rank of `--gpus N` holds in HBM (no GPU is touched): the shard's input, its result buffers and the arenas of
+    the first-pass kernel as the library sizes them (wfa_amd/csrc/wfa_host.hip: a chunk of pairs owns its arena slots until
+    its backtrace has run; chunks take at most 35 % of HBM; long-pair ladders at most 60 %)."""
+    import math
+    sys.path.insert(0, ROOT)
+    from wfa_amd.shard import shard_range
+    world, hbm = max(1, args.gpus), args.hbm_gib * 2 ** 30
+    L, e = args.length, args.error
+    stride = (L + 15) // 16 * 16 + (int(L * (1 + e)) + 16 + 15) // 16 * 16  # (upper bound of the generator's bytes per pair)
+    ranks = []
+    for r in range(world):
+        first, end = shard_range(args.total_pairs, r, world) if args.total_pairs > 0 else (r * args.pairs, (r + 1) * args.pairs)
+        n = end - first
+        blob = n * stride + 16
+        idx = n * (8 + 8 + 4 + 4)
+        rec = n * 64
+        sum_len = n * (2 * L + int(L * e))
+        ops = 8 * ((sum_len + 2 * n + 1024) if (args.semi_global or L >= 20000) else int(sum_len * max(0.25, 3.0 * e)) + 8 * n + 1024)
+        if L <= 240:
+            slot = 4 * 8 * L          # rows of 32 x 16 bit, 8 L words per pair
+        elif L <= 2000 and not args.semi_global:
+            slot = 4 * 8 * L          # 16-bit tiles of wfa_duo_kernel
+        elif not args.semi_global:
+            slot = 4 * 16 * L         # 32-bit tiles / plain rows of the sliding-window instances
+        else:
+            slot = 0                  # long-pair ladder: one pool
+        if slot:
+            chunk = max(1, min(n, int(hbm * 0.35) // slot))
+            arena, n_chunks = chunk * slot, math.ceil(n / chunk)
+            prepack = chunk * 4 * (4 + 2 * ((L + int(L * e) + 16 + 15) // 16 + 2))
+        else:
+            arena, n_chunks, prepack = int(hbm * 0.60), 1, 0
+        total = blob + idx + rec + ops + arena + prepack + n * 16 + n * 8
+        ranks.append({"rank": r, "pairs": n, "first_pair": first, "input_gib": (blob + idx) / 2 ** 30, "records_gib": rec / 2 ** 30,
+                      "ops_gib": ops / 2 ** 30, "arena_gib": arena / 2 ** 30, "chunks": n_chunks, "prepack_gib": prepack / 2 ** 30,
+                      "total_gib": total / 2 ** 30, "fits": total <= 0.95 * hbm})
+    print(json.dumps({"plan": args.config, "n_gpus": world, "hbm_gib": args.hbm_gib, "pairs_total": sum(r["pairs"] for r in ranks),
+                      "gather_bytes_per_rank_step": [r["pairs"] * 44 for r in ranks], "all_fit": all(r["fits"] for r in ranks), "ranks": ranks}), flush=True)
+    return 0 if all(r["fits"] for r in ranks) else 3
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
+    if args.plan:
+        sys.exit(plan(args))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args, argv))
     run_rank(args)

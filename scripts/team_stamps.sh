@@ -9,10 +9,12 @@ D=/tmp/wfa_tstamps
 mkdir -p $D/wfa_amd/lib
 cp -r wfa_amd/*.py $D/wfa_amd/
 F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -DWFA_TEAM_STAMPS $WFA_EXTRA"
-hipcc $F -mllvm -amdgpu-atomic-optimizer-strategy=None -c -o $D/duo.o wfa_amd/csrc/wfa_duo.hip &
-for f in wfa_host.hip wfa_gen.cpp wfa_multi.cpp; do hipcc $F -c -o $D/${f%.*}.o wfa_amd/csrc/$f & done
+# (only the units the macro changes are rebuilt: the router and the long-pair kernels; the rest are the in-tree objects)
+make -s -j8 wfa_amd/lib/libwfahip.so
+for f in wfa_host.hip wfa_long.hip; do hipcc $F -c -o $D/${f%.*}.o wfa_amd/csrc/$f & done
 wait
-hipcc -fPIC --offload-arch=gfx950 -shared -o $D/wfa_amd/lib/libwfahip.so $D/wfa_host.o $D/wfa_gen.o $D/wfa_multi.o $D/duo.o
+OBJS=$(ls build/obj/*.o | grep -v "wfa_host.o\|wfa_long.o")
+hipcc -fPIC --offload-arch=gfx950 -shared -o $D/wfa_amd/lib/libwfahip.so $D/wfa_host.o $D/wfa_long.o $OBJS
 cd $D && WFAHIP_DEBUG_TIMING=1 python3 - "$@" <<'PY'
 import sys, time
 sys.path.insert(0, "/tmp/wfa_tstamps")

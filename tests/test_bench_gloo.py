@@ -59,6 +59,33 @@ def test_force_collective_with_one_rank(built):
     assert c["gather_bytes_per_rank_step"] == 700 * 11 * 4
 
 
+@pytest.mark.timeout(600)
+def test_eight_ranks_uneven_total(built):
+    """Pre-flight of the 8-GPU run the driver makes (configs[3]: pairs sharded over the ranks, shards that differ by one pair):
+    eight ranks over gloo, --total-pairs not divisible by eight, the records of every shard gathered in pair order."""
+    out = _run(["--gpus", "8", "--total-pairs", "100003", "--length", "20"], timeout=560)
+    c = out["config"]
+    assert out["n_gpus"] == 8 and out["scaling"] == "strong" and c["ranks_seen_by_collective"] == 8
+    assert c["pairs_per_rank"] == [12501, 12501, 12501, 12500, 12500, 12500, 12500, 12500] and c["total_pairs_per_step"] == 100003
+    assert c["gathered_records_complete"] is True
+
+
+def test_plan_prints_the_per_rank_footprint():
+    """`bench.py --plan`: no GPU, no child processes -- what each rank of the configs[3] run holds in HBM, and whether it fits."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--plan", "--gpus", "8", "--config", "c4"], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 0, p.stderr[-1000:]
+    d = json.loads(p.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 8 and d["pairs_total"] == 10_000_000 and d["all_fit"] is True and len(d["ranks"]) == 8
+    assert [r["pairs"] for r in d["ranks"]] == [1_250_000] * 8 and all(r["total_gib"] < 288 * 0.95 for r in d["ranks"])
+    # all ten million pairs on ONE GPU: the chunks alternate through one arena buffer, and it still fits
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--plan", "--gpus", "1", "--config", "c4"], capture_output=True, text=True, timeout=60)
+    d = json.loads(p.stdout.strip().splitlines()[-1])
+    assert p.returncode == 0 and d["ranks"][0]["chunks"] >= 3 and d["all_fit"] is True
+    # a device too small for a shard says so (exit code 3)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--plan", "--gpus", "1", "--config", "c4", "--hbm-gib", "24"], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 3 and json.loads(p.stdout.strip().splitlines()[-1])["all_fit"] is False
+
+
 def test_configs_name_the_baseline_workloads():
     sys.path.insert(0, ROOT)
     import bench

@@ -73,7 +73,7 @@ def test_submit_collect_is_the_batch(built):
     al.close()
 
 
-@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0], None])
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0], [0] * 8, None])  # ([0] * 8: the eight contexts of an 8-GPU node, here on one GPU)
 def test_context_set_shards_and_merges_in_pair_order(built, devices):
     """wfahip_create_multi / wfahip_align_batch_multi: contiguous shards balanced by sequence bytes, one host thread
     and one context per shard (here several contexts on the one GPU of the box; None = every device), merged in pair

@@ -1584,8 +1584,8 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                 std::fprintf(stderr, "[team %u] band ends: nothing fails %llu, both within 64 cells %llu, within the 512-cell windows %llu, full passes %llu; mean trim low %.1f high %.1f\n",
                              t, a[12], a[13], a[14], a[15], (double)a[16] / (double)std::max<unsigned long long>(1, a[13] + a[14]),
                              (double)a[17] / (double)std::max<unsigned long long>(1, a[13] + a[14]));
-                std::fprintf(stderr, "[team %u] inside P1 (wave 0 of workgroup 0), us: cells %.0f  wave reductions %.0f  wait for the other waves %.0f  (rest = team atomics)\n",
-                             t, a[18] / 100.0, a[19] / 100.0, a[20] / 100.0);
+                std::fprintf(stderr, "[team %u] inside P1 (wave 0 of workgroup 0), us: cells %.0f  wave reductions %.0f  wait for the other waves %.0f  (rest = team atomics); stripe-mode ring loads %llu\n",
+                             t, a[18] / 100.0, a[19] / 100.0, a[20] / 100.0, a[21]);
             }
 #endif
             if (std::getenv("WFAHIP_DEBUG_TIMING")) {
