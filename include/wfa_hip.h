@@ -307,6 +307,13 @@ void wfahip_free(void *p);
  * score index (score / gcd), diagonal k at slot k & 63; 3 = tiles of 8 score indices x 64 diagonals,
  * [(k & 63) / 4][index & 7][k & 3]; 4 = 256 words per index, slot k & 255; 5 = 32 words per index, slot k & 31.
  * Slots the kernel never wrote hold stale bytes.  Caller frees *words with wfahip_free. */
+/* Round 5: the same for a pair on wfa_teamc_kernel (wide wavefronts: option team_wgs = the team's size must be set): every row as
+ * the kernel leaves it in the arena -- ONE backtrace word per diagonal (the pre-extension offset backTrace recomputes,
+ * wfa.go:766-817, shifted left by four over the decisions of next(): bit 0 the M cell took the insertion's offset, bit 1 the
+ * mismatch's, bit 2 the D cell is a DeleteExt, bit 3 the I cell is an InsertExt; offset 0 = a seed of initComponents, bit 0
+ * Match / bit 1 Mismatch), rows[i].width words at rows[i].word_off, restricted to the band wf-adaptive kept. */
+int  wfahip_debug_team_compact(wfahip_ctx *ctx, const wfahip_params *p, const uint8_t *q, uint32_t n, const uint8_t *t, uint32_t m,
+                               wfahip_row **rows, uint64_t *n_rows, uint32_t **words, uint64_t *n_words, wfahip_results *res);
 int  wfahip_debug_compact_arena(wfahip_ctx *ctx, uint64_t pair, uint32_t **words, uint64_t *n_words, uint32_t *fmt,
                                 uint32_t *meta4);
 

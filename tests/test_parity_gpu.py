@@ -737,43 +737,57 @@ def test_team_kernel_wavefronts_word_for_word(built, penalties):
         oa.close()
 
 
-@pytest.mark.parametrize("stripe", [0, 1, 3])
-def test_team_kernel_stripe_mode(built, stripe):
-    """Stripe mode of the team kernel (round 5: contiguous stripes per workgroup, the rows the next steps source in LDS, the
-    k +- 1 sources of a stripe's edge cells from the arena) against the classic step (stripe = 0) and the oracle: every stored
-    word of pairs whose rows span several stripes and cross their edges (semi-global seeds: n + m - 1 diagonals; wf-adaptive off:
-    bands that grow until the axis has to move), with the axis positioned with 3 diagonals of slack (stripe = 3: it moves every few
-    steps), team and solo mode and the switches to wave mode and back, a penalty set with a deeper ring; then results of a
-    batch of 9 kbp pairs through three and five workgroups per team."""
+@pytest.mark.parametrize("slack", [1024, 3])
+def test_teamc_kernel_words_and_results(built, slack):
+    """wfa_teamc_kernel (round 5: one backtrace word per diagonal in the arena, the rows the next steps source in LDS stripes or the
+    team's exchange rows, reductions travelling with the barrier, the semi-global end cell found in flight) against the oracle:
+    EVERY word it leaves in the arena -- the pre-extension offset backTrace recomputes (wfa.go:766-817) and the decisions of
+    next() -- for pairs whose rows span several stripes and cross their edges (semi-global seeds: n + m - 1 diagonals;
+    wf-adaptive off: bands that grow until the axis has to move), with the axis positioned with 3 diagonals of room (slack = 3: it
+    moves every few steps), XBUF / team-stripe / solo-stripe / wave mode and the switches between them, three penalty shapes;
+    then the results of 9 kbp pairs through three and five workgroups per team against wfa_team_kernel's and the oracle's."""
     import wfa_amd as w
     from oracle import oracle as O
     blob, qo, ql, to, tl = w.generate_pairs(seed=41, n_pairs=2, length=2600, error_rate=0.08)
-    for pen in ((4, 6, 2), (2, 4, 2)):
-        for glob, ad in ((False, (10, 50, 1)), (True, None), (False, None)):
+    for pen in ((4, 6, 2), (2, 4, 2), (6, 4, 2)):
+        g = int(np.gcd.reduce([pen[0], pen[1] + pen[2], pen[2]]))
+        for glob, ad in ((False, (10, 50, 1)), (True, None), (False, None), (True, (10, 50, 1))):
             oa = O.Aligner(_oracle_params(glob, ad, pen))
-            for solo_max in (64, 4096):
+            for wgs, solo_max, wave in ((2, 64, 1), (2, 4096, 1), (1, 4096, 0), (3, 0, 1)):
                 al = _aligner(glob, ad, pen)
-                for k, v in (("packed", 0), ("team_min_len", 1), ("team_wgs", 2), ("team_solo_max", solo_max), ("team_stripe", stripe), ("arena_poison", 1)):
+                for k, v in (("packed", 0), ("team_min_len", 1), ("team_wgs", wgs), ("team_solo_max", solo_max), ("team_wave", wave),
+                             ("team_slack", slack), ("arena_poison", 1)):
                     al.set_option(k, v)
                 for i in range(len(ql)):
                     q, t = bytes(blob[qo[i]:qo[i] + ql[i]]), bytes(blob[to[i]:to[i] + tl[i]])
                     r = oa.align(q, t)
-                    want = {c: {sc: {lo + j: v for j, v in enumerate(raw) if v} for sc, (lo, hi, raw) in d.items()}
-                            for c, d in oa.dump().items()}
-                    wf, res = al.debug_wavefronts(q, t)
-                    assert res.Score == r.score and res.CIGAR(False) == r.cigar
-                    for c in "MID":
-                        assert wf[c] == {sc: row for sc, row in want[c].items() if row}, (pen, glob, ad, solo_max, i, c)
+                    exp = _expected_compact_words(oa.dump(), *pen)
+                    rows, res = al.debug_team_compact(q, t)
+                    what = (pen, glob, ad, wgs, solo_max, wave, i)
+                    assert (res.Score, res.CIGAR(False)) == (r.score, r.cigar), what
+                    assert (res.QBegin, res.QEnd, res.TBegin, res.TEnd, res.AlignLen, res.Matches, res.Gaps, res.GapRegions) == (
+                        r.qbegin, r.qend, r.tbegin, r.tend, r.align_len, r.matches, r.gaps, r.gap_regions), what
+                    for (sc, k), (wv, mask) in exp.items():
+                        have = rows.get(sc, {}).get(k, 0)
+                        assert (have & mask) == (wv & mask), (what, sc, k, hex(have), hex(wv), hex(mask))
+                    # ... and nothing else: inside a row's kept band a word is there exactly where the reference holds an M cell
+                    want_cells = {(sc, k) for (sc, k) in exp}
+                    have_cells = {(sc, k) for sc, row in rows.items() for k, wd in row.items() if wd}
+                    assert have_cells == want_cells, (what, sorted(have_cells ^ want_cells)[:8])
                 al.close()
             oa.close()
     data = w.generate_pairs(seed=42, n_pairs=6, length=9000, error_rate=0.06)
     want = O.align_batch(_oracle_params(False, (10, 50, 1)), *data, n_threads=6)
-    for wgs in (3, 5):
+    cells = []
+    for wgs, compact in ((3, 1), (5, 1), (3, 0)):
         al = _aligner(False, (10, 50, 1))
-        for k, v in (("packed", 0), ("team_min_len", 1), ("team_wgs", wgs), ("team_stripe", stripe), ("arena_poison", 1)):
+        for k, v in (("packed", 0), ("team_min_len", 1), ("team_wgs", wgs), ("team_compact", compact), ("team_slack", slack), ("arena_poison", 1)):
             al.set_option(k, v)
-        assert_batch_equal(al.align_arrays(*data), want, f"9 kbp semi-global, {wgs} workgroups per team, stripe={stripe}")
+        assert_batch_equal(al.align_arrays(*data), want, f"9 kbp semi-global, {wgs} workgroups per team, compact={compact}")
+        assert al.last_timing().main_kernel_kind == (17 if compact else 7)
+        cells.append(al.last_timing().cells_stored)
         al.close()
+    assert len(set(cells)) == 1, cells  # (the census of stored wavefront words is the reference's, whatever the arena holds)
 
 
 @pytest.mark.parametrize("penalties", [(4, 6, 2), (5, 20, 3)])

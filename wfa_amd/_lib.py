@@ -25,6 +25,7 @@ EXPORTS = [
     "wfahip_pending", "wfahip_collect", "wfahip_create_multi", "wfahip_destroy_multi", "wfahip_multi_size",
     "wfahip_multi_ctx", "wfahip_align_batch_multi", "wfahip_debug_compact_arena",
     "wfahip_generate_pairs_device", "wfahip_align_pair", "wfahip_last_error", "wfahip_debug_clock",
+    "wfahip_debug_team_compact",
 ]
 
 
@@ -87,6 +88,10 @@ def lib():
         L.wfahip_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
         L.wfahip_debug_wavefronts.restype = C.c_int
         L.wfahip_debug_wavefronts.argtypes = [vp, C.POINTER(Params), C.c_char_p, u32, C.c_char_p, u32,
+                                              C.POINTER(C.POINTER(Row)), C.POINTER(u64),
+                                              C.POINTER(C.POINTER(u32)), C.POINTER(u64), C.POINTER(Results)]
+        L.wfahip_debug_team_compact.restype = C.c_int
+        L.wfahip_debug_team_compact.argtypes = [vp, C.POINTER(Params), C.c_char_p, u32, C.c_char_p, u32,
                                               C.POINTER(C.POINTER(Row)), C.POINTER(u64),
                                               C.POINTER(C.POINTER(u32)), C.POINTER(u64), C.POINTER(Results)]
         L.wfahip_free.argtypes = [vp]

@@ -310,6 +310,28 @@ class Aligner:
     def set_option(self, key: str, value: int) -> None:
         L.check(L.lib().wfahip_set_option(self._ctx, key.encode(), int(value)), f"set_option({key})")
 
+    def debug_team_compact(self, q: bytes, t: bytes):
+        """The rows wfa_teamc_kernel leaves in its arena for one pair (include/wfa_hip.h: wfahip_debug_team_compact; option
+        team_wgs must be set): ({score: {diagonal: backtrace word}}, AlignmentResult)."""
+        rows, words = C.POINTER(L.Row)(), C.POINTER(C.c_uint32)()
+        n_rows, n_words = C.c_uint64(), C.c_uint64()
+        res = L.Results()
+        prm = self._params()
+        L.check(L.lib().wfahip_debug_team_compact(self._ctx, C.byref(prm), q, len(q), t, len(t), C.byref(rows),
+                                                  C.byref(n_rows), C.byref(words), C.byref(n_words), C.byref(res)),
+                "wfahip_debug_team_compact")
+        try:
+            out = {}
+            for i in range(n_rows.value):
+                r = rows[i]
+                out[int(r.score)] = {r.lo + j: int(words[r.word_off + j]) for j in range(r.width)}
+            br = BatchResult.from_c(res, 1)
+        finally:
+            L.lib().wfahip_free(rows)
+            L.lib().wfahip_free(words)
+            L.lib().wfahip_results_free(C.byref(res))
+        return out, br.result(0)
+
     def debug_wavefronts(self, q: bytes, t: bytes):
         """All stored M/I/D rows of one alignment: ({'M': {s: {k: raw}}, 'I': .., 'D': ..}, AlignmentResult)."""
         rows, words = C.POINTER(L.Row)(), C.POINTER(C.c_uint32)()

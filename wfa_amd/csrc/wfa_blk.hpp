@@ -236,7 +236,6 @@ WFA_DEV uint32_t ffbl_raw(uint32_t x) {  // index of the lowest set bit; 0xFFFFF
     return r;
 }
 
-WFA_DEV uint32_t umin2(uint32_t a, uint32_t b) { return a < b ? a : b; }
 WFA_DEV uint32_t umax3(uint32_t a, uint32_t b, uint32_t c) { return umax2(umax2(a, b), c); }
 
 // blk_word() of a cell computed without rejections, in eight instructions: four compares into scalar registers, then

@@ -12,6 +12,7 @@ namespace wfa {
 #define WFA_DEV __device__ __forceinline__
 
 WFA_DEV uint32_t umax2(uint32_t a, uint32_t b) { return a > b ? a : b; }
+WFA_DEV uint32_t umin2(uint32_t a, uint32_t b) { return a < b ? a : b; }
 WFA_DEV int      imin2(int a, int b) { return a < b ? a : b; }
 WFA_DEV int      imax2(int a, int b) { return a > b ? a : b; }
 
@@ -900,9 +901,11 @@ WFA_DEV void back_trace(const View &av, int lenQ, int lenT, uint32_t s, int Ak, 
 // cell M[s][Ak].  Same control flow as back_trace(); the source recomputation is replaced by the stored off0
 // (M cells) -- for a cell reached inside the I or D component the reference only tests its offset0 against 0,
 // and it cannot be 0 there: an InsExt/InsOpen (DelExt/DelOpen) tag is only given when that source existed.
+// semiGlobal (round 5, wfa_teamc_kernel): the walk starts at the end cell backtraceStartPosistion picked -- (s, Ak) name
+// that cell, h_start its extended offset -- and stops at the first row / column (wfa.go:876-879).
 template <class View, class Writer>
 WFA_DEV void back_trace_compact(const View &cv, int lenQ, int lenT, uint32_t s, int Ak, uint32_t h_start,
-                                uint32_t px, uint32_t po, uint32_t pe, Writer &ow, TraceOut &out) {
+                                uint32_t px, uint32_t po, uint32_t pe, Writer &ow, TraceOut &out, bool semiGlobal = false) {
     out.score  = s;
     out.tbegin = out.tend = out.qbegin = out.qend = 0;
     int      k = Ak, h = (int)h_start, v = h - k, h0;
@@ -945,6 +948,7 @@ WFA_DEV void back_trace_compact(const View &cv, int lenQ, int lenT, uint32_t s, 
             if (h <= 0 || v <= 0) break;
         }
         ow.add(op_letter(wfaType), 1);  // wfa.go:872-873
+        if (semiGlobal && (h == 1 || v == 1)) break;  // wfa.go:876-879
         previousFromM = true;           // wfa.go:885-909
         bool stop     = false;
         switch (wfaType) {

@@ -15,6 +15,7 @@
 #include "wfa_duo_cfg.hpp"
 #include "wfa_lane.hpp"
 #include "wfa_team.hpp"
+#include "wfa_teamc.hpp"
 #include "wfa_fwd.hpp"
 #include "wfa_long.hpp"
 #include "wfa_finalize.hpp"
@@ -180,8 +181,11 @@ struct wfahip_ctx {
     int64_t       opt_team_wave            = 1;              // rows up to 64 diagonals are done by one wave (LDS ring)
     int64_t       opt_team_strict          = 1;              // agent-scope release in every team barrier (0: see wfa_team.hpp)
     int64_t       opt_unpack_all           = 0;              // 1: host entries with packed input expand ALL of it to bytes on the device first (rounds 2-3)
-    int64_t       opt_team_stripe          = 1;              // 1: stripe mode of the team kernel (contiguous stripes per workgroup, the last rows in LDS: wfa_team.hpp);
-                                                             // n > 1: the same with at most n diagonals of slack when the axis is positioned (tests: it then moves every few steps)
+    int64_t       opt_team_compact         = 1;              // 1: wide wavefronts on wfa_teamc_kernel (round 5: one backtrace word per diagonal in the arena, the rows the next
+                                                             // steps source in LDS stripes, reductions travelling with the barrier: wfa_teamc.hpp); 0: wfa_team_kernel
+    int64_t       opt_team_slack           = 1024;           // ... diagonals of room on either side when its stripes are positioned (tests: a few, so that the axis moves often)
+    bool          dbg_teamc                = false;          // wfahip_debug_team_compact is running: the one-pair debug launch takes wfa_teamc_kernel
+    DevBuf        xbuf;                                      // ... its exchange rows
     int64_t       opt_team_paged           = 1;              // 1: the teams share one pool of arena pages (a pair holds what it needs) instead of a slot each
     DevBuf        page_ctl;                                  // ... its free-page stack and the page lists of the teams
     int64_t       opt_team_xcd             = 2;              // 1: teams of one XCD's CUs (blockIdx % 8); 2 (default): ... and a team that finds itself on one XCD keeps
@@ -490,7 +494,7 @@ extern "C" void wfahip_destroy(wfahip_ctx *ctx) {
         if (ctx->pin_ev[i]) (void)hipEventDestroy(ctx->pin_ev[i]);
     }
     for (DevBuf *b : {&ctx->arena, &ctx->fin, &ctx->team_ctl, &ctx->arena2, &ctx->meta2, &ctx->doneq, &ctx->ctrl, &ctx->redo, &ctx->work, &ctx->meta, &ctx->in_blob, &ctx->in_qoff, &ctx->in_qlen,
-                      &ctx->in_toff, &ctx->in_tlen, &ctx->out_rec, &ctx->out_ops, &ctx->in_packed, &ctx->in_small, &ctx->prepack, &ctx->one_ctl, &ctx->page_ctl})
+                      &ctx->in_toff, &ctx->in_tlen, &ctx->out_rec, &ctx->out_ops, &ctx->in_packed, &ctx->in_small, &ctx->prepack, &ctx->one_ctl, &ctx->page_ctl, &ctx->xbuf})
         release(*b);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -563,8 +567,10 @@ static int set_option_impl(wfahip_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_unpack_all = value;
     else if (k == "team_paged")
         ctx->opt_team_paged = value;
-    else if (k == "team_stripe")
-        ctx->opt_team_stripe = value;
+    else if (k == "team_compact")
+        ctx->opt_team_compact = value;
+    else if (k == "team_slack")
+        ctx->opt_team_slack = value > 0 ? value : 1;
     else if (k == "arena_poison")
         ctx->opt_arena_poison = value;
     else if (k == "fail_pass")
@@ -1348,7 +1354,7 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
     {
         uint32_t lb = 0;
         while ((2u << lb) <= max_len) lb++;
-        lkey = 1ull | ((uint64_t)lb << 1) | ((uint64_t)P.global_alignment << 8) | ((uint64_t)P.adaptive << 9) | ((uint64_t)(P.x & 0xFFF) << 12) |
+        lkey = 1ull | ((uint64_t)lb << 1) | ((uint64_t)(ctx->opt_team_compact != 0) << 7) | ((uint64_t)P.global_alignment << 8) | ((uint64_t)P.adaptive << 9) | ((uint64_t)(P.x & 0xFFF) << 12) |
                ((uint64_t)(P.oe & 0xFFF) << 24) | ((uint64_t)(P.e & 0xFFF) << 36) | ((uint64_t)(P.max_dist_diff & 0xFFFF) << 48);
     }
     int      learned_now = -1;
@@ -1432,6 +1438,17 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                 }
             }
         }
+        // wfa_teamc_kernel (round 5) instead of wfa_team_kernel when its LDS rings fit beside the sequences: rows of max(x, o+e)/g +
+        // 2 e/g x 4 098 words (the default penalties: six rows, 96 KB; a 100 kbp pair's packed sequences: 50 KB)
+        bool   team_c = false;
+        size_t lds_c  = 0;
+        if (team_T > 0 && ctx->opt_team_compact != 0 && (!debug_single || ctx->dbg_teamc) && max_len < (1u << 27)) {
+            const uint32_t rm = std::max(P.x, P.oe) / P.g, re = P.e / P.g;
+            lds_c = (2ull * cfg.lds_seq_words + 32 + TEAM_RING * (sizeof(DirEnt) / 4)) * 4ull + (size_t)team_wave_rows * 3 * 64 * 4 +
+                    (size_t)(rm + 2 * re) * TC_ROWW * 4;
+            team_c = lds_c <= LDS_MAX_BYTES;
+        }
+        if (debug_single && ctx->dbg_teamc && !team_c) return WFAHIP_ERR_UNSUPPORTED;
         // Paged arena of the team kernel: ONE pool for all teams, a pair takes pages as its rows grow.  The ladder level sizes the
         // pool (as many slot sizes as there are teams) until that reaches the budget; from there a level halves the number of
         // teams that share it -- down to one team with the whole pool.
@@ -1537,22 +1554,33 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             HIP_TRY(hipMemsetAsync(jarena.p, 0xA5, paged ? (size_t)pool_words * 4ull : (size_t)cfg.arena_words * 4ull * cfg.slots, st));
         HIP_TRY(hipEventRecord(ctx->evA, st));
         if (team_T > 0) {
-            if ((rc = ensure(ctx, ctx->team_ctl, (size_t)team_n * TEAM_CTL_WORDS * 4))) return rc;
-            HIP_TRY(hipMemsetAsync(ctx->team_ctl.p, 0, (size_t)team_n * TEAM_CTL_WORDS * 4, st));
+            const size_t ctl_words = team_c ? (size_t)TC_CTL_WORDS : (size_t)TEAM_CTL_WORDS;
+            if ((rc = ensure(ctx, ctx->team_ctl, (size_t)team_n * ctl_words * 4))) return rc;
+            HIP_TRY(hipMemsetAsync(ctx->team_ctl.p, 0, (size_t)team_n * ctl_words * 4, st));
             // teams of one XCD's CUs (team = blockIdx % 8) when at most eight teams run and the CUs divide by eight
             const bool     xmap   = ctx->opt_team_xcd != 0 && ctx->opt_team_wgs == 0 && team_n <= 8 && ctx->num_cus % 8 == 0 && ctx->num_cus >= 16;
             const uint32_t grid_t = xmap ? (uint32_t)ctx->num_cus : team_n * team_T;
             if (xmap) team_T = (uint32_t)ctx->num_cus / 8u;
-            // stripe mode (round 5): the rows the next steps source -- max(x, o+e)/g of M, e/g of I and of D -- of a workgroup's 4 096
-            // diagonals in LDS, when they fit beside the sequences (default penalties: six rows, 96 KB; a 100 kbp pair's packed
-            // sequences: 50 KB)
-            const size_t lr_bytes = (size_t)(std::max(P.x, P.oe) / P.g + 2u * (P.e / P.g)) * TEAM_STRIPE * 4u;
-            const bool   lring    = ctx->opt_team_stripe != 0 && cfg.lds_bytes + lr_bytes <= LDS_MAX_BYTES;
-            if (lring) cfg.lds_bytes += lr_bytes;
-            HIP_TRY(wfa_launch_team(P, job.mode, grid_t, cfg.lds_bytes, st, static_cast<uint32_t *>(ctx->team_ctl.p), team_T,
-                                    (uint32_t)std::max<int64_t>(0, ctx->opt_team_solo_max), team_wave_rows,
-                                    (uint32_t)(ctx->opt_team_strict != 0) | (xmap ? 2u : 0u) | (xmap && ctx->opt_team_xcd >= 2 ? 4u : 0u) | (team_n << 16),
-                                    lring ? (uint32_t)std::min<int64_t>(ctx->opt_team_stripe == 1 ? 1024 : ctx->opt_team_stripe, 1 << 20) : 0u));
+            if (team_c && team_T <= (uint32_t)TC_MAX_T) {
+                TcArgs X{};
+                const uint32_t rm = std::max(P.x, P.oe) / P.g, re = P.e / P.g;
+                X.xw         = (2u * max_len + 64u + 63u) & ~63u;
+                X.xbuf_words = (uint64_t)((rm + 1) + 2 * (re + 1)) * X.xw;
+                if ((rc = ensure(ctx, ctx->xbuf, (size_t)team_n * X.xbuf_words * 4))) return rc;
+                if (ctx->opt_arena_poison) HIP_TRY(hipMemsetAsync(ctx->xbuf.p, 0xA5, (size_t)team_n * X.xbuf_words * 4, st));
+                X.team_ctl = static_cast<uint32_t *>(ctx->team_ctl.p), X.xbuf = static_cast<uint32_t *>(ctx->xbuf.p);
+                X.T = team_T, X.n_teams = team_n, X.tpx = xmap ? 1u : 0u;
+                X.solo_max = (uint32_t)std::max<int64_t>(0, ctx->opt_team_solo_max), X.wave_rows = team_wave_rows;
+                X.strict = (uint32_t)(ctx->opt_team_strict != 0) | (xmap && ctx->opt_team_xcd >= 2 ? 4u : 0u);
+                X.slack  = (uint32_t)std::min<int64_t>(std::max<int64_t>(1, ctx->opt_team_slack), 1 << 20);
+                X.dbg    = debug_single ? d_ctrl + 4 : nullptr;
+                HIP_TRY(wfa_launch_teamc(P, X, job.mode, grid_t, lds_c, st));
+            } else {
+                team_c = false;
+                HIP_TRY(wfa_launch_team(P, job.mode, grid_t, cfg.lds_bytes, st, static_cast<uint32_t *>(ctx->team_ctl.p), team_T,
+                                        (uint32_t)std::max<int64_t>(0, ctx->opt_team_solo_max), team_wave_rows,
+                                        (uint32_t)(ctx->opt_team_strict != 0) | (xmap ? 2u : 0u) | (xmap && ctx->opt_team_xcd >= 2 ? 4u : 0u) | (team_n << 16)));
+            }
         } else {
             // wave mode of the generic kernel: directory ring + ring of the last rows in LDS, if they fit
             P.wave_rows = 0, P.wave_bt = 0;
@@ -1573,11 +1601,12 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
         std::vector<uint64_t> ent;  // {pair, status}, sorted by pair
         if ((rc = fetch_ctrl(hctrl, &ent))) return rc;
         if (team_T > 0) {  // a team barrier that ran into its spin bound
-            std::vector<uint32_t> tc((size_t)team_n * TEAM_CTL_WORDS);
+            const size_t TEAM_CTL_STRIDE = team_c ? (size_t)TC_CTL_WORDS : (size_t)TEAM_CTL_WORDS;
+            std::vector<uint32_t> tc((size_t)team_n * TEAM_CTL_STRIDE);
             HIP_TRY(hipMemcpy(tc.data(), ctx->team_ctl.p, tc.size() * 4, hipMemcpyDeviceToHost));
 #ifdef WFA_TEAM_STAMPS
             for (uint32_t t = 0; t < team_n; t++) {
-                const unsigned long long *a = reinterpret_cast<const unsigned long long *>(&tc[(size_t)t * TEAM_CTL_WORDS + 64]);
+                const unsigned long long *a = reinterpret_cast<const unsigned long long *>(&tc[(size_t)t * TEAM_CTL_STRIDE + 64]);
                 std::fprintf(stderr, "[team %u] us: P1 %.0f  barriers %.0f  P2 %.0f  P3 %.0f  tail(team) %.0f  solo steps %.0f  end search %.0f  backtrace %.0f  wave mode %.0f | steps: wave %llu solo %llu team %llu\n", t,
                              a[0] / 100.0, a[1] / 100.0, a[2] / 100.0, a[3] / 100.0, a[4] / 100.0, a[5] / 100.0, a[6] / 100.0, a[7] / 100.0,
                              a[8] / 100.0, a[9], a[10], a[11]);
@@ -1590,12 +1619,12 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
 #endif
             if (std::getenv("WFAHIP_DEBUG_TIMING")) {
                 uint32_t n_xl = 0;
-                for (uint32_t t = 0; t < team_n; t++) n_xl += tc[(size_t)t * TEAM_CTL_WORDS + 11];
-                for (uint32_t t = 0; t < team_n; t++) std::fprintf(stderr, "[wfahip]   team %u: XCC ids seen, as a mask: 0x%x\n", t, tc[(size_t)t * TEAM_CTL_WORDS + 3]);
+                for (uint32_t t = 0; t < team_n; t++) n_xl += tc[(size_t)t * TEAM_CTL_STRIDE + 11];
+                for (uint32_t t = 0; t < team_n; t++) std::fprintf(stderr, "[wfahip]   team %u: XCC ids seen, as a mask: 0x%x\n", t, tc[(size_t)t * TEAM_CTL_STRIDE + 3]);
                 std::fprintf(stderr, "[wfahip] team kernel: %u teams of %u workgroups, %u of them on one XCD each\n", team_n, team_T, n_xl);
             }
             for (uint32_t t = 0; t < team_n; t++)
-                if (tc[(size_t)t * TEAM_CTL_WORDS + 1] != 0u) {
+                if (tc[(size_t)t * TEAM_CTL_STRIDE + 1] != 0u) {
                     std::snprintf(ctx->last_error, sizeof ctx->last_error, "team kernel: barrier timeout in team %u", t);
                     return WFAHIP_ERR_INTERNAL;
                 }
@@ -1605,7 +1634,7 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
         ctx->timing.kernel_ms += ms;
         if (first) {
             ctx->timing.main_kernel_ms = ms, ctx->timing.n_main_launches = 1, first = false;
-            if (team_T > 0) ctx->timing.main_kernel_kind = 7;  // wfa_team_kernel (bench.py names the dominant kernel by this)
+            if (team_T > 0) ctx->timing.main_kernel_kind = team_c ? 17 : 7;  // wfa_teamc_kernel / wfa_team_kernel (bench.py names the dominant kernel by this)
         }
         ctx->timing.n_launches++;
 
@@ -2869,9 +2898,11 @@ static int debug_clock_impl(wfahip_ctx *ctx, double *mhz, double *mhz_min, doubl
 
 extern "C" int wfahip_debug_clock(wfahip_ctx *ctx, double *mhz, double *mhz_min, double *mhz_max) { WFAHIP_GUARD(debug_clock_impl(ctx, mhz, mhz_min, mhz_max)) }
 
+// compact: wfahip_debug_team_compact -- the pair runs on wfa_teamc_kernel (option team_wgs must name the team's size) and a row is
+// its ONE backtrace word per diagonal (blk_word(), wfa_device.hpp) instead of the M, I and D words
 static int debug_wavefronts_impl(wfahip_ctx *ctx, const wfahip_params *p, const uint8_t *q, uint32_t n,
                                  const uint8_t *t, uint32_t m, wfahip_row **rows, uint64_t *n_rows,
-                                 uint32_t **words, uint64_t *n_words, wfahip_results *res) {
+                                 uint32_t **words, uint64_t *n_words, wfahip_results *res, bool compact = false) {
     if (!ctx || !rows || !n_rows || !words || !n_words || !q || !t || n == 0 || m == 0) return WFAHIP_ERR_BAD_ARG;
     *rows = nullptr, *words = nullptr, *n_rows = 0, *n_words = 0;
     if (res) results_zero(res);
@@ -2911,9 +2942,11 @@ static int debug_wavefronts_impl(wfahip_ctx *ctx, const wfahip_params *p, const 
         ctx->opt_arena_bytes_per_slot = bytes;
         // debug_single stops after one launch, so the byte path is chosen up front for non-ACGT input
         ctx->force_mode = acgt ? 0 : 1;
+        ctx->dbg_teamc  = compact;
         rc = align_device(ctx, p, ctx->in_blob.p, blob.size(), ctx->in_qoff.p, ctx->in_qlen.p, ctx->in_toff.p,
                           ctx->in_tlen.p, 1, std::max(n, m), ctx->out_rec.p, ctx->out_ops.p, ops_cap, nullptr, st,
                           true);
+        ctx->dbg_teamc                = false;
         ctx->force_mode               = -1;
         ctx->opt_arena_bytes_per_slot = saved;
         if (rc) return rc;
@@ -2935,8 +2968,9 @@ static int debug_wavefronts_impl(wfahip_ctx *ctx, const wfahip_params *p, const 
     // entry i (score i*g) sits DIR_WORDS*(i+1) words below the slot end: {base_lo, base_hi, lo, w, stride, ...}
     auto entry = [&](uint32_t i) { return &dir[(size_t)(n_ent - 1 - i) * DIR_WORDS]; };
     uint64_t total = 0, nr = 0;
+    const uint64_t ncomp = compact ? 1ull : 3ull;
     for (uint32_t i = 0; i < n_ent; i++)
-        if ((int32_t)entry(i)[3] > 0) total += 3ull * entry(i)[3], nr++;
+        if ((int32_t)entry(i)[3] > 0) total += ncomp * entry(i)[3], nr++;
     *rows  = static_cast<wfahip_row *>(std::malloc(std::max<uint64_t>(nr, 1) * sizeof(wfahip_row)));
     *words = static_cast<uint32_t *>(std::malloc(std::max<uint64_t>(total, 1) * 4));
     if (!*rows || !*words) return WFAHIP_ERR_OOM;
@@ -2947,12 +2981,12 @@ static int debug_wavefronts_impl(wfahip_ctx *ctx, const wfahip_params *p, const 
         const uint32_t  w = e[3], stride = e[4];
         if ((int32_t)w <= 0) continue;
         const uint64_t base = (uint64_t)e[0] | ((uint64_t)e[1] << 32);
-        for (int c = 0; c < 3; c++)  // M, I, D rows are `stride` words apart
+        for (int c = 0; c < (int)ncomp; c++)  // M, I, D rows are `stride` words apart
             HIP_TRY(hipMemcpy(*words + pos + (uint64_t)c * w,
                               static_cast<uint32_t *>(ctx->arena.p) + base + (uint64_t)c * stride, 4ull * w,
                               hipMemcpyDeviceToHost));
         (*rows)[ri++] = wfahip_row{i * g, (int32_t)e[2], w, pos};
-        pos += 3ull * w;
+        pos += ncomp * w;
     }
     *n_rows = nr, *n_words = total;
     if (res) {
@@ -2969,4 +3003,10 @@ extern "C" int wfahip_debug_wavefronts(wfahip_ctx *ctx, const wfahip_params *p, 
                                        const uint8_t *t, uint32_t m, wfahip_row **rows, uint64_t *n_rows,
                                        uint32_t **words, uint64_t *n_words, wfahip_results *res) {
     WFAHIP_GUARD(debug_wavefronts_impl(ctx, p, q, n, t, m, rows, n_rows, words, n_words, res))
+}
+
+extern "C" int wfahip_debug_team_compact(wfahip_ctx *ctx, const wfahip_params *p, const uint8_t *q, uint32_t n,
+                                         const uint8_t *t, uint32_t m, wfahip_row **rows, uint64_t *n_rows,
+                                         uint32_t **words, uint64_t *n_words, wfahip_results *res) {
+    WFAHIP_GUARD(debug_wavefronts_impl(ctx, p, q, n, t, m, rows, n_rows, words, n_words, res, true))
 }

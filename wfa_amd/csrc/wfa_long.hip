@@ -2,6 +2,7 @@
 #define WFA_NO_AUX_KERNELS 1
 #include "wfa_generic.hpp"
 #include "wfa_team.hpp"
+#include "wfa_teamc.hpp"
 #include "wfa_long.hpp"
 
 namespace wfa {
@@ -32,13 +33,23 @@ hipError_t wfa_launch_generic(const KParams &P, int waves, int mode, uint32_t sl
 }
 
 hipError_t wfa_launch_team(const KParams &P, int mode, uint32_t grid, size_t lds_bytes, hipStream_t st, uint32_t *team_ctl, uint32_t T,
-                           uint32_t solo_max, uint32_t wave_rows, uint32_t strict, uint32_t lring_on) {
+                           uint32_t solo_max, uint32_t wave_rows, uint32_t strict) {
     auto kfn = mode == 0 ? wfa_team_kernel<0> : wfa_team_kernel<1>;
     if (lds_bytes > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(TEAM_THREADS), lds_bytes, st, P, team_ctl, T, solo_max, wave_rows, strict, lring_on);
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(TEAM_THREADS), lds_bytes, st, P, team_ctl, T, solo_max, wave_rows, strict);
+    return hipGetLastError();
+}
+
+hipError_t wfa_launch_teamc(const KParams &P, const TcArgs &X, int mode, uint32_t grid, size_t lds_bytes, hipStream_t st) {
+    auto kfn = mode == 0 ? wfa_teamc_kernel<0> : wfa_teamc_kernel<1>;
+    if (lds_bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(TC_THREADS), lds_bytes, st, P, X);
     return hipGetLastError();
 }
 

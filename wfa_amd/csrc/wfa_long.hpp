@@ -10,6 +10,10 @@ namespace wfa {
 hipError_t wfa_launch_generic(const KParams &P, int waves, int mode, uint32_t slots, size_t lds_bytes, hipStream_t st);
 // grid workgroups of 1 024 threads; the remaining arguments are the kernel's (wfa_team.hpp)
 hipError_t wfa_launch_team(const KParams &P, int mode, uint32_t grid, size_t lds_bytes, hipStream_t st, uint32_t *team_ctl, uint32_t T,
-                           uint32_t solo_max, uint32_t wave_rows, uint32_t strict, uint32_t lring_on);
+                           uint32_t solo_max, uint32_t wave_rows, uint32_t strict);
+
+struct TcArgs;
+// wfa_teamc_kernel (round 5, wfa_teamc.hpp): grid workgroups of 1 024 threads
+hipError_t wfa_launch_teamc(const KParams &P, const TcArgs &X, int mode, uint32_t grid, size_t lds_bytes, hipStream_t st);
 
 }  // namespace wfa

@@ -40,19 +40,6 @@
 //
 // A barrier that does not complete within the spin bound raises the team's abort flag and every workgroup leaves
 // (the host reports an internal error instead of hanging the device).
-//
-// STRIPE mode (round 5): the last rows in LDS.  Rounds 1-4 cut every row into T x 1 024-diagonal stripes dealt round-robin, so a
-// thread's cells lay 32 768 diagonals apart and all five sources of every cell (wfa.go:579-650) were loads from the arena --
-// a round trip to the L2 or the memory side in front of every cell, and 64-bit address arithmetic for each.  Now, while a row
-// fits T x 4 096 diagonals (one workgroup: 4 096), workgroup b owns the CONTIGUOUS stripe [KB + 4 096 b, KB + 4 096 (b + 1)) of
-// an absolute diagonal axis that stays fixed from step to step, and keeps the rows the next steps can source -- the last
-// max(x, o+e)/g rows of M and e/g rows of I and D -- of ITS stripe in LDS (4 096 words per row; thread t holds the diagonals
-// KB_b + t + 1 024 u, u = 0..3: conflict-free LDS accesses, coalesced arena stores).  The k +- 1 sources cross workgroups
-// only at the two edges of a stripe: those two cells are read from the arena as before, everything else from LDS.  Rows,
-// directory, reductions, barrier and the band-end scan are unchanged -- the arena still holds every row in the reference's
-// three words, so the switches to solo / wave mode and back, the end-cell search and the backtrace need nothing new, and
-// entering the mode (or moving KB when the band has drifted) is a reload of six rows from the arena.  Workgroup 0's solo
-// steps use it too (one stripe, no team barrier).
 #pragma once
 #include "wfa_device.hpp"
 #include "wfa_wave.hpp"
@@ -66,12 +53,10 @@ constexpr int TEAM_CTL_WORDS = 128;  // per team, in global memory: [0] barrier 
                                      // [16 + 16*set ..] three reduction sets [64..] diagnostic stamps
 constexpr uint32_t TEAM_SPIN_LIMIT = 1u << 24;
 constexpr int      TEAM_MAX_PAGES  = 1024;  // pages one pair can hold (its list in page_ctl)
-constexpr int      TEAM_STRIPE     = 4096;  // stripe mode: diagonals a workgroup owns (LDS words per ring row)
 #ifndef WFA_TEAM_U
-#define WFA_TEAM_U 4
+#define WFA_TEAM_U 2
 #endif
-constexpr int      TEAM_U          = WFA_TEAM_U;     // cells of a thread in flight together / kept in registers per row (stripe mode: all of its stripe's)
-static_assert(TEAM_U * TEAM_THREADS == TEAM_STRIPE, "a thread holds its whole share of a stripe in registers");
+constexpr int      TEAM_U          = WFA_TEAM_U;     // cells of a thread in flight together / kept in registers per row
 constexpr uint32_t TEAM_SOLO_MAX   = 4096;  // default: rows up to this width are done by workgroup 0 alone
 enum : uint32_t { TEAM_CMD_NONE = 0, TEAM_CMD_RESUME = 1, TEAM_CMD_DONE = 2 };  // ctl[4]; ctl[5] = score, ctl[6..7] = top
 
@@ -81,7 +66,7 @@ struct TeamRed {  // one reduction set (global memory, 16 words)
 
 template <int MODE>
 __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P, uint32_t *team_ctl, uint32_t T,
-                                                                uint32_t solo_max, uint32_t wave_rows, uint32_t strict, uint32_t lring_on) {
+                                                                uint32_t solo_max, uint32_t wave_rows, uint32_t strict) {
     constexpr int G = TEAM_THREADS;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t *const lq   = lds;
@@ -90,9 +75,6 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
     DirEnt *const   ring = reinterpret_cast<DirEnt *>(red + 16);                                   // TEAM_RING entries
     // wave mode: the last wave_rows (a power of two, 0 = wave mode off) rows, [row][component][diagonal & 63]
     uint32_t *const wring = reinterpret_cast<uint32_t *>(ring + TEAM_RING);
-    // stripe mode (lring_on): the rows of this workgroup's stripe that the next steps can source, TEAM_STRIPE words each:
-    // M rows at slot (score index) mod lrM, then I rows at lrM + index mod lrE, then D rows
-    uint32_t *const lrows = wring + wave_rows * 3u * 64u;
 
     const int      tid = threadIdx.x, lane = tid & 63;
     // Teams of one XCD's CUs (round 4; `strict` bit 1, n_teams in its upper half): team = blockIdx % 8.  Workgroups are dealt
@@ -125,7 +107,6 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
     uint32_t *const my_pages    = paged ? P.page_ctl + 4u + P.n_pages + team * (uint32_t)TEAM_MAX_PAGES : nullptr;
     const uint32_t x = P.x, oe = P.oe, e = P.e, g = P.g;
     const int64_t  stripe = (int64_t)T * G;
-    const uint32_t lrM = (x > oe ? x : oe) / g, lrE = e >= g ? e / g : 1u;  // rows of the M ring / of the I and D rings
 
 #ifdef WFA_TEAM_STAMPS
     unsigned long long tacc[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memrealtime();
@@ -309,9 +290,6 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
         uint32_t   s_final  = 0;
         uint64_t   my_cells = 0;
         bool       teamed   = true;  // team mode (all workgroups step together) / solo mode (workgroup 0 alone)
-        bool       lring    = false; // stripe mode: the rows the next step sources are in LDS (this workgroup's stripe of them)
-        bool       lr_teamed = true; // ... loaded for team mode (T stripes) / solo mode (one)
-        int        KB       = 0;     // ... first diagonal of workgroup 0's stripe
         auto dir_ptr = [&](uint32_t idx) { return A + cap - (uint64_t)DIR_WORDS * (idx + 1); };
         const DirEnt none = {0ull, 0, 0, 0u, {0u, 0u, 0u}};
         auto put_ent = [&](uint32_t idx, uint64_t base, int lo_, int w_, uint32_t stride) {
@@ -441,7 +419,7 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
                                 ring[idx % TEAM_RING] = load_dir(dir_ptr(idx));
                             }
                             n_ent  = si2;
-                            teamed = true, lring = false;
+                            teamed = true;
                             resumed = true;
                             __syncthreads();
                             break;
@@ -465,7 +443,6 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
 
             // ---- wave mode (workgroup 0, solo): wave 0 steps alone while the rows stay within 64 diagonals
             if (!teamed && wave_rows != 0u && W <= 64) {
-                lring = false;
                 if (tid < 64) {
                     unsigned long long *wsteps = nullptr;
 #ifdef WFA_TEAM_STAMPS
@@ -508,44 +485,6 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
                 __syncthreads();
                 continue;
             }
-            // ---- stripe mode: (re)position the diagonal axis and load the rings from the arena when the row fits the stripes
-            // and the rings are not in place (every active workgroup takes the same decisions: same W, lo, hi)
-            auto lr_row = [&](int comp, uint32_t idx) {
-                return lrows + (size_t)(comp == 0 ? idx % lrM : lrM + (uint32_t)(comp - 1) * lrE + idx % lrE) * TEAM_STRIPE;
-            };
-            {
-                const int64_t capd    = (int64_t)(teamed ? T : 1u) * TEAM_STRIPE;
-                const bool    want_lr = lring_on != 0u && s != 0u && W > 64 && W <= capd - 2;
-                if (lring && (!want_lr || lr_teamed != teamed || lo < KB || (int64_t)hi >= (int64_t)KB + capd)) lring = false;
-                if (!lring && want_lr) {
-                    // the band in the middle of what the stripes cover, at most 1 024 diagonals of slack on either side (its ends
-                    // move by a few diagonals per step, mostly inwards: a reload every few hundred steps at worst)
-                    // (lring_on = that bound; the tests run with a few diagonals, so that the axis moves every few steps)
-                    const int64_t slack = (capd - W) / 2;
-                    KB        = lo - (int)(slack < (int64_t)lring_on ? slack : (int64_t)lring_on);
-                    lr_teamed = teamed;
-                    const int KBl = KB + (teamed ? (int)b * TEAM_STRIPE : 0);
-                    for (uint32_t r = 1; r <= lrM && r <= si; r++) {
-                        const DirEnt d = ring[(si - r) % TEAM_RING];
-#pragma unroll
-                        for (int c = 0; c < 3; c++) {
-                            if (c != 0 && r > lrE) break;
-                            uint32_t *const dst = lr_row(c, si - r);
-#pragma unroll
-                            for (int u = 0; u < TEAM_U; u++) {
-                                const int j = tid + u * G, k = KBl + j;
-                                dst[j] = (d.w > 0 && k >= d.lo && k < d.lo + d.w) ? ldw(A + d.base + (uint64_t)c * d.stride + (uint32_t)(k - d.lo)) : 0u;
-                            }
-                        }
-                    }
-                    lring = true;
-                    __syncthreads();
-#ifdef WFA_TEAM_STAMPS
-                    tacc[21]++;
-#endif
-                }
-            }
-            const int      KBw  = KB + ((lring && teamed) ? (int)b * TEAM_STRIPE : 0);
             const uint64_t base = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)top) |
                                   ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(top >> 32)) << 32);
             uint32_t *const rowM = A + base, *const rowI = rowM + W, *const rowD = rowI + W;
@@ -554,18 +493,12 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
                 red[4] = INT32_MAX, red[5] = INT32_MIN, red[6] = 0, red[7] = INT32_MIN, red[11] = INT32_MAX, red[12] = INT32_MIN, red[13] = INT32_MAX, red[14] = INT32_MIN;
             }
             __syncthreads();
-            // (stripe mode: the thread's cells are the diagonals KBw + tid + u G of its workgroup's stripe -- row index i0 + u G, which
-            // may lie below 0 or beyond W: outside the row)
-            const int64_t i0 = lring ? (int64_t)KBw - lo + tid : (teamed ? (int64_t)b * G + tid : tid), istep = lring ? G : (teamed ? stripe : G);
+            const int64_t i0 = teamed ? (int64_t)b * G + tid : tid, istep = teamed ? stripe : G;
 
-            // the LDS rows of the three source scores (stripe mode; an entry that does not exist is never read: w == 0)
-            const uint32_t *const lO  = lr_row(0, s >= oe ? si - oe / g : 0u), *const lX = lr_row(0, s >= x ? si - x / g : 0u);
-            const uint32_t *const lE1 = lr_row(1, s >= e ? si - e / g : 0u), *const lE2 = lr_row(2, s >= e ? si - e / g : 0u);
-            auto src = [&](const DirEnt &d, int comp, int k, const uint32_t *lrow) -> uint32_t {
-                if (!(d.w > 0 && k >= d.lo && k < d.lo + d.w)) return 0u;
-                const int j = k - KBw;
-                if (lring && (uint32_t)j < (uint32_t)TEAM_STRIPE) return lrow[j];  // this workgroup's stripe: from LDS
-                return ldw(A + d.base + (uint64_t)comp * d.stride + (uint32_t)(k - d.lo));  // (the two cells beyond its edges: from the arena)
+            auto src = [&](const DirEnt &d, int comp, int k) -> uint32_t {
+                return (d.w > 0 && k >= d.lo && k < d.lo + d.w)
+                           ? ldw(A + d.base + (uint64_t)comp * d.stride + (uint32_t)(k - d.lo))
+                           : 0u;
             };
 
             // ---- P1: next + seeds + extend, store rows, partial reductions
@@ -574,27 +507,26 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
             // TEAM_U cells of a thread are in flight together (their source loads overlap: in team mode every load
             // is a memory-side round trip), and the thread's first TEAM_U cells of the row stay in registers for
             // the wf-adaptive passes below (kM = M word, kF = number of non-zero I / D words).
-            uint32_t kM[TEAM_U], kF[TEAM_U], kI[TEAM_U], kD[TEAM_U];
+            uint32_t kM[TEAM_U], kF[TEAM_U];
 #pragma unroll
-            for (int u = 0; u < TEAM_U; u++) kM[u] = 0u, kF[u] = 0u, kI[u] = 0u, kD[u] = 0u;
+            for (int u = 0; u < TEAM_U; u++) kM[u] = 0u, kF[u] = 0u;
             for (int64_t i = i0; i < W; i += TEAM_U * istep) {
-                if (lring && i != i0) break;  // (stripe mode: one pass covers the workgroup's whole stripe)
                 uint32_t sa[TEAM_U], sb[TEAM_U], sc_[TEAM_U], sd[TEAM_U], sx[TEAM_U];
 #pragma unroll
                 for (int u = 0; u < TEAM_U; u++) {
                     const int64_t iu = i + u * istep;
                     const int     k  = lo + (int)iu;
-                    const bool    on = iu >= 0 && iu < W && s != 0u;
-                    sa[u]  = on ? src(eO, 0, k - 1, lO) : 0u;
-                    sb[u]  = on ? src(eE, 1, k - 1, lE1) : 0u;
-                    sc_[u] = on ? src(eO, 0, k + 1, lO) : 0u;
-                    sd[u]  = on ? src(eE, 2, k + 1, lE2) : 0u;
-                    sx[u]  = on ? src(eX, 0, k, lX) : 0u;
+                    const bool    on = iu < W && s != 0u;
+                    sa[u]  = on ? src(eO, 0, k - 1) : 0u;
+                    sb[u]  = on ? src(eE, 1, k - 1) : 0u;
+                    sc_[u] = on ? src(eO, 0, k + 1) : 0u;
+                    sd[u]  = on ? src(eE, 2, k + 1) : 0u;
+                    sx[u]  = on ? src(eX, 0, k) : 0u;
                 }
 #pragma unroll
                 for (int u = 0; u < TEAM_U; u++) {
                     const int64_t iu = i + u * istep;
-                    if (iu < 0 || iu >= W) continue;
+                    if (iu >= W) continue;
                     const int k = lo + (int)iu;
                     Cell      c = {0u, 0u, 0u};
                     if (s != 0u) c = next_cell(sa[u], sb[u], sc_[u], sd[u], sx[u], k, n, m);
@@ -602,7 +534,7 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
                     c.M = extend_word<MODE>(sv, c.M, k);
                     stw(rowM + iu, c.M), stw(rowI + iu, c.I), stw(rowD + iu, c.D);
                     my_cells += (c.M != 0u) + (c.I != 0u) + (c.D != 0u);
-                    if (i == i0) kM[u] = c.M, kF[u] = (c.I != 0u) + (c.D != 0u), kI[u] = c.I, kD[u] = c.D;
+                    if (i == i0) kM[u] = c.M, kF[u] = (c.I != 0u) + (c.D != 0u);
                     if (c.M != 0u) {
                         mlo = imin2(mlo, k), mhi = imax2(mhi, k);
                         if (k == Ak && (int)(c.M >> TAG_BITS) >= m) term = 1;  // wfa.go:235-239
@@ -614,8 +546,8 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
 #ifdef WFA_TEAM_STAMPS
             if (teamed) TEAM_STAMP(18);  // loads, next, extend, stores issued (this wave)
 #endif
-            // the thread's j-th cell of this row: from registers for j < TEAM_U, else from the arena (stripe mode: there are no others)
-            const int64_t i_rest = lring ? W : i0 + TEAM_U * istep;
+            // the thread's j-th cell of this row: from registers for j < TEAM_U, else from the arena
+            const int64_t i_rest = i0 + TEAM_U * istep;
             mlo = wave_min(mlo), mhi = wave_max(mhi), mind = wave_min(mind), maxd = wave_max(maxd);
             fvm = wave_min(fvm), lvm = wave_max(lvm);
             term = __ballot(term) != 0ull;
@@ -631,13 +563,6 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
 #ifdef WFA_TEAM_STAMPS
             if (teamed) TEAM_STAMP(20);  // the other waves of the workgroup
 #endif
-            if (lring) {
-                // the new rows enter the rings: in the slots of the oldest rows, which every thread of the workgroup has finished
-                // reading (the barrier above); they are read again after the barriers that end the step
-                uint32_t *const nM = lr_row(0, si), *const nI = lr_row(1, si), *const nD = lr_row(2, si);
-#pragma unroll
-                for (int u = 0; u < TEAM_U; u++) nM[tid + u * G] = kM[u], nI[tid + u * G] = kI[u], nD[tid + u * G] = kD[u];
-            }
             if (teamed) {
                 team_min(&tr->mlo, 0), team_max(&tr->mhi, 1), team_or(&tr->term, 2), team_min(&tr->mind, 3), team_max(&tr->maxd, 12);
                 team_min(&tr->fvm, 13), team_max(&tr->lvm, 14);
@@ -719,7 +644,7 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
 #pragma unroll
                         for (int u = 0; u < TEAM_U; u++) {
                             const int k = lo + (int)(i0 + u * istep);
-                            if (i0 + u * istep >= 0 && i0 + u * istep < W && (k < nlo || k > nhi)) my_cells -= (kM[u] != 0u) + kF[u];
+                            if (i0 + u * istep < W && (k < nlo || k > nhi)) my_cells -= (kM[u] != 0u) + kF[u];
                         }
                         for (int64_t i = i_rest; i < W; i += istep) {
                             const int k = lo + (int)i;
@@ -751,7 +676,7 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
                 };
 #pragma unroll
                 for (int u = 0; u < TEAM_U; u++)
-                    if (i0 + u * istep >= 0 && i0 + u * istep < W) p2cell(kM[u], lo + (int)(i0 + u * istep));
+                    if (i0 + u * istep < W) p2cell(kM[u], lo + (int)(i0 + u * istep));
                 for (int64_t i = i_rest; i < W; i += istep) p2cell(ldw(rowM + i), lo + (int)i);
                 first_ok = wave_min(first_ok), last_ok = wave_max(last_ok), hitmin = wave_min(hitmin);
                 anyfail  = __ballot(anyfail) != 0ull;
@@ -781,7 +706,7 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
                     };
 #pragma unroll
                     for (int u = 0; u < TEAM_U; u++)
-                        if (i0 + u * istep >= 0 && i0 + u * istep < W) fixcell(kM[u], kF[u], lo + (int)(i0 + u * istep));
+                        if (i0 + u * istep < W) fixcell(kM[u], kF[u], lo + (int)(i0 + u * istep));
                     for (int64_t i = i_rest; i < W; i += istep)
                         fixcell(ldw(rowM + i), (ldw(rowI + i) != 0u) + (ldw(rowD + i) != 0u), lo + (int)i);
                 } else if (anyfail) {
@@ -790,7 +715,7 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
 #pragma unroll
                     for (int u = 0; u < TEAM_U; u++) {
                         const int k = lo + (int)(i0 + u * istep);
-                        if (i0 + u * istep >= 0 && i0 + u * istep < W && k < first_ok && reduce_dist(kM[u], k, n, m) >= 0) lead = imax2(lead, k);
+                        if (i0 + u * istep < W && k < first_ok && reduce_dist(kM[u], k, n, m) >= 0) lead = imax2(lead, k);
                     }
                     for (int64_t i = i_rest; i < W; i += istep) {
                         const int k = lo + (int)i;
@@ -815,7 +740,7 @@ __global__ __launch_bounds__(TEAM_THREADS) void wfa_team_kernel(const KParams P,
 #pragma unroll
                     for (int u = 0; u < TEAM_U; u++) {
                         const int k = lo + (int)(i0 + u * istep);
-                        if (i0 + u * istep >= 0 && i0 + u * istep < W && (k < nlo || k > nhi)) my_cells -= (kM[u] != 0u) + kF[u];
+                        if (i0 + u * istep < W && (k < nlo || k > nhi)) my_cells -= (kM[u] != 0u) + kF[u];
                     }
                     for (int64_t i = i_rest; i < W; i += istep) {
                         const int k = lo + (int)i;

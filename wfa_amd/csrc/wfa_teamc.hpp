@@ -1,0 +1,1206 @@
+// wfa_teamc.hpp -- kernel E2 (round 5): the team kernel for WIDE wavefronts with the blocked kernels' cell.
+//
+// wfa_team_kernel (rounds 1-4, wfa_team.hpp) keeps the reference's storage as it is: three words per diagonal and score
+// (M, I, D: offset<<3 | tag, wfa_wavefront.go:93) in the arena, every cell of a step sourced from the arena rows of earlier
+// scores.  A 100 kbp semi-global pair whose band does not collapse stores 7.5e9 words (30 GB) that way -- which is what
+// bounded the number of teams in flight to eight --, every cell costs five loads, three stores and ~230 vector instructions,
+// and the end-cell search (wfa.go:270-375) re-reads every M row when the alignment is over.  Here:
+//   * ONE backtrace word per diagonal and score goes to the arena -- blk_word(): the pre-extension offset backTrace
+//     recomputes (wfa.go:766-817) and the four decisions of next() (wfa_device.hpp) -- a third of the footprint and of the
+//     stores; the walk is back_trace_compact(), one load per step instead of five;
+//   * the rows the next steps source -- the last max(x, o+e)/g rows of M and e/g rows of I and D, as BARE extended offsets
+//     (0 = absent, exactly Get's semantics: what wf-adaptive deletes is zeroed) -- never go to the arena.  In STRIPE mode
+//     (rows that fit T x 4 096 diagonals) workgroup b keeps them for its contiguous stripe [KB + 4 096 b, + 4 096) of a fixed
+//     diagonal axis in LDS, with one halo cell at either end; a cell is five LDS reads, the exact rules of next() in the
+//     blocked kernels' form (lean_next(): ~45 instructions), WF_EXTEND, one coalesced 4-byte store;
+//   * the two edge cells of a stripe travel through the team's exchange rows in global memory (`xbuf`: (R+1) + 2 (E+1) rows of
+//     n + m words, indexed by diagonal).  Rows wider than the stripes (the first scores of a semi-global pair: n + m - 1
+//     seeds) are stepped in XBUF mode -- cells dealt round-robin, sources from the exchange rows --, rows of at most 64
+//     diagonals in WAVE mode (one wave, LDS ring, as before); every change of mode, and every move of the axis, goes through
+//     the exchange rows (dump, barrier, load);
+//   * the reductions of a step travel WITH its barrier: every workgroup stores its eight values with the step's sequence
+//     number into its slot, and one wave per workgroup polls all T slots until they carry that number and reduces them --
+//     one store and one round trip instead of seven atomics, an arrive, a spin and seven loads;
+//   * the ends of the band wf-adaptive keeps (wfa.go:496-524) are found by the cells' owners from their registers and
+//     combined by a second exchange (the arena no longer holds extended offsets for everybody to scan);
+//   * the semi-global end cell (wfa.go:270-375) is found while the rows are in flight: every cell that ends the reference's
+//     scan on its side of the final diagonal -- it leaves the matrix, or lies on the last row / column -- is combined per
+//     score with an atomic minimum on (distance from that diagonal, hit or stop) in the score's directory entry; when the
+//     alignment is over the lowest score whose nearest such cell is a hit is read off the directory.
+// Same results as wfa_team_kernel, which stays for the penalties this kernel does not take (e = 0, rings too deep for LDS)
+// and for wfahip_debug_wavefronts (Plot, the word-for-word tests of the three-word storage).
+#pragma once
+#include "wfa_device.hpp"
+#include "wfa_team.hpp"
+
+namespace wfa {
+
+constexpr int      TC_THREADS  = 1024;
+constexpr int      TC_STRIPE   = 4096;             // diagonals of a workgroup's stripe
+constexpr int      TC_U        = TC_STRIPE / TC_THREADS;
+constexpr int      TC_ROWW     = TC_STRIPE + 2;    // LDS words of a ring row: the stripe and a halo cell at either end
+constexpr int      TC_SLOT_U64 = 8;                // a workgroup's exchange slot: eight (sequence number, value) words
+constexpr int      TC_MAX_T    = 64;               // workgroups per team (one lane of the polling wave each)
+// per team in global memory: the control words of wfa_team_kernel (TEAM_CTL_WORDS: [0] barrier count [1] abort [2] work index
+// [3] XCC mask [4] command [5] score [6..7] arena top [8..9] - [10] end flags [11] on one XCD [12..13] stored cells
+// [112..114] page hand-over [115] KB [116] mode) followed by two sets of exchange slots
+constexpr int      TC_CTL_WORDS = TEAM_CTL_WORDS + 2 * TC_MAX_T * TC_SLOT_U64 * 2;
+enum : uint32_t { TC_XBUF = 0, TC_STRIPE_T = 1, TC_STRIPE_S = 2, TC_WAVE = 3 };
+
+struct TcArgs {
+    uint32_t *team_ctl;
+    uint32_t *xbuf;        // exchange rows, xbuf_words per team
+    uint64_t  xbuf_words;
+    uint32_t  xw;          // words of one exchange row (>= n + m of the longest pair)
+    uint32_t  T, n_teams, tpx;  // workgroups per team; teams; teams per XCD (0: team = blockIdx / T)
+    uint32_t  solo_max, wave_rows, strict, slack;
+    uint32_t *dbg;         // debug (one pair): [0] directory entries [1] final score [2] start score [3] start diagonal
+};
+
+// next() for one diagonal on BARE offsets (0 = absent), by its exact rules -- the rejections (wfa.go:581-588,616-623,651-654),
+// mismatch-wins ties (wfa.go:657-693) and backTrace's recomputation of the pre-extension offset from the unrejected sources
+// (wfa.go:766-817) -- in the blocked kernels' form: wd = blk_word() (wfa_device.hpp), 0 when the M cell does not exist.
+struct LCell {
+    uint32_t M, I, D, wd;
+};
+WFA_DEV LCell lean_next(uint32_t a0, uint32_t b0, uint32_t c0, uint32_t d0, uint32_t x0, int k, int n, int m) {
+    const uint32_t a = (int)a0 > m ? 0u : a0, b = (int)b0 > m ? 0u : b0;
+    const uint32_t c = (int)c0 - k > n ? 0u : c0, d = (int)d0 - k > n ? 0u : d0;
+    const uint32_t x = ((int)x0 > m || (int)x0 - k > n) ? 0u : x0;
+    const uint32_t mi = umax2(a, b), Isk = mi + (mi != 0u ? 1u : 0u);
+    const uint32_t Dsk = umax2(c, d);
+    const uint32_t x1  = x + (x != 0u ? 1u : 0u);
+    const uint32_t Msk = umax2(umax2(Isk, Dsk), x1);
+    const bool     fromX = x != 0u && Msk == x1;
+    const bool     fromI = !fromX && Msk == Isk;
+    const uint32_t mu = umax2(a0, b0), Iu = mu + (mu != 0u ? 1u : 0u), Du = umax2(c0, d0), Xu = x0 + (x0 != 0u ? 1u : 0u);
+    const bool     iext = a < b, dext = c < d;
+    const uint32_t o0   = (fromI && iext) ? Iu : ((!fromX && !fromI && dext) ? Du : umax2(umax2(Iu, Du), Xu));
+    LCell r;
+    r.M = Msk, r.I = Isk, r.D = Dsk;
+    r.wd = Msk != 0u ? blk_word(o0, iext, dext, fromX, fromI) : 0u;
+    return r;
+}
+// the seed of initComponents on diagonal k that belongs to score s, as a bare offset (0: none); *match: its class
+template <int MODE>
+WFA_DEV uint32_t lean_seed(const SeqView<MODE> &sv, int k, uint32_t s, uint32_t x, bool glob, bool &match) {
+    const uint32_t w = seed_word<MODE>(sv, k, s, x, glob);
+    match            = (w & TAG_MASK) == TAG_MATCH;
+    return w >> TAG_BITS;
+}
+// WF_EXTEND on a bare offset (wfa.go:394-455)
+template <int MODE>
+WFA_DEV uint32_t lean_extend(const SeqView<MODE> &sv, uint32_t h, int k) {
+    const int v = (int)h - k;
+    if (h == 0u || v <= 0 || v >= sv.n || (int)h >= sv.m) return h;
+    return h + (uint32_t)sv.lcp(v, (int)h);
+}
+// remaining distance of wf-adaptive on a bare offset (wfa.go:474-494): -1 when absent or at / past a sequence end
+WFA_DEV int lean_dist(uint32_t h, int k, int n, int m) {
+    const int v = (int)h - k;
+    if (h == 0u || v < 0 || v >= n || (int)h >= m) return -1;
+    return imax2(m - (int)h, n - v);
+}
+// backtraceStartPosistion's view of a cell (wfa.go:301-361): 0 = the scan passes it, 1 = it ends the scan (the cell leaves the
+// matrix), 2 = hit through v == n (h = n + k), 3 = hit through h == m
+WFA_DEV uint32_t lean_endclass(uint32_t h, int k, int n, int m) {
+    if (h == 0u) return 0u;
+    const int v = (int)h - k;
+    if (v <= 0 || v > n || (int)h > m) return 1u;
+    if (v == n && (int)h >= n) return 2u;
+    if ((int)h == m && v >= m) return 3u;
+    return 0u;
+}
+// key of a scan-ending cell on its side of the final diagonal: (distance << 2) | 0 / 2 / 3 for a hit (class - 1 ... 1 = stop sorts last)
+WFA_DEV uint32_t lean_endkey(uint32_t cls, uint32_t dist) { return (dist << 2) | (cls == 1u ? 3u : (cls == 2u ? 0u : 1u)); }
+
+// The compact rows of the arena seen by a wave that walks the backtrace together: directory entries of a 64-score window in
+// LDS (as ArenaViewWave), one word per cell.
+struct DirCompactViewWave {
+    const uint32_t *A;
+    uint64_t        cap;
+    uint32_t        g, n_ent;
+    DirEnt         *win;
+    mutable uint32_t win_lo, win_hi;
+    WFA_DEV void init(const uint32_t *A_, uint64_t cap_, uint32_t g_, uint32_t n_ent_, DirEnt *lds_win) {
+        A = A_, cap = cap_, g = g_, n_ent = n_ent_, win = lds_win, win_lo = 1u, win_hi = 0u;
+    }
+    WFA_DEV void refill(uint32_t top, int k) const {
+        const uint32_t hi = top < n_ent ? top : n_ent - 1u;
+        const uint32_t lo = hi >= 63u ? hi - 63u : 0u;
+        const uint32_t j  = lo + (uint32_t)(threadIdx.x & 63);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (j <= hi) {
+            const DirEnt d = load_dir(A + cap - (uint64_t)DIR_WORDS * (j + 1));
+            win[j & 63u]   = d;
+            if (d.w > 0) {  // the cells the walk can reach while the window lasts: their lines in one round trip
+                const int k0 = k - 66 > d.lo ? k - 66 : d.lo, k1 = k + 66 < d.lo + d.w - 1 ? k + 66 : d.lo + d.w - 1;
+                uint32_t  acc = 0;
+                const uint32_t *row = A + d.base - d.lo;
+                for (int kk = k0; kk <= k1; kk += 32) acc ^= row[kk];
+                if (k1 >= k0) acc ^= row[k1];
+                asm volatile("" ::"v"(acc));
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        win_lo = lo, win_hi = hi;
+    }
+    WFA_DEV uint32_t word(uint32_t idx, int k) const {
+        if (idx >= n_ent) return 0u;
+        if (WFA_RARE(idx < win_lo || idx > win_hi)) refill(idx, k);
+        const DirEnt e = win[idx & 63u];
+        const bool   ok = e.w > 0 && k >= e.lo && k < e.lo + e.w;
+        const uint32_t v = A[ok ? e.base + (uint32_t)(k - e.lo) : 0ull];
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)(ok ? v : 0u));
+    }
+    WFA_DEV uint32_t tag(int comp, uint32_t idx, int k, uint32_t &off0) const { return blk_tag(word(idx, k), comp, off0); }
+};
+
+template <int MODE>
+__global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, const TcArgs X) {
+    constexpr int G = TC_THREADS;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t *const lq   = lds;
+    uint32_t *const lt   = lds + P.lds_seq_words;
+    int *const      red  = reinterpret_cast<int *>(lds + 2 * (MODE == 0 ? P.lds_seq_words : 0));  // 32 ints
+    DirEnt *const   ring = reinterpret_cast<DirEnt *>(red + 32);                                   // TEAM_RING entries
+    uint32_t *const wring = reinterpret_cast<uint32_t *>(ring + TEAM_RING);                       // wave mode: [row][component][diagonal & 63]
+    uint32_t *const lrows = wring + X.wave_rows * 3u * 64u;                                       // stripe mode: ring rows of TC_ROWW words
+
+    const int      tid = threadIdx.x, lane = tid & 63;
+    const uint32_t T   = X.T;
+    // teams of one XCD's workgroups (tpx teams per XCD: workgroups are dealt round-robin over the eight XCDs, so those with
+    // the same blockIdx % 8 share an L2), or plainly consecutive workgroups
+    uint32_t team, b;
+    if (X.tpx != 0u) {
+        const uint32_t xcd = blockIdx.x % 8u, ix = blockIdx.x / 8u;
+        team = xcd * X.tpx + ix / T, b = ix % T;
+        if (ix / T >= X.tpx) return;
+    } else {
+        team = blockIdx.x / T, b = blockIdx.x % T;
+    }
+    if (team >= X.n_teams) return;
+    uint32_t *const ctl = X.team_ctl + (uint64_t)team * TC_CTL_WORDS;
+    unsigned long long *const slots = reinterpret_cast<unsigned long long *>(ctl + TEAM_CTL_WORDS);  // [set][workgroup][TC_SLOT_U64]
+    uint32_t *const xb  = X.xbuf + (uint64_t)team * X.xbuf_words;
+    const bool      paged = P.page_ctl != nullptr;
+    uint32_t *const A     = paged ? P.arena : P.arena + (uint64_t)team * P.arena_words;
+    const uint64_t  cap   = paged ? P.arena_words - (uint64_t)team * P.dir_region_words : P.arena_words;
+    const uint32_t  dir_entries = paged ? (uint32_t)(P.dir_region_words / DIR_WORDS) : 0u;
+    const uint64_t  page_words  = 1ull << P.page_words_log2;
+    uint32_t *const my_pages    = paged ? P.page_ctl + 4u + P.n_pages + team * (uint32_t)TEAM_MAX_PAGES : nullptr;
+    const uint32_t x = P.x, oe = P.oe, e = P.e, g = P.g;
+    const uint32_t dx = x / g, doe = oe / g, de = e / g;
+    const uint32_t RM = dx > doe ? dx : doe, RE = de;  // rows of the M ring / of the I and D rings (LDS; the exchange rows hold one more each)
+    const bool     strict = (X.strict & 1u) != 0u, xl_ok = (X.strict & 4u) != 0u;
+
+    uint32_t bar_target = 0, xseq = 0;
+    bool     aborted = false, xl = false;
+    const auto ald = [](const uint32_t *p_) { return __hip_atomic_load(p_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    const auto ast = [](uint32_t *p_, uint32_t v_) { __hip_atomic_store(p_, v_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    // counted barrier with fences (mode switches, the start and the end of a pair): wfa_team_kernel's
+    auto team_barrier = [&]() {
+        __syncthreads();
+        if (tid == 0) {
+            bar_target += T;
+            __threadfence();
+            bool bad = false;
+            if ((int32_t)(atomicAdd(&ctl[0], 1u) + 1u - bar_target) < 0) {
+                uint32_t spins = 0;
+                while ((int32_t)(ald(&ctl[0]) - bar_target) < 0) {
+                    if ((++spins & 1023u) == 0u && (spins > TEAM_SPIN_LIMIT || ald(&ctl[1]) != 0u)) {
+                        atomicExch(&ctl[1], 1u);
+                        bad = true;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(4);
+                }
+            }
+            __threadfence();
+            red[31] = bad ? 1 : 0;
+        }
+        __syncthreads();
+        aborted = red[31] != 0;
+    };
+    // EXCHANGE: barrier + reduction in one.  Every workgroup hands in eight ints (red[16 .. 23], written by its thread 0 before
+    // the call); when the call returns red[16 .. 23] hold the MINIMUM of each over the team (a maximum travels negated, a flag
+    // as 0 / -1).  Thread 0 stores the eight values tagged with this exchange's sequence number into the workgroup's slot (eight
+    // 64-bit relaxed atomic stores: no word can be seen half-written); wave 0 polls the T slots, a workgroup per lane, until
+    // every word carries the number, and reduces.  Two sets of slots alternate: a workgroup can only overwrite a set two exchanges
+    // later, which it reaches only after every workgroup has read this one.  What the workgroup stored before the call -- the
+    // edge cells of its stripe in the exchange rows, rows in XBUF mode -- is ordered before the slot by the release (memory-side
+    // protocol), or is in the XCD's L2 once the stores have been acknowledged, which the barrier in front waits for (teams on
+    // one XCD; see wfa_team.hpp).
+    auto exchange = [&]() {
+        __syncthreads();
+        xseq += 1u;
+        if (T == 1u) return;  // (a team of one: the values are the reduction)
+        if (tid < 64) {
+            unsigned long long *const set = slots + (size_t)(xseq & 1u) * TC_MAX_T * TC_SLOT_U64;
+            if (tid == 0) {
+                if (strict && !xl) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#pragma unroll
+                for (int f = 0; f < TC_SLOT_U64; f++)
+                    __hip_atomic_store(set + (size_t)b * TC_SLOT_U64 + f, ((unsigned long long)xseq << 32) | (uint32_t)red[16 + f], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+            }
+            int      v[TC_SLOT_U64];
+            uint32_t spins = 0;
+            bool     bad   = false;
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int f = 0; f < TC_SLOT_U64; f++) {
+                    const unsigned long long w =
+                        (uint32_t)lane < T ? __hip_atomic_load(set + (size_t)lane * TC_SLOT_U64 + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                           : ((unsigned long long)xseq << 32) | 0x7FFFFFFFull;
+                    ok   = ok && (uint32_t)(w >> 32) == xseq;
+                    v[f] = (int)(uint32_t)w;
+                }
+                if (__ballot(!ok) == 0ull) break;
+                if ((++spins & 255u) == 0u && (spins > (TEAM_SPIN_LIMIT >> 2) || ald(&ctl[1]) != 0u)) {
+                    atomicExch(&ctl[1], 1u);
+                    bad = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+#pragma unroll
+            for (int f = 0; f < TC_SLOT_U64; f++) {
+                const int r = wave_min(v[f]);
+                if (lane == 0) red[16 + f] = r;
+            }
+            if (lane == 0) red[31] = bad ? 1 : 0;
+        }
+        __syncthreads();
+        aborted = red[31] != 0;
+    };
+
+    // ---- where the team's workgroups sit (teams per XCD): one bit per XCC id seen
+    if (X.tpx != 0u) {
+        if (tid == 0) atomicOr(&ctl[3], 1u << (__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | ((4 - 1) << 11)) & 15u));
+        team_barrier();
+        if (aborted) return;
+        const uint32_t seen = ald(&ctl[3]);
+        xl = xl_ok && (seen & (seen - 1u)) == 0u;
+        if (b == 0 && tid == 0) ctl[11] = xl ? 1u : 0u;
+    }
+    // ---- pages (wfa_team_kernel's pool: a stack of free page ids behind a spin lock)
+    uint32_t n_pg = 0;
+    auto page_lock = [&]() -> bool {
+        uint32_t spins = 0;
+        for (;;) {
+            uint32_t expect = 0u;
+            if (__hip_atomic_compare_exchange_strong(&P.page_ctl[0], &expect, 1u, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return true;
+            if (++spins > TEAM_SPIN_LIMIT) return false;
+            __builtin_amdgcn_s_sleep(8);
+        }
+    };
+    auto page_unlock = [&]() { __hip_atomic_store(&P.page_ctl[0], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); };
+    auto page_alloc = [&]() -> uint32_t {
+        if (n_pg >= (uint32_t)TEAM_MAX_PAGES) return 0xFFFFFFFFu;
+        uint32_t pg = 0xFFFFFFFFu, spins = 0;
+        bool     waiting = false;
+        for (;;) {
+            if (!page_lock()) break;
+            const uint32_t nf = ald(&P.page_ctl[1]);
+            if (nf != 0u) pg = ald(&P.page_ctl[4u + nf - 1u]), ast(&P.page_ctl[1], nf - 1u);
+            page_unlock();
+            if (pg != 0xFFFFFFFFu) break;
+            if (!waiting) waiting = true, atomicAdd(&P.page_ctl[2], 1u);
+            const uint32_t holders = ald(&P.page_ctl[3]), waiters = ald(&P.page_ctl[2]);
+            const uint32_t others_holding = holders - (n_pg != 0u ? 1u : 0u), others_waiting = waiters - 1u;
+            if (others_waiting >= others_holding || ++spins > (1u << 20)) break;
+            __builtin_amdgcn_s_sleep(64);
+        }
+        if (waiting) atomicSub(&P.page_ctl[2], 1u);
+        if (pg != 0xFFFFFFFFu) {
+            if (n_pg == 0u) atomicAdd(&P.page_ctl[3], 1u);
+            my_pages[n_pg++] = pg;
+        }
+        return pg;
+    };
+    auto page_free_all = [&]() {
+        if (n_pg == 0u) return;
+        if (page_lock()) {
+            uint32_t nf = ald(&P.page_ctl[1]);
+            for (uint32_t i = 0; i < n_pg; i++) ast(&P.page_ctl[4u + nf++], my_pages[i]);
+            ast(&P.page_ctl[1], nf);
+            page_unlock();
+        }
+        atomicSub(&P.page_ctl[3], 1u);
+        n_pg = 0u;
+    };
+
+    for (;;) {
+        // ---- the team's next pair
+        if (b == 0 && tid == 0) {
+            const uint32_t w0 = atomicAdd(P.queue_head, 1u);
+            ast(&ctl[2], w0), ast(&ctl[12], 0u), ast(&ctl[13], 0u), ast(&ctl[4], (uint32_t)TEAM_CMD_NONE);
+        }
+        team_barrier();
+        if (aborted) return;
+        const uint32_t wi = ald(&ctl[2]);
+        if (wi >= P.n_work) return;
+        const uint32_t pair = P.work ? P.work[wi] : wi;
+        uint32_t *const rec = P.rec + (uint64_t)pair * REC_WORDS;
+        const bool      lead_wg = (b == 0);
+
+        const uint32_t nq = P.q_len[pair], mt = P.t_len[pair];
+        if (nq == 0 || mt == 0 || nq > 0x1FFFFFFFu || mt > 0x1FFFFFFFu) {  // wfa.go:204-209
+            if (lead_wg && tid < REC_WORDS) rec[tid] = (tid == REC_STATUS) ? ((nq == 0 || mt == 0) ? ST_EMPTY : ST_TOO_LONG) : 0u;
+            continue;
+        }
+        const int n = (int)nq, m = (int)mt, Ak = m - n;
+        if ((uint64_t)nq + mt > (uint64_t)X.xw || nq >= (1u << 27) || mt >= (1u << 27)) {  // (cannot happen: the host sizes the exchange rows by the longest pair)
+            if (lead_wg && tid == 0) rec[REC_STATUS] = ST_REDO_ARENA, push_redo(P, pair, ST_REDO_ARENA);
+            continue;
+        }
+
+        SeqView<MODE> sv;
+        sv.n = n, sv.m = m;
+        if constexpr (MODE == 0) {
+            const uint32_t need = ((imax2(n, m) + 15) >> 4) + 1;
+            if (need > P.lds_seq_words) {
+                if (lead_wg && tid == 0) rec[REC_STATUS] = ST_REDO_LDS, push_redo(P, pair, ST_REDO_LDS);
+                continue;
+            }
+            if (tid == 0) red[9] = 0;
+            __syncthreads();
+            bool bad = stage_pack<G>(P.blob, P.q_off[pair], nq, lq, tid);
+            bad |= stage_pack<G>(P.blob, P.t_off[pair], mt, lt, tid);
+            if (__ballot(bad) != 0ull && lane == 0) red[9] = 1;
+            __syncthreads();
+            if (red[9]) {
+                if (lead_wg && tid == 0) rec[REC_STATUS] = ST_REDO_BYTES, push_redo(P, pair, ST_REDO_BYTES);
+                continue;
+            }
+            sv.q = lq, sv.t = lt;
+        } else {
+            sv.q = P.blob + P.q_off[pair];
+            sv.t = P.blob + P.t_off[pair];
+        }
+
+        // ---- score loop
+        const bool glob    = P.global_alignment != 0;
+        const int  seed_lo = glob ? 0 : -(n - 1), seed_hi = glob ? 0 : m - 1;
+        const int  xoff    = n - 1;  // exchange rows are indexed by k + n - 1
+        uint64_t   top = 0, page_end = 0;
+        uint32_t   n_ent = 0, s_final = 0, h_final = 0;
+        bool       overflow = false, done = false;
+        uint64_t   my_cells = 0;
+        uint32_t   mode = TC_XBUF;  // every workgroup active: XBUF / STRIPE_T; workgroup 0 alone: STRIPE_S / WAVE
+        int        KB   = 0;        // stripe modes: first diagonal of workgroup 0's stripe
+        int        SWd  = TC_STRIPE;  // ... and the diagonals of a stripe: the row's width dealt evenly over the team's workgroups (a multiple of 64, at
+                                      // most TC_STRIPE) -- every workgroup then has the same number of cells per thread, and the step takes what its
+                                      // busiest workgroup takes
+        bool       rings_in_lds = false;  // the LDS rings hold the rows of the scores before s (else they are in the exchange rows)
+        auto dir_ptr = [&](uint32_t idx) { return A + cap - (uint64_t)DIR_WORDS * (idx + 1); };
+        const DirEnt none = {0ull, 0, 0, 0u, {0u, 0u, 0u}};
+        auto put_ent = [&](uint32_t idx, uint64_t base, int lo_, int w_) {
+            if (tid == 0) {
+                DirEnt d;
+                d.base = base, d.lo = lo_, d.w = w_, d.stride = 0u, d.pad[0] = d.pad[1] = d.pad[2] = 0u;
+                ring[idx % TEAM_RING] = d;
+                if (lead_wg) store_dir(dir_ptr(idx), base, lo_, w_, 0u);
+            }
+        };
+        // exchange rows: M row of score index i at slot i mod (RM + 1), I / D rows at i mod (RE + 1) behind them
+        auto xrow = [&](int comp, uint32_t idx) {
+            return xb + (size_t)(comp == 0 ? idx % (RM + 1u) : (RM + 1u) + (uint32_t)(comp - 1) * (RE + 1u) + idx % (RE + 1u)) * X.xw;
+        };
+        auto lrow = [&](int comp, uint32_t idx) {
+            return lrows + (size_t)(comp == 0 ? idx % RM : RM + (uint32_t)(comp - 1) * RE + idx % RE) * TC_ROWW;
+        };
+        auto xld = [&](const uint32_t *p_) { return (mode == TC_XBUF || mode == TC_STRIPE_T) ? ald(p_) : *p_; };
+        auto xst = [&](uint32_t *p_, uint32_t v_) {
+            if ((mode == TC_XBUF || mode == TC_STRIPE_T) && !xl) ast(p_, v_);
+            else *p_ = v_;
+        };
+        auto cst = [&](uint32_t *p_, uint32_t v_) { *p_ = v_; };  // compact words: nobody reads them before the pair's last (fenced) barrier
+        // the rings of this workgroup's stripe -> exchange rows (every cell of the stripe: what lies outside a row's band is zero)
+        auto dump_rings = [&](uint32_t si) {
+            const int KBw = KB + (mode == TC_STRIPE_T ? (int)b * SWd : 0);
+            for (uint32_t r = 1; r <= RM && r <= si; r++) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    if (c != 0 && r > RE) break;
+                    const uint32_t *const src = lrow(c, si - r);
+                    uint32_t *const       dst = xrow(c, si - r);
+#pragma unroll
+                    for (int u = 0; u < TC_U; u++) {
+                        const int j = tid + u * G, kx = KBw + j + xoff;
+                        if (j < SWd && kx >= 0 && kx < (int)X.xw) xst(dst + kx, src[j + 1]);
+                    }
+                }
+            }
+        };
+        // exchange rows -> the rings of this workgroup's stripe (cells outside a row's kept band: zero; halo cells included)
+        auto load_rings = [&](uint32_t si) {
+            const int KBw = KB + (mode == TC_STRIPE_T ? (int)b * SWd : 0);
+            for (uint32_t r = 1; r <= RM && r <= si; r++) {
+                const DirEnt d = ring[(si - r) % TEAM_RING];
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    if (c != 0 && r > RE) break;
+                    const uint32_t *const src = xrow(c, si - r);
+                    uint32_t *const       dst = lrow(c, si - r);
+                    for (int j = tid - 1; j <= SWd; j += G) {
+                        const int k = KBw + j;
+                        dst[j + 1]  = (d.w > 0 && k >= d.lo && k < d.lo + d.w) ? xld(src + k + xoff) : 0u;
+                    }
+                }
+            }
+        };
+
+        uint32_t s = 0;
+        for (;; s += g) {
+            const uint32_t si = s / g;
+            auto uni = [](DirEnt d) {
+                auto r = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+                DirEnt u;
+                u.base   = (uint64_t)r((uint32_t)d.base) | ((uint64_t)r((uint32_t)(d.base >> 32)) << 32);
+                u.lo     = (int)r((uint32_t)d.lo), u.w = (int)r((uint32_t)d.w), u.stride = 0u;
+                u.pad[0] = u.pad[1] = u.pad[2] = 0u;
+                return u;
+            };
+            const DirEnt eX = uni((s >= x) ? ring[(si - dx) % TEAM_RING] : none);
+            const DirEnt eO = uni((s >= oe) ? ring[(si - doe) % TEAM_RING] : none);
+            const DirEnt eE = uni((s >= e) ? ring[(si - de) % TEAM_RING] : none);
+            const bool   seeded = (s == 0u) || (s == x);
+            int lo = INT32_MAX, hi = INT32_MIN;
+            if (eX.w > 0) lo = imin2(lo, eX.lo - 1), hi = imax2(hi, eX.lo + eX.w);
+            if (eO.w > 0) lo = imin2(lo, eO.lo - 1), hi = imax2(hi, eO.lo + eO.w);
+            if (eE.w > 0) lo = imin2(lo, eE.lo - 1), hi = imax2(hi, eE.lo + eE.w);
+            lo = imax2(lo, -(n - 1));  // wfa.go:562-563
+            hi = imin2(hi, m - 1);
+            if (s == 0u) lo = INT32_MAX, hi = INT32_MIN;
+            if (seeded) lo = imin2(lo, seed_lo), hi = imax2(hi, seed_hi);
+            const int64_t W = (hi >= lo) ? ((int64_t)hi - lo + 1) : 0;
+
+            // ---- room for the row (one word per diagonal) and its directory entry
+            if (!paged) {
+                if (top + (uint64_t)W + (uint64_t)DIR_WORDS * (si + 2) > cap) {
+                    overflow = true;
+                    break;
+                }
+            } else {
+                if (si + 2u > dir_entries || (uint64_t)W > page_words) {
+                    overflow = true;
+                    break;
+                }
+                if (top + (uint64_t)W > page_end) {
+                    uint32_t pg;
+                    if (mode == TC_XBUF || mode == TC_STRIPE_T) {
+                        if (lead_wg && tid == 0) ast(&ctl[112], page_alloc());
+                        team_barrier();
+                        if (aborted) return;
+                        pg = ald(&ctl[112]);
+                    } else {
+                        if (tid == 0) red[8] = (int)page_alloc();
+                        __syncthreads();
+                        pg = (uint32_t)red[8];
+                        __syncthreads();
+                    }
+                    if (pg == 0xFFFFFFFFu) {
+                        overflow = true;
+                        break;
+                    }
+                    top = (uint64_t)pg << P.page_words_log2, page_end = top + page_words;
+                }
+            }
+            __syncthreads();  // everybody has read the ring entries before the slot of this score is rewritten
+
+            // ---- the mode of this step (every active workgroup computes the same W)
+            const int64_t capT = (int64_t)T * TC_STRIPE - 2, capS = (int64_t)TC_STRIPE - 2;
+            uint32_t want = W > capT ? (uint32_t)TC_XBUF
+                            : (W > (int64_t)X.solo_max || W > capS) && T > 1u ? (uint32_t)TC_STRIPE_T
+                            : (W <= 64 && X.wave_rows != 0u && s != 0u) ? (uint32_t)TC_WAVE
+                                                                       : (W > capS ? (uint32_t)TC_XBUF : (uint32_t)TC_STRIPE_S);
+            if (T == 1u && want == TC_STRIPE_T) want = W > capS ? (uint32_t)TC_XBUF : (uint32_t)TC_STRIPE_S;
+            const bool was_team = mode == TC_XBUF || mode == TC_STRIPE_T, will_team = want == TC_XBUF || want == TC_STRIPE_T;
+            // a stripe mode whose axis no longer holds the row is left and entered again
+            const bool stripe_now = mode == TC_STRIPE_T || mode == TC_STRIPE_S;
+            const int64_t capd = mode == TC_STRIPE_T ? (int64_t)T * SWd : (int64_t)SWd;
+            // the stripe width a team would pick for this row now: when the band has shrunk by 128 diagonals per workgroup the stripes
+            // are dealt anew (the step takes what the workgroup with the most cells per thread takes)
+            const int64_t slk   = (int64_t)X.slack < 256 ? (int64_t)X.slack : 256;
+            int64_t       sw_t  = ((W + 2 * slk + (int64_t)T - 1) / (int64_t)T + 63) & ~63ll;
+            sw_t                = sw_t > TC_STRIPE ? TC_STRIPE : sw_t;
+            const bool moved = stripe_now && want == mode &&
+                               (lo < KB || (int64_t)hi >= (int64_t)KB + capd || (mode == TC_STRIPE_T && sw_t + 128 <= (int64_t)SWd));
+            if (want != mode || moved) {
+                if (rings_in_lds) {  // the rings go to the exchange rows, where every mode can pick them up
+                    dump_rings(si);
+                    rings_in_lds = false;
+                }
+                if (was_team && T > 1u) {
+                    team_barrier();  // (fenced: the dumps, and in XBUF mode the rows, are visible to whoever loads them next)
+                    if (aborted) return;
+                } else {
+                    __threadfence();
+                    __syncthreads();
+                }
+                if (was_team && !will_team && T > 1u && !lead_wg) {
+                    // ---- parked: workgroup 0 goes on alone until the row is wide again or the pair is over
+                    bool resumed = false;
+                    for (;;) {
+                        team_barrier();
+                        if (aborted) return;
+                        const uint32_t cmd = ald(&ctl[4]);
+                        if (cmd == TEAM_CMD_DONE) {
+                            s_final = ald(&ctl[5]);
+                            const uint32_t fl = ald(&ctl[10]);
+                            done = (fl & 1u) != 0u, overflow = (fl & 2u) != 0u;
+                            break;
+                        }
+                        if (cmd == TEAM_CMD_RESUME) {
+                            s   = ald(&ctl[5]);
+                            top = (uint64_t)ald(&ctl[6]) | ((uint64_t)ald(&ctl[7]) << 32);
+                            page_end = (uint64_t)ald(&ctl[113]) | ((uint64_t)ald(&ctl[114]) << 32);
+                            const uint32_t si2 = s / g;
+                            if (tid < TEAM_RING && (uint32_t)tid < si2) {
+                                const uint32_t idx = si2 - 1u - (uint32_t)tid;
+                                ring[idx % TEAM_RING] = load_dir(dir_ptr(idx));
+                            }
+                            n_ent = si2;
+                            mode  = TC_XBUF;  // (the loop head of score s decides the real one; the rings are in the exchange rows)
+                            resumed = true;
+                            __syncthreads();
+                            break;
+                        }
+                    }
+                    if (!resumed) break;
+                    s -= g;
+                    continue;
+                }
+                if (!was_team && will_team && T > 1u) {
+                    // ---- workgroup 0 wakes the others: where the pair is
+                    if (tid == 0) {
+                        ast(&ctl[5], s), ast(&ctl[6], (uint32_t)top), ast(&ctl[7], (uint32_t)(top >> 32));
+                        ast(&ctl[113], (uint32_t)page_end), ast(&ctl[114], (uint32_t)(page_end >> 32));
+                        ast(&ctl[4], (uint32_t)TEAM_CMD_RESUME);
+                    }
+                    team_barrier();
+                    if (aborted) return;
+                    // (like the workgroups it has woken: the loop head of score s again, as a team, the rings in the exchange rows --
+                    // every workgroup then takes the same path into the mode the row asks for)
+                    mode = TC_XBUF;
+                    s -= g;
+                    continue;
+                }
+                mode = want;
+                if (mode == TC_STRIPE_T || mode == TC_STRIPE_S) {
+                    SWd = mode == TC_STRIPE_T ? (int)sw_t : TC_STRIPE;
+                    const int64_t cd = mode == TC_STRIPE_T ? (int64_t)T * SWd : (int64_t)SWd, slack = (cd - W) / 2;
+                    KB = lo - (int)(slack < (int64_t)X.slack ? slack : (int64_t)X.slack);
+                    load_rings(si);
+                    rings_in_lds = true;
+                    __syncthreads();
+                }
+            }
+
+            // ---- WAVE mode (workgroup 0): wave 0 steps alone while the rows stay within 64 diagonals
+            if (mode == TC_WAVE) {
+                if (tid < 64) {
+                    const uint32_t rmask = X.wave_rows - 1u;
+                    auto wrow = [&](uint32_t idx, int comp) { return wring + (((idx & rmask) * 3u + (uint32_t)comp) << 6); };
+                    auto rfl  = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+                    // the rows the next steps can source: from the exchange rows into the LDS ring
+                    for (uint32_t r = 1; r <= X.wave_rows && r <= si && r <= RM; r++) {
+                        const DirEnt d = ring[(si - r) % TEAM_RING];
+                        if (d.w > 0 && d.w <= 64 && lane < d.w) {
+                            const uint32_t sl = (uint32_t)(d.lo + lane) & 63u;
+#pragma unroll
+                            for (int c = 0; c < 3; c++)
+                                if (c == 0 || r <= RE) wrow(si - r, c)[sl] = xrow(c, si - r)[d.lo + lane + xoff];
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    const int2 *const ring_lw = reinterpret_cast<const int2 *>(ring);
+                    uint32_t wflags = 0, su = rfl(s), sj = rfl(si);
+                    uint64_t utop = (uint64_t)rfl((uint32_t)top) | ((uint64_t)rfl((uint32_t)(top >> 32)) << 32);
+                    uint64_t wcells = 0;
+                    for (;; su += g, sj++) {
+                        int xlo = 0, xw_ = 0, olo = 0, ow_ = 0, elo = 0, ew = 0;
+                        if (su >= x) {
+                            const int2 v = ring_lw[((sj - dx) % TEAM_RING) * 4u + 1u];
+                            xlo = (int)rfl((uint32_t)v.x), xw_ = (int)rfl((uint32_t)v.y);
+                        }
+                        if (su >= oe) {
+                            const int2 v = ring_lw[((sj - doe) % TEAM_RING) * 4u + 1u];
+                            olo = (int)rfl((uint32_t)v.x), ow_ = (int)rfl((uint32_t)v.y);
+                        }
+                        if (su >= e) {
+                            const int2 v = ring_lw[((sj - de) % TEAM_RING) * 4u + 1u];
+                            elo = (int)rfl((uint32_t)v.x), ew = (int)rfl((uint32_t)v.y);
+                        }
+                        const bool wseed = (su == 0u) || (su == x);
+                        int wlo = INT32_MAX, whi = INT32_MIN;
+                        if (xw_ > 0) wlo = imin2(wlo, xlo - 1), whi = imax2(whi, xlo + xw_);
+                        if (ow_ > 0) wlo = imin2(wlo, olo - 1), whi = imax2(whi, olo + ow_);
+                        if (ew > 0) wlo = imin2(wlo, elo - 1), whi = imax2(whi, elo + ew);
+                        wlo = imax2(wlo, -(n - 1)), whi = imin2(whi, m - 1);
+                        if (su == 0u) wlo = INT32_MAX, whi = INT32_MIN;
+                        if (wseed) wlo = imin2(wlo, seed_lo), whi = imax2(whi, seed_hi);
+                        const int64_t WW = (whi >= wlo) ? ((int64_t)whi - wlo + 1) : 0;
+                        if (WFA_RARE(dir_entries == 0u ? utop + (uint64_t)WW + (uint64_t)DIR_WORDS * (sj + 2) > cap
+                                                       : (utop + (uint64_t)WW > page_end || sj + 2u > dir_entries))) {
+                            wflags = WAVE_OVERFLOW;
+                            break;
+                        }
+                        if (WFA_RARE(WW > 64)) {
+                            wflags = WAVE_WIDE;
+                            break;
+                        }
+                        auto wput = [&](uint64_t base_, int lo_, int w_, uint32_t kd, uint32_t ku) {
+                            if (lane == 0) {
+                                DirEnt d;
+                                d.base = base_, d.lo = lo_, d.w = w_, d.stride = 0u, d.pad[0] = kd, d.pad[1] = ku, d.pad[2] = 0u;
+                                ring[sj % TEAM_RING] = d;
+                                uint32_t *const dp = dir_ptr(sj);
+                                store_dir(dp, base_, lo_, w_, 0u);
+                                dp[5] = kd, dp[6] = ku;
+                            }
+                        };
+                        if (WFA_RARE(WW == 0)) {
+                            wput(0ull, 0, 0, 0xFFFFFFFFu, 0xFFFFFFFFu);
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            continue;
+                        }
+                        const uint64_t wbase = utop;
+                        const int      k     = wlo + lane;
+                        const bool     on    = lane < (int)WW;
+                        const uint32_t sl    = (uint32_t)k & 63u;
+                        auto wsrc = [&](int dlo, int dw, uint32_t idx, int comp, int kk) -> uint32_t {
+                            return (kk >= dlo && kk < dlo + dw) ? wrow(idx, comp)[(uint32_t)kk & 63u] : 0u;
+                        };
+                        LCell c = {0u, 0u, 0u, 0u};
+                        if (on) {
+                            if (su != 0u)
+                                c = lean_next(wsrc(olo, ow_, sj - doe, 0, k - 1), wsrc(elo, ew, sj - de, 1, k - 1), wsrc(olo, ow_, sj - doe, 0, k + 1),
+                                              wsrc(elo, ew, sj - de, 2, k + 1), wsrc(xlo, xw_, sj - dx, 0, k), k, n, m);
+                            if (wseed && c.M == 0u) {
+                                bool mt_ = false;
+                                c.M = lean_seed<MODE>(sv, k, su, x, glob, mt_);
+                                c.wd = c.M != 0u ? (mt_ ? BLK_SEED_MATCH : BLK_SEED_MISMATCH) : 0u;
+                            }
+                            c.M = lean_extend<MODE>(sv, c.M, k);
+                            A[wbase + lane] = c.wd;
+                            wrow(sj, 0)[sl] = c.M, wrow(sj, 1)[sl] = c.I, wrow(sj, 2)[sl] = c.D;
+                            // (write-through to the exchange rows: a wider row takes over from there)
+                            xrow(0, sj)[k + xoff] = c.M, xrow(1, sj)[k + xoff] = c.I, xrow(2, sj)[k + xoff] = c.D;
+                            wcells += (c.M != 0u) + (c.I != 0u) + (c.D != 0u);
+                        }
+                        utop += (uint64_t)WW;
+                        const unsigned long long bM = __ballot(c.M != 0u);
+                        if (WFA_RARE(bM == 0ull)) {
+                            wput(0ull, 0, 0, 0xFFFFFFFFu, 0xFFFFFFFFu);
+                        } else {
+                            const int  wmlo = wlo + (int)__builtin_ctzll(bM), wmhi = wlo + 63 - (int)__builtin_clzll(bM);
+                            const int  dd   = lean_dist(c.M, k, n, m);
+                            const bool hitf = c.M != 0u && k == Ak && (int)c.M >= m;
+                            int wnlo = wmlo, wnhi = wmhi;
+                            const bool fin = __ballot(hitf) != 0ull;
+                            const unsigned long long bV = __ballot(dd >= 0);
+                            if (!fin && P.adaptive && (wmhi - wmlo + 1) >= (int)P.min_wf_len && bV != 0ull) {
+                                const int wmind = wave_min(dd >= 0 ? dd : INT32_MAX);
+                                const unsigned long long bFail = __ballot(dd >= 0 && dd - wmind > (int)P.max_dist_diff);
+                                const unsigned long long bOk   = bV & ~bFail;
+                                if (bFail != 0ull) {
+                                    const int first_ok = wlo + (int)__builtin_ctzll(bOk), last_ok = wlo + 63 - (int)__builtin_clzll(bOk);
+                                    const unsigned long long bEnd = bM & ~bV;
+                                    const int hitmin = bEnd != 0ull ? wlo + (int)__builtin_ctzll(bEnd) : INT32_MAX;
+                                    if (hitmin >= first_ok) {
+                                        wnlo = first_ok, wnhi = last_ok;
+                                    } else {
+                                        const unsigned long long below = bV & ((1ull << (first_ok - wlo)) - 1ull);
+                                        wnlo = below != 0ull ? wlo + 63 - (int)__builtin_clzll(below) + 1 : wmlo;
+                                        wnhi = last_ok;
+                                    }
+                                    if (on && (k < wnlo || k > wnhi)) wcells -= (c.M != 0u) + (c.I != 0u) + (c.D != 0u);
+                                }
+                            }
+                            // the cells that end the reference's end-cell scan on either side of the final diagonal (semi-global)
+                            uint32_t kd = 0xFFFFFFFFu, ku = 0xFFFFFFFFu;
+                            if (!glob) {
+                                const bool     keep = on && k >= wnlo && k <= wnhi;
+                                const uint32_t cls  = keep ? lean_endclass(c.M, k, n, m) : 0u;
+                                const uint32_t key  = cls != 0u ? lean_endkey(cls, (uint32_t)(k <= Ak ? Ak - k : k - Ak - 1)) : 0xFFFFFFFFu;
+                                kd = (uint32_t)wave_min((int)((k <= Ak ? key : 0xFFFFFFFFu) ^ 0x80000000u)) ^ 0x80000000u;
+                                ku = (uint32_t)wave_min((int)((k > Ak ? key : 0xFFFFFFFFu) ^ 0x80000000u)) ^ 0x80000000u;
+                            }
+                            if (wnhi >= wnlo) wput(wbase + (uint64_t)(wnlo - wlo), wnlo, wnhi - wnlo + 1, kd, ku);
+                            else wput(0ull, 0, 0, 0xFFFFFFFFu, 0xFFFFFFFFu);
+                            if (WFA_RARE(fin)) {
+                                const int hfl = hitf ? (int)c.M : 0;
+                                h_final = (uint32_t)wave_max(hfl);
+                                wflags  = WAVE_DONE;
+                                break;
+                            }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    if (tid == 0) {
+                        unsigned int *const ur = reinterpret_cast<unsigned int *>(red);
+                        ur[0] = su, ur[1] = (uint32_t)utop, ur[2] = (uint32_t)(utop >> 32), ur[3] = (wflags == WAVE_DONE) ? sj + 1u : sj, ur[4] = wflags,
+                        ur[5] = h_final;
+                    }
+                    my_cells += wcells;
+                }
+                __syncthreads();
+                {
+                    const unsigned int *const ur = reinterpret_cast<const unsigned int *>(red);
+                    s = ur[0], top = (uint64_t)ur[1] | ((uint64_t)ur[2] << 32), n_ent = ur[3];
+                    const uint32_t wf = ur[4];
+                    if (wf & WAVE_DONE) done = true, s_final = s, h_final = ur[5];
+                    if ((wf & WAVE_OVERFLOW) && !(paged && s / g + 2u <= dir_entries)) overflow = true;
+                }
+                __syncthreads();
+                if (done || overflow) break;
+                s -= g;  // the row at s is wider than 64 (or its page is full): redo the loop head for it
+                continue;
+            }
+
+            if (W == 0) {
+                put_ent(si, 0ull, 0, 0);
+                if (lead_wg && tid == 0) dir_ptr(si)[5] = 0xFFFFFFFFu, dir_ptr(si)[6] = 0xFFFFFFFFu;
+                n_ent = si + 1;
+                __syncthreads();
+                continue;
+            }
+            const uint64_t base = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)top) |
+                                  ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(top >> 32)) << 32);
+            uint32_t *const rowC = A + base;  // the row's backtrace words, diagonal lo first
+            const bool team_now = mode == TC_XBUF || mode == TC_STRIPE_T;
+            if (tid == 0) {
+                red[0] = INT32_MAX, red[1] = INT32_MIN, red[2] = 0, red[3] = INT32_MAX, red[4] = INT32_MAX, red[5] = INT32_MIN, red[6] = INT32_MAX,
+                red[7] = INT32_MIN, red[11] = INT32_MAX, red[12] = INT32_MIN, red[13] = INT32_MAX, red[14] = INT32_MIN, red[10] = 0;
+                // the end-cell keys of this score's directory entry start as "none" (atomic minima below; semi-global only)
+                if (lead_wg && !glob) ast(dir_ptr(si) + 5, 0xFFFFFFFFu), ast(dir_ptr(si) + 6, 0xFFFFFFFFu);
+            }
+            // stripe modes: the halo cells of the newest rows (score index si - 1: the neighbours' edge cells, through the exchange
+            // rows; older rows got theirs when they were the newest)
+            const int KBw = KB + (mode == TC_STRIPE_T ? (int)b * SWd : 0);
+            if (mode == TC_STRIPE_T && si >= 1u && tid < 6) {
+                const int    c = tid >> 1, hiside = tid & 1;
+                const DirEnt d = ring[(si - 1u) % TEAM_RING];
+                const int    k = hiside ? KBw + SWd : KBw - 1;
+                lrow(c, si - 1u)[hiside ? SWd + 1 : 0] = (d.w > 0 && k >= d.lo && k < d.lo + d.w && k + xoff >= 0 && k + xoff < (int)X.xw) ? ald(xrow(c, si - 1u) + k + xoff) : 0u;
+            }
+            __syncthreads();
+
+            // ---- P1: next + seeds + extend, the row's backtrace words, partial reductions
+            int mlo = INT32_MAX, mhi = INT32_MIN, term = 0, mind = INT32_MAX, maxd = INT32_MIN, fvm = INT32_MAX, lvm = INT32_MIN;
+            uint32_t kM[TC_U], kI[TC_U], kD[TC_U];
+            int      kK[TC_U];  // the thread's cells of this row: diagonal (INT32_MIN: none), extended M, I, D
+#pragma unroll
+            for (int u = 0; u < TC_U; u++) kM[u] = kI[u] = kD[u] = 0u, kK[u] = INT32_MIN;
+            const bool stripe_mode = mode == TC_STRIPE_T || mode == TC_STRIPE_S;
+            const bool hO = eO.w > 0, hX = eX.w > 0, hE = eE.w > 0;
+            const uint32_t *const lO = lrow(0, s >= oe ? si - doe : 0u), *const lXr = lrow(0, s >= x ? si - dx : 0u);
+            const uint32_t *const lE1 = lrow(1, s >= e ? si - de : 0u), *const lE2 = lrow(2, s >= e ? si - de : 0u);
+            const uint32_t *const xO = xrow(0, s >= oe ? si - doe : 0u), *const xX = xrow(0, s >= x ? si - dx : 0u);
+            const uint32_t *const xE1 = xrow(1, s >= e ? si - de : 0u), *const xE2 = xrow(2, s >= e ? si - de : 0u);
+            auto xsrc = [&](const DirEnt &d, const uint32_t *row, int k) -> uint32_t {
+                return (d.w > 0 && k >= d.lo && k < d.lo + d.w) ? ald(row + k + xoff) : 0u;
+            };
+            // XBUF mode: cells dealt round-robin over the team (or the workgroup), as many passes as the row needs
+            const int64_t xstep = (int64_t)(team_now ? T : 1u) * G, x0i = team_now ? (int64_t)b * G + tid : tid;
+            const int     npass = stripe_mode ? 1 : (int)((W + TC_U * xstep - 1) / (TC_U * xstep));
+            for (int pass = 0; pass < npass; pass++) {
+                uint32_t sa[TC_U], sb[TC_U], sc_[TC_U], sd[TC_U], sx[TC_U];
+                int      kk[TC_U];
+#pragma unroll
+                for (int u = 0; u < TC_U; u++) {
+                    int  k;
+                    bool on;
+                    if (stripe_mode) {
+                        const int j = tid + u * G;
+                        k = KBw + j, on = j < SWd && k >= lo && k <= hi;
+                        // (the rings hold zero wherever a row has no cell: no range checks -- but a score without a row has no slot)
+                        sa[u] = hO ? lO[j] : 0u, sb[u] = hE ? lE1[j] : 0u, sc_[u] = hO ? lO[j + 2] : 0u, sd[u] = hE ? lE2[j + 2] : 0u, sx[u] = hX ? lXr[j + 1] : 0u;
+                    } else {
+                        const int64_t i = x0i + ((int64_t)pass * TC_U + u) * xstep;
+                        on = i < W, k = lo + (int)(on ? i : 0);
+                        const bool rd = on && s != 0u;
+                        sa[u] = rd ? xsrc(eO, xO, k - 1) : 0u, sb[u] = rd ? xsrc(eE, xE1, k - 1) : 0u;
+                        sc_[u] = rd ? xsrc(eO, xO, k + 1) : 0u, sd[u] = rd ? xsrc(eE, xE2, k + 1) : 0u;
+                        sx[u] = rd ? xsrc(eX, xX, k) : 0u;
+                    }
+                    kk[u] = on ? k : INT32_MIN;
+                }
+#pragma unroll
+                for (int u = 0; u < TC_U; u++) {
+                    if (kk[u] == INT32_MIN) continue;
+                    const int k = kk[u];
+                    LCell     c = {0u, 0u, 0u, 0u};
+                    if (s != 0u) c = lean_next(sa[u], sb[u], sc_[u], sd[u], sx[u], k, n, m);
+                    if (seeded && c.M == 0u) {  // Set = last write wins (R2)
+                        bool mt_ = false;
+                        c.M  = lean_seed<MODE>(sv, k, s, x, glob, mt_);
+                        c.wd = c.M != 0u ? (mt_ ? BLK_SEED_MATCH : BLK_SEED_MISMATCH) : 0u;
+                    }
+                    c.M = lean_extend<MODE>(sv, c.M, k);
+                    cst(rowC + (k - lo), c.wd);
+                    my_cells += (c.M != 0u) + (c.I != 0u) + (c.D != 0u);
+                    if (!stripe_mode) {  // the row itself lives in the exchange rows
+                        uint32_t *const nx = xrow(0, si), *const ni = xrow(1, si), *const nd = xrow(2, si);
+                        xst(nx + k + xoff, c.M), xst(ni + k + xoff, c.I), xst(nd + k + xoff, c.D);
+                    }
+                    if (pass == 0) kM[u] = c.M, kI[u] = c.I, kD[u] = c.D, kK[u] = k;
+                    if (c.M != 0u) {
+                        mlo = imin2(mlo, k), mhi = imax2(mhi, k);
+                        if (k == Ak && (int)c.M >= m) term = 1, h_final = c.M;  // wfa.go:235-239
+                        const int d = lean_dist(c.M, k, n, m);
+                        if (d >= 0) mind = imin2(mind, d), maxd = imax2(maxd, d), fvm = imin2(fvm, k), lvm = imax2(lvm, k);
+                    }
+                }
+            }
+            mlo = wave_min(mlo), mhi = wave_max(mhi), mind = wave_min(mind), maxd = wave_max(maxd);
+            fvm = wave_min(fvm), lvm = wave_max(lvm);
+            {
+                const unsigned long long bt = __ballot(term);
+                if (bt != 0ull && lane == 0) red[2] = 1;
+                if (term) red[10] = (int)h_final;  // (one cell of the team sits on the final diagonal)
+            }
+            if (lane == 0) {
+                atomicMin(&red[0], mlo), atomicMax(&red[1], mhi), atomicMin(&red[3], mind), atomicMax(&red[12], maxd);
+                atomicMin(&red[13], fvm), atomicMax(&red[14], lvm);
+            }
+            __syncthreads();
+            if (stripe_mode) {
+                // the new rows enter the rings (the slots of the oldest rows: everybody has read them), and the stripe's two edge
+                // cells go to the exchange rows for the neighbours
+                uint32_t *const nM = lrow(0, si), *const nI = lrow(1, si), *const nD = lrow(2, si);
+#pragma unroll
+                for (int u = 0; u < TC_U; u++)
+                    if (tid + u * G < SWd) nM[tid + u * G + 1] = kM[u], nI[tid + u * G + 1] = kI[u], nD[tid + u * G + 1] = kD[u];
+                if (mode == TC_STRIPE_T) {
+#pragma unroll
+                    for (int u = 0; u < TC_U; u++) {
+                        const int j = tid + u * G;
+                        if (j == 0 || j == SWd - 1) {  // the stripe's first / last cell: its neighbours' halo
+                            const int kx = KBw + j + xoff;
+                            if (kx >= 0 && kx < (int)X.xw) xst(xrow(0, si) + kx, kM[u]), xst(xrow(1, si) + kx, kI[u]), xst(xrow(2, si) + kx, kD[u]);
+                        }
+                    }
+                } else if (tid < 6) {  // (one stripe: nothing lies beyond it)
+                    lrow(tid >> 1, si)[(tid & 1) ? SWd + 1 : 0] = 0u;
+                }
+            }
+            // ---- exchange 1: the row's ranges, termination, the distances
+            if (tid == 0) {
+                red[16] = red[0], red[17] = -red[1], red[18] = red[2] ? -1 : 0, red[19] = red[3], red[20] = -red[12], red[21] = red[13], red[22] = -red[14],
+                red[23] = red[2] ? -red[10] : 0;
+            }
+            if (team_now) {
+                exchange();
+                if (aborted) return;
+            } else {
+                __syncthreads();
+            }
+            mlo = red[16], mhi = -red[17], term = red[18] != 0, mind = red[19], maxd = -red[20], fvm = red[21], lvm = -red[22];
+            if (term) h_final = (uint32_t)(-red[23]);
+            top += (uint64_t)W;
+            n_ent = si + 1;
+
+            // ---- reduce (wfa.go:461-540): the band wf-adaptive keeps, from the cells' owners
+            int nlo = mlo, nhi = mhi;
+            if (!term && P.adaptive && mhi >= mlo && (mhi - mlo + 1) >= (int)P.min_wf_len && mind != INT32_MAX && maxd - mind > (int)P.max_dist_diff) {
+                const int thr = mind + (int)P.max_dist_diff;
+                int f_ok = INT32_MAX, l_ok = INT32_MIN, hmin = INT32_MAX;
+                auto p2 = [&](uint32_t hM, int k) {
+                    const int d = lean_dist(hM, k, n, m);
+                    if (d >= 0) {
+                        if (d <= thr) f_ok = imin2(f_ok, k), l_ok = imax2(l_ok, k);
+                    } else if (hM != 0u) {
+                        hmin = imin2(hmin, k);  // a present cell at / past a sequence end
+                    }
+                };
+#pragma unroll
+                for (int u = 0; u < TC_U; u++)
+                    if (kK[u] != INT32_MIN) p2(kM[u], kK[u]);
+                if (!stripe_mode)
+                    for (int pass = 1; pass < npass; pass++)
+#pragma unroll
+                        for (int u = 0; u < TC_U; u++) {
+                            const int64_t i = x0i + ((int64_t)pass * TC_U + u) * xstep;
+                            if (i < W) p2(xld(xrow(0, si) + lo + (int)i + xoff), lo + (int)i);
+                        }
+                f_ok = wave_min(f_ok), l_ok = wave_max(l_ok), hmin = wave_min(hmin);
+                if (lane == 0) atomicMin(&red[4], f_ok), atomicMax(&red[5], l_ok), atomicMin(&red[11], hmin);
+                __syncthreads();
+                if (tid == 0) {
+                    red[16] = red[4], red[17] = -red[5], red[18] = red[11];
+#pragma unroll
+                    for (int f = 19; f < 24; f++) red[f] = 0;
+                }
+                if (team_now) {
+                    exchange();
+                    if (aborted) return;
+                } else {
+                    __syncthreads();
+                }
+                const int first_ok = red[16], last_ok = -red[17], hitmin = red[18];
+                if (hitmin >= first_ok) {
+                    // wfa.go:509-511 with no present-but-unusable cell below first_ok: the entries between the last leading failure
+                    // and first_ok are holes, and dropping or keeping a hole is the same row
+                    nlo = first_ok, nhi = last_ok;
+                } else {
+                    // _lo: one past the last valid entry before the first non-failing one (wfa.go:503-516)
+                    int lead = INT32_MIN;
+                    auto p3 = [&](uint32_t hM, int k) {
+                        if (k < first_ok && lean_dist(hM, k, n, m) >= 0) lead = imax2(lead, k);
+                    };
+#pragma unroll
+                    for (int u = 0; u < TC_U; u++)
+                        if (kK[u] != INT32_MIN) p3(kM[u], kK[u]);
+                    if (!stripe_mode)
+                        for (int pass = 1; pass < npass; pass++)
+#pragma unroll
+                            for (int u = 0; u < TC_U; u++) {
+                                const int64_t i = x0i + ((int64_t)pass * TC_U + u) * xstep;
+                                if (i < W) p3(xld(xrow(0, si) + lo + (int)i + xoff), lo + (int)i);
+                            }
+                    lead = wave_max(lead);
+                    if (lane == 0) atomicMax(&red[7], lead);
+                    __syncthreads();
+                    if (tid == 0) {
+                        red[16] = -red[7];
+#pragma unroll
+                        for (int f = 17; f < 24; f++) red[f] = 0;
+                    }
+                    if (team_now) {
+                        exchange();
+                        if (aborted) return;
+                    } else {
+                        __syncthreads();
+                    }
+                    lead = -red[16];
+                    nlo  = (lead != INT32_MIN) ? lead + 1 : mlo;
+                    nhi  = last_ok;  // wfa.go:517-524
+                }
+                // Delete of wfa.go:526-535: the cells outside [nlo, nhi] stop existing -- in the rings (zero), in the census
+                if (stripe_mode) {
+                    uint32_t *const nM = lrow(0, si), *const nI = lrow(1, si), *const nD = lrow(2, si);
+#pragma unroll
+                    for (int u = 0; u < TC_U; u++)
+                        if (kK[u] != INT32_MIN && (kK[u] < nlo || kK[u] > nhi)) {
+                            my_cells -= (kM[u] != 0u) + (kI[u] != 0u) + (kD[u] != 0u);
+                            nM[tid + u * G + 1] = 0u, nI[tid + u * G + 1] = 0u, nD[tid + u * G + 1] = 0u;  // (kK[u] exists: inside the stripe)
+                            kM[u] = 0u;
+                        }
+                } else {
+                    for (int pass = 0; pass < npass; pass++)
+#pragma unroll
+                        for (int u = 0; u < TC_U; u++) {
+                            const int64_t i = x0i + ((int64_t)pass * TC_U + u) * xstep;
+                            const int     k = lo + (int)i;
+                            if (i < W && (k < nlo || k > nhi)) {
+                                my_cells -= (xld(xrow(0, si) + k + xoff) != 0u) + (xld(xrow(1, si) + k + xoff) != 0u) + (xld(xrow(2, si) + k + xoff) != 0u);
+                                if (pass == 0) kM[u] = 0u;
+                            }
+                        }
+                }
+            }
+            // ---- the cells that end the reference's end-cell scan (semi-global, wfa.go:301-361): nearest to the final diagonal on
+            // either side, among the cells the row keeps
+            if (!glob) {
+                uint32_t kd = 0xFFFFFFFFu, ku = 0xFFFFFFFFu;
+                auto p4 = [&](uint32_t hM, int k) {
+                    if (k < nlo || k > nhi) return;
+                    const uint32_t cls = lean_endclass(hM, k, n, m);
+                    if (cls == 0u) return;
+                    if (k <= Ak) kd = umin2(kd, lean_endkey(cls, (uint32_t)(Ak - k)));
+                    else ku = umin2(ku, lean_endkey(cls, (uint32_t)(k - Ak - 1)));
+                };
+#pragma unroll
+                for (int u = 0; u < TC_U; u++)
+                    if (kK[u] != INT32_MIN) p4(kM[u], kK[u]);
+                if (!stripe_mode)
+                    for (int pass = 1; pass < npass; pass++)
+#pragma unroll
+                        for (int u = 0; u < TC_U; u++) {
+                            const int64_t i = x0i + ((int64_t)pass * TC_U + u) * xstep;
+                            if (i < W) p4(xld(xrow(0, si) + lo + (int)i + xoff), lo + (int)i);
+                        }
+                if (__ballot(kd != 0xFFFFFFFFu || ku != 0xFFFFFFFFu) != 0ull) {
+                    kd = (uint32_t)wave_min((int)(kd ^ 0x80000000u)) ^ 0x80000000u;
+                    ku = (uint32_t)wave_min((int)(ku ^ 0x80000000u)) ^ 0x80000000u;
+                    if (lane == 0) {
+                        // (the entry's key words were set to "none" before exchange 1 of this step; the pair's last barrier is fenced)
+                        if (kd != 0xFFFFFFFFu) atomicMin(dir_ptr(si) + 5, kd);
+                        if (ku != 0xFFFFFFFFu) atomicMin(dir_ptr(si) + 6, ku);
+                    }
+                }
+            }
+            if (nhi >= nlo) put_ent(si, base + (uint64_t)(nlo - lo), nlo, nhi - nlo + 1);
+            else put_ent(si, 0ull, 0, 0);
+            if (term) {
+                done    = true;
+                s_final = s;
+                break;
+            }
+            __syncthreads();
+        }
+
+        // ---- a pair that ends with workgroup 0 alone: wake the parked workgroups
+        const bool alone = mode == TC_STRIPE_S || mode == TC_WAVE;
+        if (alone && lead_wg && T > 1u) {
+            if (tid == 0) {
+                ast(&ctl[5], s_final), ast(&ctl[10], (done ? 1u : 0u) | (overflow ? 2u : 0u));
+                ast(&ctl[4], (uint32_t)TEAM_CMD_DONE);
+            }
+            team_barrier();
+            if (aborted) return;
+        }
+        // ---- stored cells across the team
+        if (tid == 0) red[26] = 0, red[27] = 0;
+        __syncthreads();
+        {
+            unsigned long long wsum = my_cells;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) wsum += __shfl_xor(wsum, o, 64);
+            if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(&red[26]), wsum);
+        }
+        __syncthreads();
+        if (tid == 0) atomicAdd(reinterpret_cast<unsigned long long *>(ctl + 12), *reinterpret_cast<unsigned long long *>(&red[26]));
+        team_barrier();  // every row, the directory with its end-cell keys and the cell count are visible to workgroup 0
+        if (aborted) return;
+        if (!lead_wg) continue;  // what follows is workgroup 0's (the others wait at the next pair's barrier)
+
+        if (overflow || !done) {
+            if (tid == 0) {
+                rec[REC_STATUS] = ST_REDO_ARENA;
+                push_redo(P, pair, ST_REDO_ARENA);
+                if (paged) page_free_all();
+            }
+            continue;
+        }
+        // ---- the semi-global end cell (backtraceStartPosistion, wfa.go:270-375): the hit at the LOWEST score that has one; a score has
+        // one when the nearest scan-ending cell above the final diagonal is a hit, else when the nearest one at / below it is
+        // (the upward scan overrides the downward one at equal score, wfa.go:319-361)
+        uint32_t minS = s_final, h_start = h_final;
+        int      lastK = Ak;
+        if (!glob) {
+            unsigned long long best = ~0ull;
+            for (uint32_t idx = (uint32_t)tid; idx <= s_final / g; idx += G) {
+                const uint32_t *const dp = dir_ptr(idx);
+                if ((int)dp[3] <= 0) continue;  // !M.HasScore(_s)
+                const uint32_t kd = dp[5], ku = dp[6];
+                uint32_t key = 0xFFFFFFFFu;
+                int      kk  = 0;
+                if (ku != 0xFFFFFFFFu && (ku & 3u) != 3u) key = ku, kk = Ak + 1 + (int)(ku >> 2);
+                else if (kd != 0xFFFFFFFFu && (kd & 3u) != 3u) key = kd, kk = Ak - (int)(kd >> 2);
+                if (key != 0xFFFFFFFFu) {
+                    const unsigned long long v = ((unsigned long long)idx << 32) | (uint32_t)(kk + 0x40000000) << 1 | (key & 1u);
+                    best = v < best ? v : best;
+                }
+            }
+            // (minimum over the workgroup: score index first)
+            unsigned long long wb = best;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const unsigned long long ot = __shfl_xor(wb, o, 64);
+                wb = ot < wb ? ot : wb;
+            }
+            unsigned long long *const lb = reinterpret_cast<unsigned long long *>(&red[28]);
+            if (tid == 0) *lb = ~0ull;
+            __syncthreads();
+            if (lane == 0 && wb != ~0ull) atomicMin(lb, wb);
+            __syncthreads();
+            const unsigned long long fb = *lb;
+            if (fb != ~0ull) {
+                minS  = (uint32_t)(fb >> 32) * g;
+                lastK = (int)(((uint32_t)fb >> 1) & 0x7FFFFFFFu) - 0x40000000;
+                h_start = (fb & 1ull) ? (uint32_t)m : (uint32_t)(n + lastK);  // hit through h == m / through v == n
+            }
+            __syncthreads();
+        }
+        if (X.dbg && tid == 0) X.dbg[0] = n_ent, X.dbg[1] = s_final, X.dbg[2] = minS, X.dbg[3] = (uint32_t)lastK;
+
+        // ---- backtrace: wave 0 walks together over the compact rows; process() by its 64 lanes
+        uint64_t scratch_end = 0;
+        bool     no_scratch  = false;
+        if (paged) {
+            const uint64_t need = 2ull * ((uint64_t)n + (uint64_t)m + 8ull);
+            if (tid == 0) red[8] = (page_end - top < need) ? (int)page_alloc() : -2;
+            __syncthreads();
+            const int r8 = red[8];
+            if (r8 == -1) no_scratch = true;
+            else if (r8 >= 0) top = (uint64_t)(uint32_t)r8 << P.page_words_log2, page_end = top + page_words;
+            scratch_end = page_end;
+            __syncthreads();
+        }
+        if (tid < 64) {
+            bool ok = !no_scratch;
+            if (ok) {
+                DirCompactViewWave cv;
+                cv.init(A, cap, g, n_ent, ring);
+                const uint64_t scratch0 = (top + 1ull) & ~1ull;
+                const uint64_t dir_lo   = scratch_end != 0ull ? scratch_end : cap - (uint64_t)DIR_WORDS * (uint64_t)n_ent;
+                const uint64_t room     = dir_lo > scratch0 ? (dir_lo - scratch0) / 2ull : 0ull;
+                OpsWriter ow;
+                ow.init(reinterpret_cast<uint64_t *>(A + scratch0), (uint32_t)(room > 0xFFFFFFFFull ? 0xFFFFFFFFull : room));
+                TraceOut to;
+                back_trace_compact(cv, n, m, minS, lastK, h_start, x, P.o, e, ow, to, !glob);
+                ok = !ow.overflow;
+                if (ok) {
+                    const uint32_t L = ow.n;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    uint32_t off_lo = 0, off_hi = 0;
+                    if (lane == 0) {
+                        const uint64_t o = atomicAdd(P.ops_cursor, (unsigned long long)L);
+                        off_lo = (uint32_t)o, off_hi = (uint32_t)(o >> 32);
+                    }
+                    const uint64_t off = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)off_lo) |
+                                         ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)off_hi) << 32);
+                    int firstM = INT32_MAX, lastM = INT32_MIN;
+                    for (uint32_t i = (uint32_t)lane; i < L; i += 64u) {
+                        const uint64_t op = ow.buf[L - 1 - i];
+                        if ((uint32_t)(op >> 32) == 'M') firstM = imin2(firstM, (int)i), lastM = imax2(lastM, (int)i);
+                        if (off + i < P.ops_cap) P.ops[off + i] = op;
+                    }
+                    firstM = wave_min(firstM), lastM = wave_max(lastM);
+                    const uint32_t begin = firstM != INT32_MAX ? (uint32_t)firstM : 0u, end = firstM != INT32_MAX ? (uint32_t)lastM : 0u;
+                    unsigned int *const acc = reinterpret_cast<unsigned int *>(red);
+                    if (lane == 0) acc[0] = acc[1] = acc[2] = acc[3] = 0u;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    uint32_t alen = 0, matches = 0, gaps = 0, regions = 0;
+                    for (uint32_t i = begin + (uint32_t)lane; i <= end && i < L; i += 64u) {
+                        const uint64_t op  = ow.buf[L - 1 - i];
+                        const uint32_t cnt = (uint32_t)op, o = (uint32_t)(op >> 32);
+                        alen += cnt;
+                        if (o == 'M') matches += cnt;
+                        else if (o == 'I' || o == 'D') gaps += cnt, regions++;
+                    }
+                    atomicAdd(&acc[0], alen), atomicAdd(&acc[1], matches), atomicAdd(&acc[2], gaps), atomicAdd(&acc[3], regions);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane == 0) {
+                        rec[REC_STATUS] = ST_OK, rec[REC_SCORE] = to.score;
+                        rec[REC_TBEGIN] = (uint32_t)to.tbegin, rec[REC_TEND] = (uint32_t)to.tend;
+                        rec[REC_QBEGIN] = (uint32_t)to.qbegin, rec[REC_QEND] = (uint32_t)to.qend;
+                        rec[REC_ALIGN_LEN] = acc[0], rec[REC_MATCHES] = acc[1], rec[REC_GAPS] = acc[2], rec[REC_GAP_REGIONS] = acc[3];
+                        rec[REC_OPS_LEN] = L, rec[REC_OPS_OFF_LO] = (uint32_t)off, rec[REC_OPS_OFF_HI] = (uint32_t)(off >> 32);
+                        rec[REC_CELLS_LO] = ald(&ctl[12]), rec[REC_CELLS_HI] = ald(&ctl[13]), rec[REC_N_SCORES] = s_final;
+                    }
+                }
+            }
+            if (!ok && tid == 0) {
+                rec[REC_STATUS] = ST_REDO_ARENA;
+                push_redo(P, pair, ST_REDO_ARENA);
+            }
+            if (paged && tid == 0 && !X.dbg) page_free_all();
+        }
+    }
+}
+
+}  // namespace wfa
