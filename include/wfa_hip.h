@@ -121,7 +121,8 @@ typedef struct {
                                   10 = wfa_lane_kernel (a lane per pair, short reads), 11 / 12 / 13 = wfa_blk_kernel<16 / 32 / 64, .., LONG>
                                   (sliding sequence windows: reads of any length, 64 / 128 / 256 diagonals), 14 / 15 = wfa_blk_kernel<64, 1, false, 1 / 2, .., LONG>
                                   (a wave per pair, one / two diagonals per lane: batches too small to fill the GPU),
-                                  16 = wfa_blk_kernel<64, 1, false, 1, false, false> (wfahip_align_pair: one launch, forward pass and backtrace) */
+                                  16 = wfa_blk_kernel<64, 1, false, 1, false, false> (wfahip_align_pair: one launch, forward pass and backtrace),
+                                  17 = wfa_teamc_kernel (wide wavefronts: a team of workgroups per pair, one backtrace word per diagonal) */
     uint32_t ladder_start_level; /* arena level the long-pair ladder of this call started on (0 unless a learned hint applied) */
 } wfahip_timing;
 

@@ -1625,6 +1625,21 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             }
             for (uint32_t t = 0; t < team_n; t++)
                 if (tc[(size_t)t * TEAM_CTL_STRIDE + 1] != 0u) {
+                    if (team_c && std::getenv("WFAHIP_DEBUG_TIMING")) {  // (wfa_teamc_kernel: where every workgroup of the team was)
+                        const uint32_t *tr = &tc[(size_t)t * TEAM_CTL_STRIDE + TC_TRACE_OFF];
+                        for (uint32_t w = 0; w < team_T && w < (uint32_t)TC_MAX_T; w++) {
+                            std::fprintf(stderr, "[wfahip]   team %u workgroup %u: last mode change at score %u (%u -> %u), last park wake at %u (cmd %u), last wave exit at %u (flags %u), "
+                                         "pair left at %u (mode %u done %u overflow %u alone %u); ctl: cmd %u score %u flags %u\n", t, w, tr[2 * TC_MAX_T + w] >> 8, tr[2 * TC_MAX_T + w] & 15u,
+                                         (tr[2 * TC_MAX_T + w] >> 4) & 15u, tr[3 * TC_MAX_T + w] >> 8, tr[3 * TC_MAX_T + w] & 255u, tr[4 * TC_MAX_T + w] >> 8, tr[4 * TC_MAX_T + w] & 255u,
+                                         tr[5 * TC_MAX_T + w] >> 8, tr[5 * TC_MAX_T + w] & 15u, (tr[5 * TC_MAX_T + w] >> 4) & 1u, (tr[5 * TC_MAX_T + w] >> 5) & 1u, (tr[5 * TC_MAX_T + w] >> 6) & 1u,
+                                         tc[(size_t)t * TEAM_CTL_STRIDE + 4], tc[(size_t)t * TEAM_CTL_STRIDE + 5], tc[(size_t)t * TEAM_CTL_STRIDE + 10]);
+                            if ((tr[w] >> 24) == 0xABu)
+                                std::fprintf(stderr, "[wfahip]   team %u workgroup %u: left after an aborted barrier at wfa_teamc.hpp:%u, exchanges %u\n", t, w, tr[w] & 0xFFFFFFu, tr[TC_MAX_T + w]);
+                            else
+                                std::fprintf(stderr, "[wfahip]   team %u workgroup %u: score %u phase %u mode %u, exchanges %u, barrier count %u\n", t, w, tr[w] >> 8,
+                                             tr[w] & 15u, (tr[w] >> 4) & 15u, tr[TC_MAX_T + w], tc[(size_t)t * TEAM_CTL_STRIDE]);
+                        }
+                    }
                     std::snprintf(ctx->last_error, sizeof ctx->last_error, "team kernel: barrier timeout in team %u", t);
                     return WFAHIP_ERR_INTERNAL;
                 }

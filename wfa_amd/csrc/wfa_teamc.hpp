@@ -44,7 +44,9 @@ constexpr int      TC_MAX_T    = 64;               // workgroups per team (one l
 // per team in global memory: the control words of wfa_team_kernel (TEAM_CTL_WORDS: [0] barrier count [1] abort [2] work index
 // [3] XCC mask [4] command [5] score [6..7] arena top [8..9] - [10] end flags [11] on one XCD [12..13] stored cells
 // [112..114] page hand-over [115] KB [116] mode) followed by two sets of exchange slots
-constexpr int      TC_CTL_WORDS = TEAM_CTL_WORDS + 2 * TC_MAX_T * TC_SLOT_U64 * 2;
+constexpr int      TC_TRACE_OFF = TEAM_CTL_WORDS + 2 * TC_MAX_T * TC_SLOT_U64 * 2;  // then a progress word per workgroup: (score << 8) | phase
+constexpr int      TC_CTL_WORDS = TC_TRACE_OFF + 8 * TC_MAX_T;                       // ... the sequence number of its latest exchange, and the latest
+                                                                                     // word of a few kinds (slot s at TC_MAX_T * (2 + s)): mode changes, wave mode, the end of the pair
 enum : uint32_t { TC_XBUF = 0, TC_STRIPE_T = 1, TC_STRIPE_S = 2, TC_WAVE = 3 };
 
 struct TcArgs {
@@ -185,6 +187,22 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
     uint32_t *const ctl = X.team_ctl + (uint64_t)team * TC_CTL_WORDS;
     unsigned long long *const slots = reinterpret_cast<unsigned long long *>(ctl + TEAM_CTL_WORDS);  // [set][workgroup][TC_SLOT_U64]
     uint32_t *const xb  = X.xbuf + (uint64_t)team * X.xbuf_words;
+    // where every workgroup is: written by its thread 0 as it goes (one fire-and-forget store per phase), printed by the host when a
+    // barrier has timed out -- a hang then names the score and the phase of each workgroup instead of nothing
+    uint32_t *const trace = ctl + TC_TRACE_OFF;
+#define TC_ABORT_RET                                                                                                    \
+    do {                                                                                                                \
+        if (tid == 0) __hip_atomic_store(trace + b, 0xAB000000u | (uint32_t)__LINE__, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+        return;                                                                                                         \
+    } while (0)
+#define TC_TRACEN(slot, sc, ph)                                                   \
+    do {                                                                          \
+        if (tid == 0) __hip_atomic_store(trace + TC_MAX_T * (2 + (slot)) + b, ((uint32_t)(sc) << 8) | (uint32_t)(ph), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+    } while (0)
+#define TC_TRACE(sc, ph)                                                          \
+    do {                                                                          \
+        if (tid == 0) __hip_atomic_store(trace + b, ((uint32_t)(sc) << 8) | (uint32_t)(ph), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+    } while (0)
     const bool      paged = P.page_ctl != nullptr;
     uint32_t *const A     = paged ? P.arena : P.arena + (uint64_t)team * P.arena_words;
     const uint64_t  cap   = paged ? P.arena_words - (uint64_t)team * P.dir_region_words : P.arena_words;
@@ -225,7 +243,7 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
         aborted = red[31] != 0;
     };
     // EXCHANGE: barrier + reduction in one.  Every workgroup hands in eight ints (red[16 .. 23], written by its thread 0 before
-    // the call); when the call returns red[16 .. 23] hold the MINIMUM of each over the team (a maximum travels negated, a flag
+    // the call); when the call returns red[16 .. 23] hold the MINIMUM of each over the team (a maximum travels as its complement, a flag
     // as 0 / -1).  Thread 0 stores the eight values tagged with this exchange's sequence number into the workgroup's slot (eight
     // 64-bit relaxed atomic stores: no word can be seen half-written); wave 0 polls the T slots, a workgroup per lane, until
     // every word carries the number, and reduces.  Two sets of slots alternate: a workgroup can only overwrite a set two exchanges
@@ -236,15 +254,20 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
     auto exchange = [&]() {
         __syncthreads();
         xseq += 1u;
+        if (tid == 0) __hip_atomic_store(trace + TC_MAX_T + b, xseq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (T == 1u) return;  // (a team of one: the values are the reduction)
         if (tid < 64) {
             unsigned long long *const set = slots + (size_t)(xseq & 1u) * TC_MAX_T * TC_SLOT_U64;
             if (tid == 0) {
                 if (strict && !xl) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                // (a team on one XCD: plain stores -- the words stay in that XCD's L2, where the others' polling loads find them;
+                // a write-through store would drop them from it and send every poll to the memory side)
 #pragma unroll
-                for (int f = 0; f < TC_SLOT_U64; f++)
-                    __hip_atomic_store(set + (size_t)b * TC_SLOT_U64 + f, ((unsigned long long)xseq << 32) | (uint32_t)red[16 + f], __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
+                for (int f = 0; f < TC_SLOT_U64; f++) {
+                    const unsigned long long wv = ((unsigned long long)xseq << 32) | (uint32_t)red[16 + f];
+                    if (xl) set[(size_t)b * TC_SLOT_U64 + f] = wv;
+                    else __hip_atomic_store(set + (size_t)b * TC_SLOT_U64 + f, wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
             int      v[TC_SLOT_U64];
             uint32_t spins = 0;
@@ -282,7 +305,7 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
     if (X.tpx != 0u) {
         if (tid == 0) atomicOr(&ctl[3], 1u << (__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | ((4 - 1) << 11)) & 15u));
         team_barrier();
-        if (aborted) return;
+        if (aborted) TC_ABORT_RET;
         const uint32_t seen = ald(&ctl[3]);
         xl = xl_ok && (seen & (seen - 1u)) == 0u;
         if (b == 0 && tid == 0) ctl[11] = xl ? 1u : 0u;
@@ -341,7 +364,7 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
             ast(&ctl[2], w0), ast(&ctl[12], 0u), ast(&ctl[13], 0u), ast(&ctl[4], (uint32_t)TEAM_CMD_NONE);
         }
         team_barrier();
-        if (aborted) return;
+        if (aborted) TC_ABORT_RET;
         const uint32_t wi = ald(&ctl[2]);
         if (wi >= P.n_work) return;
         const uint32_t pair = P.work ? P.work[wi] : wi;
@@ -479,10 +502,12 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
             if (s == 0u) lo = INT32_MAX, hi = INT32_MIN;
             if (seeded) lo = imin2(lo, seed_lo), hi = imax2(hi, seed_hi);
             const int64_t W = (hi >= lo) ? ((int64_t)hi - lo + 1) : 0;
+            TC_TRACE(s, 1u | (mode << 4));
 
             // ---- room for the row (one word per diagonal) and its directory entry
             if (!paged) {
                 if (top + (uint64_t)W + (uint64_t)DIR_WORDS * (si + 2) > cap) {
+                    TC_TRACE(s, 11u);
                     overflow = true;
                     break;
                 }
@@ -496,7 +521,7 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
                     if (mode == TC_XBUF || mode == TC_STRIPE_T) {
                         if (lead_wg && tid == 0) ast(&ctl[112], page_alloc());
                         team_barrier();
-                        if (aborted) return;
+                        if (aborted) TC_ABORT_RET;
                         pg = ald(&ctl[112]);
                     } else {
                         if (tid == 0) red[8] = (int)page_alloc();
@@ -532,13 +557,15 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
             const bool moved = stripe_now && want == mode &&
                                (lo < KB || (int64_t)hi >= (int64_t)KB + capd || (mode == TC_STRIPE_T && sw_t + 128 <= (int64_t)SWd));
             if (want != mode || moved) {
+                TC_TRACE(s, 2u | (want << 4));
+                TC_TRACEN(0, s, mode | (want << 4));
                 if (rings_in_lds) {  // the rings go to the exchange rows, where every mode can pick them up
                     dump_rings(si);
                     rings_in_lds = false;
                 }
                 if (was_team && T > 1u) {
                     team_barrier();  // (fenced: the dumps, and in XBUF mode the rows, are visible to whoever loads them next)
-                    if (aborted) return;
+                    if (aborted) TC_ABORT_RET;
                 } else {
                     __threadfence();
                     __syncthreads();
@@ -548,8 +575,10 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
                     bool resumed = false;
                     for (;;) {
                         team_barrier();
-                        if (aborted) return;
+                        if (aborted) TC_ABORT_RET;
                         const uint32_t cmd = ald(&ctl[4]);
+                        TC_TRACE(s, 6u | (cmd << 4));
+                        TC_TRACEN(1, s, cmd);
                         if (cmd == TEAM_CMD_DONE) {
                             s_final = ald(&ctl[5]);
                             const uint32_t fl = ald(&ctl[10]);
@@ -584,7 +613,7 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
                         ast(&ctl[4], (uint32_t)TEAM_CMD_RESUME);
                     }
                     team_barrier();
-                    if (aborted) return;
+                    if (aborted) TC_ABORT_RET;
                     // (like the workgroups it has woken: the loop head of score s again, as a team, the rings in the exchange rows --
                     // every workgroup then takes the same path into the mode the row asks for)
                     mode = TC_XBUF;
@@ -758,6 +787,8 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
                     const unsigned int *const ur = reinterpret_cast<const unsigned int *>(red);
                     s = ur[0], top = (uint64_t)ur[1] | ((uint64_t)ur[2] << 32), n_ent = ur[3];
                     const uint32_t wf = ur[4];
+                    TC_TRACE(s, 7u | (wf << 4));
+                    TC_TRACEN(2, s, wf);
                     if (wf & WAVE_DONE) done = true, s_final = s, h_final = ur[5];
                     if ((wf & WAVE_OVERFLOW) && !(paged && s / g + 2u <= dir_entries)) overflow = true;
                 }
@@ -795,6 +826,7 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
             }
             __syncthreads();
 
+            TC_TRACE(s, 3u | (mode << 4));
             // ---- P1: next + seeds + extend, the row's backtrace words, partial reductions
             int mlo = INT32_MAX, mhi = INT32_MIN, term = 0, mind = INT32_MAX, maxd = INT32_MIN, fvm = INT32_MAX, lvm = INT32_MIN;
             uint32_t kM[TC_U], kI[TC_U], kD[TC_U];
@@ -896,17 +928,20 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
             }
             // ---- exchange 1: the row's ranges, termination, the distances
             if (tid == 0) {
-                red[16] = red[0], red[17] = -red[1], red[18] = red[2] ? -1 : 0, red[19] = red[3], red[20] = -red[12], red[21] = red[13], red[22] = -red[14],
-                red[23] = red[2] ? -red[10] : 0;
+                // (a maximum travels as its complement ~v: order-reversing like the negation, and "none" -- INT32_MIN -- has one)
+                red[16] = red[0], red[17] = ~red[1], red[18] = red[2] ? -1 : 0, red[19] = red[3], red[20] = ~red[12], red[21] = red[13], red[22] = ~red[14],
+                red[23] = red[2] ? ~red[10] : INT32_MAX;
             }
+            TC_TRACE(s, 4u | (mode << 4));
             if (team_now) {
                 exchange();
-                if (aborted) return;
+                if (aborted) TC_ABORT_RET;
             } else {
                 __syncthreads();
             }
-            mlo = red[16], mhi = -red[17], term = red[18] != 0, mind = red[19], maxd = -red[20], fvm = red[21], lvm = -red[22];
-            if (term) h_final = (uint32_t)(-red[23]);
+            TC_TRACE(s, 5u | (mode << 4));
+            mlo = red[16], mhi = ~red[17], term = red[18] != 0, mind = red[19], maxd = ~red[20], fvm = red[21], lvm = ~red[22];
+            if (term) h_final = (uint32_t)(~red[23]);
             top += (uint64_t)W;
             n_ent = si + 1;
 
@@ -937,17 +972,17 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
                 if (lane == 0) atomicMin(&red[4], f_ok), atomicMax(&red[5], l_ok), atomicMin(&red[11], hmin);
                 __syncthreads();
                 if (tid == 0) {
-                    red[16] = red[4], red[17] = -red[5], red[18] = red[11];
+                    red[16] = red[4], red[17] = ~red[5], red[18] = red[11];
 #pragma unroll
                     for (int f = 19; f < 24; f++) red[f] = 0;
                 }
                 if (team_now) {
                     exchange();
-                    if (aborted) return;
+                    if (aborted) TC_ABORT_RET;
                 } else {
                     __syncthreads();
                 }
-                const int first_ok = red[16], last_ok = -red[17], hitmin = red[18];
+                const int first_ok = red[16], last_ok = ~red[17], hitmin = red[18];
                 if (hitmin >= first_ok) {
                     // wfa.go:509-511 with no present-but-unusable cell below first_ok: the entries between the last leading failure
                     // and first_ok are holes, and dropping or keeping a hole is the same row
@@ -972,17 +1007,17 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
                     if (lane == 0) atomicMax(&red[7], lead);
                     __syncthreads();
                     if (tid == 0) {
-                        red[16] = -red[7];
+                        red[16] = ~red[7];
 #pragma unroll
                         for (int f = 17; f < 24; f++) red[f] = 0;
                     }
                     if (team_now) {
                         exchange();
-                        if (aborted) return;
+                        if (aborted) TC_ABORT_RET;
                     } else {
                         __syncthreads();
                     }
-                    lead = -red[16];
+                    lead = ~red[16];
                     nlo  = (lead != INT32_MIN) ? lead + 1 : mlo;
                     nhi  = last_ok;  // wfa.go:517-524
                 }
@@ -1052,13 +1087,14 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
 
         // ---- a pair that ends with workgroup 0 alone: wake the parked workgroups
         const bool alone = mode == TC_STRIPE_S || mode == TC_WAVE;
+        TC_TRACEN(3, s, mode | (done ? 16u : 0u) | (overflow ? 32u : 0u) | (alone ? 64u : 0u));
         if (alone && lead_wg && T > 1u) {
             if (tid == 0) {
                 ast(&ctl[5], s_final), ast(&ctl[10], (done ? 1u : 0u) | (overflow ? 2u : 0u));
                 ast(&ctl[4], (uint32_t)TEAM_CMD_DONE);
             }
             team_barrier();
-            if (aborted) return;
+            if (aborted) TC_ABORT_RET;
         }
         // ---- stored cells across the team
         if (tid == 0) red[26] = 0, red[27] = 0;
@@ -1071,8 +1107,10 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
         }
         __syncthreads();
         if (tid == 0) atomicAdd(reinterpret_cast<unsigned long long *>(ctl + 12), *reinterpret_cast<unsigned long long *>(&red[26]));
+        TC_TRACE(s_final, 9u);
         team_barrier();  // every row, the directory with its end-cell keys and the cell count are visible to workgroup 0
-        if (aborted) return;
+        if (aborted) TC_ABORT_RET;
+        TC_TRACE(s_final, 10u);
         if (!lead_wg) continue;  // what follows is workgroup 0's (the others wait at the next pair's barrier)
 
         if (overflow || !done) {
