@@ -749,11 +749,12 @@ def test_teamc_kernel_words_and_results(built, slack):
     import wfa_amd as w
     from oracle import oracle as O
     blob, qo, ql, to, tl = w.generate_pairs(seed=41, n_pairs=2, length=2600, error_rate=0.08)
+    blob, qo, ql, to, tl = w.generate_pairs(seed=41, n_pairs=1, length=2600 if slack == 3 else 1500, error_rate=0.08)
     for pen in ((4, 6, 2), (2, 4, 2), (6, 4, 2)):
-        g = int(np.gcd.reduce([pen[0], pen[1] + pen[2], pen[2]]))
         for glob, ad in ((False, (10, 50, 1)), (True, None), (False, None), (True, (10, 50, 1))):
             oa = O.Aligner(_oracle_params(glob, ad, pen))
-            for wgs, solo_max, wave in ((2, 64, 1), (2, 4096, 1), (1, 4096, 0), (3, 0, 1)):
+            # (the default penalties see every shape of team; the others the two that differ most)
+            for wgs, solo_max, wave in (((2, 64, 1), (2, 4096, 1), (1, 4096, 0), (3, 0, 1)) if pen == (4, 6, 2) else ((2, 64, 1), (3, 0, 1))):
                 al = _aligner(glob, ad, pen)
                 for k, v in (("packed", 0), ("team_min_len", 1), ("team_wgs", wgs), ("team_solo_max", solo_max), ("team_wave", wave),
                              ("team_slack", slack), ("arena_poison", 1)):
@@ -1582,7 +1583,8 @@ def test_long_window_kernel_batch(built):
 
 
 @pytest.mark.parametrize("opts", [{}, {"mem_limit": 4 << 30}, {"team_xcd": 2}, {"team_xcd": 1}, {"team_paged": 0}])
-def test_team_kernel_paged_arena(built, opts):
+@pytest.mark.parametrize("compact", [1, 0])
+def test_team_kernel_paged_arena(built, opts, compact):
     """The team kernel with its arena as ONE pool of pages shared by up to eight teams (round 4): ten 20 kbp semi-global
     pairs (wide seeded wavefronts, then wave mode) through more teams than the four slots of old, over a poisoned pool;
     on a device made to look small (mem_limit: the pool runs dry, pairs are handed on and re-run with fewer teams); with the
@@ -1593,10 +1595,11 @@ def test_team_kernel_paged_arena(built, opts):
     want = O.align_batch(_oracle_params(False, (10, 50, 1)), *data, n_threads=8)
     al = _aligner(False, (10, 50, 1))
     al.set_option("arena_poison", 1)
+    al.set_option("team_compact", compact)  # (round 5: wfa_teamc_kernel shares the pool and its page protocol)
     for k, v in opts.items():
         al.set_option(k, v)
     for rep in range(2):
         got = al.align_arrays(*data)
-        assert al.last_timing().main_kernel_kind == 7  # wfa_team_kernel
+        assert al.last_timing().main_kernel_kind == (17 if compact else 7)  # wfa_teamc_kernel / wfa_team_kernel
         assert_batch_equal(got, want, f"paged arena {opts} pass {rep}")
     al.close()

@@ -183,6 +183,7 @@ struct wfahip_ctx {
     int64_t       opt_unpack_all           = 0;              // 1: host entries with packed input expand ALL of it to bytes on the device first (rounds 2-3)
     int64_t       opt_team_compact         = 1;              // 1: wide wavefronts on wfa_teamc_kernel (round 5: one backtrace word per diagonal in the arena, the rows the next
                                                              // steps source in LDS stripes, reductions travelling with the barrier: wfa_teamc.hpp); 0: wfa_team_kernel
+    int64_t       opt_team_fast            = 1;              // ... 1: its stripe modes run their steady state in the short step (0: every step takes the general one; tests compare the two)
     int64_t       opt_team_slack           = 1024;           // ... diagonals of room on either side when its stripes are positioned (tests: a few, so that the axis moves often)
     bool          dbg_teamc                = false;          // wfahip_debug_team_compact is running: the one-pair debug launch takes wfa_teamc_kernel
     DevBuf        xbuf;                                      // ... its exchange rows
@@ -569,6 +570,8 @@ static int set_option_impl(wfahip_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_team_paged = value;
     else if (k == "team_compact")
         ctx->opt_team_compact = value;
+    else if (k == "team_fast")
+        ctx->opt_team_fast = value;
     else if (k == "team_slack")
         ctx->opt_team_slack = value > 0 ? value : 1;
     else if (k == "arena_poison")
@@ -1444,8 +1447,8 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
         size_t lds_c  = 0;
         if (team_T > 0 && ctx->opt_team_compact != 0 && (!debug_single || ctx->dbg_teamc) && max_len < (1u << 27)) {
             const uint32_t rm = std::max(P.x, P.oe) / P.g, re = P.e / P.g;
-            lds_c = (2ull * cfg.lds_seq_words + 32 + TEAM_RING * (sizeof(DirEnt) / 4)) * 4ull + (size_t)team_wave_rows * 3 * 64 * 4 +
-                    (size_t)(rm + 2 * re) * TC_ROWW * 4;
+            lds_c = (2ull * cfg.lds_seq_words + TC_RED + TEAM_RING * (sizeof(DirEnt) / 4)) * 4ull + (size_t)team_wave_rows * 3 * 64 * 4 +
+                    (size_t)64 * TC_U * 4 + (size_t)(rm + 2 * re) * TC_ROWW * 4;
             team_c = lds_c <= LDS_MAX_BYTES;
         }
         if (debug_single && ctx->dbg_teamc && !team_c) return WFAHIP_ERR_UNSUPPORTED;
@@ -1573,6 +1576,7 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                 X.solo_max = (uint32_t)std::max<int64_t>(0, ctx->opt_team_solo_max), X.wave_rows = team_wave_rows;
                 X.strict = (uint32_t)(ctx->opt_team_strict != 0) | (xmap && ctx->opt_team_xcd >= 2 ? 4u : 0u);
                 X.slack  = (uint32_t)std::min<int64_t>(std::max<int64_t>(1, ctx->opt_team_slack), 1 << 20);
+                X.fast   = ctx->opt_team_fast != 0 ? 1u : 0u;
                 X.dbg    = debug_single ? d_ctrl + 4 : nullptr;
                 HIP_TRY(wfa_launch_teamc(P, X, job.mode, grid_t, lds_c, st));
             } else {
@@ -1605,7 +1609,17 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             std::vector<uint32_t> tc((size_t)team_n * TEAM_CTL_STRIDE);
             HIP_TRY(hipMemcpy(tc.data(), ctx->team_ctl.p, tc.size() * 4, hipMemcpyDeviceToHost));
 #ifdef WFA_TEAM_STAMPS
-            for (uint32_t t = 0; t < team_n; t++) {
+            for (uint32_t t = 0; team_c && t < team_n; t++) {  // wfa_teamc_kernel's phases (its own numbering, wfa_teamc.hpp)
+                const unsigned long long *a = reinterpret_cast<const unsigned long long *>(&tc[(size_t)t * TEAM_CTL_STRIDE + 64]);
+                const double steps = (double)std::max<unsigned long long>(1, a[16] + a[17] + a[18]);
+                std::fprintf(stderr, "[teamc %u] steps: stripe(team) %llu xbuf %llu stripe(solo) %llu, ring loads %llu | us: head %.0f cells %.0f wave-red %.0f wait-wg %.0f rings+edges %.0f "
+                             "exchange1 %.0f band-ends %.0f exchange2 %.0f tail %.0f | wave mode %.0f backtrace %.0f | per wide step %.2f us\n", t, a[16], a[17], a[18], a[19],
+                             a[0] / 100.0, a[1] / 100.0, a[2] / 100.0, a[3] / 100.0, a[4] / 100.0, a[5] / 100.0, a[6] / 100.0, a[7] / 100.0, a[8] / 100.0, a[9] / 100.0, a[10] / 100.0,
+                             (a[0] + a[1] + a[2] + a[3] + a[4] + a[5] + a[6] + a[7] + a[8] + a[11] + a[12] + a[13] + a[14]) / 100.0 / steps);
+                std::fprintf(stderr, "[teamc %u] head in detail, us: ring entries + ranges %.0f, room %.0f, first barrier %.0f, mode + scratch %.0f, second barrier %.0f\n", t, a[11] / 100.0,
+                             a[12] / 100.0, a[13] / 100.0, a[14] / 100.0, a[0] / 100.0);
+            }
+            for (uint32_t t = 0; !team_c && t < team_n; t++) {
                 const unsigned long long *a = reinterpret_cast<const unsigned long long *>(&tc[(size_t)t * TEAM_CTL_STRIDE + 64]);
                 std::fprintf(stderr, "[team %u] us: P1 %.0f  barriers %.0f  P2 %.0f  P3 %.0f  tail(team) %.0f  solo steps %.0f  end search %.0f  backtrace %.0f  wave mode %.0f | steps: wave %llu solo %llu team %llu\n", t,
                              a[0] / 100.0, a[1] / 100.0, a[2] / 100.0, a[3] / 100.0, a[4] / 100.0, a[5] / 100.0, a[6] / 100.0, a[7] / 100.0,

@@ -35,11 +35,15 @@
 
 namespace wfa {
 
-constexpr int      TC_THREADS  = 1024;
+#ifndef WFA_TC_THREADS
+#define WFA_TC_THREADS 1024
+#endif
+constexpr int      TC_THREADS  = WFA_TC_THREADS;
 constexpr int      TC_STRIPE   = 4096;             // diagonals of a workgroup's stripe
 constexpr int      TC_U        = TC_STRIPE / TC_THREADS;
 constexpr int      TC_ROWW     = TC_STRIPE + 2;    // LDS words of a ring row: the stripe and a halo cell at either end
-constexpr int      TC_SLOT_U64 = 8;                // a workgroup's exchange slot: eight (sequence number, value) words
+constexpr int      TC_SLOT_U64 = 16;               // a workgroup's exchange slot: (sequence number, value) words -- eight values to reduce, six edge cells
+constexpr int      TC_RED      = 64;               // ints of the workgroup's scratch in LDS (red[])
 constexpr int      TC_MAX_T    = 64;               // workgroups per team (one lane of the polling wave each)
 // per team in global memory: the control words of wfa_team_kernel (TEAM_CTL_WORDS: [0] barrier count [1] abort [2] work index
 // [3] XCC mask [4] command [5] score [6..7] arena top [8..9] - [10] end flags [11] on one XCD [12..13] stored cells
@@ -55,7 +59,7 @@ struct TcArgs {
     uint64_t  xbuf_words;
     uint32_t  xw;          // words of one exchange row (>= n + m of the longest pair)
     uint32_t  T, n_teams, tpx;  // workgroups per team; teams; teams per XCD (0: team = blockIdx / T)
-    uint32_t  solo_max, wave_rows, strict, slack;
+    uint32_t  solo_max, wave_rows, strict, slack, fast;
     uint32_t *dbg;         // debug (one pair): [0] directory entries [1] final score [2] start score [3] start diagonal
 };
 
@@ -166,10 +170,11 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t *const lq   = lds;
     uint32_t *const lt   = lds + P.lds_seq_words;
-    int *const      red  = reinterpret_cast<int *>(lds + 2 * (MODE == 0 ? P.lds_seq_words : 0));  // 32 ints
-    DirEnt *const   ring = reinterpret_cast<DirEnt *>(red + 32);                                   // TEAM_RING entries
+    int *const      red  = reinterpret_cast<int *>(lds + 2 * (MODE == 0 ? P.lds_seq_words : 0));  // TC_RED ints
+    DirEnt *const   ring = reinterpret_cast<DirEnt *>(red + TC_RED);                               // TEAM_RING entries
     uint32_t *const wring = reinterpret_cast<uint32_t *>(ring + TEAM_RING);                       // wave mode: [row][component][diagonal & 63]
-    uint32_t *const lrows = wring + X.wave_rows * 3u * 64u;                                       // stripe mode: ring rows of TC_ROWW words
+    uint32_t *const wsc   = wring + X.wave_rows * 3u * 64u;                                       // stripe mode: wave 0's backtrace words of the row (64 x TC_U)
+    uint32_t *const lrows = wsc + 64 * TC_U;                                                      // stripe mode: ring rows of TC_ROWW words
 
     const int      tid = threadIdx.x, lane = tid & 63;
     const uint32_t T   = X.T;
@@ -195,6 +200,9 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
         if (tid == 0) __hip_atomic_store(trace + b, 0xAB000000u | (uint32_t)__LINE__, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
         return;                                                                                                         \
     } while (0)
+    // (-DWFA_TC_TRACE: a store in front of a barrier is waited for by it -- the trace costs a few hundred nanoseconds per step -- so the
+    // shipped build only records where a workgroup LEFT after a barrier that timed out)
+#ifdef WFA_TC_TRACE
 #define TC_TRACEN(slot, sc, ph)                                                   \
     do {                                                                          \
         if (tid == 0) __hip_atomic_store(trace + TC_MAX_T * (2 + (slot)) + b, ((uint32_t)(sc) << 8) | (uint32_t)(ph), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
@@ -203,6 +211,14 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
     do {                                                                          \
         if (tid == 0) __hip_atomic_store(trace + b, ((uint32_t)(sc) << 8) | (uint32_t)(ph), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
     } while (0)
+#else
+#define TC_TRACEN(slot, sc, ph) \
+    do {                        \
+    } while (0)
+#define TC_TRACE(sc, ph) \
+    do {                 \
+    } while (0)
+#endif
     const bool      paged = P.page_ctl != nullptr;
     uint32_t *const A     = paged ? P.arena : P.arena + (uint64_t)team * P.arena_words;
     const uint64_t  cap   = paged ? P.arena_words - (uint64_t)team * P.dir_region_words : P.arena_words;
@@ -216,10 +232,32 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
 
     uint32_t bar_target = 0, xseq = 0;
     bool     aborted = false, xl = false;
+    // Workgroup barrier for LDS data only: __syncthreads() also waits for every global store the wave has issued (s_waitcnt
+    // vmcnt(0) in front of s_barrier), and a step has nine barriers -- the row's backtrace words, which nobody reads before the
+    // pair's last (fenced) barrier, would be waited for at the next of them.  Where global data IS handed over (the stripe's edge
+    // cells, rows in XBUF mode) the storing waves wait for their stores themselves, in front of the exchange.
+    const auto lds_barrier = []() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+#ifdef WFA_TEAM_STAMPS  // diagnostic build (scripts/team_stamps.sh): time per phase of workgroup 0's wave 0, summed over the team's pairs
+    unsigned long long tacc[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memrealtime();
+#define TC_STAMP(i)                                                     \
+    do {                                                                \
+        const unsigned long long _t = __builtin_amdgcn_s_memrealtime(); \
+        tacc[i] += _t - tprev;                                          \
+        tprev = _t;                                                     \
+    } while (0)
+#define TC_COUNT(i) (tacc[i]++)
+#else
+#define TC_STAMP(i) \
+    do {            \
+    } while (0)
+#define TC_COUNT(i) \
+    do {            \
+    } while (0)
+#endif
     const auto ald = [](const uint32_t *p_) { return __hip_atomic_load(p_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     const auto ast = [](uint32_t *p_, uint32_t v_) { __hip_atomic_store(p_, v_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     // counted barrier with fences (mode switches, the start and the end of a pair): wfa_team_kernel's
-    auto team_barrier = [&]() {
+    auto team_barrier = [&]() __attribute__((always_inline)) {
         __syncthreads();
         if (tid == 0) {
             bar_target += T;
@@ -251,54 +289,95 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
     // edge cells of its stripe in the exchange rows, rows in XBUF mode -- is ordered before the slot by the release (memory-side
     // protocol), or is in the XCD's L2 once the stores have been acknowledged, which the barrier in front waits for (teams on
     // one XCD; see wfa_team.hpp).
-    auto exchange = [&]() {
-        __syncthreads();
+    // edges: the payload also carries the six words of the stripe's first and last cell (red[32 .. 37], written by their owners
+    // before the call: M, I, D of the first, then of the last), and every workgroup gets its neighbours' -- the halo cells of its
+    // stripe -- back in red[40 .. 45] (M, I, D below the stripe, then above it; zero at the team's ends): the k +- 1 sources that
+    // cross a stripe's edge (wfa.go:579-650) travel with the barrier, no load, no store and no wait of their own.
+    // exchange_core: the exchange without the barrier in front (the caller has ordered red[16 ..] and red[32 ..] before wave 0's
+    // stores itself); nf = how many of the eight values travel.
+    // A slot is 128 bytes, sixteen (sequence number, value) words: [0 .. 7] the values, [8 .. 10] the stripe's first cell (M, I, D),
+    // [12 .. 14] its last.  Lane f of wave 0 stores word f -- one store instruction, one line.  Polling, lane j loads workgroup j's
+    // values as 16-byte pieces, and lanes 0 .. 3 the two pieces of each neighbour's edge cell; ALL the loads of a poll are issued
+    // before the one wait (inline assembly: the compiler puts a wait behind every atomic load of its own -- fourteen round trips a poll).
+    auto exchange_core = [&](int nf, bool edges) __attribute__((always_inline)) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         xseq += 1u;
+#ifdef WFA_TC_TRACE
         if (tid == 0) __hip_atomic_store(trace + TC_MAX_T + b, xseq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (T == 1u) return;  // (a team of one: the values are the reduction)
-        if (tid < 64) {
+#endif
+        if (T != 1u && tid < 64) {  // (a team of one: the values are the reduction)
             unsigned long long *const set = slots + (size_t)(xseq & 1u) * TC_MAX_T * TC_SLOT_U64;
-            if (tid == 0) {
+            if (lane < 16 && (lane < 8 ? lane < nf : edges)) {
                 if (strict && !xl) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 // (a team on one XCD: plain stores -- the words stay in that XCD's L2, where the others' polling loads find them;
                 // a write-through store would drop them from it and send every poll to the memory side)
-#pragma unroll
-                for (int f = 0; f < TC_SLOT_U64; f++) {
-                    const unsigned long long wv = ((unsigned long long)xseq << 32) | (uint32_t)red[16 + f];
-                    if (xl) set[(size_t)b * TC_SLOT_U64 + f] = wv;
-                    else __hip_atomic_store(set + (size_t)b * TC_SLOT_U64 + f, wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+                const int src = lane < 8 ? 16 + lane : (lane < 11 ? 32 + (lane - 8) : (lane >= 12 && lane < 15 ? 35 + (lane - 12) : 31));
+                const unsigned long long wv = ((unsigned long long)xseq << 32) | (uint32_t)((lane == 11 || lane == 15) ? 0 : red[src]);
+                if (xl) set[(size_t)b * TC_SLOT_U64 + lane] = wv;
+                else __hip_atomic_store(set + (size_t)b * TC_SLOT_U64 + lane, wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            int      v[TC_SLOT_U64];
+            const unsigned long long *const mine = set + (size_t)((uint32_t)lane < T ? lane : 0) * TC_SLOT_U64;
+            // lanes 0, 1: the last cell of workgroup b - 1 (words 12 .. 15); lanes 2, 3: the first cell of workgroup b + 1 (words 8 .. 11)
+            const int  nb     = lane < 2 ? (int)b - 1 : (int)b + 1;
+            const bool has_nb = edges && lane < 4 && nb >= 0 && nb < (int)T;
+            const unsigned long long *const edge = has_nb ? set + (size_t)nb * TC_SLOT_U64 + (lane < 2 ? 12 + 2 * lane : 8 + 2 * (lane - 2)) : mine;
+            u32x4    w0, w1, w2 = {0u, 0u, 0u, 0u}, w3 = {0u, 0u, 0u, 0u}, we = {0u, 0u, 0u, 0u};
             uint32_t spins = 0;
             bool     bad   = false;
             for (;;) {
-                bool ok = true;
-#pragma unroll
-                for (int f = 0; f < TC_SLOT_U64; f++) {
-                    const unsigned long long w =
-                        (uint32_t)lane < T ? __hip_atomic_load(set + (size_t)lane * TC_SLOT_U64 + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                           : ((unsigned long long)xseq << 32) | 0x7FFFFFFFull;
-                    ok   = ok && (uint32_t)(w >> 32) == xseq;
-                    v[f] = (int)(uint32_t)w;
+                if (nf > 4) {
+                    asm volatile(
+                        "global_load_dwordx4 %0, %5, off sc1\n\tglobal_load_dwordx4 %1, %5, off offset:16 sc1\n\tglobal_load_dwordx4 %2, %5, off offset:32 sc1\n\t"
+                        "global_load_dwordx4 %3, %5, off offset:48 sc1\n\tglobal_load_dwordx4 %4, %6, off sc1\n\ts_waitcnt vmcnt(0)"
+                        : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3), "=&v"(we)
+                        : "v"(mine), "v"(edge)
+                        : "memory");
+                } else {
+                    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+                                 : "=&v"(w0), "=&v"(w1)
+                                 : "v"(mine)
+                                 : "memory");
                 }
+                bool ok = true;
+                if ((uint32_t)lane < T) {
+                    ok = w0.y == xseq && (nf < 2 || w0.w == xseq) && (nf < 3 || w1.y == xseq) && (nf < 4 || w1.w == xseq);
+                    if (nf > 4) ok = ok && w2.y == xseq && (nf < 6 || w2.w == xseq) && (nf < 7 || w3.y == xseq) && (nf < 8 || w3.w == xseq);
+                }
+                if (has_nb) ok = ok && we.y == xseq && we.w == xseq;
                 if (__ballot(!ok) == 0ull) break;
                 if ((++spins & 255u) == 0u && (spins > (TEAM_SPIN_LIMIT >> 2) || ald(&ctl[1]) != 0u)) {
                     atomicExch(&ctl[1], 1u);
                     bad = true;
                     break;
                 }
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(1);
             }
+            const bool in = (uint32_t)lane < T;
+            const int  v[8] = {in ? (int)w0.x : INT32_MAX, in ? (int)w0.z : INT32_MAX, in ? (int)w1.x : INT32_MAX, in ? (int)w1.z : INT32_MAX,
+                               in ? (int)w2.x : INT32_MAX, in ? (int)w2.z : INT32_MAX, in ? (int)w3.x : INT32_MAX, in ? (int)w3.z : INT32_MAX};
 #pragma unroll
-            for (int f = 0; f < TC_SLOT_U64; f++) {
+            for (int f = 0; f < 8; f++) {
+                if (f >= nf) break;
                 const int r = wave_min(v[f]);
                 if (lane == 0) red[16 + f] = r;
             }
+            if (edges && lane < 4) {
+                // the halo cells of this workgroup's stripe: M, I, D below it (red[40 .. 42]) and above it (red[43 .. 45]); zero at the team's ends
+                const int ex = has_nb ? (int)we.x : 0, ez = has_nb ? (int)we.z : 0;
+                if (lane == 0) red[40] = ex, red[41] = ez;
+                if (lane == 1) red[42] = ex;
+                if (lane == 2) red[43] = ex, red[44] = ez;
+                if (lane == 3) red[45] = ex;
+            }
             if (lane == 0) red[31] = bad ? 1 : 0;
         }
-        __syncthreads();
+        lds_barrier();
         aborted = red[31] != 0;
+    };
+    auto exchange = [&](bool drain, bool edges) __attribute__((always_inline)) {
+        if (drain) __syncthreads();  // (every wave's global stores acknowledged: rows in the exchange rows)
+        else lds_barrier();          // (nothing global is handed over)
+        exchange_core(8, edges);
     };
 
     // ---- where the team's workgroups sit (teams per XCD): one bit per XCC id seen
@@ -422,7 +501,7 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
         bool       rings_in_lds = false;  // the LDS rings hold the rows of the scores before s (else they are in the exchange rows)
         auto dir_ptr = [&](uint32_t idx) { return A + cap - (uint64_t)DIR_WORDS * (idx + 1); };
         const DirEnt none = {0ull, 0, 0, 0u, {0u, 0u, 0u}};
-        auto put_ent = [&](uint32_t idx, uint64_t base, int lo_, int w_) {
+        auto put_ent = [&](uint32_t idx, uint64_t base, int lo_, int w_) __attribute__((always_inline)) {
             if (tid == 0) {
                 DirEnt d;
                 d.base = base, d.lo = lo_, d.w = w_, d.stride = 0u, d.pad[0] = d.pad[1] = d.pad[2] = 0u;
@@ -478,8 +557,291 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
             }
         };
 
+        // the mode a row of W diagonals at score s_ asks for (every active workgroup computes the same W)
+        auto want_mode = [&](int64_t W, uint32_t s_) __attribute__((always_inline)) -> uint32_t {
+            const int64_t capT = (int64_t)T * TC_STRIPE - 2, capS = (int64_t)TC_STRIPE - 2;
+            uint32_t want = W > capT ? (uint32_t)TC_XBUF
+                            : (W > (int64_t)X.solo_max || W > capS) && T > 1u ? (uint32_t)TC_STRIPE_T
+                            : (W <= 64 && X.wave_rows != 0u && s_ != 0u) ? (uint32_t)TC_WAVE
+                                                                        : (W > capS ? (uint32_t)TC_XBUF : (uint32_t)TC_STRIPE_S);
+            if (T == 1u && want == TC_STRIPE_T) want = W > capS ? (uint32_t)TC_XBUF : (uint32_t)TC_STRIPE_S;
+            return want;
+        };
+        // a stripe mode whose axis no longer holds the row [lo, hi] is left and entered again; so is a team whose stripes have
+        // become 128 diagonals wider than the row needs (the step takes what the workgroup with the most cells per thread takes;
+        // SWd - 128 is a multiple of 64: "the width a team would pick now is at least 128 smaller" without a division per step)
+        auto moved_now = [&](int lo, int hi, int64_t W) __attribute__((always_inline)) -> bool {
+            if (mode != TC_STRIPE_T && mode != TC_STRIPE_S) return false;
+            const int64_t capd = mode == TC_STRIPE_T ? (int64_t)T * SWd : (int64_t)SWd;
+            const int64_t slk  = (int64_t)X.slack < 256 ? (int64_t)X.slack : 256;
+            return lo < KB || (int64_t)hi >= (int64_t)KB + capd || (mode == TC_STRIPE_T && SWd > 128 && W + 2 * slk <= (int64_t)T * (SWd - 128));
+        };
+
         uint32_t s = 0;
         for (;; s += g) {
+            // ---- FAST STEPS: a stripe mode in its steady state -- every source score has its ring slot, no seeds, the row fits the
+            // stripes as they are dealt, the page and the directory have room.  The same step as the general one below, on fewer
+            // instructions and five workgroup barriers instead of nine: the ring slots and the score index are counters, not divisions;
+            // the row's ranges come from ballots (a wave's cells are consecutive diagonals), not wave reductions; the workgroup's
+            // partial results are collected in one of two scratch sets that alternate (the idle one is reset on the side); thread 0
+            // builds the exchange's payload right behind the barrier that completes the set.  Anything else leaves the loop: the general
+            // head below decides about score s.
+            if ((mode == TC_STRIPE_T || mode == TC_STRIPE_S) && rings_in_lds && s > x && s >= oe && X.fast != 0u) {
+                const auto rfl = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+                const bool team_now = mode == TC_STRIPE_T;
+                const int  KBw = (int)rfl((uint32_t)(KB + (team_now ? (int)b * SWd : 0))), SWf = (int)rfl((uint32_t)SWd), wbase = (int)rfl((uint32_t)(tid - lane));
+                s = rfl(s);
+                uint32_t si = rfl(s / g), pM = si % RM, pE = si % RE;
+                const int2 *const ring_lw = reinterpret_cast<const int2 *>(ring);
+                int *acc = red + 48, *accn = red;  // (the general step uses red[0 .. 14] itself and resets it in its head)
+                // reset values of a scratch set: minima start at INT32_MAX, maxima (1, 5, 7, 12, 14) at INT32_MIN, flags (2, 10) at zero
+                const auto acc_reset = [](int i) { return (i == 2 || i == 10) ? 0 : ((i == 1 || i == 5 || i == 7 || i == 12 || i == 14) ? INT32_MIN : INT32_MAX); };
+                if (tid < 16) acc[tid] = acc_reset(tid);
+                lds_barrier();
+                for (;;) {
+                    // ---- head: the three source rows' ranges -> this row's
+                    const int2 vx = ring_lw[((si - dx) % TEAM_RING) * 4u + 1u], vo = ring_lw[((si - doe) % TEAM_RING) * 4u + 1u], ve = ring_lw[((si - de) % TEAM_RING) * 4u + 1u];
+                    const int  xlo = (int)rfl((uint32_t)vx.x), xw_ = (int)rfl((uint32_t)vx.y), olo = (int)rfl((uint32_t)vo.x), ow_ = (int)rfl((uint32_t)vo.y);
+                    const int  elo = (int)rfl((uint32_t)ve.x), ew_ = (int)rfl((uint32_t)ve.y);
+                    int lo = INT32_MAX, hi = INT32_MIN;
+                    if (xw_ > 0) lo = imin2(lo, xlo - 1), hi = imax2(hi, xlo + xw_);
+                    if (ow_ > 0) lo = imin2(lo, olo - 1), hi = imax2(hi, olo + ow_);
+                    if (ew_ > 0) lo = imin2(lo, elo - 1), hi = imax2(hi, elo + ew_);
+                    lo = imax2(lo, -(n - 1)), hi = imin2(hi, m - 1);  // wfa.go:562-563
+                    if (hi < lo) break;
+                    const int W = hi - lo + 1;
+                    if (want_mode((int64_t)W, s) != mode || moved_now(lo, hi, (int64_t)W)) break;
+                    if (!paged ? top + (uint64_t)W + (uint64_t)DIR_WORDS * (si + 2) > cap
+                               : (si + 2u > dir_entries || (uint64_t)W > page_words || top + (uint64_t)W > page_end))
+                        break;
+                    const uint64_t base = top;
+                    uint32_t *const rowC = A + base;
+                    // ring slots: row si - r of the M ring sits r slots behind pM (mod RM); the I / D rows of si - de share the slot the
+                    // new row takes (de = RE rows back)
+                    const uint32_t sO = pM >= doe ? pM - doe : pM + RM - doe, sX = pM >= dx ? pM - dx : pM + RM - dx;
+                    const uint32_t *const lO = lrows + (size_t)sO * TC_ROWW, *const lXr = lrows + (size_t)sX * TC_ROWW;
+                    uint32_t *const nM = lrows + (size_t)pM * TC_ROWW, *const nI = lrows + (size_t)(RM + pE) * TC_ROWW, *const nD = lrows + (size_t)(RM + RE + pE) * TC_ROWW;
+                    const bool hO = ow_ > 0, hX = xw_ > 0, hE = ew_ > 0;
+                    if (lead_wg && !glob && tid == 0) ast(dir_ptr(si) + 5, 0xFFFFFFFFu), ast(dir_ptr(si) + 6, 0xFFFFFFFFu);
+                    TC_STAMP(0);
+
+                    // ---- P1: next + extend, the row's backtrace words; ranges from ballots
+                    int      mlo = INT32_MAX, mhi = INT32_MIN, fvm = INT32_MAX, lvm = INT32_MIN;  // (wave-uniform)
+                    int      mind = INT32_MAX, maxd = INT32_MIN;                                  // (per lane)
+                    bool     termw = false, endany = false;
+                    uint32_t kM[TC_U], kI[TC_U], kD[TC_U];
+#pragma unroll
+                    for (int u = 0; u < TC_U; u++) {
+                        const int  j = tid + u * G, k = KBw + j;
+                        const bool on = j < SWf && k >= lo && k <= hi;
+                        LCell c = {0u, 0u, 0u, 0u};
+                        int   d = -1;
+                        if (on) {
+                            // (the rings hold zero wherever a row has no cell: no range checks -- but a row of no cells has not cleared its slot)
+                            const uint32_t sa = hO ? lO[j] : 0u, sb = hE ? nI[j] : 0u, sc_ = hO ? lO[j + 2] : 0u, sd = hE ? nD[j + 2] : 0u, sx = hX ? lXr[j + 1] : 0u;
+                            c   = lean_next(sa, sb, sc_, sd, sx, k, n, m);
+                            c.M = lean_extend<MODE>(sv, c.M, k);
+                            // (wave 0 polls the exchanges: loads that would queue behind its stores -- its words wait in LDS for the end of the step)
+                            if (tid < 64) wsc[tid + 64 * u] = c.wd;
+                            else cst(rowC + (k - lo), c.wd);
+                            my_cells += (c.M != 0u) + (c.I != 0u) + (c.D != 0u);
+                            d = lean_dist(c.M, k, n, m);
+                            if (d >= 0) mind = imin2(mind, d), maxd = imax2(maxd, d);
+                            if (c.M != 0u && k == Ak && (int)c.M >= m) termw = true, h_final = c.M;  // wfa.go:235-239
+                            endany = endany || (c.M != 0u && (d < 0 || (int)c.M == k));
+                        }
+                        kM[u] = c.M, kI[u] = c.I, kD[u] = c.D;
+                        const unsigned long long bM = __ballot(c.M != 0u), bV = __ballot(d >= 0);
+                        const int kb = KBw + wbase + u * G;
+                        if (bM != 0ull) {
+                            if (mlo == INT32_MAX) mlo = kb + (int)__builtin_ctzll(bM);
+                            mhi = kb + 63 - (int)__builtin_clzll(bM);
+                        }
+                        if (bV != 0ull) {
+                            if (fvm == INT32_MAX) fvm = kb + (int)__builtin_ctzll(bV);
+                            lvm = kb + 63 - (int)__builtin_clzll(bV);
+                        }
+                        if (team_now) {  // the stripe's first / last cell: its neighbours' halo, handed over with the exchange
+                            if (j == 0) red[32] = (int)c.M, red[33] = (int)c.I, red[34] = (int)c.D;
+                            if (j == SWf - 1) red[35] = (int)c.M, red[36] = (int)c.I, red[37] = (int)c.D;
+                        }
+                    }
+                    TC_STAMP(1);
+                    if (fvm != INT32_MAX) mind = wave_min(mind), maxd = wave_max(maxd);
+                    if (__ballot(termw) != 0ull) {
+                        if (lane == 0) acc[2] = 1;
+                        if (termw) acc[10] = (int)h_final;  // (one cell of the team sits on the final diagonal)
+                    }
+                    if (lane == 0) {
+                        if (mlo != INT32_MAX) atomicMin(&acc[0], mlo), atomicMax(&acc[1], mhi);
+                        if (fvm != INT32_MAX) atomicMin(&acc[13], fvm), atomicMax(&acc[14], lvm), atomicMin(&acc[3], mind), atomicMax(&acc[12], maxd);
+                    }
+                    TC_STAMP(2);
+                    lds_barrier();  // (A) the workgroup's partial results are complete; everybody has read the rows whose slots the new row takes
+                    TC_STAMP(3);
+                    if (tid == 0) {
+                        // (a maximum travels as its complement ~v: order-reversing like the negation, and "none" -- INT32_MIN -- has one)
+                        red[16] = acc[0], red[17] = ~acc[1], red[18] = acc[2] ? -1 : 0, red[19] = acc[3], red[20] = ~acc[12], red[21] = acc[13], red[22] = ~acc[14],
+                        red[23] = acc[2] ? ~acc[10] : INT32_MAX;
+                        // (the directory keys of this score were reset in the head: acknowledged before the slot says the workgroup is here)
+                        if (lead_wg && !glob) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                    if (tid >= 64 && tid < 80) accn[tid - 64] = acc_reset(tid - 64);  // the other set, for the next step
+#pragma unroll
+                    for (int u = 0; u < TC_U; u++)
+                        if (tid + u * G < SWf) nM[tid + u * G + 1] = kM[u], nI[tid + u * G + 1] = kI[u], nD[tid + u * G + 1] = kD[u];
+                    if (!team_now && tid < 6) {  // (one stripe: nothing lies beyond it)
+                        uint32_t *const row = (tid >> 1) == 0 ? nM : ((tid >> 1) == 1 ? nI : nD);
+                        row[(tid & 1) ? SWf + 1 : 0] = 0u;
+                    }
+                    TC_STAMP(4);
+                    // ---- exchange 1: the row's ranges, termination, the distances (and the stripes' edge cells)
+                    if (team_now) {
+                        exchange_core(8, true);
+                        if (aborted) TC_ABORT_RET;
+                    } else {
+                        lds_barrier();
+                    }
+                    uint32_t halo = 0u;
+                    int      halo_k = 0;
+                    if (team_now && tid < 6) {  // the neighbours' edge cells of this row: the halo of its ring slots
+                        halo_k = (tid & 1) ? KBw + SWf : KBw - 1;
+                        halo   = (uint32_t)red[40 + 3 * (tid & 1) + (tid >> 1)];
+                    }
+                    TC_STAMP(5);
+                    const int  amlo = (int)rfl((uint32_t)red[16]), amhi = ~(int)rfl((uint32_t)red[17]), amind = (int)rfl((uint32_t)red[19]), amaxd = ~(int)rfl((uint32_t)red[20]);
+                    const bool term = rfl((uint32_t)red[18]) != 0u;
+                    if (term) h_final = ~rfl((uint32_t)red[23]);
+                    top += (uint64_t)W;
+                    n_ent = si + 1;
+
+                    // ---- reduce (wfa.go:461-540): the band wf-adaptive keeps, from the cells' owners
+                    int nlo = amlo, nhi = amhi;
+                    if (!term && P.adaptive && amhi >= amlo && (amhi - amlo + 1) >= (int)P.min_wf_len && amind != INT32_MAX && amaxd - amind > (int)P.max_dist_diff) {
+                        const int thr = amind + (int)P.max_dist_diff;
+                        int f_ok = INT32_MAX, l_ok = INT32_MIN, hmin = INT32_MAX;  // (wave-uniform)
+#pragma unroll
+                        for (int u = 0; u < TC_U; u++) {
+                            const int  j = tid + u * G, k = KBw + j;
+                            const bool on = j < SWf && k >= lo && k <= hi;
+                            const int  d = on ? lean_dist(kM[u], k, n, m) : -1;
+                            const unsigned long long bOk = __ballot(d >= 0 && d <= thr), bEnd = __ballot(on && d < 0 && kM[u] != 0u);
+                            const int kb = KBw + wbase + u * G;
+                            if (bOk != 0ull) {
+                                if (f_ok == INT32_MAX) f_ok = kb + (int)__builtin_ctzll(bOk);
+                                l_ok = kb + 63 - (int)__builtin_clzll(bOk);
+                            }
+                            if (bEnd != 0ull && hmin == INT32_MAX) hmin = kb + (int)__builtin_ctzll(bEnd);  // a present cell at / past a sequence end
+                        }
+                        if (lane == 0) {
+                            if (f_ok != INT32_MAX) atomicMin(&acc[4], f_ok), atomicMax(&acc[5], l_ok);
+                            if (hmin != INT32_MAX) atomicMin(&acc[11], hmin);
+                        }
+                        lds_barrier();  // (D)
+                        if (tid == 0) red[16] = acc[4], red[17] = ~acc[5], red[18] = acc[11];
+                        TC_STAMP(6);
+                        if (team_now) {
+                            exchange_core(3, false);
+                            if (aborted) TC_ABORT_RET;
+                        } else {
+                            lds_barrier();
+                        }
+                        TC_STAMP(7);
+                        const int first_ok = (int)rfl((uint32_t)red[16]), last_ok = ~(int)rfl((uint32_t)red[17]), hitmin = (int)rfl((uint32_t)red[18]);
+                        if (hitmin >= first_ok) {
+                            // wfa.go:509-511 with no present-but-unusable cell below first_ok: the entries between the last leading failure
+                            // and first_ok are holes, and dropping or keeping a hole is the same row
+                            nlo = first_ok, nhi = last_ok;
+                        } else {
+                            // _lo: one past the last valid entry before the first non-failing one (wfa.go:503-516)
+                            int lead = INT32_MIN;
+#pragma unroll
+                            for (int u = 0; u < TC_U; u++) {
+                                const int  j = tid + u * G, k = KBw + j;
+                                const bool on = j < SWf && k >= lo && k <= hi;
+                                if (on && k < first_ok && lean_dist(kM[u], k, n, m) >= 0) lead = imax2(lead, k);
+                            }
+                            lead = wave_max(lead);
+                            if (lane == 0) atomicMax(&acc[7], lead);
+                            lds_barrier();
+                            if (tid == 0) red[16] = ~acc[7];
+                            if (team_now) {
+                                exchange_core(1, false);
+                                if (aborted) TC_ABORT_RET;
+                            } else {
+                                lds_barrier();
+                            }
+                            lead = ~(int)rfl((uint32_t)red[16]);
+                            nlo  = (lead != INT32_MIN) ? lead + 1 : amlo;
+                            nhi  = last_ok;  // wfa.go:517-524
+                        }
+                        // Delete of wfa.go:526-535: the cells outside [nlo, nhi] stop existing -- in the rings (zero), in the census
+                        if (KBw + wbase < nlo || KBw + wbase + (TC_U - 1) * G + 63 > nhi) {
+#pragma unroll
+                            for (int u = 0; u < TC_U; u++) {
+                                const int  j = tid + u * G, k = KBw + j;
+                                const bool on = j < SWf && k >= lo && k <= hi;
+                                if (on && (k < nlo || k > nhi)) {
+                                    my_cells -= (kM[u] != 0u) + (nI[j + 1] != 0u) + (nD[j + 1] != 0u);
+                                    nM[j + 1] = 0u, nI[j + 1] = 0u, nD[j + 1] = 0u;
+                                    kM[u] = 0u;
+                                }
+                            }
+                        }
+                    }
+                    // ---- the cells that end the reference's end-cell scan (semi-global, wfa.go:301-361): nearest to the final diagonal on
+                    // either side, among the cells the row keeps
+                    if (!glob && __ballot(endany) != 0ull) {
+                        uint32_t kd = 0xFFFFFFFFu, ku = 0xFFFFFFFFu;
+#pragma unroll
+                        for (int u = 0; u < TC_U; u++) {
+                            const int  j = tid + u * G, k = KBw + j;
+                            const bool on = j < SWf && k >= lo && k <= hi && k >= nlo && k <= nhi;
+                            const uint32_t cls = on ? lean_endclass(kM[u], k, n, m) : 0u;
+                            if (cls != 0u) {
+                                if (k <= Ak) kd = umin2(kd, lean_endkey(cls, (uint32_t)(Ak - k)));
+                                else ku = umin2(ku, lean_endkey(cls, (uint32_t)(k - Ak - 1)));
+                            }
+                        }
+                        if (__ballot(kd != 0xFFFFFFFFu || ku != 0xFFFFFFFFu) != 0ull) {
+                            kd = (uint32_t)wave_min((int)(kd ^ 0x80000000u)) ^ 0x80000000u;
+                            ku = (uint32_t)wave_min((int)(ku ^ 0x80000000u)) ^ 0x80000000u;
+                            if (lane == 0) {
+                                if (kd != 0xFFFFFFFFu) atomicMin(dir_ptr(si) + 5, kd);
+                                if (ku != 0xFFFFFFFFu) atomicMin(dir_ptr(si) + 6, ku);
+                            }
+                        }
+                    }
+                    if (nhi >= nlo) put_ent(si, base + (uint64_t)(nlo - lo), nlo, nhi - nlo + 1);
+                    else put_ent(si, 0ull, 0, 0);
+                    // the halo cells of this row's ring slots: the neighbours' edge cells where the row keeps them
+                    if (team_now && tid < 6) {
+                        uint32_t *const row = (tid >> 1) == 0 ? nM : ((tid >> 1) == 1 ? nI : nD);
+                        row[(tid & 1) ? SWf + 1 : 0] = (nhi >= nlo && halo_k >= nlo && halo_k <= nhi) ? halo : 0u;
+                    }
+                    if (tid < 64) {  // (wave 0's share of the row's backtrace words)
+#pragma unroll
+                        for (int u = 0; u < TC_U; u++) {
+                            const int j = tid + u * G, k = KBw + j;
+                            if (j < SWf && k >= lo && k <= hi) cst(rowC + (k - lo), wsc[tid + 64 * u]);
+                        }
+                    }
+                    if (term) {
+                        done    = true;
+                        s_final = s;
+                        break;
+                    }
+                    lds_barrier();  // (G) the directory entry, the halo cells and the deletions, before the next head and its cells
+                    TC_STAMP(8);
+                    TC_COUNT(team_now ? 16 : 18);
+                    s += g, si += 1u;
+                    pM = pM + 1u == RM ? 0u : pM + 1u, pE = pE + 1u == RE ? 0u : pE + 1u;
+                    int *const t_ = acc;
+                    acc = accn, accn = t_;
+                }
+                if (done) break;
+                lds_barrier();  // (the general head resets red[0 .. 14]: nobody is still reading a scratch set)
+            }
             const uint32_t si = s / g;
             auto uni = [](DirEnt d) {
                 auto r = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
@@ -502,6 +864,7 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
             if (s == 0u) lo = INT32_MAX, hi = INT32_MIN;
             if (seeded) lo = imin2(lo, seed_lo), hi = imax2(hi, seed_hi);
             const int64_t W = (hi >= lo) ? ((int64_t)hi - lo + 1) : 0;
+            TC_STAMP(11);  // head: ring entries, ranges
             TC_TRACE(s, 1u | (mode << 4));
 
             // ---- room for the row (one word per diagonal) and its directory entry
@@ -536,26 +899,15 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
                     top = (uint64_t)pg << P.page_words_log2, page_end = top + page_words;
                 }
             }
-            __syncthreads();  // everybody has read the ring entries before the slot of this score is rewritten
+            TC_STAMP(12);  // head: room
+            lds_barrier();  // everybody has read the ring entries before the slot of this score is rewritten
+            TC_STAMP(13);  // head: first barrier
 
             // ---- the mode of this step (every active workgroup computes the same W)
-            const int64_t capT = (int64_t)T * TC_STRIPE - 2, capS = (int64_t)TC_STRIPE - 2;
-            uint32_t want = W > capT ? (uint32_t)TC_XBUF
-                            : (W > (int64_t)X.solo_max || W > capS) && T > 1u ? (uint32_t)TC_STRIPE_T
-                            : (W <= 64 && X.wave_rows != 0u && s != 0u) ? (uint32_t)TC_WAVE
-                                                                       : (W > capS ? (uint32_t)TC_XBUF : (uint32_t)TC_STRIPE_S);
-            if (T == 1u && want == TC_STRIPE_T) want = W > capS ? (uint32_t)TC_XBUF : (uint32_t)TC_STRIPE_S;
+            const uint32_t want = want_mode(W, s);
             const bool was_team = mode == TC_XBUF || mode == TC_STRIPE_T, will_team = want == TC_XBUF || want == TC_STRIPE_T;
-            // a stripe mode whose axis no longer holds the row is left and entered again
-            const bool stripe_now = mode == TC_STRIPE_T || mode == TC_STRIPE_S;
-            const int64_t capd = mode == TC_STRIPE_T ? (int64_t)T * SWd : (int64_t)SWd;
-            // the stripe width a team would pick for this row now: when the band has shrunk by 128 diagonals per workgroup the stripes
-            // are dealt anew (the step takes what the workgroup with the most cells per thread takes)
             const int64_t slk   = (int64_t)X.slack < 256 ? (int64_t)X.slack : 256;
-            int64_t       sw_t  = ((W + 2 * slk + (int64_t)T - 1) / (int64_t)T + 63) & ~63ll;
-            sw_t                = sw_t > TC_STRIPE ? TC_STRIPE : sw_t;
-            const bool moved = stripe_now && want == mode &&
-                               (lo < KB || (int64_t)hi >= (int64_t)KB + capd || (mode == TC_STRIPE_T && sw_t + 128 <= (int64_t)SWd));
+            const bool moved = want == mode && moved_now(lo, hi, W);
             if (want != mode || moved) {
                 TC_TRACE(s, 2u | (want << 4));
                 TC_TRACEN(0, s, mode | (want << 4));
@@ -622,12 +974,15 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
                 }
                 mode = want;
                 if (mode == TC_STRIPE_T || mode == TC_STRIPE_S) {
+                    uint32_t sw_t = (((uint32_t)(W + 2 * slk) + T - 1u) / T + 63u) & ~63u;
+                    sw_t          = sw_t > (uint32_t)TC_STRIPE ? (uint32_t)TC_STRIPE : sw_t;
                     SWd = mode == TC_STRIPE_T ? (int)sw_t : TC_STRIPE;
                     const int64_t cd = mode == TC_STRIPE_T ? (int64_t)T * SWd : (int64_t)SWd, slack = (cd - W) / 2;
                     KB = lo - (int)(slack < (int64_t)X.slack ? slack : (int64_t)X.slack);
                     load_rings(si);
                     rings_in_lds = true;
                     __syncthreads();
+                    TC_COUNT(19);
                 }
             }
 
@@ -793,6 +1148,7 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
                     if ((wf & WAVE_OVERFLOW) && !(paged && s / g + 2u <= dir_entries)) overflow = true;
                 }
                 __syncthreads();
+                TC_STAMP(9);  // wave mode
                 if (done || overflow) break;
                 s -= g;  // the row at s is wider than 64 (or its page is full): redo the loop head for it
                 continue;
@@ -815,24 +1171,20 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
                 // the end-cell keys of this score's directory entry start as "none" (atomic minima below; semi-global only)
                 if (lead_wg && !glob) ast(dir_ptr(si) + 5, 0xFFFFFFFFu), ast(dir_ptr(si) + 6, 0xFFFFFFFFu);
             }
-            // stripe modes: the halo cells of the newest rows (score index si - 1: the neighbours' edge cells, through the exchange
-            // rows; older rows got theirs when they were the newest)
             const int KBw = KB + (mode == TC_STRIPE_T ? (int)b * SWd : 0);
-            if (mode == TC_STRIPE_T && si >= 1u && tid < 6) {
-                const int    c = tid >> 1, hiside = tid & 1;
-                const DirEnt d = ring[(si - 1u) % TEAM_RING];
-                const int    k = hiside ? KBw + SWd : KBw - 1;
-                lrow(c, si - 1u)[hiside ? SWd + 1 : 0] = (d.w > 0 && k >= d.lo && k < d.lo + d.w && k + xoff >= 0 && k + xoff < (int)X.xw) ? ald(xrow(c, si - 1u) + k + xoff) : 0u;
-            }
-            __syncthreads();
+            TC_STAMP(14);  // head: mode, scratch
+            lds_barrier();
 
             TC_TRACE(s, 3u | (mode << 4));
+            TC_STAMP(0);  // loop head: ranges, room, mode, halo cells
             // ---- P1: next + seeds + extend, the row's backtrace words, partial reductions
             int mlo = INT32_MAX, mhi = INT32_MIN, term = 0, mind = INT32_MAX, maxd = INT32_MIN, fvm = INT32_MAX, lvm = INT32_MIN;
+            // the thread's cells of this row: the extended M offsets stay in registers to the end of the step (band ends, end-cell keys);
+            // I and D only until they have entered the rings; the diagonals are recomputed where they are needed (cell_k) -- the kernel
+            // lives on 128 registers, and every value that stays alive across the exchanges is one the compiler may have to spill
             uint32_t kM[TC_U], kI[TC_U], kD[TC_U];
-            int      kK[TC_U];  // the thread's cells of this row: diagonal (INT32_MIN: none), extended M, I, D
 #pragma unroll
-            for (int u = 0; u < TC_U; u++) kM[u] = kI[u] = kD[u] = 0u, kK[u] = INT32_MIN;
+            for (int u = 0; u < TC_U; u++) kM[u] = kI[u] = kD[u] = 0u;
             const bool stripe_mode = mode == TC_STRIPE_T || mode == TC_STRIPE_S;
             const bool hO = eO.w > 0, hX = eX.w > 0, hE = eE.w > 0;
             const uint32_t *const lO = lrow(0, s >= oe ? si - doe : 0u), *const lXr = lrow(0, s >= x ? si - dx : 0u);
@@ -845,47 +1197,54 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
             // XBUF mode: cells dealt round-robin over the team (or the workgroup), as many passes as the row needs
             const int64_t xstep = (int64_t)(team_now ? T : 1u) * G, x0i = team_now ? (int64_t)b * G + tid : tid;
             const int     npass = stripe_mode ? 1 : (int)((W + TC_U * xstep - 1) / (TC_U * xstep));
+            // diagonal of the thread's u-th cell of the first pass; INT32_MIN: it has none
+            const auto cell_k = [&](int u) -> int {
+                if (stripe_mode) {
+                    const int j = tid + u * G, k = KBw + j;
+                    return (j < SWd && k >= lo && k <= hi) ? k : INT32_MIN;
+                }
+                const int64_t i = x0i + (int64_t)u * xstep;
+                return i < W ? lo + (int)i : INT32_MIN;
+            };
             for (int pass = 0; pass < npass; pass++) {
-                uint32_t sa[TC_U], sb[TC_U], sc_[TC_U], sd[TC_U], sx[TC_U];
-                int      kk[TC_U];
+                // (one cell at a time: the five sources of a cell are five registers, not twenty -- the kernel has 128 to live on, and a
+                // value spilled to scratch memory is a round trip that also waits for every store in front of it)
 #pragma unroll
                 for (int u = 0; u < TC_U; u++) {
-                    int  k;
-                    bool on;
+                    int      k;
+                    bool     on;
+                    uint32_t sa = 0u, sb = 0u, sc_ = 0u, sd = 0u, sx = 0u;
                     if (stripe_mode) {
                         const int j = tid + u * G;
                         k = KBw + j, on = j < SWd && k >= lo && k <= hi;
                         // (the rings hold zero wherever a row has no cell: no range checks -- but a score without a row has no slot)
-                        sa[u] = hO ? lO[j] : 0u, sb[u] = hE ? lE1[j] : 0u, sc_[u] = hO ? lO[j + 2] : 0u, sd[u] = hE ? lE2[j + 2] : 0u, sx[u] = hX ? lXr[j + 1] : 0u;
+                        if (on) sa = hO ? lO[j] : 0u, sb = hE ? lE1[j] : 0u, sc_ = hO ? lO[j + 2] : 0u, sd = hE ? lE2[j + 2] : 0u, sx = hX ? lXr[j + 1] : 0u;
                     } else {
                         const int64_t i = x0i + ((int64_t)pass * TC_U + u) * xstep;
                         on = i < W, k = lo + (int)(on ? i : 0);
-                        const bool rd = on && s != 0u;
-                        sa[u] = rd ? xsrc(eO, xO, k - 1) : 0u, sb[u] = rd ? xsrc(eE, xE1, k - 1) : 0u;
-                        sc_[u] = rd ? xsrc(eO, xO, k + 1) : 0u, sd[u] = rd ? xsrc(eE, xE2, k + 1) : 0u;
-                        sx[u] = rd ? xsrc(eX, xX, k) : 0u;
+                        if (on && s != 0u) {
+                            sa = xsrc(eO, xO, k - 1), sb = xsrc(eE, xE1, k - 1), sc_ = xsrc(eO, xO, k + 1), sd = xsrc(eE, xE2, k + 1);
+                            sx = xsrc(eX, xX, k);
+                        }
                     }
-                    kk[u] = on ? k : INT32_MIN;
-                }
-#pragma unroll
-                for (int u = 0; u < TC_U; u++) {
-                    if (kk[u] == INT32_MIN) continue;
-                    const int k = kk[u];
-                    LCell     c = {0u, 0u, 0u, 0u};
-                    if (s != 0u) c = lean_next(sa[u], sb[u], sc_[u], sd[u], sx[u], k, n, m);
+                    if (!on) continue;
+                    LCell c = {0u, 0u, 0u, 0u};
+                    if (s != 0u) c = lean_next(sa, sb, sc_, sd, sx, k, n, m);
                     if (seeded && c.M == 0u) {  // Set = last write wins (R2)
                         bool mt_ = false;
                         c.M  = lean_seed<MODE>(sv, k, s, x, glob, mt_);
                         c.wd = c.M != 0u ? (mt_ ? BLK_SEED_MATCH : BLK_SEED_MISMATCH) : 0u;
                     }
                     c.M = lean_extend<MODE>(sv, c.M, k);
-                    cst(rowC + (k - lo), c.wd);
+                    // (wave 0 polls the exchanges: loads that would queue behind its stores -- its words wait in LDS for the end of the step)
+                    if (stripe_mode && tid < 64) wsc[tid + 64 * u] = c.wd;
+                    else cst(rowC + (k - lo), c.wd);
                     my_cells += (c.M != 0u) + (c.I != 0u) + (c.D != 0u);
                     if (!stripe_mode) {  // the row itself lives in the exchange rows
                         uint32_t *const nx = xrow(0, si), *const ni = xrow(1, si), *const nd = xrow(2, si);
                         xst(nx + k + xoff, c.M), xst(ni + k + xoff, c.I), xst(nd + k + xoff, c.D);
                     }
-                    if (pass == 0) kM[u] = c.M, kI[u] = c.I, kD[u] = c.D, kK[u] = k;
+                    if (pass == 0) kM[u] = c.M, kI[u] = c.I, kD[u] = c.D;
                     if (c.M != 0u) {
                         mlo = imin2(mlo, k), mhi = imax2(mhi, k);
                         if (k == Ak && (int)c.M >= m) term = 1, h_final = c.M;  // wfa.go:235-239
@@ -894,6 +1253,7 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
                     }
                 }
             }
+            TC_STAMP(1);  // cells
             mlo = wave_min(mlo), mhi = wave_max(mhi), mind = wave_min(mind), maxd = wave_max(maxd);
             fvm = wave_min(fvm), lvm = wave_max(lvm);
             {
@@ -905,7 +1265,9 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
                 atomicMin(&red[0], mlo), atomicMax(&red[1], mhi), atomicMin(&red[3], mind), atomicMax(&red[12], maxd);
                 atomicMin(&red[13], fvm), atomicMax(&red[14], lvm);
             }
-            __syncthreads();
+            TC_STAMP(2);  // wave reductions
+            lds_barrier();
+            TC_STAMP(3);  // the other waves of the workgroup
             if (stripe_mode) {
                 // the new rows enter the rings (the slots of the oldest rows: everybody has read them), and the stripe's two edge
                 // cells go to the exchange rows for the neighbours
@@ -917,10 +1279,9 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
 #pragma unroll
                     for (int u = 0; u < TC_U; u++) {
                         const int j = tid + u * G;
-                        if (j == 0 || j == SWd - 1) {  // the stripe's first / last cell: its neighbours' halo
-                            const int kx = KBw + j + xoff;
-                            if (kx >= 0 && kx < (int)X.xw) xst(xrow(0, si) + kx, kM[u]), xst(xrow(1, si) + kx, kI[u]), xst(xrow(2, si) + kx, kD[u]);
-                        }
+                        // the stripe's first / last cell: its neighbours' halo, handed over with the exchange
+                        if (j == 0) red[32] = (int)kM[u], red[33] = (int)kI[u], red[34] = (int)kD[u];
+                        if (j == SWd - 1) red[35] = (int)kM[u], red[36] = (int)kI[u], red[37] = (int)kD[u];
                     }
                 } else if (tid < 6) {  // (one stripe: nothing lies beyond it)
                     lrow(tid >> 1, si)[(tid & 1) ? SWd + 1 : 0] = 0u;
@@ -933,12 +1294,20 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
                 red[23] = red[2] ? ~red[10] : INT32_MAX;
             }
             TC_TRACE(s, 4u | (mode << 4));
+            TC_STAMP(4);  // rows into the rings, edge cells out
             if (team_now) {
-                exchange();
+                exchange(!stripe_mode, mode == TC_STRIPE_T);
                 if (aborted) TC_ABORT_RET;
             } else {
-                __syncthreads();
+                lds_barrier();
             }
+            uint32_t halo = 0u;
+            int      halo_k = 0;
+            if (mode == TC_STRIPE_T && tid < 6) {  // the neighbours' edge cells of this row: the halo of its ring slots
+                halo_k = (tid & 1) ? KBw + SWd : KBw - 1;
+                halo   = (uint32_t)red[40 + 3 * (tid & 1) + (tid >> 1)];
+            }
+            TC_STAMP(5);  // exchange 1
             TC_TRACE(s, 5u | (mode << 4));
             mlo = red[16], mhi = ~red[17], term = red[18] != 0, mind = red[19], maxd = ~red[20], fvm = red[21], lvm = ~red[22];
             if (term) h_final = (uint32_t)(~red[23]);
@@ -960,7 +1329,7 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
                 };
 #pragma unroll
                 for (int u = 0; u < TC_U; u++)
-                    if (kK[u] != INT32_MIN) p2(kM[u], kK[u]);
+                    if (cell_k(u) != INT32_MIN) p2(kM[u], cell_k(u));
                 if (!stripe_mode)
                     for (int pass = 1; pass < npass; pass++)
 #pragma unroll
@@ -970,18 +1339,20 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
                         }
                 f_ok = wave_min(f_ok), l_ok = wave_max(l_ok), hmin = wave_min(hmin);
                 if (lane == 0) atomicMin(&red[4], f_ok), atomicMax(&red[5], l_ok), atomicMin(&red[11], hmin);
-                __syncthreads();
+                lds_barrier();
                 if (tid == 0) {
                     red[16] = red[4], red[17] = ~red[5], red[18] = red[11];
 #pragma unroll
                     for (int f = 19; f < 24; f++) red[f] = 0;
                 }
+                TC_STAMP(6);  // band ends: the owners' candidates
                 if (team_now) {
-                    exchange();
+                    exchange(!stripe_mode, false);
                     if (aborted) TC_ABORT_RET;
                 } else {
-                    __syncthreads();
+                    lds_barrier();
                 }
+                TC_STAMP(7);  // exchange 2
                 const int first_ok = red[16], last_ok = ~red[17], hitmin = red[18];
                 if (hitmin >= first_ok) {
                     // wfa.go:509-511 with no present-but-unusable cell below first_ok: the entries between the last leading failure
@@ -995,7 +1366,7 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
                     };
 #pragma unroll
                     for (int u = 0; u < TC_U; u++)
-                        if (kK[u] != INT32_MIN) p3(kM[u], kK[u]);
+                        if (cell_k(u) != INT32_MIN) p3(kM[u], cell_k(u));
                     if (!stripe_mode)
                         for (int pass = 1; pass < npass; pass++)
 #pragma unroll
@@ -1005,17 +1376,17 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
                             }
                     lead = wave_max(lead);
                     if (lane == 0) atomicMax(&red[7], lead);
-                    __syncthreads();
+                    lds_barrier();
                     if (tid == 0) {
                         red[16] = ~red[7];
 #pragma unroll
                         for (int f = 17; f < 24; f++) red[f] = 0;
                     }
                     if (team_now) {
-                        exchange();
+                        exchange(!stripe_mode, false);
                         if (aborted) TC_ABORT_RET;
                     } else {
-                        __syncthreads();
+                        lds_barrier();
                     }
                     lead = ~red[16];
                     nlo  = (lead != INT32_MIN) ? lead + 1 : mlo;
@@ -1025,12 +1396,14 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
                 if (stripe_mode) {
                     uint32_t *const nM = lrow(0, si), *const nI = lrow(1, si), *const nD = lrow(2, si);
 #pragma unroll
-                    for (int u = 0; u < TC_U; u++)
-                        if (kK[u] != INT32_MIN && (kK[u] < nlo || kK[u] > nhi)) {
-                            my_cells -= (kM[u] != 0u) + (kI[u] != 0u) + (kD[u] != 0u);
-                            nM[tid + u * G + 1] = 0u, nI[tid + u * G + 1] = 0u, nD[tid + u * G + 1] = 0u;  // (kK[u] exists: inside the stripe)
+                    for (int u = 0; u < TC_U; u++) {
+                        const int k = cell_k(u);
+                        if (k != INT32_MIN && (k < nlo || k > nhi)) {
+                            my_cells -= (kM[u] != 0u) + (nI[tid + u * G + 1] != 0u) + (nD[tid + u * G + 1] != 0u);
+                            nM[tid + u * G + 1] = 0u, nI[tid + u * G + 1] = 0u, nD[tid + u * G + 1] = 0u;
                             kM[u] = 0u;
                         }
+                    }
                 } else {
                     for (int pass = 0; pass < npass; pass++)
 #pragma unroll
@@ -1057,7 +1430,7 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
                 };
 #pragma unroll
                 for (int u = 0; u < TC_U; u++)
-                    if (kK[u] != INT32_MIN) p4(kM[u], kK[u]);
+                    if (cell_k(u) != INT32_MIN) p4(kM[u], cell_k(u));
                 if (!stripe_mode)
                     for (int pass = 1; pass < npass; pass++)
 #pragma unroll
@@ -1077,13 +1450,29 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
             }
             if (nhi >= nlo) put_ent(si, base + (uint64_t)(nlo - lo), nlo, nhi - nlo + 1);
             else put_ent(si, 0ull, 0, 0);
+            // the halo cells of this row's ring slots: the neighbours' edge cells where the row keeps them
+            if (mode == TC_STRIPE_T && tid < 6) lrow(tid >> 1, si)[(tid & 1) ? SWd + 1 : 0] = (nhi >= nlo && halo_k >= nlo && halo_k <= nhi) ? halo : 0u;
+            if (stripe_mode && tid < 64) {  // (wave 0's share of the row's backtrace words)
+#pragma unroll
+                for (int u = 0; u < TC_U; u++) {
+                    const int k = cell_k(u);
+                    if (k != INT32_MIN) cst(rowC + (k - lo), wsc[tid + 64 * u]);
+                }
+            }
             if (term) {
                 done    = true;
                 s_final = s;
                 break;
             }
-            __syncthreads();
+            lds_barrier();
+            TC_STAMP(8);  // deletions, end-cell keys, directory entry
+            TC_COUNT(mode == TC_STRIPE_T ? 16 : mode == TC_XBUF ? 17 : 18);
         }
+#ifdef WFA_TEAM_STAMPS
+        if (lead_wg && tid == 0)
+            for (int i = 0; i < 24; i++) atomicAdd(reinterpret_cast<unsigned long long *>(ctl + 64) + i, tacc[i]), tacc[i] = 0;
+        tprev = __builtin_amdgcn_s_memrealtime();
+#endif
 
         // ---- a pair that ends with workgroup 0 alone: wake the parked workgroups
         const bool alone = mode == TC_STRIPE_S || mode == TC_WAVE;
@@ -1236,6 +1625,10 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
                 rec[REC_STATUS] = ST_REDO_ARENA;
                 push_redo(P, pair, ST_REDO_ARENA);
             }
+#ifdef WFA_TEAM_STAMPS
+            TC_STAMP(10);  // end-cell lookup + backtrace + record
+            if (tid == 0) atomicAdd(reinterpret_cast<unsigned long long *>(ctl + 64) + 10, tacc[10]), tacc[10] = 0;
+#endif
             if (paged && tid == 0 && !X.dbg) page_free_all();
         }
     }
