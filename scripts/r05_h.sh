@@ -1,37 +1,21 @@
 #!/bin/bash
+# instruction mix of the configs[4] sample's kernel (PMC passes)
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=gpurun_out/r05_h; mkdir -p $OUT
-hipcc -O3 --offload-arch=gfx950 -o /tmp/exchange_probe scripts/probes/exchange_probe.hip 2>&1 | tail -3
-{
-timeout 60 /tmp/exchange_probe 1 200000 9 8
-timeout 60 /tmp/exchange_probe 32 200000 9 8
-for T in 32 16 8; do
- for v in 0 1 2 3 4; do
-  timeout 60 /tmp/exchange_probe $T 50000 $v 8 8 1
- done
-done
-timeout 60 /tmp/exchange_probe 32 50000 0 8 14 1
-timeout 60 /tmp/exchange_probe 32 50000 1 8 14 1
-timeout 60 /tmp/exchange_probe 32 50000 4 8 14 1
-timeout 60 /tmp/exchange_probe 32 50000 0 8 4 1
-timeout 60 /tmp/exchange_probe 32 50000 0 8 8 0
-timeout 60 /tmp/exchange_probe 32 50000 0 8 8 4
-timeout 60 /tmp/exchange_probe 32 50000 1 8 8 0
-timeout 60 /tmp/exchange_probe 32 50000 0 1 8 1
-timeout 60 /tmp/exchange_probe 32 50000 1 1 8 1
-timeout 60 /tmp/exchange_probe 32 50000 2 1 8 1
-} 2>&1 | tee $OUT/probe.txt
+R=$(pwd)
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-timeout 600 rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_IFETCH --kernel-trace --output-format csv -d $R/$OUT/pmc_ic -- python3 $R/bench.py --config c5s --steps 1 --warmup 1 --cpu-sample 0 --host-entry 0 --latency 0 --other-configs 0 > $R/$OUT/pmc_ic.log 2>&1
+i=0
+for C in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" "SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_BRANCH"; do
+  i=$((i+1))
+  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/$OUT/pmc_$i -- python3 $R/bench.py --config c5s --steps 1 --warmup 1 --cpu-sample 0 --host-entry 0 --latency 0 --other-configs 0 > $R/$OUT/pmc_$i.log 2>&1
+done
 cd $R
 python3 - <<'PY'
 import csv, glob, collections
-for f in glob.glob("gpurun_out/r05_h/pmc_ic/**/*counter_collection.csv", recursive=True):
+for f in sorted(glob.glob("gpurun_out/r05_h/pmc_*/**/*counter_collection.csv", recursive=True)):
     acc = collections.defaultdict(float); n = collections.Counter()
     for r in csv.DictReader(open(f)):
-        if "teamc" in r["Kernel_Name"] or "team_kernel" in r["Kernel_Name"]:
+        if "teamc" in r["Kernel_Name"]:
             acc[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
-    print(f, dict(acc), dict(n))
+    print({k: (v / n[k]) for k, v in acc.items()}, dict(n))
 PY
-tail -3 $OUT/pmc_ic.log | cut -c1-600

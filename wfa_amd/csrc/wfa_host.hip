@@ -1616,6 +1616,16 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                              "exchange1 %.0f band-ends %.0f exchange2 %.0f tail %.0f | wave mode %.0f backtrace %.0f | per wide step %.2f us\n", t, a[16], a[17], a[18], a[19],
                              a[0] / 100.0, a[1] / 100.0, a[2] / 100.0, a[3] / 100.0, a[4] / 100.0, a[5] / 100.0, a[6] / 100.0, a[7] / 100.0, a[8] / 100.0, a[9] / 100.0, a[10] / 100.0,
                              (a[0] + a[1] + a[2] + a[3] + a[4] + a[5] + a[6] + a[7] + a[8] + a[11] + a[12] + a[13] + a[14]) / 100.0 / steps);
+                {
+                    const unsigned long long *m = reinterpret_cast<const unsigned long long *>(&tc[(size_t)t * TEAM_CTL_STRIDE + TC_TRACE_OFF]);
+                    std::fprintf(stderr, "[teamc %u] the workgroup in the middle of the team, us: head %.0f cells %.0f wave-red %.0f wait-wg %.0f rings+edges %.0f exchange1 %.0f band-ends %.0f exchange2 %.0f tail %.0f\n",
+                                 t, m[0] / 100.0, m[1] / 100.0, m[2] / 100.0, m[3] / 100.0, m[4] / 100.0, m[5] / 100.0, m[6] / 100.0, m[7] / 100.0, m[8] / 100.0);
+                }
+                {
+                    const unsigned long long *x = reinterpret_cast<const unsigned long long *>(&tc[(size_t)t * TEAM_CTL_STRIDE + TC_TRACE_OFF + 64]) - 24;
+                    std::fprintf(stderr, "[teamc %u] exchange 1 in detail (inside the figure above), us: rows into the rings + slot stored %.0f, polled %.0f (%llu polls), reduced %.0f\n", t,
+                                 x[24] / 100.0, x[25] / 100.0, x[27], x[26] / 100.0);
+                }
                 std::fprintf(stderr, "[teamc %u] head in detail, us: ring entries + ranges %.0f, room %.0f, first barrier %.0f, mode + scratch %.0f, second barrier %.0f\n", t, a[11] / 100.0,
                              a[12] / 100.0, a[13] / 100.0, a[14] / 100.0, a[0] / 100.0);
             }

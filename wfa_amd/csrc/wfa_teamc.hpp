@@ -87,6 +87,26 @@ WFA_DEV LCell lean_next(uint32_t a0, uint32_t b0, uint32_t c0, uint32_t d0, uint
     r.wd = Msk != 0u ? blk_word(o0, iext, dext, fromX, fromI) : 0u;
     return r;
 }
+// The same where no source of any of the wave's cells lies past a sequence end (a ballot: all but the waves at the matrix's
+// borders): nothing is rejected, the unrejected sources are the sources, and the offset backTrace would recompute is the M offset
+// itself (from I: Iu = Isk = Msk; from D: Du = Dsk = Msk; else the maximum of the three, Msk).
+WFA_DEV bool lean_rejects(uint32_t a0, uint32_t b0, uint32_t c0, uint32_t d0, uint32_t x0, int k, int n, int m) {
+    const uint32_t hmax = umax2(umax2(a0, b0), x0), vsrc = umax2(umax2(c0, d0), x0);
+    return (int)hmax > m || (int)vsrc - k > n;
+}
+WFA_DEV LCell lean_next_norej(uint32_t a0, uint32_t b0, uint32_t c0, uint32_t d0, uint32_t x0) {
+    const uint32_t mi = umax2(a0, b0), Isk = mi + (mi != 0u ? 1u : 0u), Dsk = umax2(c0, d0), x1 = x0 + (x0 != 0u ? 1u : 0u);
+    const uint32_t Msk = umax2(umax2(Isk, Dsk), x1);
+    const bool     fromX = x0 != 0u && Msk == x1, fromI = !fromX && Msk == Isk;
+    LCell r;
+    r.M = Msk, r.I = Isk, r.D = Dsk;
+    r.wd = Msk != 0u ? blk_word(Msk, a0 < b0, c0 < d0, fromX, fromI) : 0u;
+    return r;
+}
+WFA_DEV LCell lean_next_fast(uint32_t a0, uint32_t b0, uint32_t c0, uint32_t d0, uint32_t x0, int k, int n, int m) {
+    if (__ballot(lean_rejects(a0, b0, c0, d0, x0, k, n, m)) != 0ull) return lean_next(a0, b0, c0, d0, x0, k, n, m);
+    return lean_next_norej(a0, b0, c0, d0, x0);
+}
 // the seed of initComponents on diagonal k that belongs to score s, as a bare offset (0: none); *match: its class
 template <int MODE>
 WFA_DEV uint32_t lean_seed(const SeqView<MODE> &sv, int k, uint32_t s, uint32_t x, bool glob, bool &match) {
@@ -238,7 +258,7 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
     // cells, rows in XBUF mode) the storing waves wait for their stores themselves, in front of the exchange.
     const auto lds_barrier = []() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 #ifdef WFA_TEAM_STAMPS  // diagnostic build (scripts/team_stamps.sh): time per phase of workgroup 0's wave 0, summed over the team's pairs
-    unsigned long long tacc[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memrealtime();
+    unsigned long long tacc[32] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memrealtime();
 #define TC_STAMP(i)                                                     \
     do {                                                                \
         const unsigned long long _t = __builtin_amdgcn_s_memrealtime(); \
@@ -247,9 +267,7 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
     } while (0)
 #define TC_COUNT(i) (tacc[i]++)
 #else
-#define TC_STAMP(i) \
-    do {            \
-    } while (0)
+#define TC_STAMP(i) asm volatile("; TC_STAMP " #i)  // (a comment in the assembly listing: where a phase ends)
 #define TC_COUNT(i) \
     do {            \
     } while (0)
@@ -275,10 +293,10 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
                 }
             }
             __threadfence();
-            red[31] = bad ? 1 : 0;
+            red[46] = bad ? 1 : 0;
         }
         __syncthreads();
-        aborted = red[31] != 0;
+        aborted = red[46] != 0;
     };
     // EXCHANGE: barrier + reduction in one.  Every workgroup hands in eight ints (red[16 .. 23], written by its thread 0 before
     // the call); when the call returns red[16 .. 23] hold the MINIMUM of each over the team (a maximum travels as its complement, a flag
@@ -289,16 +307,19 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
     // edge cells of its stripe in the exchange rows, rows in XBUF mode -- is ordered before the slot by the release (memory-side
     // protocol), or is in the XCD's L2 once the stores have been acknowledged, which the barrier in front waits for (teams on
     // one XCD; see wfa_team.hpp).
-    // edges: the payload also carries the six words of the stripe's first and last cell (red[32 .. 37], written by their owners
+    // edges: the payload also carries the six words of the stripe's first and last cell (red[24 .. 26] and red[28 .. 30], written by their owners
     // before the call: M, I, D of the first, then of the last), and every workgroup gets its neighbours' -- the halo cells of its
     // stripe -- back in red[40 .. 45] (M, I, D below the stripe, then above it; zero at the team's ends): the k +- 1 sources that
     // cross a stripe's edge (wfa.go:579-650) travel with the barrier, no load, no store and no wait of their own.
-    // exchange_core: the exchange without the barrier in front (the caller has ordered red[16 ..] and red[32 ..] before wave 0's
+    // exchange_core: the exchange without the barrier in front (the caller has ordered red[16 .. 30] before wave 0's
     // stores itself); nf = how many of the eight values travel.
     // A slot is 128 bytes, sixteen (sequence number, value) words: [0 .. 7] the values, [8 .. 10] the stripe's first cell (M, I, D),
-    // [12 .. 14] its last.  Lane f of wave 0 stores word f -- one store instruction, one line.  Polling, lane j loads workgroup j's
-    // values as 16-byte pieces, and lanes 0 .. 3 the two pieces of each neighbour's edge cell; ALL the loads of a poll are issued
-    // before the one wait (inline assembly: the compiler puts a wait behind every atomic load of its own -- fourteen round trips a poll).
+    // [12 .. 14] its last.  Lane f of wave 0 stores word f -- one store instruction, one line.  Polling, lane l loads 16-byte piece
+    // l % 4 (values 2 (l % 4) and the next) of workgroup l / 4's slot, and of workgroup 16 + l / 4's: four lanes make a 64-byte
+    // request, a poll of 32 workgroups is 32 requests (a load per lane and value was 256, and the compiler waits behind every atomic
+    // load of its own -- fourteen round trips a poll; here ALL the loads of a poll are in flight before the one wait).  Lanes 0 .. 3
+    // also load the two pieces of each neighbour's edge cell.  The minimum of a value over the workgroups: two DPP steps inside each
+    // row of sixteen lanes, then one LDS atomic per row into red[16 + value] (reset by this wave after it has read its own values).
     auto exchange_core = [&](int nf, bool edges) __attribute__((always_inline)) {
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         xseq += 1u;
@@ -307,59 +328,68 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
 #endif
         if (T != 1u && tid < 64) {  // (a team of one: the values are the reduction)
             unsigned long long *const set = slots + (size_t)(xseq & 1u) * TC_MAX_T * TC_SLOT_U64;
-            if (lane < 16 && (lane < 8 ? lane < nf : edges)) {
-                if (strict && !xl) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                // (a team on one XCD: plain stores -- the words stay in that XCD's L2, where the others' polling loads find them;
-                // a write-through store would drop them from it and send every poll to the memory side)
-                const int src = lane < 8 ? 16 + lane : (lane < 11 ? 32 + (lane - 8) : (lane >= 12 && lane < 15 ? 35 + (lane - 12) : 31));
-                const unsigned long long wv = ((unsigned long long)xseq << 32) | (uint32_t)((lane == 11 || lane == 15) ? 0 : red[src]);
-                if (xl) set[(size_t)b * TC_SLOT_U64 + lane] = wv;
-                else __hip_atomic_store(set + (size_t)b * TC_SLOT_U64 + lane, wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            {
+                const bool sends = lane < 16 && (lane < 8 ? lane < nf : edges);
+                // (red[16 .. 31] in the slot's order: the values, the first cell at [24 .. 26], the last at [28 .. 30]; [27] and [31] are padding)
+                const uint32_t mine_v = sends ? (uint32_t)red[16 + lane] : 0u;
+                if (lane < 8) red[16 + lane] = INT32_MAX;  // (the minima are collected here)
+                if (sends) {
+                    if (strict && !xl) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    // (a team on one XCD: plain stores -- the words stay in that XCD's L2, where the others' polling loads find them;
+                    // a write-through store would drop them from it and send every poll to the memory side)
+                    const unsigned long long wv = ((unsigned long long)xseq << 32) | mine_v;
+                    if (xl) set[(size_t)b * TC_SLOT_U64 + lane] = wv;
+                    else __hip_atomic_store(set + (size_t)b * TC_SLOT_U64 + lane, wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
-            const unsigned long long *const mine = set + (size_t)((uint32_t)lane < T ? lane : 0) * TC_SLOT_U64;
+            if (nf == 8) TC_STAMP(24);  // exchange 1 in detail: the slot stored
+            const uint32_t pc = (uint32_t)lane & 3u;
             // lanes 0, 1: the last cell of workgroup b - 1 (words 12 .. 15); lanes 2, 3: the first cell of workgroup b + 1 (words 8 .. 11)
             const int  nb     = lane < 2 ? (int)b - 1 : (int)b + 1;
             const bool has_nb = edges && lane < 4 && nb >= 0 && nb < (int)T;
-            const unsigned long long *const edge = has_nb ? set + (size_t)nb * TC_SLOT_U64 + (lane < 2 ? 12 + 2 * lane : 8 + 2 * (lane - 2)) : mine;
-            u32x4    w0, w1, w2 = {0u, 0u, 0u, 0u}, w3 = {0u, 0u, 0u, 0u}, we = {0u, 0u, 0u, 0u};
-            uint32_t spins = 0;
-            bool     bad   = false;
-            for (;;) {
-                if (nf > 4) {
+            u32x4      we     = {0u, 0u, 0u, 0u};
+            uint32_t   spins  = 0;
+            bool       bad    = false;
+            int        va = INT32_MAX, vb = INT32_MAX;
+            // (32 workgroups a round: a team of more polls the second half of the slots in a second round; a set has room for TC_MAX_T slots,
+            // so a load beyond the team's last slot reads memory nobody writes, and is ignored)
+            for (uint32_t base = 0; base < T && !bad; base += 32u) {
+                const uint32_t sl = base + ((uint32_t)lane >> 2);
+                const unsigned long long *const p0 = set + (size_t)sl * TC_SLOT_U64 + 2u * pc;
+                const unsigned long long *const pe = (has_nb && base == 0u) ? set + (size_t)nb * TC_SLOT_U64 + (lane < 2 ? 12 + 2 * lane : 8 + 2 * (lane - 2)) : p0;
+                const unsigned long long emask = __ballot(has_nb && base == 0u);
+                u32x4 w0, w1;
+                for (;;) {
+                    unsigned long long sv_;
                     asm volatile(
-                        "global_load_dwordx4 %0, %5, off sc1\n\tglobal_load_dwordx4 %1, %5, off offset:16 sc1\n\tglobal_load_dwordx4 %2, %5, off offset:32 sc1\n\t"
-                        "global_load_dwordx4 %3, %5, off offset:48 sc1\n\tglobal_load_dwordx4 %4, %6, off sc1\n\ts_waitcnt vmcnt(0)"
-                        : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3), "=&v"(we)
-                        : "v"(mine), "v"(edge)
-                        : "memory");
-                } else {
-                    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
-                                 : "=&v"(w0), "=&v"(w1)
-                                 : "v"(mine)
-                                 : "memory");
+                        "global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:2048 sc1\n\t"
+                        "s_mov_b64 %3, exec\n\ts_and_b64 exec, exec, %6\n\tglobal_load_dwordx4 %2, %5, off sc1\n\ts_mov_b64 exec, %3\n\ts_waitcnt vmcnt(0)"
+                        : "=&v"(w0), "=&v"(w1), "+v"(we), "=&s"(sv_)
+                        : "v"(p0), "v"(pe), "s"(emask)
+                        : "memory", "scc");
+                    // the piece's two values: 2 pc and 2 pc + 1
+                    const bool c0 = 2u * pc < (uint32_t)nf, c1 = 2u * pc + 1u < (uint32_t)nf;
+                    bool ok = (!c0 || w0.y == xseq || sl >= T) && (!c1 || w0.w == xseq || sl >= T) && (!c0 || w1.y == xseq || sl + 16u >= T) && (!c1 || w1.w == xseq || sl + 16u >= T);
+                    if (has_nb && base == 0u) ok = ok && we.y == xseq && we.w == xseq;
+                    if (nf == 8) TC_COUNT(27);
+                    if (__ballot(!ok) == 0ull) break;
+                    if ((++spins & 255u) == 0u && (spins > (TEAM_SPIN_LIMIT >> 2) || ald(&ctl[1]) != 0u)) {
+                        atomicExch(&ctl[1], 1u);
+                        bad = true;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
                 }
-                bool ok = true;
-                if ((uint32_t)lane < T) {
-                    ok = w0.y == xseq && (nf < 2 || w0.w == xseq) && (nf < 3 || w1.y == xseq) && (nf < 4 || w1.w == xseq);
-                    if (nf > 4) ok = ok && w2.y == xseq && (nf < 6 || w2.w == xseq) && (nf < 7 || w3.y == xseq) && (nf < 8 || w3.w == xseq);
-                }
-                if (has_nb) ok = ok && we.y == xseq && we.w == xseq;
-                if (__ballot(!ok) == 0ull) break;
-                if ((++spins & 255u) == 0u && (spins > (TEAM_SPIN_LIMIT >> 2) || ald(&ctl[1]) != 0u)) {
-                    atomicExch(&ctl[1], 1u);
-                    bad = true;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
+                if (sl < T) va = imin2(va, (int)w0.x), vb = imin2(vb, (int)w0.z);
+                if (sl + 16u < T) va = imin2(va, (int)w1.x), vb = imin2(vb, (int)w1.z);
             }
-            const bool in = (uint32_t)lane < T;
-            const int  v[8] = {in ? (int)w0.x : INT32_MAX, in ? (int)w0.z : INT32_MAX, in ? (int)w1.x : INT32_MAX, in ? (int)w1.z : INT32_MAX,
-                               in ? (int)w2.x : INT32_MAX, in ? (int)w2.z : INT32_MAX, in ? (int)w3.x : INT32_MAX, in ? (int)w3.z : INT32_MAX};
-#pragma unroll
-            for (int f = 0; f < 8; f++) {
-                if (f >= nf) break;
-                const int r = wave_min(v[f]);
-                if (lane == 0) red[16 + f] = r;
+            if (nf == 8) TC_STAMP(25);  // ... every slot read
+            // the four workgroups of a row that hold the same piece: lanes pc, pc + 4, pc + 8, pc + 12 -> lanes 12 .. 15 of the row
+            asm("s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xe\n\ts_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xc\n\ts_nop 1" : "+v"(va));
+            asm("s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xe\n\ts_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xc\n\ts_nop 1" : "+v"(vb));
+            if ((lane & 12) == 12) {
+                if (2u * pc < (uint32_t)nf) atomicMin(&red[16 + 2 * (int)pc], va);
+                if (2u * pc + 1u < (uint32_t)nf) atomicMin(&red[17 + 2 * (int)pc], vb);
             }
             if (edges && lane < 4) {
                 // the halo cells of this workgroup's stripe: M, I, D below it (red[40 .. 42]) and above it (red[43 .. 45]); zero at the team's ends
@@ -369,10 +399,11 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
                 if (lane == 2) red[43] = ex, red[44] = ez;
                 if (lane == 3) red[45] = ex;
             }
-            if (lane == 0) red[31] = bad ? 1 : 0;
+            if (lane == 0) red[46] = bad ? 1 : 0;
+            if (nf == 8) TC_STAMP(26);  // ... reduced
         }
         lds_barrier();
-        aborted = red[31] != 0;
+        aborted = red[46] != 0;
     };
     auto exchange = [&](bool drain, bool edges) __attribute__((always_inline)) {
         if (drain) __syncthreads();  // (every wave's global stores acknowledged: rows in the exchange rows)
@@ -608,7 +639,7 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
                     if (ow_ > 0) lo = imin2(lo, olo - 1), hi = imax2(hi, olo + ow_);
                     if (ew_ > 0) lo = imin2(lo, elo - 1), hi = imax2(hi, elo + ew_);
                     lo = imax2(lo, -(n - 1)), hi = imin2(hi, m - 1);  // wfa.go:562-563
-                    if (hi < lo) break;
+                    if (hi < lo || xw_ <= 0 || ow_ <= 0 || ew_ <= 0) break;  // (a source score without a row has not cleared its ring slot)
                     const int W = hi - lo + 1;
                     if (want_mode((int64_t)W, s) != mode || moved_now(lo, hi, (int64_t)W)) break;
                     if (!paged ? top + (uint64_t)W + (uint64_t)DIR_WORDS * (si + 2) > cap
@@ -621,37 +652,80 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
                     const uint32_t sO = pM >= doe ? pM - doe : pM + RM - doe, sX = pM >= dx ? pM - dx : pM + RM - dx;
                     const uint32_t *const lO = lrows + (size_t)sO * TC_ROWW, *const lXr = lrows + (size_t)sX * TC_ROWW;
                     uint32_t *const nM = lrows + (size_t)pM * TC_ROWW, *const nI = lrows + (size_t)(RM + pE) * TC_ROWW, *const nD = lrows + (size_t)(RM + RE + pE) * TC_ROWW;
-                    const bool hO = ow_ > 0, hX = xw_ > 0, hE = ew_ > 0;
                     if (lead_wg && !glob && tid == 0) ast(dir_ptr(si) + 5, 0xFFFFFFFFu), ast(dir_ptr(si) + 6, 0xFFFFFFFFu);
+                    // the stripe's cells of this row: j in [jlo, jlo + jspan] (one unsigned comparison per cell)
+                    const int      jhi_ = imin2(hi - KBw, SWf - 1), jlo = jhi_ >= imax2(lo - KBw, 0) ? imax2(lo - KBw, 0) : (1 << 30);
+                    const uint32_t jspan = jhi_ >= jlo ? (uint32_t)(jhi_ - jlo) : 0u;
                     TC_STAMP(0);
 
                     // ---- P1: next + extend, the row's backtrace words; ranges from ballots
                     int      mlo = INT32_MAX, mhi = INT32_MIN, fvm = INT32_MAX, lvm = INT32_MIN;  // (wave-uniform)
                     int      mind = INT32_MAX, maxd = INT32_MIN;                                  // (per lane)
-                    bool     termw = false, endany = false;
-                    uint32_t kM[TC_U], kI[TC_U], kD[TC_U];
+                    bool     termw = false, endw = false;                                         // (endw: wave-uniform)
+                    int      hminw = INT32_MAX;  // (wave-uniform) the wave's first present cell at / past a sequence end
+                    uint32_t kM[TC_U], kI[TC_U], kD[TC_U], cnt = 0;
+                    // The thread's cells side by side, in straight-line code the compiler can interleave (a wave's step is a chain of LDS
+                    // round trips and dependent instructions: four chains in flight instead of one after the other).  The sources are loaded
+                    // unconditionally -- every index lies inside the ring rows -- and zeroed for a cell outside the row: next() of no
+                    // sources is no cell, which neither extends nor counts.
+                    LCell c[TC_U];
+                    {
+                        uint32_t sa[TC_U], sb[TC_U], sc_[TC_U], sd[TC_U], sx[TC_U];
+                        bool     rej = false;
+#pragma unroll
+                        for (int u = 0; u < TC_U; u++) {
+                            const int  j = tid + u * G;
+                            const bool on = (uint32_t)(j - jlo) <= jspan;
+                            sa[u] = on ? lO[j] : 0u, sb[u] = on ? nI[j] : 0u, sc_[u] = on ? lO[j + 2] : 0u, sd[u] = on ? nD[j + 2] : 0u, sx[u] = on ? lXr[j + 1] : 0u;
+                            rej = rej || lean_rejects(sa[u], sb[u], sc_[u], sd[u], sx[u], KBw + j, n, m);
+                        }
+                        if (__ballot(rej) == 0ull) {
+#pragma unroll
+                            for (int u = 0; u < TC_U; u++) c[u] = lean_next_norej(sa[u], sb[u], sc_[u], sd[u], sx[u]);
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < TC_U; u++) c[u] = lean_next(sa[u], sb[u], sc_[u], sd[u], sx[u], KBw + tid + u * G, n, m);
+                        }
+                    }
+                    // WF_EXTEND (wfa.go:394-455): the first sixteen bases of every cell side by side, the rare longer run in lean_extend's loop
+                    if constexpr (MODE == 0) {
+                        bool mo[TC_U], more = false;
+#pragma unroll
+                        for (int u = 0; u < TC_U; u++) {
+                            const int      k = KBw + tid + u * G;
+                            const uint32_t h = c[u].M;
+                            const int      v = (int)h - k;
+                            const bool     can = h != 0u && v > 0 && v < n && (int)h < m;
+                            const int      vv = can ? v : 0, hh = can ? (int)h : 0;
+                            const uint32_t xw = SeqView<0>::win16(sv.q, vv) ^ SeqView<0>::win16(sv.t, hh);
+                            const int      rem = imin2(n - vv, m - hh), l = xw != 0u ? (int)(__builtin_ctz(xw) >> 1) : 16;
+                            c[u].M = h + (can ? (uint32_t)imin2(l, rem) : 0u);
+                            mo[u]  = can && xw == 0u && rem > 16;
+                            more   = more || mo[u];
+                        }
+                        if (__ballot(more) != 0ull) {
+#pragma unroll
+                            for (int u = 0; u < TC_U; u++)
+                                if (mo[u]) c[u].M = lean_extend<MODE>(sv, c[u].M, KBw + tid + u * G);
+                        }
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < TC_U; u++) c[u].M = lean_extend<MODE>(sv, c[u].M, KBw + tid + u * G);
+                    }
 #pragma unroll
                     for (int u = 0; u < TC_U; u++) {
                         const int  j = tid + u * G, k = KBw + j;
-                        const bool on = j < SWf && k >= lo && k <= hi;
-                        LCell c = {0u, 0u, 0u, 0u};
-                        int   d = -1;
-                        if (on) {
-                            // (the rings hold zero wherever a row has no cell: no range checks -- but a row of no cells has not cleared its slot)
-                            const uint32_t sa = hO ? lO[j] : 0u, sb = hE ? nI[j] : 0u, sc_ = hO ? lO[j + 2] : 0u, sd = hE ? nD[j + 2] : 0u, sx = hX ? lXr[j + 1] : 0u;
-                            c   = lean_next(sa, sb, sc_, sd, sx, k, n, m);
-                            c.M = lean_extend<MODE>(sv, c.M, k);
-                            // (wave 0 polls the exchanges: loads that would queue behind its stores -- its words wait in LDS for the end of the step)
-                            if (tid < 64) wsc[tid + 64 * u] = c.wd;
-                            else cst(rowC + (k - lo), c.wd);
-                            my_cells += (c.M != 0u) + (c.I != 0u) + (c.D != 0u);
-                            d = lean_dist(c.M, k, n, m);
-                            if (d >= 0) mind = imin2(mind, d), maxd = imax2(maxd, d);
-                            if (c.M != 0u && k == Ak && (int)c.M >= m) termw = true, h_final = c.M;  // wfa.go:235-239
-                            endany = endany || (c.M != 0u && (d < 0 || (int)c.M == k));
-                        }
-                        kM[u] = c.M, kI[u] = c.I, kD[u] = c.D;
-                        const unsigned long long bM = __ballot(c.M != 0u), bV = __ballot(d >= 0);
+                        // (wave 0 polls the exchanges: loads that would queue behind its stores -- its words wait in LDS for the end of the step)
+                        if (tid < 64) wsc[tid + 64 * u] = c[u].wd;
+                        else if ((uint32_t)(j - jlo) <= jspan) cst(rowC + (k - lo), c[u].wd);
+                        cnt += (c[u].M != 0u) + (c[u].I != 0u) + (c[u].D != 0u);
+                        const int  v = (int)c[u].M - k;
+                        const bool valid = c[u].M != 0u && (uint32_t)v < (uint32_t)n && (int)c[u].M < m;  // (lean_dist's cell: a distance to go)
+                        const int  d = imax2(m - (int)c[u].M, n - v);
+                        if (valid) mind = imin2(mind, d), maxd = imax2(maxd, d);
+                        if (c[u].M != 0u && k == Ak && (int)c[u].M >= m) termw = true, h_final = c[u].M;  // wfa.go:235-239
+                        kM[u] = c[u].M, kI[u] = c[u].I, kD[u] = c[u].D;
+                        const unsigned long long bM = __ballot(c[u].M != 0u), bV = __ballot(valid), bZ = __ballot(valid && (int)c[u].M == k);
                         const int kb = KBw + wbase + u * G;
                         if (bM != 0ull) {
                             if (mlo == INT32_MAX) mlo = kb + (int)__builtin_ctzll(bM);
@@ -661,13 +735,23 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
                             if (fvm == INT32_MAX) fvm = kb + (int)__builtin_ctzll(bV);
                             lvm = kb + 63 - (int)__builtin_clzll(bV);
                         }
-                        if (team_now) {  // the stripe's first / last cell: its neighbours' halo, handed over with the exchange
-                            if (j == 0) red[32] = (int)c.M, red[33] = (int)c.I, red[34] = (int)c.D;
-                            if (j == SWf - 1) red[35] = (int)c.M, red[36] = (int)c.I, red[37] = (int)c.D;
+                        // (a present cell that is at / past a sequence end, or in row 0: the only ones lean_endclass can name)
+                        endw = endw || bM != bV || bZ != 0ull;
+                        if ((bM & ~bV) != 0ull && hminw == INT32_MAX) hminw = kb + (int)__builtin_ctzll(bM & ~bV);
+                    }
+                    my_cells += cnt;
+                    if (team_now) {  // the stripe's first / last cell: its neighbours' halo, handed over with the exchange
+                        if (tid == 0) red[24] = (int)kM[0], red[25] = (int)kI[0], red[26] = (int)kD[0];
+                        if (tid == ((SWf - 1) & (G - 1))) {
+                            const int uL = (SWf - 1) / G;
+#pragma unroll
+                            for (int u = 0; u < TC_U; u++)
+                                if (u == uL) red[28] = (int)kM[u], red[29] = (int)kI[u], red[30] = (int)kD[u];
                         }
                     }
                     TC_STAMP(1);
                     if (fvm != INT32_MAX) mind = wave_min(mind), maxd = wave_max(maxd);
+                    const int wmind = fvm != INT32_MAX ? mind : INT32_MAX;  // (wave-uniform: the wave's smallest distance to go)
                     if (__ballot(termw) != 0ull) {
                         if (lane == 0) acc[2] = 1;
                         if (termw) acc[10] = (int)h_final;  // (one cell of the team sits on the final diagonal)
@@ -719,19 +803,20 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
                     int nlo = amlo, nhi = amhi;
                     if (!term && P.adaptive && amhi >= amlo && (amhi - amlo + 1) >= (int)P.min_wf_len && amind != INT32_MAX && amaxd - amind > (int)P.max_dist_diff) {
                         const int thr = amind + (int)P.max_dist_diff;
-                        int f_ok = INT32_MAX, l_ok = INT32_MIN, hmin = INT32_MAX;  // (wave-uniform)
+                        int f_ok = INT32_MAX, l_ok = INT32_MIN;  // (wave-uniform)
+                        const int hmin = hminw;                  // a present cell at / past a sequence end (from P1's ballots)
+                        if (wmind <= thr) {  // (only a wave that holds a cell within the threshold has candidates: a handful of the team's waves)
 #pragma unroll
-                        for (int u = 0; u < TC_U; u++) {
-                            const int  j = tid + u * G, k = KBw + j;
-                            const bool on = j < SWf && k >= lo && k <= hi;
-                            const int  d = on ? lean_dist(kM[u], k, n, m) : -1;
-                            const unsigned long long bOk = __ballot(d >= 0 && d <= thr), bEnd = __ballot(on && d < 0 && kM[u] != 0u);
-                            const int kb = KBw + wbase + u * G;
-                            if (bOk != 0ull) {
-                                if (f_ok == INT32_MAX) f_ok = kb + (int)__builtin_ctzll(bOk);
-                                l_ok = kb + 63 - (int)__builtin_clzll(bOk);
+                            for (int u = 0; u < TC_U; u++) {
+                                const int  k = KBw + tid + u * G;
+                                const int  d = lean_dist(kM[u], k, n, m);  // (-1 for a cell that is absent: no cell outside the row)
+                                const unsigned long long bOk = __ballot(d >= 0 && d <= thr);
+                                const int kb = KBw + wbase + u * G;
+                                if (bOk != 0ull) {
+                                    if (f_ok == INT32_MAX) f_ok = kb + (int)__builtin_ctzll(bOk);
+                                    l_ok = kb + 63 - (int)__builtin_clzll(bOk);
+                                }
                             }
-                            if (bEnd != 0ull && hmin == INT32_MAX) hmin = kb + (int)__builtin_ctzll(bEnd);  // a present cell at / past a sequence end
                         }
                         if (lane == 0) {
                             if (f_ok != INT32_MAX) atomicMin(&acc[4], f_ok), atomicMax(&acc[5], l_ok);
@@ -758,7 +843,7 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
 #pragma unroll
                             for (int u = 0; u < TC_U; u++) {
                                 const int  j = tid + u * G, k = KBw + j;
-                                const bool on = j < SWf && k >= lo && k <= hi;
+                                const bool on = (uint32_t)(j - jlo) <= jspan;
                                 if (on && k < first_ok && lean_dist(kM[u], k, n, m) >= 0) lead = imax2(lead, k);
                             }
                             lead = wave_max(lead);
@@ -780,7 +865,7 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
 #pragma unroll
                             for (int u = 0; u < TC_U; u++) {
                                 const int  j = tid + u * G, k = KBw + j;
-                                const bool on = j < SWf && k >= lo && k <= hi;
+                                const bool on = (uint32_t)(j - jlo) <= jspan;
                                 if (on && (k < nlo || k > nhi)) {
                                     my_cells -= (kM[u] != 0u) + (nI[j + 1] != 0u) + (nD[j + 1] != 0u);
                                     nM[j + 1] = 0u, nI[j + 1] = 0u, nD[j + 1] = 0u;
@@ -791,12 +876,12 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
                     }
                     // ---- the cells that end the reference's end-cell scan (semi-global, wfa.go:301-361): nearest to the final diagonal on
                     // either side, among the cells the row keeps
-                    if (!glob && __ballot(endany) != 0ull) {
+                    if (!glob && endw) {
                         uint32_t kd = 0xFFFFFFFFu, ku = 0xFFFFFFFFu;
 #pragma unroll
                         for (int u = 0; u < TC_U; u++) {
                             const int  j = tid + u * G, k = KBw + j;
-                            const bool on = j < SWf && k >= lo && k <= hi && k >= nlo && k <= nhi;
+                            const bool on = (uint32_t)(j - jlo) <= jspan && k >= nlo && k <= nhi;
                             const uint32_t cls = on ? lean_endclass(kM[u], k, n, m) : 0u;
                             if (cls != 0u) {
                                 if (k <= Ak) kd = umin2(kd, lean_endkey(cls, (uint32_t)(Ak - k)));
@@ -823,7 +908,7 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
 #pragma unroll
                         for (int u = 0; u < TC_U; u++) {
                             const int j = tid + u * G, k = KBw + j;
-                            if (j < SWf && k >= lo && k <= hi) cst(rowC + (k - lo), wsc[tid + 64 * u]);
+                            if ((uint32_t)(j - jlo) <= jspan) cst(rowC + (k - lo), wsc[tid + 64 * u]);
                         }
                     }
                     if (term) {
@@ -1280,8 +1365,8 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
                     for (int u = 0; u < TC_U; u++) {
                         const int j = tid + u * G;
                         // the stripe's first / last cell: its neighbours' halo, handed over with the exchange
-                        if (j == 0) red[32] = (int)kM[u], red[33] = (int)kI[u], red[34] = (int)kD[u];
-                        if (j == SWd - 1) red[35] = (int)kM[u], red[36] = (int)kI[u], red[37] = (int)kD[u];
+                        if (j == 0) red[24] = (int)kM[u], red[25] = (int)kI[u], red[26] = (int)kD[u];
+                        if (j == SWd - 1) red[28] = (int)kM[u], red[29] = (int)kI[u], red[30] = (int)kD[u];
                     }
                 } else if (tid < 6) {  // (one stripe: nothing lies beyond it)
                     lrow(tid >> 1, si)[(tid & 1) ? SWd + 1 : 0] = 0u;
@@ -1470,7 +1555,13 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
         }
 #ifdef WFA_TEAM_STAMPS
         if (lead_wg && tid == 0)
-            for (int i = 0; i < 24; i++) atomicAdd(reinterpret_cast<unsigned long long *>(ctl + 64) + i, tacc[i]), tacc[i] = 0;
+            for (int i = 0; i < 32; i++) atomicAdd(i < 24 ? reinterpret_cast<unsigned long long *>(ctl + 64) + i : reinterpret_cast<unsigned long long *>(trace + 64) + (i - 24), tacc[i]), tacc[i] = 0;
+        // (and a workgroup in the middle of the team, for the skew between workgroups: in the trace words, unused in this build)
+        if (!lead_wg && tid == 0)
+            for (int i = 0; i < 32; i++) {
+                if (b == T / 2u && i < 24) atomicAdd(reinterpret_cast<unsigned long long *>(trace) + i, tacc[i]);
+                tacc[i] = 0;
+            }
         tprev = __builtin_amdgcn_s_memrealtime();
 #endif
 
@@ -1486,16 +1577,16 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
             if (aborted) TC_ABORT_RET;
         }
         // ---- stored cells across the team
-        if (tid == 0) red[26] = 0, red[27] = 0;
+        if (tid == 0) red[38] = 0, red[39] = 0;
         __syncthreads();
         {
             unsigned long long wsum = my_cells;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) wsum += __shfl_xor(wsum, o, 64);
-            if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(&red[26]), wsum);
+            if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(&red[38]), wsum);
         }
         __syncthreads();
-        if (tid == 0) atomicAdd(reinterpret_cast<unsigned long long *>(ctl + 12), *reinterpret_cast<unsigned long long *>(&red[26]));
+        if (tid == 0) atomicAdd(reinterpret_cast<unsigned long long *>(ctl + 12), *reinterpret_cast<unsigned long long *>(&red[38]));
         TC_TRACE(s_final, 9u);
         team_barrier();  // every row, the directory with its end-cell keys and the cell count are visible to workgroup 0
         if (aborted) TC_ABORT_RET;
