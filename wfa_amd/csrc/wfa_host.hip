@@ -184,6 +184,7 @@ struct wfahip_ctx {
     int64_t       opt_team_compact         = 1;              // 1: wide wavefronts on wfa_teamc_kernel (round 5: one backtrace word per diagonal in the arena, the rows the next
                                                              // steps source in LDS stripes, reductions travelling with the barrier: wfa_teamc.hpp); 0: wfa_team_kernel
     int64_t       opt_team_fast            = 1;              // ... 1: its stripe modes run their steady state in the short step (0: every step takes the general one; tests compare the two)
+    int64_t       opt_team_order           = 1;              // ... 1: the pairs that will keep a wide band are queued first (a scheduling hint)
     int64_t       opt_team_slack           = 1024;           // ... diagonals of room on either side when its stripes are positioned (tests: a few, so that the axis moves often)
     bool          dbg_teamc                = false;          // wfahip_debug_team_compact is running: the one-pair debug launch takes wfa_teamc_kernel
     DevBuf        xbuf;                                      // ... its exchange rows
@@ -572,6 +573,8 @@ static int set_option_impl(wfahip_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_team_compact = value;
     else if (k == "team_fast")
         ctx->opt_team_fast = value;
+    else if (k == "team_order")
+        ctx->opt_team_order = value;
     else if (k == "team_slack")
         ctx->opt_team_slack = value > 0 ? value : 1;
     else if (k == "arena_poison")
@@ -1539,7 +1542,32 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
         }
         P.lds_seq_words = cfg.lds_seq_words;
         P.n_work        = (uint32_t)n_work;
-        if (job.all) {
+        // Teams take pairs from one queue, and a pair costs a team anything from 0.1 s to 0.4 s (configs[4]): the expensive ones go
+        // first, so that no team starts one when the others are about to finish.  Under wf-adaptive a pair whose lengths differ by
+        // more than MaxDistDiff keeps a wide band for most of its scores (the first reduce cuts the final diagonal off; DESIGN.md
+        // section 4d) -- a scheduling hint only, results do not depend on the order.
+        std::vector<uint32_t> team_order;
+        if (team_T > 0 && ctx->opt_team_order != 0 && P.adaptive && n_work > team_n && n_work <= (1u << 24)) {
+            std::vector<uint32_t> ql(n_pairs), tl(n_pairs);
+            HIP_TRY(hipMemcpyAsync(ql.data(), d_q_len, n_pairs * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(tl.data(), d_t_len, n_pairs * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            team_order.resize(n_work);
+            if (job.all) std::iota(team_order.begin(), team_order.end(), 0u);
+            else std::copy(job.pairs.begin(), job.pairs.end(), team_order.begin());
+            const uint32_t mdd = P.max_dist_diff;
+            const auto wide = [&](uint32_t i) { return (ql[i] > tl[i] ? ql[i] - tl[i] : tl[i] - ql[i]) > mdd; };
+            std::stable_sort(team_order.begin(), team_order.end(), [&](uint32_t a, uint32_t b) {
+                const bool wa = wide(a), wb = wide(b);
+                if (wa != wb) return wa;
+                return std::max(ql[a], tl[a]) > std::max(ql[b], tl[b]);
+            });
+        }
+        if (!team_order.empty()) {
+            if ((rc = upload_work(team_order.data(), n_work))) return rc;
+            HIP_TRY(hipStreamSynchronize(st));  // (`team_order` is a pageable temporary when it is longer than the pinned block)
+            P.work = static_cast<const uint32_t *>(ctx->work.p);
+        } else if (job.all) {
             P.work = nullptr;
         } else {
             if ((rc = upload_work(job.pairs.data(), n_work))) return rc;

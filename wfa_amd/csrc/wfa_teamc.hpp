@@ -623,6 +623,7 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
                 const int  KBw = (int)rfl((uint32_t)(KB + (team_now ? (int)b * SWd : 0))), SWf = (int)rfl((uint32_t)SWd), wbase = (int)rfl((uint32_t)(tid - lane));
                 s = rfl(s);
                 uint32_t si = rfl(s / g), pM = si % RM, pE = si % RE;
+                uint64_t ftop = (uint64_t)rfl((uint32_t)top) | ((uint64_t)rfl((uint32_t)(top >> 32)) << 32);  // (the arena's fill in scalar registers)
                 const int2 *const ring_lw = reinterpret_cast<const int2 *>(ring);
                 int *acc = red + 48, *accn = red;  // (the general step uses red[0 .. 14] itself and resets it in its head)
                 // reset values of a scratch set: minima start at INT32_MAX, maxima (1, 5, 7, 12, 14) at INT32_MIN, flags (2, 10) at zero
@@ -642,10 +643,10 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
                     if (hi < lo || xw_ <= 0 || ow_ <= 0 || ew_ <= 0) break;  // (a source score without a row has not cleared its ring slot)
                     const int W = hi - lo + 1;
                     if (want_mode((int64_t)W, s) != mode || moved_now(lo, hi, (int64_t)W)) break;
-                    if (!paged ? top + (uint64_t)W + (uint64_t)DIR_WORDS * (si + 2) > cap
-                               : (si + 2u > dir_entries || (uint64_t)W > page_words || top + (uint64_t)W > page_end))
+                    if (!paged ? ftop + (uint64_t)W + (uint64_t)DIR_WORDS * (si + 2) > cap
+                               : (si + 2u > dir_entries || (uint64_t)W > page_words || ftop + (uint64_t)W > page_end))
                         break;
-                    const uint64_t base = top;
+                    const uint64_t base = ftop;
                     uint32_t *const rowC = A + base;
                     // ring slots: row si - r of the M ring sits r slots behind pM (mod RM); the I / D rows of si - de share the slot the
                     // new row takes (de = RE rows back)
@@ -792,11 +793,18 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
                         halo_k = (tid & 1) ? KBw + SWf : KBw - 1;
                         halo   = (uint32_t)red[40 + 3 * (tid & 1) + (tid >> 1)];
                     }
+                    if (tid < 64) {  // wave 0's share of the row's backtrace words: on their way while the band ends are worked out (the next poll waits for them)
+#pragma unroll
+                        for (int u = 0; u < TC_U; u++) {
+                            const int j = tid + u * G, k = KBw + j;
+                            if ((uint32_t)(j - jlo) <= jspan) cst(rowC + (k - lo), wsc[tid + 64 * u]);
+                        }
+                    }
                     TC_STAMP(5);
                     const int  amlo = (int)rfl((uint32_t)red[16]), amhi = ~(int)rfl((uint32_t)red[17]), amind = (int)rfl((uint32_t)red[19]), amaxd = ~(int)rfl((uint32_t)red[20]);
                     const bool term = rfl((uint32_t)red[18]) != 0u;
                     if (term) h_final = ~rfl((uint32_t)red[23]);
-                    top += (uint64_t)W;
+                    ftop += (uint64_t)W, top = ftop;
                     n_ent = si + 1;
 
                     // ---- reduce (wfa.go:461-540): the band wf-adaptive keeps, from the cells' owners
@@ -903,13 +911,6 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
                     if (team_now && tid < 6) {
                         uint32_t *const row = (tid >> 1) == 0 ? nM : ((tid >> 1) == 1 ? nI : nD);
                         row[(tid & 1) ? SWf + 1 : 0] = (nhi >= nlo && halo_k >= nlo && halo_k <= nhi) ? halo : 0u;
-                    }
-                    if (tid < 64) {  // (wave 0's share of the row's backtrace words)
-#pragma unroll
-                        for (int u = 0; u < TC_U; u++) {
-                            const int j = tid + u * G, k = KBw + j;
-                            if ((uint32_t)(j - jlo) <= jspan) cst(rowC + (k - lo), wsc[tid + 64 * u]);
-                        }
                     }
                     if (term) {
                         done    = true;
