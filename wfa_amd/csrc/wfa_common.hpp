@@ -34,7 +34,8 @@ enum : uint32_t {
     ST_REDO_BYTES = 100,       // non-ACGT byte found: needs the byte-compare path
     ST_REDO_ARENA = 101,       // wavefront arena too small: needs a bigger slot
     ST_REDO_LDS   = 102,       // sequences do not fit this launch's LDS budget
-    ST_REDO_BAND  = 103        // register-window kernel: diagonal band left the tile range
+    ST_REDO_BAND  = 103,       // register-window kernel: diagonal band left the tile range
+    ST_REDO_WIDE  = 104        // scout pass of the team kernel (one workgroup per pair): the band stays wider than a workgroup's stripe -- a team's work
 };
 
 constexpr int REC_WORDS = 16;

@@ -184,6 +184,8 @@ struct wfahip_ctx {
     int64_t       opt_team_compact         = 1;              // 1: wide wavefronts on wfa_teamc_kernel (round 5: one backtrace word per diagonal in the arena, the rows the next
                                                              // steps source in LDS stripes, reductions travelling with the barrier: wfa_teamc.hpp); 0: wfa_team_kernel
     int64_t       opt_team_fast            = 1;              // ... 1: its stripe modes run their steady state in the short step (0: every step takes the general one; tests compare the two)
+    int64_t       opt_team_scout           = 1;              // ... 1: batches of more than two pairs per team first run with ONE workgroup per pair, which hands on (ST_REDO_WIDE) the pairs
+                                                             // whose band stays wider than a stripe: the others no longer park 31 CUs each (2: whatever the batch size; 0: off)
     int64_t       opt_team_order           = 1;              // ... 1: the pairs that will keep a wide band are queued first (a scheduling hint)
     int64_t       opt_team_slack           = 1024;           // ... diagonals of room on either side when its stripes are positioned (tests: a few, so that the axis moves often)
     bool          dbg_teamc                = false;          // wfahip_debug_team_compact is running: the one-pair debug launch takes wfa_teamc_kernel
@@ -308,6 +310,7 @@ struct Job {
     std::vector<uint32_t> pairs;
     uint32_t              max_len = 0;  // length bound of these pairs (0 = the batch's)
     bool                  hint    = false;  // `level` came from an earlier call of the class (learn), not from a failed level below it
+    bool                  scout   = false;  // long pairs, first launch: may run as the team kernel's scout pass (one workgroup per pair; wide pairs are handed on)
 };
 
 constexpr size_t LDS_MAX_BYTES = 160 * 1024;
@@ -573,6 +576,8 @@ static int set_option_impl(wfahip_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_team_compact = value;
     else if (k == "team_fast")
         ctx->opt_team_fast = value;
+    else if (k == "team_scout")
+        ctx->opt_team_scout = value;
     else if (k == "team_order")
         ctx->opt_team_order = value;
     else if (k == "team_slack")
@@ -784,7 +789,7 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
     std::vector<uint32_t> h_len;   // max(q_len, t_len) per pair, only when the batch mixes short and long pairs
     uint32_t              sub_len_used = 0;
     const int             max_level = 12;
-    bool                  first     = true;
+    bool                  first     = true, after_scout = false;
 
     // ---- pass 1: sub-wave forward kernels + lane-per-pair backtrace kernel, chunk by chunk.
     //      kind 2 = register-window kernel (4 pairs per wave), kind 1 = LDS-ring packed kernel (2 pairs per wave).
@@ -1380,6 +1385,7 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             if (j.level > 0 && (++ctx->learn_calls & 15u) == 0u) j.level -= 1;  // (a probe that fails costs a launch: 72 ms of a 94 ms call on 500 x 50 kbp)
             j.hint = j.level > 0;
         }
+        j.scout = true;
         ctx->timing.ladder_start_level = (uint32_t)j.level;  // (start level of the long-pair ladder: tests of the learned hint read it)
         jobs.push_back(std::move(j));
     }
@@ -1458,13 +1464,18 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
         // Paged arena of the team kernel: ONE pool for all teams, a pair takes pages as its rows grow.  The ladder level sizes the
         // pool (as many slot sizes as there are teams) until that reaches the budget; from there a level halves the number of
         // teams that share it -- down to one team with the whole pool.
-        bool     paged = false;
+        bool     paged = false, scout_now = false;
         uint64_t pool_words = 0, dir_words = 0;
         uint32_t page_log = 0, n_pages = 0;
         if (team_T > 0 && paged_capable) {
             const uint32_t cus = (uint32_t)std::max(1, ctx->num_cus);
             const uint32_t t0  = (uint32_t)std::min<uint64_t>(cus, std::max<uint64_t>(2, (2ull * max_len + 8191) / 8192));
             uint32_t teams = (uint32_t)std::min<uint64_t>(n_work, std::max<uint32_t>(1, std::min<uint32_t>(8u, cus / t0)));
+            // scout pass (wfa_teamc_kernel only): a team is ONE workgroup, as many teams as CUs; it finishes the pairs whose band collapses and hands the
+            // others on.  Worth a launch of its own when the teams would otherwise take several pairs each.
+            scout_now = job.scout && team_c && ctx->opt_team_scout != 0 && P.adaptive && (ctx->opt_team_scout >= 2 || n_work > 2ull * teams);
+            const uint32_t teams_full = teams;
+            if (scout_now) teams = (uint32_t)std::min<uint64_t>(n_work, cus);
             const uint64_t budget_w = (uint64_t)((double)ctx->total_mem * ladder_budget(ctx)) / 4ull;
             // the first level at which `teams` slots no longer fit the budget, and how far this job is beyond it
             int over = 0;
@@ -1495,8 +1506,12 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                 cr = 2;
             } else if (n_pages >= teams) {
                 paged = true, team_n = teams, cr = 0;
-                if (ctx->opt_team_wgs == 0) team_T = std::min<uint32_t>(cus / team_n, 2 * t0);
+                if (ctx->opt_team_wgs == 0) team_T = scout_now ? 1u : std::min<uint32_t>(cus / team_n, 2 * t0);
+            } else if (scout_now && n_pages >= teams_full) {  // (too few pages for a team per CU: as many scouts as there are pages)
+                paged = true, team_n = std::min<uint32_t>(teams, n_pages), cr = 0;
+                team_T = 1u;
             }
+            if (!paged) scout_now = false;
         }
         if (no_slot_fits && !paged) cr = 2;  // (the configuration of a lower level was only borrowed for the paged launch)
         if (cr == 2 || job.level > max_level) {
@@ -1605,6 +1620,7 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                 X.strict = (uint32_t)(ctx->opt_team_strict != 0) | (xmap && ctx->opt_team_xcd >= 2 ? 4u : 0u);
                 X.slack  = (uint32_t)std::min<int64_t>(std::max<int64_t>(1, ctx->opt_team_slack), 1 << 20);
                 X.fast   = ctx->opt_team_fast != 0 ? 1u : 0u;
+                X.scout  = scout_now ? 1u : 0u;
                 X.dbg    = debug_single ? d_ctrl + 4 : nullptr;
                 HIP_TRY(wfa_launch_teamc(P, X, job.mode, grid_t, lds_c, st));
             } else {
@@ -1702,6 +1718,9 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
         if (first) {
             ctx->timing.main_kernel_ms = ms, ctx->timing.n_main_launches = 1, first = false;
             if (team_T > 0) ctx->timing.main_kernel_kind = team_c ? 17 : 7;  // wfa_teamc_kernel / wfa_team_kernel (bench.py names the dominant kernel by this)
+            after_scout = scout_now;
+        } else if (after_scout && team_T > 0 && team_c) {  // (the scout pass and the teams behind it are one kernel: its launches add up)
+            ctx->timing.main_kernel_ms += ms, ctx->timing.n_main_launches++;
         }
         ctx->timing.n_launches++;
 
@@ -1712,14 +1731,16 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             if (learned_now < 0 && 10 * team_done >= 9 * team_total) learned_now = job.level;
         }
         if (n_redo) {
-            ctx->timing.n_retried_pairs += n_redo;
-            Job jb, ja;
+            Job jb, ja, jw;
             jb.mode = 1, jb.level = job.level, jb.all = false, jb.max_len = job.max_len;
             ja.mode = job.mode, ja.level = job.level + 1, ja.all = false, ja.max_len = job.max_len;
+            jw.mode = job.mode, jw.level = job.level, jw.all = false, jw.max_len = job.max_len, jw.hint = job.hint;  // (handed on by the scout pass: a team's work, same level)
             for (uint32_t i = 0; i < n_redo; i++) {
                 const uint32_t stw = (uint32_t)(ent[i] >> 32);
-                (stw == ST_REDO_BYTES || stw == ST_REDO_LDS ? jb : ja).pairs.push_back((uint32_t)ent[i]);
+                (stw == ST_REDO_WIDE ? jw : (stw == ST_REDO_BYTES || stw == ST_REDO_LDS ? jb : ja)).pairs.push_back((uint32_t)ent[i]);
             }
+            ctx->timing.n_retried_pairs += n_redo - (uint32_t)jw.pairs.size();  // (a pair the scouts hand on has not failed anything)
+            if (!jw.pairs.empty()) jobs.push_front(std::move(jw));
             if (!jb.pairs.empty()) jobs.push_back(std::move(jb));
             if (!ja.pairs.empty()) jobs.push_back(std::move(ja));
         }

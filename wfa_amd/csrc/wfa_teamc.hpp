@@ -60,6 +60,7 @@ struct TcArgs {
     uint32_t  xw;          // words of one exchange row (>= n + m of the longest pair)
     uint32_t  T, n_teams, tpx;  // workgroups per team; teams; teams per XCD (0: team = blockIdx / T)
     uint32_t  solo_max, wave_rows, strict, slack, fast;
+    uint32_t  scout;       // 1: teams of one workgroup that hand a pair on (ST_REDO_WIDE) as soon as a row past the seeds is wider than a stripe
     uint32_t *dbg;         // debug (one pair): [0] directory entries [1] final score [2] start score [3] start diagonal
 };
 
@@ -522,7 +523,7 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
         const int  xoff    = n - 1;  // exchange rows are indexed by k + n - 1
         uint64_t   top = 0, page_end = 0;
         uint32_t   n_ent = 0, s_final = 0, h_final = 0;
-        bool       overflow = false, done = false;
+        bool       overflow = false, done = false, too_wide = false;
         uint64_t   my_cells = 0;
         uint32_t   mode = TC_XBUF;  // every workgroup active: XBUF / STRIPE_T; workgroup 0 alone: STRIPE_S / WAVE
         int        KB   = 0;        // stripe modes: first diagonal of workgroup 0's stripe
@@ -989,6 +990,11 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
             lds_barrier();  // everybody has read the ring entries before the slot of this score is rewritten
             TC_STAMP(13);  // head: first barrier
 
+            // ---- scout pass: a row past the seeds that one workgroup's stripe cannot hold is a team's work
+            if (X.scout != 0u && T == 1u && s > x && W > (int64_t)TC_STRIPE - 2) {
+                too_wide = true;
+                break;
+            }
             // ---- the mode of this step (every active workgroup computes the same W)
             const uint32_t want = want_mode(W, s);
             const bool was_team = mode == TC_XBUF || mode == TC_STRIPE_T, will_team = want == TC_XBUF || want == TC_STRIPE_T;
@@ -1596,8 +1602,9 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
 
         if (overflow || !done) {
             if (tid == 0) {
-                rec[REC_STATUS] = ST_REDO_ARENA;
-                push_redo(P, pair, ST_REDO_ARENA);
+                const uint32_t why = (too_wide && !overflow) ? (uint32_t)ST_REDO_WIDE : (uint32_t)ST_REDO_ARENA;
+                rec[REC_STATUS] = why;
+                push_redo(P, pair, why);
                 if (paged) page_free_all();
             }
             continue;
