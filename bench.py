@@ -431,6 +431,10 @@ def run_rank(args):
     achieved = alg_bytes / (main_k_ms * 1e-3) / 1e9 if main_k_ms > 0 else 0.0  # GB/s over the dominant kernel's launches of one step
 
     kname = KNAMES[min(int(timing.main_kernel_kind), len(KNAMES) - 1)]
+    if kname == "wfa_duo_kernel":  # (round 5: an instance per penalty shape -- x/g and (o+e)/g are its template arguments; <false: without the census)
+        import math
+        g = math.gcd(math.gcd(args.pen[0], args.pen[1] + args.pen[2]), args.pen[2])
+        kname = f"wfa_duo_kernel<false, {args.pen[0] // g}, {(args.pen[1] + args.pen[2]) // g}>"
 
     out = None
     if rank == 0:

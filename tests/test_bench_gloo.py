@@ -118,13 +118,16 @@ def test_committed_profiles_hold_the_kernels_the_lines_name():
     that were recorded before the kernel template got its latest argument."""
     sys.path.insert(0, ROOT)
     import bench
-    for cfg, kname, census_arg in (("c3", "wfa_duo_kernel", None), ("c2", "wfa_lane_kernel", None), ("c2m", "wfa_lane_kernel", None),
-                                   ("c5s", "wfa_team_kernel", None), ("k10", "wfa_blk_kernel<16", "false"),
+    for cfg, kname, census_arg in (("c3", "wfa_duo_kernel<false, 2, 4>", None), ("p242", "wfa_duo_kernel<false, 1, 3>", None),
+                                   ("c2", "wfa_lane_kernel", None), ("c2m", "wfa_lane_kernel", None),
+                                   ("c5s", "wfa_teamc_kernel", None), ("k10", "wfa_blk_kernel<16", "false"),
                                    ("l5", bench.KNAMES[15], "false"), ("L5", bench.KNAMES[11], "false"), ("l20", bench.KNAMES[13], "false")):
         pm = bench.find_profile(cfg, kname)
         assert pm is not None and pm["traffic"] > 0, (cfg, kname)
         if census_arg is not None:  # wfa_blk_kernel<G, BATCH, STREAM, PPT, CENSUS, ...>: the timed steps run CENSUS = false
             assert pm["kernel"].split(", ")[4].rstrip(">") == census_arg, (cfg, pm["kernel"])
-    # a six-argument name of before round 4's LDSA argument still finds today's seven-argument instance
+    # a six-argument name of before round 4's LDSA argument still finds today's instance (round 5: nine arguments -- the penalty shape)
     old = bench.KNAMES[15].rsplit(", ", 1)[0] + ">"
-    assert bench.find_profile("l5", old)["kernel"] == bench.KNAMES[15]
+    assert bench.find_profile("l5", old)["kernel"].startswith(bench.KNAMES[15][:-1])
+    # the instance of the line's own penalty shape, not another shape's that ran in the same profile
+    assert "<false, 2, 4>" in bench.find_profile("c3", "wfa_duo_kernel<false, 2, 4>")["kernel"]
