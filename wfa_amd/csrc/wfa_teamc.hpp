@@ -143,68 +143,44 @@ WFA_DEV uint32_t lean_endkey(uint32_t cls, uint32_t dist) { return (dist << 2) |
 
 // The compact rows of the arena seen by a wave that walks the backtrace together: directory entries of a 64-score window in
 // LDS (as ArenaViewWave), one word per cell.
-// The 64 scores below `top` x the 128 diagonals around k, from the arena into LDS (DirCompactViewWave below); returns lo | hi << 32, the
-// score indices the region holds.  Not inlined: sixteen rows in flight are 32 registers, and the step loop of a 128-register kernel
-// has none to give; everything goes in and out by value, so the view itself stays in registers.
-__device__ __attribute__((noinline)) inline uint64_t dcv_refill(const uint32_t *A, uint64_t cap, uint32_t n_ent, DirEnt *win, uint32_t *reg, uint32_t top, int k) {
-    constexpr int  REGW = 128;
-    const uint32_t hi = top < n_ent ? top : n_ent - 1u;
-    const uint32_t lo = hi >= 63u ? hi - 63u : 0u;
-    const int      lane = (int)(threadIdx.x & 63);
-    const uint32_t j  = lo + (uint32_t)lane;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if (j <= hi) win[j & 63u] = load_dir(A + cap - (uint64_t)DIR_WORDS * (j + 1));
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const int k0 = k - 64;
-    for (uint32_t r0 = lo; r0 <= hi; r0 += 16u) {
-        uint32_t v0[16], v1[16];
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const uint32_t r = r0 + (uint32_t)i;
-            v0[i] = v1[i] = 0u;
-            if (r <= hi) {
-                const DirEnt e = win[r & 63u];
-                const int    ka = k0 + lane, kb = k0 + 64 + lane;
-                if (e.w > 0 && ka >= e.lo && ka < e.lo + e.w) v0[i] = A[e.base + (uint32_t)(ka - e.lo)];
-                if (e.w > 0 && kb >= e.lo && kb < e.lo + e.w) v1[i] = A[e.base + (uint32_t)(kb - e.lo)];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const uint32_t r = r0 + (uint32_t)i;
-            if (r <= hi) reg[(r & 63u) * REGW + lane] = v0[i], reg[(r & 63u) * REGW + 64 + lane] = v1[i];
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    return (uint64_t)lo | ((uint64_t)hi << 32);
-}
-
-// The compact rows of the arena seen by a wave that walks the backtrace together: the directory entries of a 64-score window and
-// the rows' words for the 128 diagonals around the walk in LDS.  A walk step moves at most one diagonal and a few scores, so a
-// region lasts ~25 steps -- which then are LDS reads instead of a chain of dependent misses in a 70 GB arena (1.8 us a step
-// before; wfa.go:703-983 is that chain).
 struct DirCompactViewWave {
-    static constexpr int REGW = 128;  // diagonals of the region: [kc - 64, kc + 63]
     const uint32_t *A;
     uint64_t        cap;
     uint32_t        g, n_ent;
     DirEnt         *win;
-    uint32_t       *reg;  // LDS: 64 rows of REGW words (the ring rows' space: the forward pass is over)
     mutable uint32_t win_lo, win_hi;
-    mutable int      kc;
-    WFA_DEV void init(const uint32_t *A_, uint64_t cap_, uint32_t g_, uint32_t n_ent_, DirEnt *lds_win, uint32_t *lds_reg) {
-        A = A_, cap = cap_, g = g_, n_ent = n_ent_, win = lds_win, reg = lds_reg, win_lo = 1u, win_hi = 0u, kc = 0;
+    WFA_DEV void init(const uint32_t *A_, uint64_t cap_, uint32_t g_, uint32_t n_ent_, DirEnt *lds_win) {
+        A = A_, cap = cap_, g = g_, n_ent = n_ent_, win = lds_win, win_lo = 1u, win_hi = 0u;
+    }
+    WFA_DEV void refill(uint32_t top, int k) const {
+        const uint32_t hi = top < n_ent ? top : n_ent - 1u;
+        const uint32_t lo = hi >= 63u ? hi - 63u : 0u;
+        const uint32_t j  = lo + (uint32_t)(threadIdx.x & 63);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (j <= hi) {
+            const DirEnt d = load_dir(A + cap - (uint64_t)DIR_WORDS * (j + 1));
+            win[j & 63u]   = d;
+            if (d.w > 0) {  // the cells the walk can reach while the window lasts: their lines in one round trip
+                const int k0 = k - 66 > d.lo ? k - 66 : d.lo, k1 = k + 66 < d.lo + d.w - 1 ? k + 66 : d.lo + d.w - 1;
+                uint32_t  acc = 0;
+                const uint32_t *row = A + d.base - d.lo;
+                for (int kk = k0; kk <= k1; kk += 32) acc ^= row[kk];
+                if (k1 >= k0) acc ^= row[k1];
+                asm volatile("" ::"v"(acc));
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        win_lo = lo, win_hi = hi;
     }
     WFA_DEV uint32_t word(uint32_t idx, int k) const {
         if (idx >= n_ent) return 0u;
-        if (WFA_RARE(idx < win_lo || idx > win_hi || k < kc - 64 || k > kc + 63)) {
-            const uint64_t r = dcv_refill(A, cap, n_ent, win, reg, idx, k);
-            win_lo = (uint32_t)r, win_hi = (uint32_t)(r >> 32), kc = k;
-        }
-        return (uint32_t)__builtin_amdgcn_readfirstlane((int)reg[(idx & 63u) * REGW + (uint32_t)(k - kc + 64)]);
+        if (WFA_RARE(idx < win_lo || idx > win_hi)) refill(idx, k);
+        const DirEnt e = win[idx & 63u];
+        const bool   ok = e.w > 0 && k >= e.lo && k < e.lo + e.w;
+        const uint32_t v = A[ok ? e.base + (uint32_t)(k - e.lo) : 0ull];
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)(ok ? v : 0u));
     }
     WFA_DEV uint32_t tag(int comp, uint32_t idx, int k, uint32_t &off0) const { return blk_tag(word(idx, k), comp, off0); }
 };
@@ -1192,6 +1168,8 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
                             c.M = lean_extend<MODE>(sv, c.M, k);
                             A[wbase + lane] = c.wd;
                             wrow(sj, 0)[sl] = c.M, wrow(sj, 1)[sl] = c.I, wrow(sj, 2)[sl] = c.D;
+                            // (write-through to the exchange rows: a wider row takes over from there)
+                            xrow(0, sj)[k + xoff] = c.M, xrow(1, sj)[k + xoff] = c.I, xrow(2, sj)[k + xoff] = c.D;
                             wcells += (c.M != 0u) + (c.I != 0u) + (c.D != 0u);
                         }
                         utop += (uint64_t)WW;
@@ -1243,21 +1221,6 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
                         }
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                         __builtin_amdgcn_wave_barrier();
-                    }
-                    // a wider row (or another page) takes over from the exchange rows: the last rows go there now -- not with every step,
-                    // as they did until round 5 (three stores and three runtime modulos a step for the 1.8e4 steps of a collapsed band)
-                    if (wflags != WAVE_DONE) {
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        for (uint32_t r = 1; r <= RM && r <= sj; r++) {
-                            const DirEnt d = ring[(sj - r) % TEAM_RING];
-                            if (d.w > 0 && d.w <= 64 && lane < d.w) {
-                                const uint32_t sl = (uint32_t)(d.lo + lane) & 63u;
-#pragma unroll
-                                for (int c = 0; c < 3; c++)
-                                    if (c == 0 || r <= RE) xrow(c, sj - r)[d.lo + lane + xoff] = wrow(sj - r, c)[sl];
-                            }
-                        }
                     }
                     if (tid == 0) {
                         unsigned int *const ur = reinterpret_cast<unsigned int *>(red);
@@ -1705,7 +1668,7 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
             bool ok = !no_scratch;
             if (ok) {
                 DirCompactViewWave cv;
-                cv.init(A, cap, g, n_ent, ring, lrows);
+                cv.init(A, cap, g, n_ent, ring);
                 const uint64_t scratch0 = (top + 1ull) & ~1ull;
                 const uint64_t dir_lo   = scratch_end != 0ull ? scratch_end : cap - (uint64_t)DIR_WORDS * (uint64_t)n_ent;
                 const uint64_t room     = dir_lo > scratch0 ? (dir_lo - scratch0) / 2ull : 0ull;
