@@ -1,10 +1,10 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=gpurun_out/r05_l; mkdir -p $OUT
-for c in c5s c5s32; do
-timeout 900 python bench.py --config $c --steps 2 --warmup 1 --cpu-sample 0 --host-entry 0 --latency 0 --other-configs 0 > $OUT/bench_$c.json 2> $OUT/bench_$c.err
+for c in c5s; do
+timeout 900 python bench.py --config $c --steps 3 --warmup 1 --cpu-sample 0 --host-entry 0 --latency 0 --other-configs 0 > $OUT/bench_$c.json 2> $OUT/bench_$c.err
 python3 -c "
 import json; d=json.load(open('$OUT/bench_$c.json')); c=d['config']; print('$c: value', round(d['value'],2), 'ms', round(d['ms_per_step'],1), 'ok', c['status_ok'], 'kernel_ms', round(c['main_kernel_ms'],1), 'launches', c['launches_per_step'], 'retried', c['retried_pairs'])" || tail -5 $OUT/bench_$c.err
 done
-timeout 900 bash scripts/team_stamps.sh 8 > $OUT/stamps.txt 2>&1; grep "teamc [0-9]\] steps\|^wall" $OUT/stamps.txt | tail -9 | cut -c1-420
-timeout 2400 python -m pytest tests/test_parity_gpu.py -m gpu -q -x --durations=5 -k "team or config5 or learned_start or semiglobal or generic_kernel" > $OUT/team.log 2>&1; echo "team tests rc $?" | tee -a $OUT/team.log; tail -5 $OUT/team.log
+timeout 900 bash scripts/team_stamps.sh 8 > $OUT/stamps.txt 2>&1; grep "teamc [0-9]\] steps\|^wall" $OUT/stamps.txt | tail -9 | grep "stripe(team) [0-9][0-9][0-9][0-9][0-9]\|^wall" | cut -c1-420
+timeout 2400 python -m pytest tests/test_parity_gpu.py -m gpu -q -x --durations=5 -k "teamc or team_kernel or config5 or learned_start or semiglobal" > $OUT/team.log 2>&1; echo "team tests rc $?" | tee -a $OUT/team.log; tail -5 $OUT/team.log
