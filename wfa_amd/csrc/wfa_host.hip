@@ -184,6 +184,7 @@ struct wfahip_ctx {
     int64_t       opt_team_compact         = 1;              // 1: wide wavefronts on wfa_teamc_kernel (round 5: one backtrace word per diagonal in the arena, the rows the next
                                                              // steps source in LDS stripes, reductions travelling with the barrier: wfa_teamc.hpp); 0: wfa_team_kernel
     int64_t       opt_team_fast            = 1;              // ... 1: its stripe modes run their steady state in the short step (0: every step takes the general one; tests compare the two)
+    int64_t       opt_team_pipe            = 1;              // ... 1: its team stripe steps are pipelined (a row's exchanges beside the next row's cells)
     int64_t       opt_team_scout           = 0;              // ... 1: batches of more than two pairs per team first run with ONE workgroup per pair, which hands on (ST_REDO_WIDE) the pairs
                                                              // whose band stays wider than a stripe: the others no longer park 31 CUs each (2: whatever the batch size; 0: off).
                                                              // Off by default: 26 of configs[4]'s first 32 pairs keep a wide band, the six others cost a team 0.09 s each -- 32 pairs
@@ -578,6 +579,8 @@ static int set_option_impl(wfahip_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_team_compact = value;
     else if (k == "team_fast")
         ctx->opt_team_fast = value;
+    else if (k == "team_pipe")
+        ctx->opt_team_pipe = value;
     else if (k == "team_scout")
         ctx->opt_team_scout = value;
     else if (k == "team_order")
@@ -1623,6 +1626,7 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                 X.slack  = (uint32_t)std::min<int64_t>(std::max<int64_t>(1, ctx->opt_team_slack), 1 << 20);
                 X.fast   = ctx->opt_team_fast != 0 ? 1u : 0u;
                 X.scout  = scout_now ? 1u : 0u;
+                X.pipe   = ctx->opt_team_pipe != 0 ? 1u : 0u;
                 X.dbg    = debug_single ? d_ctrl + 4 : nullptr;
                 HIP_TRY(wfa_launch_teamc(P, X, job.mode, grid_t, lds_c, st));
             } else {
@@ -1671,6 +1675,11 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                     const unsigned long long *x = reinterpret_cast<const unsigned long long *>(&tc[(size_t)t * TEAM_CTL_STRIDE + TC_TRACE_OFF + 64]) - 24;
                     std::fprintf(stderr, "[teamc %u] exchange 1 in detail (inside the figure above), us: rows into the rings + slot stored %.0f, polled %.0f (%llu polls), reduced %.0f\n", t,
                                  x[24] / 100.0, x[25] / 100.0, x[27], x[26] / 100.0);
+                }
+                {
+                    const unsigned long long *x = reinterpret_cast<const unsigned long long *>(&tc[(size_t)t * TEAM_CTL_STRIDE + TC_TRACE_OFF + 64]) - 24;
+                    std::fprintf(stderr, "[teamc %u] pipelined steps: committed %llu, left (row not eligible) %llu, deep %llu, complex %llu, not entered %llu | us of wave 0: head %.0f, row S + late cells %.0f, "
+                                 "wait for the cell waves %.0f, commit %.0f\n", t, a[20], a[21], a[22], a[23], x[28], a[0] / 100.0, x[29] / 100.0, x[30] / 100.0, x[31] / 100.0);
                 }
                 std::fprintf(stderr, "[teamc %u] head in detail, us: ring entries + ranges %.0f, room %.0f, first barrier %.0f, mode + scratch %.0f, second barrier %.0f\n", t, a[11] / 100.0,
                              a[12] / 100.0, a[13] / 100.0, a[14] / 100.0, a[0] / 100.0);

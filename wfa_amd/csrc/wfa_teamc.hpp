@@ -43,7 +43,7 @@ constexpr int      TC_STRIPE   = 4096;             // diagonals of a workgroup's
 constexpr int      TC_U        = TC_STRIPE / TC_THREADS;
 constexpr int      TC_ROWW     = TC_STRIPE + 2;    // LDS words of a ring row: the stripe and a halo cell at either end
 constexpr int      TC_SLOT_U64 = 16;               // a workgroup's exchange slot: (sequence number, value) words -- eight values to reduce, six edge cells
-constexpr int      TC_RED      = 64;               // ints of the workgroup's scratch in LDS (red[])
+constexpr int      TC_RED      = 80;               // ints of the workgroup's scratch in LDS (red[])
 constexpr int      TC_MAX_T    = 64;               // workgroups per team (one lane of the polling wave each)
 // per team in global memory: the control words of wfa_team_kernel (TEAM_CTL_WORDS: [0] barrier count [1] abort [2] work index
 // [3] XCC mask [4] command [5] score [6..7] arena top [8..9] - [10] end flags [11] on one XCD [12..13] stored cells
@@ -60,6 +60,7 @@ struct TcArgs {
     uint32_t  xw;          // words of one exchange row (>= n + m of the longest pair)
     uint32_t  T, n_teams, tpx;  // workgroups per team; teams; teams per XCD (0: team = blockIdx / T)
     uint32_t  solo_max, wave_rows, strict, slack, fast;
+    uint32_t  pipe;        // 1: the team's stripe steps overlap a row's exchanges with the next row's cells (the pipelined steps)
     uint32_t  scout;       // 1: teams of one workgroup that hand a pair on (ST_REDO_WIDE) as soon as a row past the seeds is wider than a stripe
     uint32_t *dbg;         // debug (one pair): [0] directory entries [1] final score [2] start score [3] start diagonal
 };
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
     // load of its own -- fourteen round trips a poll; here ALL the loads of a poll are in flight before the one wait).  Lanes 0 .. 3
     // also load the two pieces of each neighbour's edge cell.  The minimum of a value over the workgroups: two DPP steps inside each
     // row of sixteen lanes, then one LDS atomic per row into red[16 + value] (reset by this wave after it has read its own values).
-    auto exchange_core = [&](int nf, bool edges) __attribute__((always_inline)) {
+    auto exchange_core = [&](int nf, bool edges, bool wgb = true) __attribute__((always_inline)) {
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         xseq += 1u;
 #ifdef WFA_TC_TRACE
@@ -402,9 +403,16 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
             }
             if (lane == 0) red[46] = bad ? 1 : 0;
             if (nf == 8) TC_STAMP(26);  // ... reduced
+            if (!wgb) {  // (the pipelined steps: wave 0 exchanges on its own, the others are computing cells)
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                aborted = bad;
+            }
         }
-        lds_barrier();
-        aborted = red[46] != 0;
+        if (wgb) {
+            lds_barrier();
+            aborted = red[46] != 0;
+        }
     };
     auto exchange = [&](bool drain, bool edges) __attribute__((always_inline)) {
         if (drain) __syncthreads();  // (every wave's global stores acknowledged: rows in the exchange rows)
@@ -610,7 +618,505 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
         };
 
         uint32_t s = 0;
+        int      fast_budget = -1;  // steps the plain stripe loop may take before the pipelined one is tried again (-1: no pipelined steps in this launch / mode)
         for (;; s += g) {
+            // ---- PIPELINED STEPS (team stripes, wf-adaptive, de = 1): the exchanges of row S overlap the cells of row N = S + 1.
+            // A step is a chain -- cells, exchange 1, band ends, exchange 2, deletions -- and only the cells near the band's ends and at the
+            // stripe's two edges depend on what the exchanges of the row before decide (98 % of the steps cut fewer than PZ cells).  So
+            // wave 0 ("sync wave") owns no interior cell: it runs row S's exchanges, band ends (from the row's two end zones in LDS), deletions,
+            // directory entry and halo, then computes row N's LATE cells (the end zones and the stripe's first and last cell); waves 1 .. 15
+            // compute row N's INTERIOR cells meanwhile.  One workgroup barrier joins them, the row is committed (statistics into the scratch
+            // set, cells into the rings), a second barrier, next row.  Anything unusual finishes row S and leaves for the steps below with
+            // row N dropped (nothing of it has been committed): a cut deeper than the zones, a cell at a sequence end below the first
+            // passing one, a row that does not fit the stripes / the page, termination.
+            if (X.pipe != 0u && mode == TC_STRIPE_T && T > 1u && rings_in_lds && P.adaptive && de == 1u && dx >= 2u && s > x && s >= oe && X.fast != 0u) {
+                constexpr int PZ  = 48;        // depth of an end zone
+                constexpr int PCW = G - 64;    // threads that own interior cells
+                constexpr int PU  = 4;         // cells per thread of the cell waves: stripes of up to PU x PCW = 3 840 diagonals (wider ones: the steps below)
+                const auto rfl = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+                const bool syncw = tid < 64;
+                const int  ct0 = tid - 64, cbase0 = (int)rfl((uint32_t)(tid - lane)) - 64;  // cell-thread index; its wave's first
+                const int  KBw0 = (int)rfl((uint32_t)(KB + (int)b * SWd)), SWf0 = (int)rfl((uint32_t)SWd);
+                s = rfl(s);
+                uint32_t si = rfl(s / g), pM = si % RM;
+                uint64_t ftop = (uint64_t)rfl((uint32_t)top) | ((uint64_t)rfl((uint32_t)(top >> 32)) << 32);
+                const int2 *const ring_lw = reinterpret_cast<const int2 *>(ring);
+                int *acc = red + 48, *accn = red;
+                const auto acc_reset = [](int i) { return (i == 2 || i == 10) ? 0 : ((i == 1 || i == 5 || i == 7 || i == 12 || i == 14) ? INT32_MIN : INT32_MAX); };
+                int *const pf = red + 64;  // flags of the sync wave for everybody: [0] term [1] complex [2] deep [3] nlo [4] nhi [5] h_final [6] W of row S [7] abort
+                if (tid < 16) acc[tid] = acc_reset(tid), accn[tid] = acc_reset(tid);
+                lds_barrier();
+                bool     first = true;
+                int      loS = 0, hiS = -1, loSs = 0, iloS = 0, ihiS = -1;  // row S: its true range, its storage origin, its interior as it was dealt
+                uint64_t baseS = 0;
+                bool     leave = false;
+                for (;;) {
+                    // (the loop's invariants pass through an empty asm every iteration: what is derived from them is a handful of additions, and
+                    // hoisted out of the loop it would sit in registers the kernel does not have -- reloaded from scratch memory inside the loop)
+                    int ct = ct0, cbase = cbase0, KBw = KBw0, SWf = SWf0;
+                    asm volatile("" : "+v"(ct), "+s"(cbase), "+s"(KBw), "+s"(SWf));
+                    // ---- row N's storage range: from the sources' ranges, row S's uncut (its kept band is not known yet)
+                    const int2 vx = ring_lw[((si - dx) % TEAM_RING) * 4u + 1u], vo = ring_lw[((si - doe) % TEAM_RING) * 4u + 1u];
+                    const int  xlo = (int)rfl((uint32_t)vx.x), xw_ = (int)rfl((uint32_t)vx.y), olo = (int)rfl((uint32_t)vo.x), ow_ = (int)rfl((uint32_t)vo.y);
+                    int elo, ew_;
+                    if (first) {
+                        const int2 ve = ring_lw[((si - 1u) % TEAM_RING) * 4u + 1u];
+                        elo = (int)rfl((uint32_t)ve.x), ew_ = (int)rfl((uint32_t)ve.y);
+                    } else {
+                        elo = loS, ew_ = hiS - loS + 1;
+                    }
+                    int lo = INT32_MAX, hi = INT32_MIN;
+                    if (xw_ > 0) lo = imin2(lo, xlo - 1), hi = imax2(hi, xlo + xw_);
+                    if (ow_ > 0) lo = imin2(lo, olo - 1), hi = imax2(hi, olo + ow_);
+                    if (ew_ > 0) lo = imin2(lo, elo - 1), hi = imax2(hi, elo + ew_);
+                    lo = imax2(lo, -(n - 1)), hi = imin2(hi, m - 1);
+                    const int W = hi >= lo ? hi - lo + 1 : 0;
+                    // the interior: cells whose three sources in row S lie deeper than PZ inside its range; the two end zones before / behind it
+                    const int ilo = elo + PZ + 2, ihi = elo + ew_ - 1 - PZ - 2;
+                    bool last = W <= 0 || xw_ <= 0 || ow_ <= 0 || ew_ <= 0 || ihi < ilo || SWf > PU * PCW || ilo - lo > 64 || hi - ihi > 64 || want_mode((int64_t)W, s) != mode ||
+                                moved_now(lo, hi, (int64_t)W) ||
+                                (!paged ? ftop + (uint64_t)W + (uint64_t)DIR_WORDS * (si + 2) > cap : (si + 2u > dir_entries || (uint64_t)W > page_words || ftop + (uint64_t)W > page_end));
+                    if (first && last) {
+                        TC_COUNT(28);
+                        fast_budget = 16;  // (not a row for these steps: a stretch of the plain ones)
+                        break;
+                    }
+                    TC_STAMP(0);
+                    const uint64_t baseN = ftop;
+                    uint32_t *const rowC = A + baseN;
+                    const uint32_t sO = pM >= doe ? pM - doe : pM + RM - doe, sX = pM >= dx ? pM - dx : pM + RM - dx, sS = pM >= 1u ? pM - 1u : RM - 1u;
+                    const uint32_t *const lO = lrows + (size_t)sO * TC_ROWW, *const lXr = lrows + (size_t)sX * TC_ROWW;
+                    uint32_t *const rS = lrows + (size_t)sS * TC_ROWW;                                          // row S's M cells (where the sync wave deletes)
+                    uint32_t *const nM = lrows + (size_t)pM * TC_ROWW, *const nI = lrows + (size_t)RM * TC_ROWW, *const nD = lrows + (size_t)(RM + 1u) * TC_ROWW;
+                    // (de = 1: one I and one D row; row S's until row N's replace them at the commit)
+
+                    int      mlo = INT32_MAX, mhi = INT32_MIN, fvm = INT32_MAX, lvm = INT32_MIN, hminw = INT32_MAX;  // (wave-uniform)
+                    int      mind = INT32_MAX, maxd = INT32_MIN;
+                    bool     termw = false, endw = false;
+                    uint32_t kM[PU], kI[PU], kD[PU], cnt = 0, ekd = 0xFFFFFFFFu, eku = 0xFFFFFFFFu;
+#pragma unroll
+                    for (int u = 0; u < PU; u++) kM[u] = kI[u] = kD[u] = 0u;
+                    // one cell: sources from the rings, next, extend, the backtrace word, the statistics
+                    auto cell = [&](int u, int j, int k, bool on) __attribute__((always_inline)) {
+                        LCell c = {0u, 0u, 0u, 0u};
+                        bool  valid = false;
+                        if (on) {
+                            c   = lean_next_fast(lO[j], nI[j], lO[j + 2], nD[j + 2], lXr[j + 1], k, n, m);
+                            c.M = lean_extend<MODE>(sv, c.M, k);
+                            cst(rowC + (k - lo), c.wd);
+                            cnt += (c.M != 0u) + (c.I != 0u) + (c.D != 0u);
+                            const int v = (int)c.M - k;
+                            valid = c.M != 0u && (uint32_t)v < (uint32_t)n && (int)c.M < m;
+                            const int d = imax2(m - (int)c.M, n - v);
+                            if (valid) mind = imin2(mind, d), maxd = imax2(maxd, d);
+                            if (c.M != 0u && k == Ak && (int)c.M >= m) termw = true, h_final = c.M;
+                        }
+                        kM[u] = c.M, kI[u] = c.I, kD[u] = c.D;
+                        return valid;
+                    };
+
+                    if (syncw) {
+                        // ================= the sync wave: row S's exchanges, band ends, deletions, entry; then row N's late cells
+                        int  nloS = loS, nhiS = hiS;
+                        bool termS = false, complexS = false, deepS = false;
+                        if (!first) {
+                            const uint32_t siS = si - 1u;
+                            if (lane == 0) {
+                                red[16] = acc[0], red[17] = ~acc[1], red[18] = acc[2] ? -1 : 0, red[19] = acc[3], red[20] = ~acc[12], red[21] = acc[13], red[22] = ~acc[14],
+                                red[23] = acc[2] ? ~acc[10] : INT32_MAX;
+                                if (lead_wg && !glob) {
+                                    ast(dir_ptr(siS) + 5, 0xFFFFFFFFu), ast(dir_ptr(siS) + 6, 0xFFFFFFFFu);
+                                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                                }
+                            }
+                            exchange_core(8, true, false);
+                            const int  amlo = (int)rfl((uint32_t)red[16]), amhi = ~(int)rfl((uint32_t)red[17]), amind = (int)rfl((uint32_t)red[19]), amaxd = ~(int)rfl((uint32_t)red[20]);
+                            termS = rfl((uint32_t)red[18]) != 0u;
+                            if (termS) h_final = ~rfl((uint32_t)red[23]);
+                            nloS = amlo, nhiS = amhi;
+                            if (lane == 0) pf[12] = amlo, pf[13] = amhi, pf[14] = amind;
+                            if (!aborted && !termS && amhi >= amlo && (amhi - amlo + 1) >= (int)P.min_wf_len && amind != INT32_MAX && amaxd - amind > (int)P.max_dist_diff) {
+                                const int thr = amind + (int)P.max_dist_diff;
+                                // (a passing cell has a distance to go: the scans start at the row's first / last such cell, not at the ends of its M
+                                // range -- a band whose end has reached a sequence end keeps a run of cells there that neither pass nor fail)
+                                const int zl = (int)rfl((uint32_t)red[21]), zh = ~(int)rfl((uint32_t)red[22]);
+                                int f_ok = INT32_MAX, l_ok = INT32_MIN;
+                                {
+                                    const int  k = zl + lane, j = k - KBw;
+                                    const bool in = j >= 0 && j < SWf && k <= zh;
+                                    const int  d = in ? lean_dist(rS[j + 1], k, n, m) : -1;
+                                    const unsigned long long bb = __ballot(d >= 0 && d <= thr);
+                                    if (bb != 0ull) f_ok = zl + (int)__builtin_ctzll(bb);
+                                }
+                                {
+                                    const int  k = zh - 63 + lane, j = k - KBw;
+                                    const bool in = j >= 0 && j < SWf && k >= zl;
+                                    const int  d = in ? lean_dist(rS[j + 1], k, n, m) : -1;
+                                    const unsigned long long bb = __ballot(d >= 0 && d <= thr);
+                                    if (bb != 0ull) l_ok = zh - (int)__builtin_clzll(bb);
+                                }
+                                if (lane == 0) red[16] = f_ok, red[17] = ~l_ok, red[18] = acc[11];
+                                exchange_core(3, false, false);
+                                const int first_ok = (int)rfl((uint32_t)red[16]), last_ok = ~(int)rfl((uint32_t)red[17]), hitmin = (int)rfl((uint32_t)red[18]);
+                                if (first_ok != INT32_MAX && last_ok != INT32_MIN && hitmin >= first_ok) {
+                                    nloS = first_ok, nhiS = last_ok;
+                                } else if (first_ok != INT32_MAX && last_ok != INT32_MIN && !aborted) {
+                                    // a cell at a sequence end below the first passing one (wfa.go:503-516): _lo is one past the last valid entry
+                                    // before the first non-failing one -- every cell below first_ok lies in the low zone, so one more exchange of the
+                                    // sync waves settles it (pairs whose band's low end has reached a sequence end take this on every row)
+                                    int lead = INT32_MIN;
+                                    {
+                                        const int  k = zl + lane, j = k - KBw;  // (a valid cell below first_ok lies in [zl, first_ok): inside the scanned zone)
+                                        const bool in = j >= 0 && j < SWf && k <= zh && k < first_ok;
+                                        const unsigned long long bb = __ballot(in && lean_dist(rS[j + 1], k, n, m) >= 0);
+                                        if (bb != 0ull) lead = zl + 63 - (int)__builtin_clzll(bb);
+                                    }
+                                    if (lane == 0) red[16] = ~lead;
+                                    exchange_core(1, false, false);
+                                    lead = ~(int)rfl((uint32_t)red[16]);
+                                    nloS = (lead != INT32_MIN) ? lead + 1 : amlo;
+                                    nhiS = last_ok;
+                                } else {
+                                    complexS = true;  // (no passing cell within 64 diagonals of an end: the full pass over the row, by everybody, below)
+                                }
+                            }
+                            if (!complexS && !aborted) {
+                                deepS = !termS && (nloS > loS + PZ + 1 || nhiS < hiS - PZ - 1);
+                                // Delete of wfa.go:526-535 in the rings and in the census: within 64 diagonals of the M range's ends (else: deep)
+                                if (!deepS && !termS) {
+#pragma unroll
+                                    for (int z = 0; z < 2; z++) {
+                                        const int  k = z == 0 ? amlo + lane : amhi - 63 + lane, j = k - KBw;
+                                        const bool cut = j >= 0 && j < SWf && k >= amlo && k <= amhi && (k < nloS || k > nhiS) && (z == 0 || k > amlo + 63);
+                                        if (cut) {
+                                            my_cells -= (rS[j + 1] != 0u) + (nI[j + 1] != 0u) + (nD[j + 1] != 0u);
+                                            rS[j + 1] = 0u, nI[j + 1] = 0u, nD[j + 1] = 0u;
+                                        }
+                                    }
+                                }
+                                // the end-cell keys of row S (semi-global): what the cell waves collected in the interior + the kept cells of the zones
+                                if (!glob && !deepS) {
+                                    // (the scratch words start at INT32_MAX: "none")
+                                    uint32_t kd = acc[8] == INT32_MAX ? 0xFFFFFFFFu : (uint32_t)acc[8], ku = acc[9] == INT32_MAX ? 0xFFFFFFFFu : (uint32_t)acc[9];
+                                    // row S's late cells as they were dealt: below its interior, above it, the stripe's first and last cell
+#pragma unroll
+                                    for (int z = 0; z < 3; z++) {
+                                        int  k, j;
+                                        bool in;
+                                        if (z == 0) k = loSs + lane, j = k - KBw, in = j > 0 && j < SWf - 1 && k < iloS;
+                                        else if (z == 1) k = ihiS + 1 + lane, j = k - KBw, in = j > 0 && j < SWf - 1 && k <= hiS;
+                                        else j = lane == 0 ? 0 : SWf - 1, k = KBw + j, in = lane < 2 && (lane == 0 || SWf > 1);
+                                        in = in && k >= loS && k <= hiS && k >= nloS && k <= nhiS;
+                                        const uint32_t cls = in ? lean_endclass(rS[j + 1], k, n, m) : 0u;
+                                        if (cls != 0u) {
+                                            if (k <= Ak) kd = umin2(kd, lean_endkey(cls, (uint32_t)(Ak - k)));
+                                            else ku = umin2(ku, lean_endkey(cls, (uint32_t)(k - Ak - 1)));
+                                        }
+                                    }
+                                    if (__ballot(kd != 0xFFFFFFFFu || ku != 0xFFFFFFFFu) != 0ull) {
+                                        kd = (uint32_t)wave_min((int)(kd ^ 0x80000000u)) ^ 0x80000000u;
+                                        ku = (uint32_t)wave_min((int)(ku ^ 0x80000000u)) ^ 0x80000000u;
+                                        if (lane == 0) {
+                                            if (kd != 0xFFFFFFFFu) atomicMin(dir_ptr(siS) + 5, kd);
+                                            if (ku != 0xFFFFFFFFu) atomicMin(dir_ptr(siS) + 6, ku);
+                                        }
+                                    }
+                                }
+                                if (!deepS) {
+                                    if (nhiS >= nloS) put_ent(siS, baseS + (uint64_t)(nloS - loSs), nloS, nhiS - nloS + 1);
+                                    else put_ent(siS, 0ull, 0, 0);
+                                    if (lane < 6) {  // the halo cells of row S's ring slots: the neighbours' edge cells where the row keeps them
+                                        const int halo_k = (lane & 1) ? KBw + SWf : KBw - 1;
+                                        uint32_t *const row = (lane >> 1) == 0 ? rS : ((lane >> 1) == 1 ? nI : nD);
+                                        row[(lane & 1) ? SWf + 1 : 0] = (nhiS >= nloS && halo_k >= nloS && halo_k <= nhiS) ? (uint32_t)red[40 + 3 * (lane & 1) + (lane >> 1)] : 0u;
+                                    }
+                                }
+                            }
+                        }
+                        // ---- row N's late cells: its true range is known now
+                        int loN = lo, hiN = hi;
+                        if (!first) {
+                            loN = INT32_MAX, hiN = INT32_MIN;
+                            const int sw = nhiS >= nloS ? nhiS - nloS + 1 : 0;
+                            if (xw_ > 0) loN = imin2(loN, xlo - 1), hiN = imax2(hiN, xlo + xw_);
+                            if (ow_ > 0) loN = imin2(loN, olo - 1), hiN = imax2(hiN, olo + ow_);
+                            if (sw > 0) loN = imin2(loN, nloS - 1), hiN = imax2(hiN, nloS + sw);
+                            loN = imax2(loN, -(n - 1)), hiN = imin2(hiN, m - 1);
+                        }
+                        if (!last && !termS && !complexS && !deepS && !aborted) {
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            // pass 0: the zone below the interior; pass 1: the zone above it; pass 2: the stripe's first / last cell if they are interior cells' gap
+#pragma unroll
+                            for (int u = 0; u < 3; u++) {
+                                int  k, j;
+                                bool on;
+                                if (u == 0) k = lo + lane, j = k - KBw, on = j > 0 && j < SWf - 1 && k < ilo && k >= loN && k <= hiN;
+                                else if (u == 1) k = ihi + 1 + lane, j = k - KBw, on = j > 0 && j < SWf - 1 && k > ihi && k >= loN && k <= hiN;
+                                else j = lane == 0 ? 0 : SWf - 1, k = KBw + j, on = lane < 2 && (lane == 0 || SWf > 1) && k >= loN && k <= hiN;
+                                const bool valid = cell(u, on ? j : 0, k, on);
+                                const unsigned long long bM = __ballot(kM[u] != 0u), bV = __ballot(valid), bZ = __ballot(valid && (int)kM[u] == k);
+                                if (u < 2) {
+                                    const int kb = u == 0 ? lo : ihi + 1;
+                                    if (bM != 0ull) mlo = imin2(mlo, kb + (int)__builtin_ctzll(bM)), mhi = imax2(mhi, kb + 63 - (int)__builtin_clzll(bM));
+                                    if (bV != 0ull) fvm = imin2(fvm, kb + (int)__builtin_ctzll(bV)), lvm = imax2(lvm, kb + 63 - (int)__builtin_clzll(bV));
+                                    if ((bM & ~bV) != 0ull) hminw = imin2(hminw, kb + (int)__builtin_ctzll(bM & ~bV));
+                                } else {  // (two unrelated diagonals)
+#pragma unroll
+                                    for (int q = 0; q < 2; q++) {
+                                        const int kq = KBw + (q == 0 ? 0 : SWf - 1);
+                                        if ((bM >> q) & 1ull) mlo = imin2(mlo, kq), mhi = imax2(mhi, kq);
+                                        if ((bV >> q) & 1ull) fvm = imin2(fvm, kq), lvm = imax2(lvm, kq);
+                                        if (((bM & ~bV) >> q) & 1ull) hminw = imin2(hminw, kq);
+                                    }
+                                }
+                                endw = endw || bM != bV || bZ != 0ull;
+                            }
+                        }
+                        if (lane == 0) {
+                            pf[0] = termS ? 1 : 0, pf[1] = complexS ? 1 : 0, pf[2] = deepS ? 1 : 0, pf[3] = nloS, pf[4] = nhiS, pf[5] = (int)h_final, pf[7] = aborted ? 1 : 0;
+                            pf[10] = loN, pf[11] = hiN;
+                        }
+                    } else if (!last) {
+                        // ================= the cell waves: row N's interior
+#pragma unroll
+                        for (int u = 0; u < PU; u++) {
+                            const int  j = ct + u * PCW, k = KBw + j;
+                            const bool on = j > 0 && j < SWf - 1 && k >= ilo && k <= ihi;
+                            const bool valid = cell(u, j, k, on);
+                            const unsigned long long bM = __ballot(kM[u] != 0u), bV = __ballot(valid), bZ = __ballot(valid && (int)kM[u] == k);
+                            const int kb = KBw + cbase + u * PCW;
+                            if (bM != 0ull) {
+                                if (mlo == INT32_MAX) mlo = kb + (int)__builtin_ctzll(bM);
+                                mhi = kb + 63 - (int)__builtin_clzll(bM);
+                            }
+                            if (bV != 0ull) {
+                                if (fvm == INT32_MAX) fvm = kb + (int)__builtin_ctzll(bV);
+                                lvm = kb + 63 - (int)__builtin_clzll(bV);
+                            }
+                            endw = endw || bM != bV || bZ != 0ull;
+                            if ((bM & ~bV) != 0ull && hminw == INT32_MAX) hminw = kb + (int)__builtin_ctzll(bM & ~bV);
+                        }
+                        // the end-cell keys of the interior cells (they are kept unless the row is dropped)
+                        if (!glob && endw) {
+#pragma unroll
+                            for (int u = 0; u < PU; u++) {
+                                const int      k = KBw + ct + u * PCW;
+                                const uint32_t cls = lean_endclass(kM[u], k, n, m);  // (0 for a cell that does not exist)
+                                if (cls != 0u) {
+                                    if (k <= Ak) ekd = umin2(ekd, lean_endkey(cls, (uint32_t)(Ak - k)));
+                                    else eku = umin2(eku, lean_endkey(cls, (uint32_t)(k - Ak - 1)));
+                                }
+                            }
+                        }
+                    }
+                    TC_STAMP(29);
+                    lds_barrier();  // (B1) row S is final, row N's cells are computed
+                    TC_STAMP(30);
+                    const bool termS = pf[0] != 0, complexS = pf[1] != 0, deepS = pf[2] != 0;
+                    int        nloS = (int)rfl((uint32_t)pf[3]), nhiS = (int)rfl((uint32_t)pf[4]);
+                    if (pf[7] != 0) {
+                        aborted = true;
+                        TC_ABORT_RET;
+                    }
+                    if (!first) n_ent = si;  // (row S = si - 1 has its entry, or gets it below)
+                    if (termS) {
+                        h_final = (uint32_t)pf[5];
+                        done    = true;
+                        s_final = s - g;
+                        leave   = true;
+                        break;
+                    }
+                    if (complexS) {
+                        TC_COUNT(23);
+                        // ---- the full pass over row S (wfa.go:497-524), everybody, out of the rings; then the row's deletions, keys, entry and halo
+                        const uint32_t siS = si - 1u;
+                        const int thr = (int)rfl((uint32_t)pf[14]) + (int)P.max_dist_diff;
+                        const int amlo = (int)rfl((uint32_t)pf[12]), amhi = (int)rfl((uint32_t)pf[13]);
+                        int f_ok = INT32_MAX, l_ok = INT32_MIN;
+                        if (!syncw) {
+#pragma unroll
+                            for (int u = 0; u < PU; u++) {
+                                const int  j = ct + u * PCW, k = KBw + j;
+                                const int  d = (j < SWf && k >= loS && k <= hiS) ? lean_dist(rS[j + 1], k, n, m) : -1;
+                                const unsigned long long bOk = __ballot(d >= 0 && d <= thr);
+                                const int kb = KBw + cbase + u * PCW;
+                                if (bOk != 0ull) {
+                                    if (f_ok == INT32_MAX) f_ok = kb + (int)__builtin_ctzll(bOk);
+                                    l_ok = kb + 63 - (int)__builtin_clzll(bOk);
+                                }
+                            }
+                            if (lane == 0 && f_ok != INT32_MAX) atomicMin(&acc[4], f_ok), atomicMax(&acc[5], l_ok);
+                        }
+                        lds_barrier();
+                        if (tid == 0) red[16] = acc[4], red[17] = ~acc[5], red[18] = acc[11];
+                        exchange_core(3, false);
+                        if (aborted) TC_ABORT_RET;
+                        const int first_ok = (int)rfl((uint32_t)red[16]), last_ok = ~(int)rfl((uint32_t)red[17]), hitmin = (int)rfl((uint32_t)red[18]);
+                        if (hitmin >= first_ok) {
+                            nloS = first_ok, nhiS = last_ok;
+                        } else {
+                            int lead = INT32_MIN;
+                            if (!syncw) {
+#pragma unroll
+                                for (int u = 0; u < PU; u++) {
+                                    const int j = ct + u * PCW, k = KBw + j;
+                                    if (j < SWf && k >= loS && k <= hiS && k < first_ok && lean_dist(rS[j + 1], k, n, m) >= 0) lead = imax2(lead, k);
+                                }
+                            }
+                            lead = wave_max(lead);
+                            if (lane == 0) atomicMax(&acc[7], lead);
+                            lds_barrier();
+                            if (tid == 0) red[16] = ~acc[7];
+                            exchange_core(1, false);
+                            if (aborted) TC_ABORT_RET;
+                            lead = ~(int)rfl((uint32_t)red[16]);
+                            nloS = (lead != INT32_MIN) ? lead + 1 : amlo;
+                            nhiS = last_ok;
+                        }
+                        uint32_t kd = 0xFFFFFFFFu, ku = 0xFFFFFFFFu;
+                        if (!syncw) {
+#pragma unroll
+                            for (int u = 0; u < PU; u++) {
+                                const int j = ct + u * PCW, k = KBw + j;
+                                if (j < SWf && k >= loS && k <= hiS) {
+                                    if (k < nloS || k > nhiS) {
+                                        my_cells -= (rS[j + 1] != 0u) + (nI[j + 1] != 0u) + (nD[j + 1] != 0u);
+                                        rS[j + 1] = 0u, nI[j + 1] = 0u, nD[j + 1] = 0u;
+                                    } else if (!glob) {
+                                        const uint32_t cls = lean_endclass(rS[j + 1], k, n, m);
+                                        if (cls != 0u) {
+                                            if (k <= Ak) kd = umin2(kd, lean_endkey(cls, (uint32_t)(Ak - k)));
+                                            else ku = umin2(ku, lean_endkey(cls, (uint32_t)(k - Ak - 1)));
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                        if (!glob && __ballot(kd != 0xFFFFFFFFu || ku != 0xFFFFFFFFu) != 0ull) {
+                            kd = (uint32_t)wave_min((int)(kd ^ 0x80000000u)) ^ 0x80000000u;
+                            ku = (uint32_t)wave_min((int)(ku ^ 0x80000000u)) ^ 0x80000000u;
+                            if (lane == 0) {
+                                if (kd != 0xFFFFFFFFu) atomicMin(dir_ptr(siS) + 5, kd);
+                                if (ku != 0xFFFFFFFFu) atomicMin(dir_ptr(siS) + 6, ku);
+                            }
+                        }
+                        if (nhiS >= nloS) put_ent(siS, baseS + (uint64_t)(nloS - loSs), nloS, nhiS - nloS + 1);
+                        else put_ent(siS, 0ull, 0, 0);
+                        if (tid < 6) {
+                            const int halo_k = (tid & 1) ? KBw + SWf : KBw - 1;
+                            uint32_t *const row = (tid >> 1) == 0 ? rS : ((tid >> 1) == 1 ? nI : nD);
+                            row[(tid & 1) ? SWf + 1 : 0] = (nhiS >= nloS && halo_k >= nloS && halo_k <= nhiS) ? (uint32_t)red[40 + 3 * (tid & 1) + (tid >> 1)] : 0u;
+                        }
+                        lds_barrier();
+                        leave = true;
+                        break;
+                    }
+                    if (deepS) TC_COUNT(22);
+                    if (deepS) {  // row S's deletions reach the interior's sources: the sync wave has not applied them -- everybody does, then row N is dropped
+                        const uint32_t siS = si - 1u;
+                        uint32_t kd = 0xFFFFFFFFu, ku = 0xFFFFFFFFu;
+                        if (!syncw) {
+#pragma unroll
+                            for (int u = 0; u < PU; u++) {
+                                const int j = ct + u * PCW, k = KBw + j;
+                                if (j < SWf && k >= loS && k <= hiS) {
+                                    if (k < nloS || k > nhiS) {
+                                        my_cells -= (rS[j + 1] != 0u) + (nI[j + 1] != 0u) + (nD[j + 1] != 0u);
+                                        rS[j + 1] = 0u, nI[j + 1] = 0u, nD[j + 1] = 0u;
+                                    } else if (!glob) {
+                                        const uint32_t cls = lean_endclass(rS[j + 1], k, n, m);
+                                        if (cls != 0u) {
+                                            if (k <= Ak) kd = umin2(kd, lean_endkey(cls, (uint32_t)(Ak - k)));
+                                            else ku = umin2(ku, lean_endkey(cls, (uint32_t)(k - Ak - 1)));
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                        if (!glob && __ballot(kd != 0xFFFFFFFFu || ku != 0xFFFFFFFFu) != 0ull) {
+                            kd = (uint32_t)wave_min((int)(kd ^ 0x80000000u)) ^ 0x80000000u;
+                            ku = (uint32_t)wave_min((int)(ku ^ 0x80000000u)) ^ 0x80000000u;
+                            if (lane == 0) {
+                                if (kd != 0xFFFFFFFFu) atomicMin(dir_ptr(siS) + 5, kd);
+                                if (ku != 0xFFFFFFFFu) atomicMin(dir_ptr(siS) + 6, ku);
+                            }
+                        }
+                        if (nhiS >= nloS) put_ent(siS, baseS + (uint64_t)(nloS - loSs), nloS, nhiS - nloS + 1);
+                        else put_ent(siS, 0ull, 0, 0);
+                        if (tid < 6) {
+                            const int halo_k = (tid & 1) ? KBw + SWf : KBw - 1;
+                            uint32_t *const row = (tid >> 1) == 0 ? rS : ((tid >> 1) == 1 ? nI : nD);
+                            row[(tid & 1) ? SWf + 1 : 0] = (nhiS >= nloS && halo_k >= nloS && halo_k <= nhiS) ? (uint32_t)red[40 + 3 * (tid & 1) + (tid >> 1)] : 0u;
+                        }
+                        lds_barrier();
+                        leave = true;
+                        break;
+                    }
+                    if (last) {
+                        TC_COUNT(21);
+                        leave = true;
+                        break;
+                    }
+                    // ---- commit row N: the arena, the census, the statistics into the scratch set, the cells into the rings
+                    const int loN = (int)rfl((uint32_t)pf[10]), hiN = (int)rfl((uint32_t)pf[11]);
+                    ftop += (uint64_t)W, top = ftop;
+                    my_cells += cnt;
+                    if (fvm != INT32_MAX) mind = wave_min(mind), maxd = wave_max(maxd);
+                    if (__ballot(termw) != 0ull) {
+                        if (lane == 0) accn[2] = 1;
+                        if (termw) accn[10] = (int)h_final;
+                    }
+                    if (!glob && __ballot(ekd != 0xFFFFFFFFu || eku != 0xFFFFFFFFu) != 0ull) {
+                        ekd = (uint32_t)wave_min((int)(ekd ^ 0x80000000u)) ^ 0x80000000u;
+                        eku = (uint32_t)wave_min((int)(eku ^ 0x80000000u)) ^ 0x80000000u;
+                        if (lane == 0) atomicMin(reinterpret_cast<unsigned int *>(&accn[8]), ekd), atomicMin(reinterpret_cast<unsigned int *>(&accn[9]), eku);
+                    }
+                    if (lane == 0) {
+                        if (mlo != INT32_MAX) atomicMin(&accn[0], mlo), atomicMax(&accn[1], mhi);
+                        if (fvm != INT32_MAX) atomicMin(&accn[13], fvm), atomicMax(&accn[14], lvm), atomicMin(&accn[3], mind), atomicMax(&accn[12], maxd);
+                        if (hminw != INT32_MAX) atomicMin(&accn[11], hminw);
+                    }
+                    // (row N's I / D take row S's slots: every cell of row N has read them.)  The cell waves write every cell of the stripe that is
+                    // not a late cell -- zero where row N has none: the slot held row N - RM --, the sync wave the late ones
+                    if (syncw) {
+#pragma unroll
+                        for (int u = 0; u < 3; u++) {
+                            int  j;
+                            bool mine;
+                            if (u == 0) j = lo + lane - KBw, mine = j > 0 && j < SWf - 1 && lo + lane < ilo;
+                            else if (u == 1) j = ihi + 1 + lane - KBw, mine = j > 0 && j < SWf - 1 && ihi + 1 + lane <= hi;
+                            else j = lane == 0 ? 0 : SWf - 1, mine = lane < 2 && (lane == 0 || SWf > 1);
+                            if (mine) nM[j + 1] = kM[u], nI[j + 1] = kI[u], nD[j + 1] = kD[u];
+                        }
+                        // the stripe's first / last cell: the neighbours' halo, handed over with the next exchange
+                        if (lane == 0) red[24] = (int)kM[2], red[25] = (int)kI[2], red[26] = (int)kD[2];
+                        if (lane == (SWf > 1 ? 1 : 0)) red[28] = (int)kM[2], red[29] = (int)kI[2], red[30] = (int)kD[2];
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < PU; u++) {
+                            const int j = ct + u * PCW, k = KBw + j;
+                            if (j > 0 && j < SWf - 1 && !(k >= lo && k < ilo) && !(k > ihi && k <= hi)) nM[j + 1] = kM[u], nI[j + 1] = kI[u], nD[j + 1] = kD[u];
+                        }
+                    }
+                    lds_barrier();  // (A) row N is in the rings, its statistics are complete
+                    if (tid >= 64 && tid < 80) acc[tid - 64] = acc_reset(tid - 64);  // row S's set: idle until the row after next
+                    {
+                        int *const t_ = acc;
+                        acc = accn, accn = t_;
+                    }
+                    loS = loN, hiS = hiN, loSs = lo, baseS = baseN, iloS = ilo, ihiS = ihi;
+                    TC_STAMP(31);
+                    TC_COUNT(20);
+                    first = false;
+                    s += g, si += 1u;
+                    pM = pM + 1u == RM ? 0u : pM + 1u;
+                }
+                top = ftop;
+                if (done) break;
+                lds_barrier();
+                if (leave) fast_budget = 2;  // (the row that made the pipelined steps leave, and one more; then they are tried again)
+            }
             // ---- FAST STEPS: a stripe mode in its steady state -- every source score has its ring slot, no seeds, the row fits the
             // stripes as they are dealt, the page and the directory have room.  The same step as the general one below, on fewer
             // instructions and five workgroup barriers instead of nine: the ring slots and the score index are counters, not divisions;
@@ -621,6 +1127,7 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
             if ((mode == TC_STRIPE_T || mode == TC_STRIPE_S) && rings_in_lds && s > x && s >= oe && X.fast != 0u) {
                 const auto rfl = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
                 const bool team_now = mode == TC_STRIPE_T;
+                bool       back_to_pipe = false;
                 const int  KBw = (int)rfl((uint32_t)(KB + (team_now ? (int)b * SWd : 0))), SWf = (int)rfl((uint32_t)SWd), wbase = (int)rfl((uint32_t)(tid - lane));
                 s = rfl(s);
                 uint32_t si = rfl(s / g), pM = si % RM, pE = si % RE;
@@ -925,9 +1432,18 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
                     pM = pM + 1u == RM ? 0u : pM + 1u, pE = pE + 1u == RE ? 0u : pE + 1u;
                     int *const t_ = acc;
                     acc = accn, accn = t_;
+                    if (fast_budget > 0 && --fast_budget == 0) {  // back to the pipelined steps
+                        back_to_pipe = true;
+                        break;
+                    }
                 }
                 if (done) break;
                 lds_barrier();  // (the general head resets red[0 .. 14]: nobody is still reading a scratch set)
+                if (back_to_pipe) {
+                    fast_budget = -1;
+                    s -= g;  // (the loop head again, for score s)
+                    continue;
+                }
             }
             const uint32_t si = s / g;
             auto uni = [](DirEnt d) {
