@@ -755,11 +755,12 @@ def test_teamc_kernel_words_and_results(built, slack):
             oa = O.Aligner(_oracle_params(glob, ad, pen))
             # (the default penalties see every shape of team; the others the two that differ most)
             # (fast = 0: every step of the stripe modes takes the general step instead of the short one of their steady state)
-            for wgs, solo_max, wave, fast in (((2, 64, 1, 1), (2, 4096, 1, 1), (1, 4096, 0, 1), (3, 0, 1, 1), (2, 64, 1, 0)) if pen == (4, 6, 2)
+            # (fast = 2: the short steps without the pipelined ones, which are the default and need wf-adaptive, a team and e/g = 1, x/g >= 2)
+            for wgs, solo_max, wave, fast in (((2, 64, 1, 1), (2, 4096, 1, 1), (1, 4096, 0, 1), (3, 0, 1, 1), (2, 64, 1, 0), (3, 0, 1, 2)) if pen == (4, 6, 2)
                                               else ((2, 64, 1, 1), (3, 0, 1, 1))):
                 al = _aligner(glob, ad, pen)
                 for k, v in (("packed", 0), ("team_min_len", 1), ("team_wgs", wgs), ("team_solo_max", solo_max), ("team_wave", wave),
-                             ("team_slack", slack), ("team_fast", fast), ("arena_poison", 1)):
+                             ("team_slack", slack), ("team_fast", min(fast, 1)), ("team_pipe", 0 if fast == 2 else 1), ("arena_poison", 1)):
                     al.set_option(k, v)
                 for i in range(len(ql)):
                     q, t = bytes(blob[qo[i]:qo[i] + ql[i]]), bytes(blob[to[i]:to[i] + tl[i]])
@@ -782,10 +783,10 @@ def test_teamc_kernel_words_and_results(built, slack):
     data = w.generate_pairs(seed=42, n_pairs=6, length=9000, error_rate=0.06)
     want = O.align_batch(_oracle_params(False, (10, 50, 1)), *data, n_threads=6)
     cells = []
-    for wgs, compact, fast in ((3, 1, 1), (5, 1, 1), (3, 1, 0), (3, 0, 1)):
+    for wgs, compact, fast in ((3, 1, 1), (5, 1, 1), (3, 1, 0), (3, 1, 2), (3, 0, 1)):
         al = _aligner(False, (10, 50, 1))
-        for k, v in (("packed", 0), ("team_min_len", 1), ("team_wgs", wgs), ("team_compact", compact), ("team_slack", slack), ("team_fast", fast),
-                     ("team_order", fast), ("arena_poison", 1)):
+        for k, v in (("packed", 0), ("team_min_len", 1), ("team_wgs", wgs), ("team_compact", compact), ("team_slack", slack), ("team_fast", min(fast, 1)),
+                     ("team_pipe", 0 if fast == 2 else 1), ("team_order", min(fast, 1)), ("arena_poison", 1)):
             al.set_option(k, v)
         assert_batch_equal(al.align_arrays(*data), want, f"9 kbp semi-global, {wgs} workgroups per team, compact={compact}, fast={fast}")
         assert al.last_timing().main_kernel_kind == (17 if compact else 7)
