@@ -1,4 +1,5 @@
 #!/bin/bash
+# after the closing run has committed its PMC profiles: smoke, the headline line with its eleven other legs, c5s and p242 -- so that the stored lines name profiles of the same sources
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=gpurun_out/r05_n; mkdir -p $OUT
 timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
