@@ -178,6 +178,8 @@ struct wfahip_ctx {
                                                     // per pair) in the generic ladder; 0 = never
     int64_t       opt_team_wgs             = 0;     // workgroups per team, 0 = automatic
     int64_t       opt_team_solo_max        = TEAM_SOLO_MAX;  // rows up to this width are done by one workgroup
+    bool          opt_team_solo_max_set    = false;          // (wfa_teamc_kernel takes 512 unless the option was set: its pipelined team rows cost ~6 us, a row of workgroup 0 alone
+                                                             // ~8 -- configs[4] x 32 pairs, two of which spend 3.5e4 rows between 65 and 4 096 diagonals: 30.8 -> 32.5 pairs/s)
     int64_t       opt_team_wave            = 1;              // rows up to 64 diagonals are done by one wave (LDS ring)
     int64_t       opt_team_strict          = 1;              // agent-scope release in every team barrier (0: see wfa_team.hpp)
     int64_t       opt_unpack_all           = 0;              // 1: host entries with packed input expand ALL of it to bytes on the device first (rounds 2-3)
@@ -564,7 +566,7 @@ static int set_option_impl(wfahip_ctx *ctx, const char *key, int64_t value) {
     else if (k == "team_wgs")
         ctx->opt_team_wgs = value;
     else if (k == "team_solo_max")
-        ctx->opt_team_solo_max = value;
+        ctx->opt_team_solo_max = value, ctx->opt_team_solo_max_set = true;
     else if (k == "team_wave")
         ctx->opt_team_wave = value;
     else if (k == "team_strict")
@@ -1621,7 +1623,7 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                 if (ctx->opt_arena_poison) HIP_TRY(hipMemsetAsync(ctx->xbuf.p, 0xA5, (size_t)team_n * X.xbuf_words * 4, st));
                 X.team_ctl = static_cast<uint32_t *>(ctx->team_ctl.p), X.xbuf = static_cast<uint32_t *>(ctx->xbuf.p);
                 X.T = team_T, X.n_teams = team_n, X.tpx = xmap ? 1u : 0u;
-                X.solo_max = (uint32_t)std::max<int64_t>(0, ctx->opt_team_solo_max), X.wave_rows = team_wave_rows;
+                X.solo_max = (uint32_t)std::max<int64_t>(0, ctx->opt_team_solo_max_set ? ctx->opt_team_solo_max : std::min<int64_t>(ctx->opt_team_solo_max, 512)), X.wave_rows = team_wave_rows;
                 X.strict = (uint32_t)(ctx->opt_team_strict != 0) | (xmap && ctx->opt_team_xcd >= 2 ? 4u : 0u);
                 X.slack  = (uint32_t)std::min<int64_t>(std::max<int64_t>(1, ctx->opt_team_slack), 1 << 20);
                 X.fast   = ctx->opt_team_fast != 0 ? 1u : 0u;
