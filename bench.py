@@ -24,6 +24,7 @@ Prints ONE JSON line (rank 0).  `value` = pairs aligned by all ranks / max-over-
 import argparse
 import json
 import os
+import re
 import socket
 import subprocess
 import sys
@@ -468,7 +469,7 @@ def run_rank(args):
                "timed_region_s": elapsed,
                "clock_mhz_under_load": clock["mean"] if clock else None, "clock_mhz_under_load_range": [clock["min"], clock["max"]] if clock else None,
                "clock_note": "shader MHz while the library's probe kernel keeps every SIMD issuing (s_memtime / s_memrealtime), right after the timed region",
-               "rocm_smi_before": smi_before, "rocm_smi_after": smi_after,
+               "gpu_sysfs_before": smi_before, "gpu_sysfs_after": smi_after,
                "steady_state": f"the timed steps re-align the resident batch after {args.warmup + setup_steps} untimed call(s) of the same workload class: "
                                "what the context learns per class (rows per pair, first window, arena level) is in place; a first call "
                                "of a class also allocates its arenas (seconds, include/wfa_hip.h)"}
@@ -561,7 +562,7 @@ def other_configs(w, L, torch, dev, dev_index):
     for name, steps, warmup in OTHER_LEGS:
         c = CONFIGS[name]
         t_leg = time.perf_counter()
-        al = None
+        al = d = d_rec = d_ops = step = None
         try:
             n = c["pairs"] or c["total"]  # (c4: all 1e7 pairs on the one GPU)
             pen = tuple(c.get("pen", (4, 6, 2)))
@@ -620,30 +621,57 @@ def other_configs(w, L, torch, dev, dev_index):
                                       "algorithmic_bytes_per_launch": alg_bytes, "peak": 8000.0, "unit": "GB/s"},
                          "status_ok": int((rec[:, L.REC_STATUS] == 0).sum()), "pairs": n,
                          "retried_pairs": int(timing.n_retried_pairs), "leg_s": None}
-            del d, d_rec, d_ops
         except Exception as e:  # noqa: BLE001 -- reported, not raised: the headline line must still be printed
             res[name] = {"error": f"{type(e).__name__}: {e}"}
         finally:
             if al is not None:
                 w.RecycleAligner(al)
+            d = d_rec = d_ops = step = None  # (a failed leg must not keep its tensors alive into the next one)
             torch.cuda.empty_cache()
         res[name]["leg_s"] = time.perf_counter() - t_leg
     return res
 
 
 def gpu_telemetry(dev_index):
-    """rocm-smi's view of the GPU (clocks, power, temperature), or the error that kept it from being read."""
+    """The GPU's clocks, power and temperature as amdgpu's sysfs files give them, or the error that kept them from being
+    read.  No child process: under `rocprofv3 --pmc` a child (`rocm-smi` is a `#!/usr/bin/env python3` script) would inherit the
+    profiler's preload, initialise the GPU inside `env` and then exec -- the hop this pool forbids."""
+    import glob
     try:
-        r = subprocess.run(["rocm-smi", "-d", str(dev_index), "--showclocks", "--showpower", "--showtemp", "--showperflevel", "--json"],
-                           capture_output=True, text=True, timeout=20)
-        d = json.loads(r.stdout)
-        card = next(iter(d.values())) if d else {}
-        keep = {}
-        for k, v in card.items():
-            kl = k.lower()
-            if any(t in kl for t in ("sclk", "mclk", "fclk", "socclk", "power", "temperature", "performance level")):
-                keep[k] = v
-        return keep or {"raw": r.stdout[:400], "stderr": r.stderr[:200]}
+        cards = []
+        for dev in sorted(glob.glob("/sys/class/drm/card[0-9]*/device"), key=lambda d: int(re.search(r"card(\d+)", d).group(1))):
+            try:
+                if open(os.path.join(dev, "vendor")).read().strip() == "0x1002" and os.path.exists(os.path.join(dev, "pp_dpm_sclk")):
+                    cards.append(dev)
+            except OSError:
+                continue
+        if not cards:
+            return {"error": "no amdgpu device under /sys/class/drm"}
+        dev = cards[min(dev_index, len(cards) - 1)]
+        keep = {"sysfs": dev}
+
+        def current_level(name):
+            for line in open(os.path.join(dev, name)).read().splitlines():
+                if line.rstrip().endswith("*"):
+                    return line.split(":", 1)[1].replace("*", "").strip()
+            return None
+        for name in ("pp_dpm_sclk", "pp_dpm_mclk", "pp_dpm_fclk", "pp_dpm_socclk"):
+            try:
+                keep[name] = current_level(name)
+            except OSError:
+                pass
+        try:
+            keep["performance_level"] = open(os.path.join(dev, "power_dpm_force_performance_level")).read().strip()
+        except OSError:
+            pass
+        for hw in glob.glob(os.path.join(dev, "hwmon", "hwmon*")):
+            for f, key, scale in (("power1_average", "power_w", 1e-6), ("power1_input", "power_w", 1e-6), ("temp1_input", "temperature_edge_c", 1e-3),
+                                  ("temp2_input", "temperature_junction_c", 1e-3), ("temp3_input", "temperature_mem_c", 1e-3), ("freq1_input", "sclk_hz", 1.0)):
+                try:
+                    keep.setdefault(key, round(int(open(os.path.join(hw, f)).read().strip()) * scale, 1))
+                except (OSError, ValueError):
+                    pass
+        return keep
     except Exception as e:  # noqa: BLE001 -- telemetry must never take the bench line with it
         return {"error": f"{type(e).__name__}: {e}"}
 

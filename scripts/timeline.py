@@ -9,6 +9,6 @@ rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if pat in r["Kernel_Name"]]
 i0 = idx[-1]
 t0 = int(rows[i0]["Start_Timestamp"])
-for r in rows[max(0, i0 - 3):]:
+for r in rows[max(0, i0 - int(sys.argv[3]) if len(sys.argv) > 3 else i0 - 3):]:
     a, b = (int(r["Start_Timestamp"]) - t0) / 1e6, (int(r["End_Timestamp"]) - t0) / 1e6
     print(f"{a:9.3f} {b:9.3f} {b - a:8.3f}  q{r['Queue_Id']}  {r['Kernel_Name'][:70]}")

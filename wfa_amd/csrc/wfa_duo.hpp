@@ -39,44 +39,47 @@
 
 namespace wfa {
 
-// Group reductions: three butterfly stages inside the 8 lanes of a half row, and a fourth (row_mirror) whose result
-// only the lanes of a 16-lane pair keep.
+// Group reductions: three butterfly stages inside the 8 lanes of a half row, and a fourth (row_mirror) that only the lanes
+// of a 16-lane pair execute: EXEC is narrowed to the wave's wide pairs for it (wm = ballot of `wide`; both halves of a wide
+// pair are in the mask, so every active lane's mirror partner is active too).  Round 6: before, the fourth stage ran on a
+// copy in all lanes and a select kept it for the wide ones -- two more vector instructions per reduced value, ten per step.
+// (wait states: a DPP source written by the previous stage is read at least two instructions later; EXEC is written by
+// the scalar unit, which a DPP instruction need not wait for.)
 struct DuoRed {
 #define WFA_DUO_3(opa, opb, opc)                                                                                    \
+    unsigned long long sv;                                                                                          \
     asm("s_nop 1\n\t" opa " %0, %0, %0 " WFA_DPP_CTL_XOR1 "\n\t" opb " %1, %1, %1 " WFA_DPP_CTL_XOR1 "\n\t" opc      \
         " %2, %2, %2 " WFA_DPP_CTL_XOR1 "\n\t" opa " %0, %0, %0 " WFA_DPP_CTL_XOR2 "\n\t" opb " %1, %1, %1 "        \
         WFA_DPP_CTL_XOR2 "\n\t" opc " %2, %2, %2 " WFA_DPP_CTL_XOR2 "\n\t" opa " %0, %0, %0 " WFA_DPP_CTL_HMIR "\n\t" \
-        opb " %1, %1, %1 " WFA_DPP_CTL_HMIR "\n\t" opc " %2, %2, %2 " WFA_DPP_CTL_HMIR                              \
-        : "+v"(a), "+v"(b), "+v"(c));                                                                               \
-    int a2 = a, b2 = b, c2 = c;                                                                                     \
-    asm("s_nop 1\n\t" opa " %0, %0, %0 " WFA_DPP_CTL_MIR "\n\t" opb " %1, %1, %1 " WFA_DPP_CTL_MIR "\n\t" opc        \
-        " %2, %2, %2 " WFA_DPP_CTL_MIR                                                                              \
-        : "+v"(a2), "+v"(b2), "+v"(c2));                                                                            \
-    a = wide ? a2 : a, b = wide ? b2 : b, c = wide ? c2 : c;
+        opb " %1, %1, %1 " WFA_DPP_CTL_HMIR "\n\t" opc " %2, %2, %2 " WFA_DPP_CTL_HMIR "\n\t"                         \
+        "s_and_saveexec_b64 %3, %4\n\t" opa " %0, %0, %0 " WFA_DPP_CTL_MIR "\n\t" opb " %1, %1, %1 " WFA_DPP_CTL_MIR    \
+        "\n\t" opc " %2, %2, %2 " WFA_DPP_CTL_MIR "\n\ts_mov_b64 exec, %3"                                            \
+        : "+v"(a), "+v"(b), "+v"(c), "=&s"(sv)                                                                      \
+        : "s"(wm));
 #define WFA_DUO_2(opa, opb)                                                                                         \
+    unsigned long long sv;                                                                                          \
     asm("s_nop 1\n\t" opa " %0, %0, %0 " WFA_DPP_CTL_XOR1 "\n\t" opb " %1, %1, %1 " WFA_DPP_CTL_XOR1 "\n\ts_nop 0\n\t" \
         opa " %0, %0, %0 " WFA_DPP_CTL_XOR2 "\n\t" opb " %1, %1, %1 " WFA_DPP_CTL_XOR2 "\n\ts_nop 0\n\t" opa        \
-        " %0, %0, %0 " WFA_DPP_CTL_HMIR "\n\t" opb " %1, %1, %1 " WFA_DPP_CTL_HMIR                                   \
-        : "+v"(a), "+v"(b));                                                                                        \
-    int a2 = a, b2 = b;                                                                                             \
-    asm("s_nop 1\n\t" opa " %0, %0, %0 " WFA_DPP_CTL_MIR "\n\t" opb " %1, %1, %1 " WFA_DPP_CTL_MIR                   \
-        : "+v"(a2), "+v"(b2));                                                                                      \
-    a = wide ? a2 : a, b = wide ? b2 : b;
+        " %0, %0, %0 " WFA_DPP_CTL_HMIR "\n\t" opb " %1, %1, %1 " WFA_DPP_CTL_HMIR "\n\t"                            \
+        "s_and_saveexec_b64 %2, %3\n\t" opa " %0, %0, %0 " WFA_DPP_CTL_MIR "\n\t" opb " %1, %1, %1 " WFA_DPP_CTL_MIR    \
+        "\n\ts_mov_b64 exec, %2"                                                                                    \
+        : "+v"(a), "+v"(b), "=&s"(sv)                                                                               \
+        : "s"(wm));
 #define WFA_DUO_1(opa)                                                                                              \
+    unsigned long long sv;                                                                                          \
     asm("s_nop 1\n\t" opa " %0, %0, %0 " WFA_DPP_CTL_XOR1 "\n\ts_nop 1\n\t" opa " %0, %0, %0 " WFA_DPP_CTL_XOR2      \
-        "\n\ts_nop 1\n\t" opa " %0, %0, %0 " WFA_DPP_CTL_HMIR                                                       \
-        : "+v"(a));                                                                                                 \
-    int a2 = a;                                                                                                     \
-    asm("s_nop 1\n\t" opa " %0, %0, %0 " WFA_DPP_CTL_MIR : "+v"(a2));                                                \
-    a = wide ? a2 : a;
-    static WFA_DEV void min_max_min(int &a, int &b, int &c, bool wide) { WFA_DUO_3("v_min_i32_dpp", "v_max_i32_dpp", "v_min_i32_dpp") }
-    static WFA_DEV void min_max(int &a, int &b, bool wide) { WFA_DUO_2("v_min_i32_dpp", "v_max_i32_dpp") }
-    static WFA_DEV void max_add(int &a, int &b, bool wide) { WFA_DUO_2("v_max_i32_dpp", "v_add_u32_dpp") }
-    static WFA_DEV int  max1(int a, bool wide) {
+        "\n\ts_nop 1\n\t" opa " %0, %0, %0 " WFA_DPP_CTL_HMIR "\n\t"                                                \
+        "s_and_saveexec_b64 %1, %2\n\ts_nop 0\n\t" opa " %0, %0, %0 " WFA_DPP_CTL_MIR "\n\ts_mov_b64 exec, %1"       \
+        : "+v"(a), "=&s"(sv)                                                                                        \
+        : "s"(wm));
+    static WFA_DEV void min_max_min(int &a, int &b, int &c, unsigned long long wm) { WFA_DUO_3("v_min_i32_dpp", "v_max_i32_dpp", "v_min_i32_dpp") }
+    static WFA_DEV void min_max(int &a, int &b, unsigned long long wm) { WFA_DUO_2("v_min_i32_dpp", "v_max_i32_dpp") }
+    static WFA_DEV void max_add(int &a, int &b, unsigned long long wm) { WFA_DUO_2("v_max_i32_dpp", "v_add_u32_dpp") }
+    static WFA_DEV int  max1(int a, unsigned long long wm) {
         WFA_DUO_1("v_max_i32_dpp")
         return a;
     }
-    static WFA_DEV int or1(int a, bool wide) {
+    static WFA_DEV int or1(int a, unsigned long long wm) {
         WFA_DUO_1("v_or_b32_dpp")
         return a;
     }
@@ -87,7 +90,10 @@ struct DuoRed {
 
 // DX / DOE: the penalty shape, as in wfa_blk_kernel (R = max(DX, DOE) rows in the M ring)
 template <bool CENSUS, int DX = 2, int DOE = 4>
-__global__ __launch_bounds__(64, WFA_DUO_WAVES) void wfa_duo_kernel(const KParams P) {
+#ifndef WFA_DUO_VGPRS
+#define WFA_DUO_VGPRS 64  // (the attribute counts register PAIRS on gfx90a and later: 64 = no cap below the 128 of four waves per SIMD; 60 = 120 VGPRs)
+#endif
+__global__ __launch_bounds__(64, WFA_DUO_WAVES) __attribute__((amdgpu_num_vgpr(WFA_DUO_VGPRS))) void wfa_duo_kernel(const KParams P) {
     constexpr int PP = 4;
     static_assert(DX >= 1 && DOE >= 1 && DX <= 4 && DOE <= 4, "ring depths of one to four score steps");
     constexpr int R = DX > DOE ? DX : DOE;
@@ -476,6 +482,7 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) void wfa_duo_kernel(const KParam
     const auto step = [&](auto ph_c) __attribute__((always_inline)) {
         constexpr int ph = decltype(ph_c)::value;
         const bool run = (st == 1);
+        const unsigned long long wm = __ballot(wide);  // lanes of the 16-lane pairs (DuoRed's fourth stage)
         WFA_EVT(0, 1), WFA_EVT(6, __builtin_popcountll(__ballot(run)) / 8);
 
         uint32_t(&Mo)[PP] = M[(ph + R - DOE) % R];  // M[s-o-e]
@@ -599,7 +606,7 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) void wfa_duo_kernel(const KParam
             bool tl = false;
 #pragma unroll
             for (int p = 0; p < PP; p++) tl |= (k0 + p == m - n && nz[p] && (int)nM[p] >= m);
-            const int r = DuoRed::or1((hitl ? 1 : 0) | (tl ? 2 : 0), wide);
+            const int r = DuoRed::or1((hitl ? 1 : 0) | (tl ? 2 : 0), wm);
             ghit = (r & 1) != 0;
             slow |= ghit;
             term = run && (r & 2) != 0;
@@ -619,7 +626,7 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) void wfa_duo_kernel(const KParam
                 dd[p] = lmx[p] - (int)nM[p];
                 mind  = nz[p] ? imin2(mind, dd[p]) : mind;
             }
-            DuoRed::min_max_min(glo, ghi, mind, wide);
+            DuoRed::min_max_min(glo, ghi, mind, wm);
             anyM = ghi >= 0;
             const bool want = run && adaptive && anyM && (ghi - glo + 1) >= minwf;
             const int  thr  = want ? mind + mdd : BK_BIG;
@@ -628,7 +635,7 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) void wfa_duo_kernel(const KParam
             for (int p = PP - 1; p >= 0; p--) first_ok = (nz[p] && dd[p] <= thr) ? PP * j + p : first_ok;
 #pragma unroll
             for (int p = 0; p < PP; p++) last_ok = (nz[p] && dd[p] <= thr) ? PP * j + p : last_ok;
-            DuoRed::min_max(first_ok, last_ok, wide);
+            DuoRed::min_max(first_ok, last_ok, wm);
             ilo = first_ok, ihi = last_ok;
 #pragma unroll
             for (int p = 0; p < PP; p++) {  // Delete of wfa.go:526-535: the words never exist
@@ -643,7 +650,7 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) void wfa_duo_kernel(const KParam
             for (int p = PP - 1; p >= 0; p--) glo = nz[p] ? PP * j + p : glo;
 #pragma unroll
             for (int p = 0; p < PP; p++) ghi = nz[p] ? PP * j + p : ghi;
-            DuoRed::min_max(glo, ghi, wide);
+            DuoRed::min_max(glo, ghi, wm);
             anyM = ghi >= 0;
             ilo = glo, ihi = ghi;
             csum = 0u;
@@ -660,7 +667,7 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) void wfa_duo_kernel(const KParam
                     mind  = vd[p] ? imin2(mind, dd[p]) : mind;
                     maxd  = vd[p] ? imax2(maxd, dd[p]) : maxd;
                 }
-                DuoRed::min_max(mind, maxd, wide);
+                DuoRed::min_max(mind, maxd, wm);
                 const int  thr   = mind + mdd;
                 const bool found = want_reduce && mind != BK_BIG && maxd > thr;  // some distance fails (wfa.go:507)
                 if (__ballot(found) != 0ull) {
@@ -669,12 +676,12 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) void wfa_duo_kernel(const KParam
                     for (int p = PP - 1; p >= 0; p--) first_ok = (vd[p] && dd[p] <= thr) ? PP * j + p : first_ok;
 #pragma unroll
                     for (int p = 0; p < PP; p++) last_ok = (vd[p] && dd[p] <= thr) ? PP * j + p : last_ok;
-                    DuoRed::min_max(first_ok, last_ok, wide);
+                    DuoRed::min_max(first_ok, last_ok, wm);
                     // wfa.go:509-511 (see wfa_blk.hpp: per pair, not per wave)
                     int leadp = -1;
 #pragma unroll
                     for (int p = 0; p < PP; p++) leadp = (vd[p] && PP * j + p < first_ok) ? PP * j + p : leadp;
-                    leadp = DuoRed::max1(leadp, wide);
+                    leadp = DuoRed::max1(leadp, wm);
                     const int newlo = ghit ? (leadp >= 0 ? leadp + 1 : glo) : first_ok;
                     if (found) ilo = newlo, ihi = last_ok;  // wfa.go:517-524
                     csum = 0u;
@@ -694,7 +701,7 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) void wfa_duo_kernel(const KParam
         const bool keepl = anyM && ihi >= ilo && !no_room;
         if constexpr (CENSUS) {  // (instrumentation instance only: the pair's total, the same in all its lanes)
             int cs = (int)csum, dummy = 0;
-            DuoRed::max_add(dummy, cs, wide);
+            DuoRed::max_add(dummy, cs, wm);
             cells += keepl ? (uint32_t)cs : 0u;
         }
         rowp += 2;
@@ -714,7 +721,7 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) void wfa_duo_kernel(const KParam
 #pragma unroll
             for (int p = 0; p < PP; p++)
                 if (k0 + p == m - n) hf = (int)Mn[p];
-            hf = DuoRed::max1(hf, wide);
+            hf = DuoRed::max1(hf, wm);
             if (fin && j == 0) {
                 if (no_room) {
                     P.pair_meta[pidx] = make_uint4(ST_REDO_ARENA, 0u, 0u, 0u);
