@@ -291,6 +291,8 @@ def run_rank(args):
         al = w.New(w.Penalties(*args.pen), w.Options(GlobalAlignment=not args.semi_global), device=dev_index)
         if not args.no_adaptive:
             assert al.AdaptiveReduction(w.DefaultAdaptiveOption) is None
+        if args.opt:
+            os.environ.setdefault("WFAHIP_DEBUG", "1")  # (--opt sets experiment knobs: refused otherwise)
         for kv in args.opt:
             key, val = kv.split("=")
             L.check(L.lib().wfahip_set_option(al._ctx, key.encode(), int(val)), "wfahip_set_option")

@@ -55,6 +55,27 @@ var ErrEmptySeq error = fmt.Errorf("wfa: invalid empty sequence")
 
 const MaxSeqLen int = 1<<(32-3) - 1
 
+// The C header's enum constants as TYPED Go constants.  cgo hands enum constants over as constants whose type depends on
+// the toolchain (untyped integers with some versions, the enum's C type with others); array lengths, indices and `case`
+// labels below use these conversions, which are constant expressions either way.
+const (
+	recWords      = int(C.WFAHIP_REC_WORDS)
+	recStatus     = int(C.WFAHIP_REC_STATUS)
+	recScore      = int(C.WFAHIP_REC_SCORE)
+	recTBegin     = int(C.WFAHIP_REC_TBEGIN)
+	recTEnd       = int(C.WFAHIP_REC_TEND)
+	recQBegin     = int(C.WFAHIP_REC_QBEGIN)
+	recQEnd       = int(C.WFAHIP_REC_QEND)
+	recAlignLen   = int(C.WFAHIP_REC_ALIGN_LEN)
+	recMatches    = int(C.WFAHIP_REC_MATCHES)
+	recGaps       = int(C.WFAHIP_REC_GAPS)
+	recGapRegions = int(C.WFAHIP_REC_GAP_REGIONS)
+	recOpsLen     = int(C.WFAHIP_REC_OPS_LEN)
+	pairOK        = uint32(C.WFAHIP_PAIR_OK)
+	pairEmpty     = uint32(C.WFAHIP_PAIR_EMPTY)
+	pairTooLong   = uint32(C.WFAHIP_PAIR_TOO_LONG)
+)
+
 var ErrSeqTooLong error = fmt.Errorf("wfa: sequences longer than %d are not supported", MaxSeqLen)
 
 // Aligner holds one device context.  Like the reference's (wfa.go:73-78) it must not be used from several
@@ -160,7 +181,7 @@ func (algn *Aligner) AlignPointers(q, t *[]byte) (*AlignmentResult, error) {
 	if len(algn.oneOps) < need {
 		algn.oneOps = make([]C.uint64_t, 2*need+64)
 	}
-	var rec [C.WFAHIP_REC_WORDS]C.uint32_t
+	var rec [recWords]C.uint32_t
 	var nOps C.uint64_t
 	p := algn.params()
 	rc := C.wfahip_align_pair(algn.ctx, &p, (*C.uint8_t)(unsafe.Pointer(&(*q)[0])), C.uint32_t(len(*q)),
@@ -170,12 +191,12 @@ func (algn *Aligner) AlignPointers(q, t *[]byte) (*AlignmentResult, error) {
 	if rc != 0 {
 		return nil, fmt.Errorf("wfa: %s", C.GoString(C.wfahip_strerror(rc)))
 	}
-	switch rec[C.WFAHIP_REC_STATUS] {
-	case C.WFAHIP_PAIR_EMPTY:
+	switch uint32(rec[recStatus]) {
+	case pairEmpty:
 		return nil, ErrEmptySeq
-	case C.WFAHIP_PAIR_TOO_LONG:
+	case pairTooLong:
 		return nil, ErrSeqTooLong
-	case C.WFAHIP_PAIR_OK:
+	case pairOK:
 	default:
 		return nil, fmt.Errorf("wfa: not enough device memory for this pair")
 	}
@@ -185,11 +206,11 @@ func (algn *Aligner) AlignPointers(q, t *[]byte) (*AlignmentResult, error) {
 	for i := 0; i < int(nOps); i++ {
 		r.Ops = append(r.Ops, uint64(algn.oneOps[i]))
 	}
-	r.Score = uint32(rec[C.WFAHIP_REC_SCORE])
-	r.TBegin, r.TEnd = int(int32(rec[C.WFAHIP_REC_TBEGIN])), int(int32(rec[C.WFAHIP_REC_TEND]))
-	r.QBegin, r.QEnd = int(int32(rec[C.WFAHIP_REC_QBEGIN])), int(int32(rec[C.WFAHIP_REC_QEND]))
-	r.AlignLen, r.Matches = uint32(rec[C.WFAHIP_REC_ALIGN_LEN]), uint32(rec[C.WFAHIP_REC_MATCHES])
-	r.Gaps, r.GapRegions = uint32(rec[C.WFAHIP_REC_GAPS]), uint32(rec[C.WFAHIP_REC_GAP_REGIONS])
+	r.Score = uint32(rec[recScore])
+	r.TBegin, r.TEnd = int(int32(rec[recTBegin])), int(int32(rec[recTEnd]))
+	r.QBegin, r.QEnd = int(int32(rec[recQBegin])), int(int32(rec[recQEnd]))
+	r.AlignLen, r.Matches = uint32(rec[recAlignLen]), uint32(rec[recMatches])
+	r.Gaps, r.GapRegions = uint32(rec[recGaps]), uint32(rec[recGapRegions])
 	return r, nil
 }
 
@@ -262,8 +283,8 @@ func (algn *Aligner) unpack(rc C.int, out *C.wfahip_results, n int) ([]*Alignmen
 		ops = unsafe.Slice((*uint64)(unsafe.Pointer(out.ops)), int(out.n_ops))
 	}
 	for i := 0; i < n; i++ {
-		switch status[i] {
-		case 0:
+		switch uint32(status[i]) {
+		case pairOK:
 			r := NewAlignmentResult(algn.opt.GlobalAlignment)
 			r.Ops = append(r.Ops[:0], ops[oo[i]:oo[i]+uint64(ol[i])]...) // copied into pool-owned memory
 			r.Score = score[i]
@@ -271,9 +292,9 @@ func (algn *Aligner) unpack(rc C.int, out *C.wfahip_results, n int) ([]*Alignmen
 			r.AlignLen, r.Matches, r.Gaps, r.GapRegions = al[i], ma[i], ga[i], gr[i]
 			r.proccessed = true // ops arrive reversed + merged (process(), wfa_cigar.go:136-214, ran on the device)
 			results[i] = r
-		case 1:
+		case pairEmpty:
 			errs[i] = ErrEmptySeq
-		case 2:
+		case pairTooLong:
 			errs[i] = ErrSeqTooLong
 		default:
 			errs[i] = fmt.Errorf("wfa: out of device memory for this pair")

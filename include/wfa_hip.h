@@ -227,7 +227,20 @@ int         wfahip_align_batch_multi(wfahip_multi *m, const wfahip_params *p, co
 
 int  wfahip_last_timing(const wfahip_ctx *ctx, wfahip_timing *out);
 
-/* Tuning knobs (optional; results never depend on them).  Keys:
+/* Options (optional; results never depend on them).
+ *
+ * PUBLIC keys -- always accepted:
+ *   "census"  0|1          count the wavefront words every pair stores (WFAHIP_REC_CELLS, timing.cells_stored)     default 0
+ *   "learn"  0|1           long pairs start on the arena level the previous call of the same kind needed            default 1
+ *   "mem_limit"  bytes     device memory the context may plan with (0 = all of it)
+ *   "arena_budget_pct"     share of that memory the long-pair arenas may take                                       default 80
+ *   "autopack"  0|1        the host entry 2-bit packs ACGT-only batches before the upload                           default 1
+ *   "pair_fast", "pair_lds"   wfahip_align_pair's path (described at the end of the list below)
+ *
+ * DEBUG keys -- every other key below: a routing experiment, a test aid or the knob of one kernel family.  They are refused
+ * with WFAHIP_ERR_UNSUPPORTED unless WFAHIP_DEBUG=1 is set in the environment of the process (tests/conftest.py, bench.py
+ * --opt and the scripts under scripts/ set it).  Some change what is SAFE, not only what is fast ("team_strict" 0,
+ * "fail_pass"); none belongs in a deployment.
  *   "blk"  16 | 8 | 0      blocked register-window forward kernel, lanes per pair (0 = off)       default 16
  *   "reg", "packed"  0|1   allow the strided register-window / LDS-ring forward kernels           default 1
  *   "packed_arena_bytes"   per-pair arena of the sub-wave pipeline (0 = automatic)

@@ -1,4 +1,5 @@
 #!/bin/bash
+export WFAHIP_DEBUG=1  # (the option knobs below are debug / experiment knobs)
 # wave mode of the generic kernel: parity tests that run through it, then timings with and without it
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $REPO

@@ -1,4 +1,5 @@
 #!/bin/bash
+export WFAHIP_DEBUG=1  # (the option knobs below are debug / experiment knobs)
 # Diagnostic (GPU box): one pass of the headline workload with the stamped library build/variants/stamps.so
 # (HOST=1 scripts/mkvariant.sh stamps -DWFA_STAMPS): per-phase s_memtime shares + event counts of the forward kernel on
 # stderr.  Never used for timing numbers.  Usage: scripts/stamps.sh [pairs [length [error]]]   WFA_OPTS=key=value,...

@@ -2,6 +2,7 @@
 """Soak of the team kernel (GPU): the configs[4] sample (8 x 100 kbp semi-global pairs) aligned `reps` times over a poisoned
 pool with the given options; every pass must reproduce the first one bit for bit (the first pass of the default options is
 what tests/test_parity_gpu.py::test_config5_full_length_pair checks against the oracle).  Usage: team_soak.py reps key=value ..."""
+import os; os.environ.setdefault("WFAHIP_DEBUG", "1")  # (these are debug / experiment knobs)
 import sys, time
 import numpy as np
 sys.path.insert(0, ".")

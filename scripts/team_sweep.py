@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic (GPU): team kernel time vs workgroups per team on long semi-global pairs."""
+import os; os.environ.setdefault("WFAHIP_DEBUG", "1")  # (these are debug / experiment knobs)
 import sys, time, numpy as np
 sys.path.insert(0, ".")
 import wfa_amd as w

@@ -8,6 +8,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# the tests force kernels, poison arenas and inject failures through wfahip_set_option: debug knobs, refused without this
+os.environ.setdefault("WFAHIP_DEBUG", "1")
 
 
 def pytest_configure(config):

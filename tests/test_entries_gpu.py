@@ -1,5 +1,7 @@
 """GPU: the round-2 entry points of the C-ABI -- pre-packed 2-bit input, per-pair submit / collect, the context set
 over several GPUs -- each against the plain batch entry and the oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -262,3 +264,68 @@ def test_host_entry_packs_on_the_fly(built):
     wk = O.align_batch(_oracle_params(True, (10, 50, 1)), blob2, q_off[k:k + 1], q_len[k:k + 1], t_off[k:k + 1], t_len[k:k + 1], n_threads=1)
     assert int(c.score[k]) == int(wk.score[0]) and np.array_equal(c.pair_ops(k), wk.pair_ops(0))
     al.close()
+
+
+def test_debug_options_need_the_environment_switch(built):
+    """wfahip_set_option: the public keys are always accepted; routing experiments and test aids (here "team_strict", which
+    drops a release the team kernel needs, and "fail_pass", which injects a failure) are refused with WFAHIP_ERR_UNSUPPORTED
+    unless WFAHIP_DEBUG=1 is in the environment (tests/conftest.py sets it for the suite)."""
+    import wfa_amd as w
+    from wfa_amd import _lib as L
+    al = w.New()
+    lib = L.lib()
+    saved = os.environ.pop("WFAHIP_DEBUG", None)
+    try:
+        assert lib.wfahip_set_option(al._ctx, b"census", 1) == L.OK
+        assert lib.wfahip_set_option(al._ctx, b"census", 0) == L.OK
+        assert lib.wfahip_set_option(al._ctx, b"learn", 1) == L.OK
+        for key in (b"team_strict", b"fail_pass", b"arena_poison", b"unpack_all", b"duo", b"chunk_pairs"):
+            assert lib.wfahip_set_option(al._ctx, key, 0) == L.ERR_UNSUPPORTED, key
+        assert b"WFAHIP_DEBUG" in lib.wfahip_last_error(al._ctx)
+        os.environ["WFAHIP_DEBUG"] = "0"
+        assert lib.wfahip_set_option(al._ctx, b"team_strict", 1) == L.ERR_UNSUPPORTED
+        os.environ["WFAHIP_DEBUG"] = "1"
+        assert lib.wfahip_set_option(al._ctx, b"team_strict", 1) == L.OK
+        assert lib.wfahip_set_option(al._ctx, b"no_such_option", 1) == L.ERR_BAD_ARG
+    finally:
+        if saved is None:
+            os.environ.pop("WFAHIP_DEBUG", None)
+        else:
+            os.environ["WFAHIP_DEBUG"] = saved
+    al.close()
+
+
+def test_two_contexts_run_team_kernels_on_one_gpu(built):
+    """Two contexts on ONE GPU, each aligning 2 x 40 kbp semi-global pairs on its own host thread at the same time (what
+    wfahip_create_multi with repeated device ids, or bench.py --share-gpus, produces).  The team kernels spin on barriers
+    between workgroups and need their whole launch resident: two such launches side by side would starve each other until
+    the barrier timeout.  The library serialises team launches per device (TeamLaunchLock, wfa_host.hip): both calls must
+    finish, bit-exact against the oracle, with the team kernel having run in both -- three rounds, over poisoned arenas."""
+    import threading
+    import wfa_amd as w
+    from oracle import oracle as O
+    sets = [w.generate_pairs(seed=700 + i, n_pairs=2, length=40000, error_rate=0.08, n_threads=2) for i in range(2)]
+    prm = _oracle_params(False, (10, 50, 1))
+    wants = [O.align_batch(prm, *d, n_threads=2) for d in sets]
+    als = [_aligner(False, (10, 50, 1)) for _ in range(2)]
+    for al in als:
+        al.set_option("arena_poison", 1)
+    for rnd in range(3):
+        gots, errs = [None, None], [None, None]
+
+        def run(i):
+            try:
+                gots[i] = als[i].align_arrays(*sets[i])
+            except Exception as e:  # noqa: BLE001 -- reported below, on the test's thread
+                errs[i] = e
+        ths = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join(timeout=600)
+        assert not any(t.is_alive() for t in ths), "a call did not come back"
+        assert errs == [None, None], errs
+        for i in range(2):
+            assert_batch_equal(gots[i], wants[i], f"two contexts, round {rnd}, context {i}")
+    for al in als:
+        al.close()

@@ -244,17 +244,18 @@ WFA_DEV uint32_t umax3(uint32_t a, uint32_t b, uint32_t c) { return umax2(umax2(
 // (a scalar register written by a vector instruction may be read as an operand two wait states later).
 WFA_DEV uint32_t blk_word_asm(uint32_t Msk, uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t x1, uint32_t t, uint32_t Isk,
                               uint32_t Dsk) {
-    uint32_t w = Msk;
+    // (the first add-with-carry reads Msk and writes the word: no copy of Msk in front of the block -- round 6)
+    uint32_t w;
     asm("v_cmp_lt_u32_e64 s[40:41], %1, %2\n\t"
         "v_cmp_lt_u32_e64 s[42:43], %3, %4\n\t"
         "v_cmp_ge_u32_e64 s[44:45], %5, %6\n\t"
         "v_cmp_ge_u32_e64 s[46:47], %7, %8\n\t"
-        "v_addc_co_u32_e64 %0, vcc, %0, %0, s[40:41]\n\t"
+        "v_addc_co_u32_e64 %0, vcc, %9, %9, s[40:41]\n\t"
         "v_addc_co_u32_e64 %0, vcc, %0, %0, s[42:43]\n\t"
         "v_addc_co_u32_e64 %0, vcc, %0, %0, s[44:45]\n\t"
         "v_addc_co_u32_e64 %0, vcc, %0, %0, s[46:47]"
-        : "+v"(w)
-        : "v"(a), "v"(b), "v"(c), "v"(d), "v"(x1), "v"(t), "v"(Isk), "v"(Dsk)
+        : "=&v"(w)
+        : "v"(a), "v"(b), "v"(c), "v"(d), "v"(x1), "v"(t), "v"(Isk), "v"(Dsk), "v"(Msk)
         : "vcc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47");
     return w;
 }

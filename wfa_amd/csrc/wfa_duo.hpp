@@ -166,7 +166,10 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) __attribute__((amdgpu_num_vgpr(W
         for (int p = 0; p < PP; p++) lim[p] = imax2(1, imin2(n + k0 + p, m)), lmx[p] = imax2(n + k0 + p, m);
         lq   = lds + sbuf * PW + 4u;
         lt   = lq + SW;
-        rowp = P.arena + (uint64_t)pidx * cap + (uint64_t)(si >> 3) * 256u + (si & 7u) * 2u;
+        if constexpr (DUO_ARENA_FMT == 9u)  // [group of four diagonals][score]: the lane's group, then 8 bytes per score
+            rowp = P.arena + (uint64_t)pidx * cap + (((uint32_t)k0 & 60u) >> 2) * (uint32_t)(rows_cap * 2) + si * 2u;
+        else
+            rowp = P.arena + (uint64_t)pidx * cap + (uint64_t)(si >> 3) * 256u + (si & 7u) * 2u;
     };
     const auto clear_rings = [&]() {
 #pragma unroll
@@ -556,7 +559,7 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) __attribute__((amdgpu_num_vgpr(W
 #pragma unroll
             for (int p = 0; p < PP; p++) anyc |= nM[p];
             if (run && !no_room && anyc != 0u)
-                *reinterpret_cast<uint2 *>(rowp + (((uint32_t)k0 & 60u) << 2)) = make_uint2(wd[0] | (wd[1] << 16), wd[2] | (wd[3] << 16));
+                *reinterpret_cast<uint2 *>(rowp + (DUO_ARENA_FMT == 9u ? 0u : (((uint32_t)k0 & 60u) << 2))) = make_uint2(wd[0] | (wd[1] << 16), wd[2] | (wd[3] << 16));
         }
         WFA_STAMP(2);  // next + store
 
@@ -565,8 +568,9 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) __attribute__((amdgpu_num_vgpr(W
 #pragma unroll
         for (int p = 0; p < PP; p++) {
             const int      h    = (int)nM[p];
-            const int      rem  = lim[p] - h;
-            const uint32_t room = h ? (uint32_t)imax2(rem, 0) : 0u;
+            uint32_t       rem;  // max(lim - h, 0): one saturating subtraction
+            asm("v_sub_u32_e64 %0, %1, %2 clamp" : "=v"(rem) : "v"(lim[p]), "v"(h));
+            const uint32_t room = h ? rem : 0u;
             const int      v    = h - (k0 + p);
             const uint32_t xr   = SeqView<0>::win16(lq, v) ^ SeqView<0>::win16(lt, h);
             const uint32_t rn   = umin2(ffbl_raw(xr) >> 1, room);
@@ -617,24 +621,27 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) __attribute__((amdgpu_num_vgpr(W
         bool     anyM = false;
         uint32_t csum = 0u;
         if (__builtin_expect(!hit_any, 1)) {
-            int glo = BK_BIG, ghi = -BK_BIG, mind = BK_BIG, dd[PP];
+            // (an absent cell's distance is ABSENT, above every threshold: the tests below need no "exists and")
+            constexpr int ABSENT = BK_BIG + 1;
+            int glo = BK_BIG, ghi = -BK_BIG, dd[PP];
 #pragma unroll
             for (int p = PP - 1; p >= 0; p--) glo = nz[p] ? PP * j + p : glo;
 #pragma unroll
             for (int p = 0; p < PP; p++) {
                 ghi   = nz[p] ? PP * j + p : ghi;
-                dd[p] = lmx[p] - (int)nM[p];
-                mind  = nz[p] ? imin2(mind, dd[p]) : mind;
+                dd[p] = nz[p] ? lmx[p] - (int)nM[p] : ABSENT;
             }
+            static_assert(PP == 4, "minimum of four distances");
+            int mind = imin2(imin2(dd[0], dd[1]), imin2(dd[2], dd[3]));
             DuoRed::min_max_min(glo, ghi, mind, wm);
             anyM = ghi >= 0;
             const bool want = run && adaptive && anyM && (ghi - glo + 1) >= minwf;
             const int  thr  = want ? mind + mdd : BK_BIG;
             int        first_ok = BK_BIG, last_ok = -BK_BIG;
 #pragma unroll
-            for (int p = PP - 1; p >= 0; p--) first_ok = (nz[p] && dd[p] <= thr) ? PP * j + p : first_ok;
+            for (int p = PP - 1; p >= 0; p--) first_ok = dd[p] <= thr ? PP * j + p : first_ok;
 #pragma unroll
-            for (int p = 0; p < PP; p++) last_ok = (nz[p] && dd[p] <= thr) ? PP * j + p : last_ok;
+            for (int p = 0; p < PP; p++) last_ok = dd[p] <= thr ? PP * j + p : last_ok;
             DuoRed::min_max(first_ok, last_ok, wm);
             ilo = first_ok, ihi = last_ok;
 #pragma unroll
@@ -705,7 +712,7 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) __attribute__((amdgpu_num_vgpr(W
             cells += keepl ? (uint32_t)cs : 0u;
         }
         rowp += 2;
-        rowp += (((uint32_t)(uintptr_t)rowp & 0x38u) == 0u) ? 240 : 0;  // past the tile's 8th score: next tile
+        if constexpr (DUO_ARENA_FMT != 9u) rowp += (((uint32_t)(uintptr_t)rowp & 0x38u) == 0u) ? 240 : 0;  // past the tile's 8th score: next tile
 
         // ------------------------------------------------------------ the new row enters the rings
 #pragma unroll

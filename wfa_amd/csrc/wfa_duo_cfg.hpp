@@ -22,6 +22,15 @@ namespace wfa {
 #ifndef WFA_DUO_NARROW_AT
 #define WFA_DUO_NARROW_AT 21
 #endif
+#ifndef WFA_DUO_GROUP_MAJOR
+#define WFA_DUO_GROUP_MAJOR 1
+#endif
+// Arena layout of wfa_duo_kernel (16-bit words).  0: CompactView fmt 7 -- tiles of 8 scores x 64 diagonals (1 KB), inside a tile
+// [diagonal / 4][score & 7][diagonal & 3].  1 (round 6): fmt 9 -- GROUP-major, [diagonal / 4 & 15][score][diagonal & 3]: the 64-byte
+// lines are the same (8 scores of 4 diagonals), but the lines of one group of four diagonals are contiguous over all the
+// pair's scores (rows_cap x 8 bytes), so the backtrace's walk -- which stays within a few groups -- reads from a handful of
+// DRAM pages instead of one per tile, and the forward kernel's row pointer advances by a constant.
+constexpr uint32_t DUO_ARENA_FMT = WFA_DUO_GROUP_MAJOR ? 9u : 7u;
 constexpr int DUO_PARK       = WFA_DUO_PARK;           // park records per wave
 constexpr int DUO_PARK_WORDS = 8 * 12 + 16;            // rings of 8 lanes, two 16-bit offsets per word (reads under 2 048 bases) + 16 scalars
 constexpr int DUO_BUFS       = 8 + 1 + DUO_PARK;       // sequence buffers per wave: running pairs, staging, parked pairs (one pair per fetch)

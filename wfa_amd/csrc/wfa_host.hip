@@ -37,6 +37,10 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <fcntl.h>
+#include <optional>
+#include <sys/file.h>
+#include <unistd.h>
 
 using namespace wfa;
 
@@ -297,6 +301,37 @@ uint32_t gcd_u32(uint32_t a, uint32_t b) {
 // re-runs of the pairs that outgrow them (see the option).
 inline double ladder_budget(const wfahip_ctx *ctx) { return std::min(0.9, std::max(0.1, (double)ctx->opt_arena_budget_pct / 100.0)); }
 
+// wfa_team_kernel / wfa_teamc_kernel synchronise their workgroups with barriers they spin on: every workgroup of a launch
+// must be resident, which holds for ONE such launch on a GPU (the grid is sized by its CUs) and not for two -- two contexts
+// on one device (wfahip_create_multi with repeated ids, bench.py --share-gpus, two processes of one job) would each hold part
+// of the GPU and wait for the rest until the barrier timeout reports WFAHIP_ERR_INTERNAL.  So team launches on a device
+// are serialised: a mutex per device inside the process, an advisory file lock per device (named by its PCI bus id)
+// between processes.  Held from the launch to the stream synchronisation behind it; the sub-wave kernels never take it.
+struct TeamLaunchLock {
+    std::mutex *mx = nullptr;
+    int         fd = -1;
+    explicit TeamLaunchLock(int device) {
+        static std::mutex per_device[64];
+        mx = &per_device[device & 63];
+        mx->lock();
+        char bus[64] = {0};
+        if (hipDeviceGetPCIBusId(bus, (int)sizeof bus - 1, device) != hipSuccess) std::snprintf(bus, sizeof bus, "dev%d", device);
+        for (char *c = bus; *c; c++)
+            if (*c == ':' || *c == '/' || *c == '.') *c = '_';
+        const char *tmp = std::getenv("TMPDIR");
+        char        path[256];
+        std::snprintf(path, sizeof path, "%s/wfahip_team_%s.lock", (tmp && *tmp) ? tmp : "/tmp", bus);
+        fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+        if (fd >= 0 && flock(fd, LOCK_EX) != 0) close(fd), fd = -1;  // (no lock file: the process-wide mutex alone)
+    }
+    ~TeamLaunchLock() {
+        if (fd >= 0) (void)flock(fd, LOCK_UN), close(fd);
+        if (mx) mx->unlock();
+    }
+    TeamLaunchLock(const TeamLaunchLock &) = delete;
+    TeamLaunchLock &operator=(const TeamLaunchLock &) = delete;
+};
+
 struct LaunchCfg {
     int      waves;        // 1, 4 or 16 waves per pair
     int      mode;         // 0 = 2-bit LDS, 1 = bytes in global memory
@@ -520,9 +555,26 @@ extern "C" void wfahip_destroy(wfahip_ctx *ctx) {
     delete ctx;
 }
 
+// The options a deployment may set.  Every other key is a routing experiment, a test aid or a knob of one kernel family
+// (include/wfa_hip.h lists them): those are refused unless WFAHIP_DEBUG=1 is in the environment -- some change what is safe
+// ("team_strict" 0 drops a release the team kernel needs; "fail_pass" injects a failure), none belongs in production.
+static bool public_option(const std::string &k) {
+    static const char *const keys[] = {"census", "learn", "mem_limit", "arena_budget_pct", "autopack", "pair_fast", "pair_lds"};
+    for (const char *p : keys)
+        if (k == p) return true;
+    return false;
+}
+
 static int set_option_impl(wfahip_ctx *ctx, const char *key, int64_t value) {
     if (!ctx || !key) return WFAHIP_ERR_BAD_ARG;
     std::string k(key);
+    if (!public_option(k)) {
+        const char *dbg = std::getenv("WFAHIP_DEBUG");
+        if (!dbg || !*dbg || std::strcmp(dbg, "0") == 0) {
+            std::snprintf(ctx->last_error, sizeof ctx->last_error, "option \"%.60s\" is a debug / experiment knob: set WFAHIP_DEBUG=1 in the environment to use it", key);
+            return WFAHIP_ERR_UNSUPPORTED;
+        }
+    }
     if (k == "arena_bytes_per_slot")
         ctx->opt_arena_bytes_per_slot = value;
     else if (k == "slots")
@@ -919,7 +971,7 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                                           : kind == 10 ? std::max<uint64_t>((words_dir * arena_mult + 511) & ~511ull, 1024)  // rows of 32 x 16 bit
                                           : kind >= 3 ? std::max<uint64_t>((words_dir * 2 * arena_mult + 511) & ~511ull, 2048)
                                                       : words_dir;
-            P.arena_words = words, P.compact_fmt = kind == 10 ? 8u : kind == 8 ? 7u : kind == 6 ? 5u : bkind == 5 ? 4u : bkind == 9 ? 6u : (kind >= 3 ? (WFA_BLK_TILED ? 3u : 1u) : 0u);
+            P.arena_words = words, P.compact_fmt = kind == 10 ? 8u : kind == 8 ? DUO_ARENA_FMT : kind == 6 ? 5u : bkind == 5 ? 4u : bkind == 9 ? 6u : (kind >= 3 ? (WFA_BLK_TILED ? 3u : 1u) : 0u);
             const uint32_t waves_lds    = (uint32_t)std::min<size_t>(32, LDS_MAX_BYTES / lds_bytes);
             const bool     overlap      = ctx->opt_overlap != 0;
             uint32_t       waves_per_cu = is_long ? std::min<uint32_t>(waves_lds, (kind == 11 && !P.census) ? 4 * WFA_BLK_WAVES : 16)
@@ -1568,8 +1620,11 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
         // first, so that no team starts one when the others are about to finish.  Under wf-adaptive a pair whose lengths differ by
         // more than MaxDistDiff keeps a wide band for most of its scores (the first reduce cuts the final diagonal off; DESIGN.md
         // section 4d) -- a scheduling hint only, results do not depend on the order.
+        std::optional<TeamLaunchLock> team_lock;  // (released at the end of this job, behind the synchronisation that follows its launch)
+        if (team_T > 0) team_lock.emplace(ctx->device);
         std::vector<uint32_t> team_order;
-        if (team_T > 0 && ctx->opt_team_order != 0 && P.adaptive && n_work > team_n && n_work <= (1u << 24)) {
+        // (the hint reads the batch's length arrays: not for a handful of long pairs out of millions of short ones)
+        if (team_T > 0 && ctx->opt_team_order != 0 && P.adaptive && n_work > team_n && n_work <= (1u << 24) && (n_pairs <= (1u << 20) || n_pairs <= 64 * n_work)) {
             std::vector<uint32_t> ql(n_pairs), tl(n_pairs);
             HIP_TRY(hipMemcpyAsync(ql.data(), d_q_len, n_pairs * 4, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipMemcpyAsync(tl.data(), d_t_len, n_pairs * 4, hipMemcpyDeviceToHost, st));
@@ -3040,16 +3095,21 @@ static int debug_wavefronts_impl(wfahip_ctx *ctx, const wfahip_params *p, const 
     uint32_t      recw[REC_WORDS];
     uint32_t      hctrl[CTRL_WORDS];
     for (int attempt = 0;; attempt++) {
-        ctx->opt_arena_bytes_per_slot = bytes;
-        // debug_single stops after one launch, so the byte path is chosen up front for non-ACGT input
-        ctx->force_mode = acgt ? 0 : 1;
-        ctx->dbg_teamc  = compact;
-        rc = align_device(ctx, p, ctx->in_blob.p, blob.size(), ctx->in_qoff.p, ctx->in_qlen.p, ctx->in_toff.p,
-                          ctx->in_tlen.p, 1, std::max(n, m), ctx->out_rec.p, ctx->out_ops.p, ops_cap, nullptr, st,
-                          true);
-        ctx->dbg_teamc                = false;
-        ctx->force_mode               = -1;
-        ctx->opt_arena_bytes_per_slot = saved;
+        {
+            // (the three fields steer the one debug launch; they are restored on every way out of this scope)
+            struct Restore {
+                wfahip_ctx *c;
+                int64_t     saved;
+                ~Restore() { c->dbg_teamc = false, c->force_mode = -1, c->opt_arena_bytes_per_slot = saved; }
+            } restore{ctx, saved};
+            ctx->opt_arena_bytes_per_slot = bytes;
+            // debug_single stops after one launch, so the byte path is chosen up front for non-ACGT input
+            ctx->force_mode = acgt ? 0 : 1;
+            ctx->dbg_teamc  = compact;
+            rc = align_device(ctx, p, ctx->in_blob.p, blob.size(), ctx->in_qoff.p, ctx->in_qlen.p, ctx->in_toff.p,
+                              ctx->in_tlen.p, 1, std::max(n, m), ctx->out_rec.p, ctx->out_ops.p, ops_cap, nullptr, st,
+                              true);
+        }
         if (rc) return rc;
         HIP_TRY(hipMemcpy(recw, ctx->out_rec.p, sizeof recw, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(hctrl, ctx->ctrl.p, sizeof hctrl, hipMemcpyDeviceToHost));
