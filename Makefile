@@ -9,9 +9,9 @@ CSRC    := wfa_amd/csrc
 HDR     := $(wildcard $(CSRC)/*.hpp) $(wildcard $(CSRC)/*.inc) include/wfa_hip.h
 OBJDIR  := build/obj
 # one translation unit per penalty shape of the sub-wave forward kernels (wfa_fwd.hpp), one for wfa_duo_kernel, one for the
-# long-pair kernels, one for the router and the C-ABI: they compile side by side (make -j)
+# long-pair kernels, three for the host side (router, host entries, debug aids: wfa_ctx.hpp): they compile side by side (make -j)
 SHAPES  := s24 s13 s12 s23 s22 s33
-UNITS   := wfa_host wfa_long wfa_duo $(addprefix wfa_fwd_,$(SHAPES))
+UNITS   := wfa_host wfa_entry wfa_debug wfa_long wfa_duo $(addprefix wfa_fwd_,$(SHAPES))
 OBJS    := $(addprefix $(OBJDIR)/,$(addsuffix .o,$(UNITS))) $(OBJDIR)/wfa_gen.o $(OBJDIR)/wfa_multi.o
 
 all: $(LIB) oracle

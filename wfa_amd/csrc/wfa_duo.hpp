@@ -540,7 +540,7 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) __attribute__((amdgpu_num_vgpr(W
             }
         }
         // seeds of initComponents (wfa.go:155-160): M[0][0] = 1/Match or M[x][0] = 1/Mismatch
-        if (__ballot(run && (si == 0u || si == seed_si)) != 0ull) {
+        if (__builtin_expect(__ballot(run && si <= seed_si) != 0ull, 0)) {  // (ONE compare on the step's path; `want` below is the exact test)
             const bool want = run && ((si == 0u && first_eq) || (si == seed_si && !first_eq));
 #pragma unroll
             for (int p = 0; p < PP; p++)
