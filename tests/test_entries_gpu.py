@@ -329,3 +329,34 @@ def test_two_contexts_run_team_kernels_on_one_gpu(built):
             assert_batch_equal(gots[i], wants[i], f"two contexts, round {rnd}, context {i}")
     for al in als:
         al.close()
+
+
+def test_two_contexts_run_the_headline_shape_on_one_gpu(built):
+    """Two contexts on ONE GPU, each aligning the headline shape (1e6 x 1 kbp @5 %, global + wf-adaptive: a 32 GiB arena
+    per context) on its own host thread at the same time -- a second tenant on the device.  Both must return the records and
+    CIGARs a lone context returns for the same batch (which test_full_size_parity_c3 holds against the oracle), in two rounds."""
+    import threading
+    import wfa_amd as w
+    data = w.generate_pairs(seed=3, n_pairs=1_000_000, length=1000, error_rate=0.05, n_threads=32)
+    lone = _aligner(True, (10, 50, 1))
+    want = lone.align_arrays(*data)
+    assert (want.status == 0).all()
+    others = [lone, _aligner(True, (10, 50, 1))]
+    for rnd in range(2):
+        gots, errs = [None, None], [None, None]
+
+        def run(i):
+            try:
+                gots[i] = others[i].align_arrays(*data)
+            except Exception as e:  # noqa: BLE001 -- reported on the test's thread
+                errs[i] = e
+        ths = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join(timeout=600)
+        assert not any(t.is_alive() for t in ths) and errs == [None, None], errs
+        for i in range(2):
+            assert_batch_equal(gots[i], want, f"two tenants, round {rnd}, context {i}")
+    for al in others:
+        al.close()
