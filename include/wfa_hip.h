@@ -20,7 +20,7 @@
  * concurrently (mirrors "one Aligner per goroutine", wfa.go:73-78).
  *
  * First call of a workload: a context allocates its device buffers on demand and keeps them -- wavefront arenas sized
- * for the batch (64 KB per 1 kbp pair: 61 GiB for a million pairs), staging buffers, the page-locked blocks of the
+ * for the batch (34 KB per 1 kbp pair: 32 GiB for a million pairs), staging buffers, the page-locked blocks of the
  * host entry.  hipMalloc of tens of GB and hipHostMalloc of hundreds of MB take SECONDS (2.5-4 s measured for the first
  * 1e6 x 1 kbp call of a context against 20-60 ms for every later one), so a service should align one batch of its
  * largest expected shape right after wfahip_create, before it takes traffic; later calls of the same or a smaller shape
@@ -319,7 +319,10 @@ void wfahip_free(void *p);
  * recomputes (wfa.go:766-817); a seed of initComponents has offset 0 and bit 0 = Match / bit 1 = Mismatch.  Whether a
  * cell exists is not recorded (the walk only visits cells a stored decision names).  *fmt = layout: 1 = 64 words per
  * score index (score / gcd), diagonal k at slot k & 63; 3 = tiles of 8 score indices x 64 diagonals,
- * [(k & 63) / 4][index & 7][k & 3]; 4 = 256 words per index, slot k & 255; 5 = 32 words per index, slot k & 31.
+ * [(k & 63) / 4][index & 7][k & 3]; 4 = 256 words per index, slot k & 255; 5 = 32 words per index, slot k & 31; 6 = 128 words
+ * per index, slot k & 127; 8 = 32 HALFWORDS per index (wfa_lane_kernel); 10 = halfwords, groups of four diagonals two by two
+ * (wfa_duo_kernel, round 6): [(k & 63) / 8][index / 8][(k / 4) & 1][index & 7][k & 3] with n_words / 32 indices per pair of groups
+ * (7: fmt 3 with halfwords, its tiled predecessor; 9: one group after the other, [(k & 63) / 4][index][k & 3]).
  * Slots the kernel never wrote hold stale bytes.  Caller frees *words with wfahip_free. */
 /* Round 5: the same for a pair on wfa_teamc_kernel (wide wavefronts: option team_wgs = the team's size must be set): every row as
  * the kernel leaves it in the arena -- ONE backtrace word per diagonal (the pre-extension offset backTrace recomputes,

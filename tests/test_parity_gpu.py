@@ -1079,6 +1079,8 @@ def _expected_compact_words(dump, x, o, e):
 
 
 def _arena_slot(fmt, i, k, n_words=0):
+    if fmt == 10:      # (wfa_duo_kernel, round 6: groups two by two -- [diagonal / 8 & 7][index / 8][diagonal / 4 & 1][index & 7][diagonal & 3])
+        return ((k & 56) >> 3) * (n_words // 64) * 8 + 64 * (i >> 3) + ((k & 4) << 3) + ((i & 7) << 2) + (k & 3)
     if fmt == 9:       # (wfa_duo_kernel, round 6: group-major halfwords -- [diagonal / 4 & 15][score index][diagonal & 3], n_words / 64 score indices)
         return ((k & 60) >> 2) * (n_words // 64) * 4 + 4 * i + (k & 3)
     if fmt in (3, 7):  # (fmt 7: the same tiles with 16-bit words -- the caller views the arena as uint16)
@@ -1132,8 +1134,8 @@ def _arena_word_check(length, err, pen, ad, fmt, census, duo, lane, min_pairs=No
     checked = pairs = 0
     for i in range(n):
         words, f, meta = al.debug_compact_arena(i)
-        assert f == (9 if duo else fmt)
-        if f in (7, 8, 9):
+        assert f == (10 if duo else fmt)
+        if f in (7, 8, 9, 10):
             words = words.view(np.uint16)
         if meta[0] != 0:  # handed on to another kernel (band / arena): its slot is not the final state
             continue

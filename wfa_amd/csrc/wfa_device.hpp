@@ -563,6 +563,9 @@ struct CompactView {
         if (fmt == 6u) return ld(128ull * idx + ((uint32_t)k & 127u));
         if (fmt == 7u)  // fmt 3's tiles with 16-bit words (wfa_duo_kernel: reads under 2 048 bases)
             return reinterpret_cast<const uint16_t *>(A)[512ull * (idx >> 3) + (((uint32_t)k & 60u) << 3) + ((idx & 7u) << 2) + ((uint32_t)k & 3u)];
+        if (fmt == 10u)  // pairs of groups, 16-bit words (wfa_duo_kernel, round 6): [diagonal / 8 & 7][index / 8][diagonal / 4 & 1][index & 7][diagonal & 3]
+            return reinterpret_cast<const uint16_t *>(A)[(uint64_t)(((uint32_t)k & 56u) >> 3) * (uint32_t)(cap >> 5) * 8u + 64ull * (idx >> 3) + (((uint32_t)k & 4u) << 3) +
+                                                         ((idx & 7u) << 2) + ((uint32_t)k & 3u)];
         if (fmt == 9u)  // group-major, 16-bit words (wfa_duo_kernel, round 6): [diagonal / 4 & 15][score index][diagonal & 3], cap / 32 score indices
             return reinterpret_cast<const uint16_t *>(A)[(uint64_t)(((uint32_t)k & 60u) >> 2) * (uint32_t)(cap >> 5) * 4u + 4ull * idx + ((uint32_t)k & 3u)];
         if (fmt == 8u)  // 32 diagonals per score, 16-bit words (wfa_lane_kernel: reads of at most 240 bases)

@@ -166,7 +166,9 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) __attribute__((amdgpu_num_vgpr(W
         for (int p = 0; p < PP; p++) lim[p] = imax2(1, imin2(n + k0 + p, m)), lmx[p] = imax2(n + k0 + p, m);
         lq   = lds + sbuf * PW + 4u;
         lt   = lq + SW;
-        if constexpr (DUO_ARENA_FMT == 9u)  // [group of four diagonals][score]: the lane's group, then 8 bytes per score
+        if constexpr (DUO_ARENA_FMT == 10u)  // [pair of groups][score / 8][group & 1][score & 7]: the lane's base; the score's part is added at the store
+            rowp = P.arena + (uint64_t)pidx * cap + (((uint32_t)k0 & 56u) >> 3) * (uint32_t)(rows_cap * 4) + (((uint32_t)k0 >> 2) & 1u) * 16u;
+        else if constexpr (DUO_ARENA_FMT == 9u)  // [group of four diagonals][score]: the lane's group, then 8 bytes per score
             rowp = P.arena + (uint64_t)pidx * cap + (((uint32_t)k0 & 60u) >> 2) * (uint32_t)(rows_cap * 2) + si * 2u;
         else
             rowp = P.arena + (uint64_t)pidx * cap + (uint64_t)(si >> 3) * 256u + (si & 7u) * 2u;
@@ -558,8 +560,10 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) __attribute__((amdgpu_num_vgpr(W
             uint32_t anyc = 0u;
 #pragma unroll
             for (int p = 0; p < PP; p++) anyc |= nM[p];
+            // (fmt 10: score index si -> word (si & ~7) * 4 + (si & 7) * 2 = 2 (si + (si & ~7)) behind the lane's base)
+            const uint32_t row_off = DUO_ARENA_FMT == 10u ? 2u * (si + (si & ~7u)) : DUO_ARENA_FMT == 9u ? 0u : (((uint32_t)k0 & 60u) << 2);
             if (run && !no_room && anyc != 0u)
-                *reinterpret_cast<uint2 *>(rowp + (DUO_ARENA_FMT == 9u ? 0u : (((uint32_t)k0 & 60u) << 2))) = make_uint2(wd[0] | (wd[1] << 16), wd[2] | (wd[3] << 16));
+                *reinterpret_cast<uint2 *>(rowp + row_off) = make_uint2(wd[0] | (wd[1] << 16), wd[2] | (wd[3] << 16));
         }
         WFA_STAMP(2);  // next + store
 
@@ -711,8 +715,8 @@ __global__ __launch_bounds__(64, WFA_DUO_WAVES) __attribute__((amdgpu_num_vgpr(W
             DuoRed::max_add(dummy, cs, wm);
             cells += keepl ? (uint32_t)cs : 0u;
         }
-        rowp += 2;
-        if constexpr (DUO_ARENA_FMT != 9u) rowp += (((uint32_t)(uintptr_t)rowp & 0x38u) == 0u) ? 240 : 0;  // past the tile's 8th score: next tile
+        if constexpr (DUO_ARENA_FMT != 10u) rowp += 2;
+        if constexpr (DUO_ARENA_FMT == 7u) rowp += (((uint32_t)(uintptr_t)rowp & 0x38u) == 0u) ? 240 : 0;  // past the tile's 8th score: next tile
 
         // ------------------------------------------------------------ the new row enters the rings
 #pragma unroll

@@ -23,14 +23,20 @@ namespace wfa {
 #define WFA_DUO_NARROW_AT 21
 #endif
 #ifndef WFA_DUO_GROUP_MAJOR
-#define WFA_DUO_GROUP_MAJOR 1
+#define WFA_DUO_GROUP_MAJOR 2
 #endif
-// Arena layout of wfa_duo_kernel (16-bit words).  0: CompactView fmt 7 -- tiles of 8 scores x 64 diagonals (1 KB), inside a tile
-// [diagonal / 4][score & 7][diagonal & 3].  1 (round 6): fmt 9 -- GROUP-major, [diagonal / 4 & 15][score][diagonal & 3]: the 64-byte
-// lines are the same (8 scores of 4 diagonals), but the lines of one group of four diagonals are contiguous over all the
-// pair's scores (rows_cap x 8 bytes), so the backtrace's walk -- which stays within a few groups -- reads from a handful of
-// DRAM pages instead of one per tile, and the forward kernel's row pointer advances by a constant.
-constexpr uint32_t DUO_ARENA_FMT = WFA_DUO_GROUP_MAJOR ? 9u : 7u;
+// Arena layout of wfa_duo_kernel (16-bit words; a lane's four diagonals of a score are one 8-byte store, and 8 scores of them
+// one 64-byte piece, in every one of the three):
+//   0  CompactView fmt 7 (round 3) -- tiles of 8 scores x 64 diagonals (1 KB), inside a tile [diagonal / 4][score & 7][diagonal & 3]:
+//      the row pointer needs "next score, and the next tile after every eighth" -- seven vector instructions a step;
+//   1  fmt 9 (round 6) -- group-major, [diagonal / 4 & 15][score][diagonal & 3]: a constant stride, and the backtrace's walk,
+//      which stays within a few groups, reads from a handful of DRAM pages instead of one per tile.  But ONE lane fills a
+//      128-byte line, over 16 steps: twice the dirty lines in L2, evicted half-written and written again -- WRITE_SIZE 26 GB
+//      per 1e6 x 1 kbp pairs instead of 10.8;
+//   2  fmt 10 (round 6, the default) -- the groups two by two: [diagonal / 8 & 7][score / 8][diagonal / 4 & 1][score & 7][diagonal & 3].
+//      A 128-byte line is filled by two neighbouring lanes in 8 steps as in the tiles, a pair of groups is contiguous over
+//      all the scores as in fmt 9, and the address comes from the score index (and, add, shift-add) with no pointer to carry.
+constexpr uint32_t DUO_ARENA_FMT = WFA_DUO_GROUP_MAJOR == 2 ? 10u : WFA_DUO_GROUP_MAJOR == 1 ? 9u : 7u;
 constexpr int DUO_PARK       = WFA_DUO_PARK;           // park records per wave
 constexpr int DUO_PARK_WORDS = 8 * 12 + 16;            // rings of 8 lanes, two 16-bit offsets per word (reads under 2 048 bases) + 16 scalars
 constexpr int DUO_BUFS       = 8 + 1 + DUO_PARK;       // sequence buffers per wave: running pairs, staging, parked pairs (one pair per fetch)

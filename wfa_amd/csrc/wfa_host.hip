@@ -1361,8 +1361,8 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
         P.n_work        = (uint32_t)n_work;
         // Teams take pairs from one queue, and a pair costs a team anything from 0.1 s to 0.4 s (configs[4]): the expensive ones go
         // first, so that no team starts one when the others are about to finish.  Under wf-adaptive a pair whose lengths differ by
-        // more than MaxDistDiff keeps a wide band for most of its scores (the first reduce cuts the final diagonal off; DESIGN.md
-        // section 4d) -- a scheduling hint only, results do not depend on the order.
+        // more than MaxDistDiff keeps a wide band for most of its scores (the first reduce cuts the final diagonal off; KERNELS.md
+        // 4d) -- a scheduling hint only, results do not depend on the order.
         std::optional<TeamLaunchLock> team_lock;  // (released at the end of this job, behind the synchronisation that follows its launch)
         if (team_T > 0) team_lock.emplace(ctx->device);
         std::vector<uint32_t> team_order;

@@ -29,7 +29,7 @@
 // lanes of an access at the same ring slot fall on different banks.
 // A pair whose row would span more than 30 diagonals (32 slots less the k-1 and k+1 a cell reads), or which runs out of
 // arena rows, is handed on (ST_REDO_BAND / ST_REDO_ARENA) to the sub-wave kernels like any pair that leaves a window.
-// What bounds it (profiles/r03_c2_*): instructions.  A generation is ~25 000 wave instructions, a wave
+// What bounds it (profiles/r03_c2_*; KERNELS.md 4b): instructions.  A generation is ~25 000 wave instructions, a wave
 // issues one per 4.25 cycles (a lone wave: 45 us of issue + 39 % of its cycles in s_waitcnt = ~100 us for 64 x 150-base
 // pairs, whether the launch holds a thousand pairs or a hundred thousand), and the two waves per SIMD that LDS allows share
 // the SIMD's issue slots.  Measured and dropped: two cells per round side by side (more instructions per cell than the
