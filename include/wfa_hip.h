@@ -122,6 +122,7 @@ typedef struct {
                                   (sliding sequence windows: reads of any length, 64 / 128 / 256 diagonals), 14 / 15 = wfa_blk_kernel<64, 1, false, 1 / 2, .., LONG>
                                   (a wave per pair, one / two diagonals per lane: batches too small to fill the GPU),
                                   16 = wfa_blk_kernel<64, 1, false, 1, false, false> (wfahip_align_pair: one launch, forward pass and backtrace),
+                                  18 = wfa_wide_kernel (round 6: semi-global short reads, a wave per pair with the rows in 16-bit LDS rings),
                                   17 = wfa_teamc_kernel (wide wavefronts: a team of workgroups per pair, one backtrace word per diagonal) */
     uint32_t ladder_start_level; /* arena level the long-pair ladder of this call started on (0 unless a learned hint applied) */
 } wfahip_timing;

@@ -1657,3 +1657,112 @@ def test_team_kernel_paged_arena(built, opts, compact):
         assert al.last_timing().main_kernel_kind == (17 if compact else 7)  # wfa_teamc_kernel / wfa_team_kernel
         assert_batch_equal(got, want, f"paged arena {opts} pass {rep}")
     al.close()
+
+
+def _semi_global_cases(rng, n_pairs, lo, hi, flank=None):
+    """Semi-global shapes the n + m - 1 seeds care about: a read inside a longer target (any offset), a target inside a
+    longer query, equal lengths, overhangs at either end, plus plain edited copies -- lengths in [lo, hi].
+    flank: the longest run of extra bases on a side (None: up to hi / 2, and unrelated pairs too).  Under wf-adaptive the
+    batches keep |m - n| under MaxDistDiff: with a larger difference the reference's first reduce cuts the final diagonal
+    off (wfa.go:235-239 only ever looks at M[s][m - n]) and the alignment runs on for thousands of scores until a gap chain
+    finds its way back -- the reference's behaviour, minutes per pair in the oracle, and not what these tests are about."""
+    qs, ts = [], []
+    for i in range(n_pairs):
+        L = int(rng.integers(lo, hi + 1))
+        core = rng.integers(0, 4, L)
+        edited = list(core)
+        for _ in range(int(L * (0.02 + 0.1 * rng.random()))):
+            kind_e, pos = int(rng.integers(0, 3)), int(rng.integers(0, max(1, len(edited))))
+            if kind_e == 0 and edited:
+                edited[pos] = int(rng.integers(0, 4))
+            elif kind_e == 1:
+                edited.insert(pos, int(rng.integers(0, 4)))
+            elif edited:
+                del edited[pos]
+        a, b = list(core), edited
+        shape = i % 6
+        fl = hi // 2 if flank is None else flank
+        if shape == 0:    # read inside a longer target
+            b = list(rng.integers(0, 4, int(rng.integers(1, fl + 1)))) + b + list(rng.integers(0, 4, int(rng.integers(0, fl + 1))))
+        elif shape == 1:  # target inside a longer query
+            a = list(rng.integers(0, 4, int(rng.integers(1, fl + 1)))) + a + list(rng.integers(0, 4, int(rng.integers(0, fl + 1))))
+        elif shape == 2:  # overhangs: suffix of one against prefix of the other
+            cut = int(rng.integers(1, max(2, min(L // 2, fl))))
+            a, b = a[cut:], b[:max(1, len(b) - cut)]
+        elif shape == 3 and flank is None:  # unrelated sequences
+            b = list(rng.integers(0, 4, int(rng.integers(lo, hi + 1))))
+        a, b = a[:hi], b[:hi]
+        if not a:
+            a = [0]
+        if not b:
+            b = [1]
+        qs.append(bytes(b"ACGT"[c] for c in a))
+        ts.append(bytes(b"ACGT"[c] for c in b))
+    return qs, ts
+
+
+@pytest.mark.parametrize("pen", [(4, 6, 2), (2, 4, 2), (1, 1, 1), (4, 4, 2), (6, 6, 3)])
+@pytest.mark.parametrize("ad", [(10, 50, 1), None, (4, 8, 1)])
+def test_wide_kernel_semi_global_shapes(built, pen, ad):
+    """wfa_wide_kernel (round 6: a wave per pair, the rows in 16-bit LDS rings of any width, the semi-global end cell found in
+    flight, one 16-bit backtrace word per diagonal) against the oracle on every field and every CIGAR op: reads inside longer
+    targets and the other way round, overhangs, unrelated sequences, lengths from 1 to 700 (tiles that start and end
+    anywhere, rows narrower than a tile), five penalty shapes, wf-adaptive on / off / aggressive; twice over a poisoned arena."""
+    import wfa_amd as w
+    from oracle import oracle as O
+    rng = np.random.default_rng(77 + pen[0] * 10 + pen[1])
+    qs, ts = _semi_global_cases(rng, 600, 1, 700, flank=None if ad is None else 12)
+    qs[:6] = [b"A", b"ACGT", b"A", b"ACGTACGTAC", b"C", b"GATTACA"]
+    ts[:6] = [b"A", b"A", b"ACGT", b"ACGTTCGTAC", b"G", b"TTGATTACATT"]
+    data = w.make_blob(qs, ts)
+    want = O.align_batch(_oracle_params(False, ad, pen), *data, n_threads=max(8, (os.cpu_count() or 8) // 2))
+    al = _aligner(False, ad, pen)
+    al.set_option("arena_poison", 1)
+    al.set_option("wide_max_len", 2047)  # (by default batches of reads beyond 512 bases stay on the ladder's kernels)
+    for rep in range(2):
+        got = al.align_arrays(*data)
+        assert al.last_timing().main_kernel_kind == 18
+        assert_batch_equal(got, want, f"wide kernel pen={pen} ad={ad} rep={rep}")
+    if ad is not None:  # one launch per chunk: every pair runs to its end in the wide rings (no hand-over to the narrow phase)
+        al.set_option("wide", 3)
+        assert_batch_equal(al.align_arrays(*data), want, f"wide kernel, one phase, pen={pen} ad={ad}")
+    # the same batch on the ladder's kernels: the same records
+    al.set_option("wide", 0)
+    assert_batch_equal(al.align_arrays(*data), want, f"ladder pen={pen} ad={ad}")
+    al.close()
+
+
+@pytest.mark.parametrize("ad", [(10, 50, 1), None])
+def test_wide_kernel_semi_global_1kbp(built, ad):
+    """1e5 x 1 kbp @5 % pairs, semi-global, wf-adaptive on and off: every record and every CIGAR op
+    against the oracle on the host's cores; with a small arena, the pairs that overflow it finish on the ladder."""
+    import wfa_amd as w
+    from oracle import oracle as O
+    n = 100_000 if ad is not None else 20_000  # (adaptive off: 3e5 cells per pair in the oracle too)
+    data = w.generate_pairs(seed=63, n_pairs=n, length=1000, error_rate=0.05, n_threads=32)
+    want = O.align_batch(_oracle_params(False, ad), *data, n_threads=max(8, (os.cpu_count() or 8) // 2))
+    al = _aligner(False, ad)
+    al.set_option("wide_max_len", 2047)
+    got = al.align_arrays(*data)
+    assert al.last_timing().main_kernel_kind == 18
+    assert_batch_equal(got, want, f"1 kbp semi-global ad={ad}")
+    if ad is not None:
+        al.set_option("packed_arena_bytes", 72 * 1024)  # (some pairs narrow late: their rows do not fit, the ladder finishes them)
+        got = al.align_arrays(*data)
+        assert al.last_timing().n_retried_pairs > 0
+        assert_batch_equal(got, want, "1 kbp semi-global, small arena")
+    al.close()
+
+
+def test_wide_kernel_is_the_default_for_short_semi_global_reads(built):
+    """Batches of semi-global reads of at most 512 bases start on wfa_wide_kernel without any option; longer ones on the ladder."""
+    import wfa_amd as w
+    from oracle import oracle as O
+    for length, kind in ((300, 18), (800, 0)):
+        data = w.generate_pairs(seed=64, n_pairs=4000, length=length, error_rate=0.06, n_threads=8)
+        want = O.align_batch(_oracle_params(False, (10, 50, 1)), *data, n_threads=8)
+        al = _aligner(False, (10, 50, 1))
+        got = al.align_arrays(*data)
+        assert al.last_timing().main_kernel_kind == kind
+        assert_batch_equal(got, want, f"semi-global {length} bp, default routing")
+        al.close()

@@ -121,6 +121,8 @@ struct KParams {
     uint32_t  lds_arena_off;         // wfa_blk_kernel<.., LDSA = true>: word offset of the pair's arena rows inside the workgroup's LDS
     uint32_t  one_n, one_m;          // ... and the lengths of its one pair (query at blob offset 0, target at (one_n + 15) & ~15): the kernel arguments carry
                                      // them, so that neither the refill nor the walk fetches them from the host's mapped block (a PCIe round trip each)
+    uint32_t *wide_ckpt;             // wfa_wide_kernel: WIDE_CKPT_WORDS words per pair of the chunk -- what its first launch hands its second (wfa_wide.hpp)
+    uint32_t  wide_ckpt_on;          // ... 1: the first launch hands pairs on once their rows are narrow; 0: it runs every pair to its end
     uint32_t  compact_fmt;           // compact arena layout (CompactView): 0 = rows + directory; no directory: 1 = 64 words
                                      // per score, diagonal k at slot k & 63; 3 = tiles of 8 scores x 64 diagonals;
                                      // 4 = 256 words per score, slot k & 255; 5 = 32 words per score, slot k & 31

@@ -573,6 +573,7 @@ struct CompactView {
         const uint4 e = *reinterpret_cast<const uint4 *>(A + cap - 4ull * (idx + 1));
         const int   lo = (int)e.y, w = (int)e.z;
         if (w <= 0 || k < lo || k >= lo + w) return 0u;
+        if (fmt == 11u) return reinterpret_cast<const uint16_t *>(A)[e.x + (uint32_t)(k - lo)];  // wfa_wide_kernel: rows of 16-bit blk_word()s
         return A[e.x + (uint32_t)(k - lo)];
     }
     // tag of the cell of component comp (0 = M, 1 = I, 2 = D) at (score index idx, k); 0 = absent

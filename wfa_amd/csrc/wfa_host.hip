@@ -18,6 +18,7 @@
 #include "wfa_teamc.hpp"
 #include "wfa_fwd.hpp"
 #include "wfa_long.hpp"
+#include "wfa_wide.hpp"
 
 using namespace wfa;
 static_assert(TEAM_SOLO_MAX == 4096, "wfa_ctx.hpp: default of opt_team_solo_max");
@@ -43,6 +44,32 @@ hipError_t wfa_launch_pair(int shape, bool lds_arena, const KParams &P, size_t l
     case 3: return wfa_launch_pair_s23(lds_arena, P, lds_bytes, st);
     case 4: return wfa_launch_pair_s22(lds_arena, P, lds_bytes, st);
     case 5: return wfa_launch_pair_s33(lds_arena, P, lds_bytes, st);
+    }
+    return hipErrorInvalidValue;
+}
+// wfa_wide_kernel of penalty shape `shape` (wfa_fwd.hpp: fwd_shape())
+hipError_t wfa_launch_wide(int shape, int phase, const KParams &P, uint32_t grid, size_t lds_bytes, hipStream_t st) {
+    const auto go = [&](auto kern) -> hipError_t {
+        if (lds_bytes > 64 * 1024) {  // (per device: the attribute belongs to the kernel as loaded there)
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds_bytes, st, P);
+        return hipGetLastError();
+    };
+    switch (shape * 2 + (phase ? 1 : 0)) {
+    case 0: return go(wfa_wide_kernel<2, 4, 0>);
+    case 1: return go(wfa_wide_kernel<2, 4, 1>);
+    case 2: return go(wfa_wide_kernel<1, 3, 0>);
+    case 3: return go(wfa_wide_kernel<1, 3, 1>);
+    case 4: return go(wfa_wide_kernel<1, 2, 0>);
+    case 5: return go(wfa_wide_kernel<1, 2, 1>);
+    case 6: return go(wfa_wide_kernel<2, 3, 0>);
+    case 7: return go(wfa_wide_kernel<2, 3, 1>);
+    case 8: return go(wfa_wide_kernel<2, 2, 0>);
+    case 9: return go(wfa_wide_kernel<2, 2, 1>);
+    case 10: return go(wfa_wide_kernel<3, 3, 0>);
+    case 11: return go(wfa_wide_kernel<3, 3, 1>);
     }
     return hipErrorInvalidValue;
 }
@@ -292,7 +319,7 @@ extern "C" void wfahip_destroy(wfahip_ctx *ctx) {
         if (ctx->pin_ev[i]) (void)hipEventDestroy(ctx->pin_ev[i]);
     }
     for (DevBuf *b : {&ctx->arena, &ctx->fin, &ctx->team_ctl, &ctx->arena2, &ctx->meta2, &ctx->doneq, &ctx->ctrl, &ctx->redo, &ctx->work, &ctx->meta, &ctx->in_blob, &ctx->in_qoff, &ctx->in_qlen,
-                      &ctx->in_toff, &ctx->in_tlen, &ctx->out_rec, &ctx->out_ops, &ctx->in_packed, &ctx->in_small, &ctx->prepack, &ctx->one_ctl, &ctx->page_ctl, &ctx->xbuf})
+                      &ctx->in_toff, &ctx->in_tlen, &ctx->out_rec, &ctx->out_ops, &ctx->in_packed, &ctx->in_small, &ctx->prepack, &ctx->one_ctl, &ctx->page_ctl, &ctx->xbuf, &ctx->wide_ckpt})
         release(*b);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -420,6 +447,12 @@ static int set_option_impl(wfahip_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_long_min_len = value;
     else if (k == "long_window_words")
         ctx->opt_long_window_words = (value >= 64 && value <= 4096 && value % 4 == 0) ? value : 240;  // (64 words: a window every ~500 bases -- tests)
+    else if (k == "wide")
+        ctx->opt_wide = value;
+    else if (k == "wide_min_pairs")
+        ctx->opt_wide_min_pairs = value;
+    else if (k == "wide_max_len")
+        ctx->opt_wide_max_len = value;
     else if (k == "duo")
         ctx->opt_duo = value;
     else if (k == "duo_min_pairs")
@@ -593,10 +626,88 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
     const int             max_level = 12;
     bool                  first     = true, after_scout = false;
 
+    bool packed_done = false;
+    // ---- semi-global short reads (round 6): wfa_wide_kernel -- a wave per pair, the last rows as 16-bit offsets in LDS rings of
+    //      any width, one 16-bit backtrace word per diagonal in the arena -- + the lane-per-pair backtrace kernel, chunk by chunk.
+    //      What it cannot hold (bytes outside ACGT, an arena that overflows) goes to the ladder below, like the leftovers of pass 1.
+    if (ctx->opt_packed && ctx->opt_wide != 0 && !debug_single && ctx->force_mode < 0 && !P.global_alignment && P.e != 0u && max_len <= WIDE_MAX_LEN &&
+        (int64_t)max_len <= ctx->opt_wide_max_len && (int64_t)n_pairs >= ctx->opt_wide_min_pairs && !ctx->pk_words) {
+        const uint32_t dx = P.x / P.g, doe = P.oe / P.g, de = P.e / P.g;
+        const int      shape = fwd_shape(dx, doe, de);
+        if (shape >= 0) {
+            const uint32_t seq_words = (max_len + 15) / 16 + 1;
+            const uint32_t row_hw    = wide_row_hw(max_len);
+            const size_t   lds_bytes = (size_t)wide_lds_words(seq_words, max_len) * 4;
+            // rows: with wf-adaptive the n + m - 1 seeds live for a dozen score steps, then a band of a few dozen diagonals; without it
+            // every row keeps them.  (A pair that needs more is re-run by the ladder: ST_REDO_ARENA.)
+            uint64_t words = P.adaptive ? 36ull * max_len + 4096 : 2ull * max_len * (uint64_t)(max_len / 3 + 64) / 2 + 8192;
+            if (ctx->opt_packed_arena_bytes > 0) words = std::max<uint64_t>(1024, ctx->opt_packed_arena_bytes / 4);
+            words = (words + 511) & ~511ull;
+            const uint64_t budget = (uint64_t)((double)ctx->total_mem * 0.35);
+            const uint64_t chunk  = std::max<uint64_t>(1, std::min<uint64_t>(n_pairs, std::min<uint64_t>(budget / (words * 4ull),
+                                                                             ctx->opt_chunk_pairs > 0 ? (uint64_t)ctx->opt_chunk_pairs : ~0ull)));
+            if ((rc = ensure(ctx, ctx->arena, (size_t)(words * 4ull * chunk)))) return rc;
+            if ((rc = ensure(ctx, ctx->meta, chunk * 16))) return rc;
+            // two launches per chunk when wf-adaptive narrows the rows: the first runs the wide rows, the second -- rings of 256
+            // diagonals, the CU's full complement of waves -- the rest (wfa_wide.hpp)
+            const bool two_phase = P.adaptive != 0 && ctx->opt_wide >= 1 && ctx->opt_wide != 3;
+            if (two_phase && (rc = ensure(ctx, ctx->wide_ckpt, (size_t)chunk * WIDE_CKPT_WORDS * 4))) return rc;
+            P.wide_ckpt = static_cast<uint32_t *>(ctx->wide_ckpt.p), P.wide_ckpt_on = two_phase ? 1u : 0u;
+            const size_t lds_narrow = (size_t)wide_lds_words_narrow(seq_words) * 4;
+            ctx->timing.arena_bytes = std::max<uint64_t>(ctx->timing.arena_bytes, words * 4ull * chunk);
+            P.dx = dx, P.doe = doe, P.de = de, P.dm = std::max(dx, doe) + 1, P.di = de + 1;
+            P.lds_seq_words = seq_words, P.sub_lds_words = row_hw, P.min_xe = std::min(P.x, P.e);
+            P.arena_words = words, P.compact_fmt = WIDE_FMT;
+            P.prepack = nullptr, P.prepack_words = 0, P.done_q = nullptr, P.done_ctl = nullptr, P.n_stream_wgs = 0, P.work = nullptr;
+            const uint64_t n_chunks = (n_pairs + chunk - 1) / chunk;
+            while (ctx->evpool.size() < 4 * n_chunks) {
+                hipEvent_t e;
+                HIP_TRY(hipEventCreate(&e));
+                ctx->evpool.push_back(e);
+            }
+            ctrl_zeroed = false;
+            for (uint64_t c = 0; c < n_chunks; c++) {
+                const uint64_t c0 = c * chunk, cn = std::min<uint64_t>(chunk, n_pairs - c0);
+                P.arena = static_cast<uint32_t *>(ctx->arena.p), P.pair_meta = static_cast<uint4 *>(ctx->meta.p);
+                P.chunk_first = (uint32_t)c0, P.chunk_n = (uint32_t)cn;
+                if (c > 0) HIP_TRY(hipMemsetAsync(d_ctrl, 0, 4, st));  // queue_head
+                if (ctx->opt_arena_poison) HIP_TRY(hipMemsetAsync(P.arena, 0xA5, (size_t)(words * 4ull * cn), st));
+                const uint32_t grid = (uint32_t)cn;  // (a workgroup -- one wave -- per pair)
+                HIP_TRY(hipEventRecord(ctx->evpool[4 * c], st));
+                HIP_TRY(wfa_launch_wide(shape, 0, P, grid, lds_bytes, st));
+                if (two_phase) HIP_TRY(wfa_launch_wide(shape, 1, P, grid, lds_narrow, st));
+                HIP_TRY(hipEventRecord(ctx->evpool[4 * c + 1], st));
+                hipLaunchKernelGGL(wfa_backtrace_kernel, dim3((uint32_t)((cn + BT_THREADS - 1) / BT_THREADS)), dim3(BT_THREADS), 0, st, P);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipEventRecord(ctx->evpool[4 * c + 3], st));
+            }
+            uint32_t              hc[CTRL_WORDS];
+            std::vector<uint64_t> redo;
+            HIP_TRY(hipEventRecord(ctx->ev1, st));
+            if ((rc = fetch_ctrl(hc, &redo))) return rc;
+            ctrl_fresh = true, std::memcpy(hc_last, hc, sizeof hc_last);
+            for (uint64_t c = 0; c < n_chunks; c++) {
+                float msF = 0, msB = 0;
+                HIP_TRY(hipEventElapsedTime(&msF, ctx->evpool[4 * c], ctx->evpool[4 * c + 1]));
+                HIP_TRY(hipEventElapsedTime(&msB, ctx->evpool[4 * c + 1], ctx->evpool[4 * c + 3]));
+                ctx->timing.kernel_ms += msF + msB, ctx->timing.main_kernel_ms += msF, ctx->timing.n_main_launches++, ctx->timing.n_launches += 2;
+            }
+            ctx->timing.main_kernel_kind = 18;
+            ctx->timing.n_packed_pairs   = (uint32_t)(n_pairs - redo.size());
+            ctx->timing.n_retried_pairs += (uint32_t)redo.size();
+            Job jb, ja;
+            jb.mode = 1, jb.level = 0, jb.all = false;
+            ja.mode = 0, ja.level = 0, ja.all = false;
+            for (uint64_t e : redo) ((uint32_t)(e >> 32) == ST_REDO_BYTES ? jb : ja).pairs.push_back((uint32_t)e);
+            std::sort(ja.pairs.begin(), ja.pairs.end());
+            for (Job *jp : {&ja, &jb})
+                if (!jp->pairs.empty()) jobs.push_back(std::move(*jp));
+            first = false, packed_done = true;
+        }
+    }
     // ---- pass 1: sub-wave forward kernels + lane-per-pair backtrace kernel, chunk by chunk.
     //      kind 2 = register-window kernel (4 pairs per wave), kind 1 = LDS-ring packed kernel (2 pairs per wave).
-    bool packed_done = false;
-    if (ctx->opt_packed && !debug_single && ctx->force_mode < 0 && P.global_alignment && P.e != 0u) {
+    if (!packed_done && ctx->opt_packed && !debug_single && ctx->force_mode < 0 && P.global_alignment && P.e != 0u) {
         const uint32_t dx = P.x / P.g, doe = P.oe / P.g, de = P.e / P.g;
         const uint32_t dm = std::max(dx, doe) + 1, di = de + 1;
         // Mixed lengths: the sub-wave kernels keep both sequences of a pair in a few KB of LDS.  When the longest

@@ -302,7 +302,8 @@ __global__ __launch_bounds__(64, 7) void wfa_packed_kernel(const KParams P) {
 // entries of the ops region of a pair of final score s: 2 * score / min(x, e) + 8, rounded up to the writer's store group
 // (with the buffer aligned every region ends on a store boundary)
 WFA_DEV uint32_t ops_bound(const KParams &P, uint32_t s_final) {
-    return (2u * (s_final / P.min_xe) + 8u + OpsWriterRev::GROUP - 1u) & ~(OpsWriterRev::GROUP - 1u);
+    // (semi-global: up to three flank runs more -- I / H in front, I or H behind: wfa.go:746-750,970-976)
+    return (2u * (s_final / P.min_xe) + (P.global_alignment ? 8u : 12u) + OpsWriterRev::GROUP - 1u) & ~(OpsWriterRev::GROUP - 1u);
 }
 
 // off_given: where the pair's ops region starts (the caller has carved it), or OPS_OFF_OWN: carve it here
@@ -323,7 +324,10 @@ WFA_DEV void backtrace_one(const KParams &P, uint32_t idx, uint32_t s_final, uin
     const bool     fits = off + bound <= P.ops_cap;
     ow.init(P.ops + off, fits ? bound : 0u);
     TraceOut to;
-    back_trace_compact(cv, n, m, s_final, m - n, h_end, P.x, P.o, P.e, ow, to);
+    if (P.compact_fmt == 11u)  // wfa_wide_kernel: the walk starts at the cell its forward pass found (semi-global: wfa.go:270-375) -- offset | (diagonal + 32768) << 16
+        back_trace_compact(cv, n, m, s_final, (int)(h_end >> 16) - 32768, h_end & 0xFFFFu, P.x, P.o, P.e, ow, to, P.global_alignment == 0u);
+    else
+        back_trace_compact(cv, n, m, s_final, m - n, h_end, P.x, P.o, P.e, ow, to);
     ow.finish();
     // (when the ops buffer is too small the host sees ops_cursor > ops_cap and re-runs with a bigger one)
     const uint64_t first = off + bound - ow.n;

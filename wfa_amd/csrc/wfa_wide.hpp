@@ -1,0 +1,407 @@
+// wfa_wide.hpp -- kernel W (round 6): a WAVE per pair with the last rows in 16-bit LDS rings of ANY width.
+//
+// For what the register-window kernels cannot hold: semi-global alignments of short reads (wfa.go:163-183 seeds every one
+// of the n + m - 1 diagonals, and wf-adaptive cuts nothing until the leading diagonal is MaxDistDiff bases ahead: a 1 kbp
+// pair keeps ~2 000 diagonals for its first dozen score steps, eight times the cells of its global alignment), with
+// wf-adaptive on or off.  Until round 6 those batches went to wfa_generic_kernel -- one workgroup per pair, the sources of
+// WF_NEXT read back from the arena in global memory, three 32-bit words per diagonal stored: 2.5e6 pairs/s on 1e6 x 1 kbp,
+// a 23-fold cliff behind the same pairs aligned globally.
+//
+// Here a wave owns a pair from its first score to its last:
+//   * a workgroup of ONE wave per pair (the hardware dispatcher is the pair queue); both sequences 2-bit packed in LDS
+//     (packed by the wave itself, stage_pack), and the rows the next scores source as
+//     BARE 16-bit offsets in LDS rings indexed by diagonal: four M rows (slot = score index & 3), one I and one D row
+//     (penalties with e / g == 1: the sub-wave kernels' shapes).  6 x (n + m) x 2 bytes -- 25 KB for a 1 kbp pair;
+//   * a row is computed in tiles of 64 diagonals, a lane per diagonal: the exact WF_NEXT (wfa.go:549-700, rejections
+//     included: a semi-global row always has cells at sequence ends), the seeds (wfa.go:155-183), WF_EXTEND on the packed
+//     LDS words (wfa.go:381-458).  The new M row overwrites the slot of M[s-o-e] and the I / D rows are updated in place:
+//     the cells a tile overwrites that the next tile still sources (M[s-o-e][k-1], I[s-e][k-1] at the tile's first
+//     diagonal) travel in registers;
+//   * wf-adaptive (wfa.go:461-540) as wave reductions over the tiles' partial results; a row that cuts cells is swept
+//     once more to delete them from the rings;
+//   * the semi-global end cell (wfa.go:270-375) is found while the rows are in LDS: the reference scans every score from
+//     the last down to 0 and keeps the LOWEST score with a hit -- the first one in ascending order;
+//   * per diagonal and score ONE 16-bit word goes to the arena -- the blocked kernels' blk_word(): the pre-extension
+//     offset backTrace recomputes (wfa.go:766-817) over the four decisions of next() -- in rows laid back to back with a
+//     16-byte directory entry {first halfword, lo, width} per score index growing down from the end of the pair's slot
+//     (CompactView fmt 11); wfa_backtrace_kernel walks it with back_trace_compact().
+// Everything is per pair and per wave: no workgroup barrier, no second pass of another kernel; what the wave cannot hold
+// (an arena that overflows) is handed to the generic ladder like every sub-wave kernel does.
+#pragma once
+#include "wfa_device.hpp"
+
+namespace wfa {
+
+constexpr uint32_t WIDE_MAX_LEN = 2047;  // 16-bit ring offsets and 12-bit arena offsets (blk_word() in a halfword)
+constexpr uint32_t WIDE_FMT     = 11u;   // CompactView: rows of 16-bit blk_word()s + the 16-byte directory of fmt 0
+// halfwords of one ring row: a slot per diagonal of [-(n-1), m-1] plus guards on both sides, a multiple of 64
+__host__ __device__ inline uint32_t wide_row_hw(uint32_t max_len) { return (2u * max_len + 96u + 63u) & ~63u; }
+// LDS words of a wave: the two packed sequences, then the six rows
+__host__ __device__ inline uint32_t wide_lds_words(uint32_t seq_words, uint32_t max_len) {
+    return ((2u * seq_words + 3u) & ~3u) + 6u * wide_row_hw(max_len) / 2u;
+}
+// pair_meta of a finished pair: {ST_OK, score of the walk's start, its extended offset | (its diagonal + WIDE_KBIAS) << 16, cells}
+constexpr uint32_t WIDE_KBIAS = 32768u;
+// Two launches per chunk.  PHASE 0 runs a pair from its seeds while its rows are wide -- 25 KB of rings per wave: six waves per
+// CU -- and leaves as soon as every row in the rings spans at most WIDE_NARROW diagonals (a score step or four after
+// wf-adaptive's first cut: the older rows leave the rings); it hands the pair on as a CHECKPOINT: the rings' live part, already
+// in PHASE 1's layout, + the loop's state, WIDE_CKPT_WORDS words per pair.  PHASE 1 picks the pair up with rings of
+// WIDE_RW diagonals indexed modulo (3 KB: the CU's full complement of waves) and runs it to its end; same code, same arena,
+// same directory -- the backtrace sees one pair.  A pair that never narrows (wf-adaptive off) finishes in PHASE 0.
+constexpr int      WIDE_RW = 256, WIDE_NARROW = 200;
+constexpr uint32_t WIDE_CKPT_HDR = 24u, WIDE_CKPT_WORDS = WIDE_CKPT_HDR + 6u * WIDE_RW / 2u;
+__host__ __device__ inline uint32_t wide_lds_words_narrow(uint32_t seq_words) { return ((2u * seq_words + 3u) & ~3u) + 6u * WIDE_RW / 2u; }
+
+// DX / DOE: the penalty shape x/g : (o+e)/g (e/g == 1), as in the sub-wave kernels (wfa_fwd.hpp)
+template <int DX = 2, int DOE = 4, int PHASE = 0>
+__global__ __launch_bounds__(64) void wfa_wide_kernel(const KParams P) {
+    static_assert(DX >= 1 && DOE >= 1 && DX <= 4 && DOE <= 4, "ring depths of one to four score steps");
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int       lane = threadIdx.x;
+    const uint32_t  SW   = P.lds_seq_words;
+    const uint32_t  WH   = PHASE ? (uint32_t)WIDE_RW : P.sub_lds_words;  // halfwords of a ring row (PHASE 0: wide_row_hw of the launch's longest pair)
+    uint32_t *const lq   = lds;
+    uint32_t *const lt   = lds + SW;
+    uint16_t *const ring = reinterpret_cast<uint16_t *>(lds + ((2u * SW + 3u) & ~3u));
+    uint16_t *const rowI = ring + 4u * WH, *const rowD = ring + 5u * WH;
+    const auto      rowM = [&](uint32_t i) -> uint16_t * { return ring + (i & 3u) * WH; };
+    const auto      rfl  = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+    const auto      lds_sync = [] {  // what one lane of the wave stored, another lane reads: in order, and not from a stale register
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+
+    const uint32_t x = P.x, g = P.g;
+    const uint64_t cap      = P.arena_words;  // 32-bit words of a pair's slot
+    const bool     glob     = P.global_alignment != 0;
+    const bool     adaptive = P.adaptive != 0;
+    const int      mdd = (int)P.max_dist_diff, minwf = (int)P.min_wf_len;
+    constexpr int  BIG = 0x3FFFFFFF;
+
+    {
+        // ---------------------------------------------------------------- the workgroup's pair (one wave, one pair: the dispatcher is the queue --
+        // a persistent wave's queue loop around a body of this size had the compiler spill the loop's exit mask to a VGPR lane
+        // and, in one build, not bring it back: the wave never left)
+        const uint32_t idx = blockIdx.x;
+        if (idx >= P.chunk_n) return;
+        uint32_t *const ck = P.wide_ckpt + (uint64_t)idx * WIDE_CKPT_WORDS;  // (only touched when the launch works in two phases)
+        if constexpr (PHASE == 1) {
+            if (rfl(ck[0]) != 1u) return;  // finished, or handed on, by the first launch
+        } else {
+            if (P.wide_ckpt_on != 0u && lane == 0) ck[0] = 0u;
+        }
+        const uint32_t pair = rfl(P.work ? P.work[idx] : P.chunk_first + idx);
+        const uint32_t nq = rfl(P.q_len[pair]), mt = rfl(P.t_len[pair]);
+        uint32_t       status = ST_PENDING;
+        if (nq == 0 || mt == 0)
+            status = ST_EMPTY;  // wfa.go:204-206
+        else if (nq > 0x1FFFFFFFu || mt > 0x1FFFFFFFu)
+            status = ST_TOO_LONG;  // wfa.go:207-209
+        else if ((nq > mt ? nq : mt) > WIDE_MAX_LEN || ((nq > mt ? nq : mt) + 15u) / 16u + 1u > SW || (PHASE == 0 && wide_row_hw(nq > mt ? nq : mt) > WH))
+            status = ST_REDO_LDS;
+        if (status == ST_PENDING) {
+            bool bad = stage_pack<64>(P.blob, P.q_off[pair], nq, lq, lane);
+            bad |= stage_pack<64>(P.blob, P.t_off[pair], mt, lt, lane);
+            if (__ballot(bad) != 0ull) status = ST_REDO_BYTES;  // a byte outside ACGT: the byte-compare path takes the pair
+        }
+        if (status != ST_PENDING) {
+            if (lane == 0) {
+                P.pair_meta[idx] = make_uint4(status, 0u, 0u, 0u);
+                if (status >= ST_REDO_BYTES) push_redo(P, pair, status);
+            }
+            return;
+        }
+        const int n = (int)nq, m = (int)mt, Ak = m - n;
+        SeqView<0> sv;
+        sv.q = lq, sv.t = lt, sv.n = n, sv.m = m;
+        if constexpr (PHASE == 1) {  // the checkpoint's rings (already in this phase's layout: slot = diagonal modulo WIDE_RW)
+            const uint4 *const c4 = reinterpret_cast<const uint4 *>(ck + WIDE_CKPT_HDR);
+            uint4 *const       r4 = reinterpret_cast<uint4 *>(ring);
+            for (uint32_t i = (uint32_t)lane; i < 6u * WIDE_RW / 8u; i += 64u) r4[i] = c4[i];
+        } else {  // rings: all absent
+            uint4 *const r4 = reinterpret_cast<uint4 *>(ring);
+            for (uint32_t i = (uint32_t)lane; i < 6u * WH / 8u; i += 64u) r4[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        lds_sync();
+        const int KOFF = n - 1 + 32;  // PHASE 0: ring index of diagonal k = k + KOFF (guards of 32 below and above); PHASE 1: k modulo WIDE_RW
+        const auto RI = [&](int k) -> uint32_t { return PHASE ? ((uint32_t)k & (uint32_t)(WIDE_RW - 1)) : (uint32_t)(k + KOFF); };
+        uint16_t *const arow = reinterpret_cast<uint16_t *>(P.arena + (uint64_t)idx * cap);  // rows, halfwords
+        uint32_t *const adir = P.arena + (uint64_t)idx * cap + cap;                          // directory entry i: adir - 4 (i + 1)
+
+        // bands (absolute diagonals, empty = (BIG, -BIG)) of the rows in the rings: M by slot, the I / D rows = the previous row's
+        int      blo0 = BIG, blo1 = BIG, blo2 = BIG, blo3 = BIG, bhi0 = -BIG, bhi1 = -BIG, bhi2 = -BIG, bhi3 = -BIG;
+        int      plo = BIG, phi = -BIG;
+        // (selects, not arrays indexed at run time: those would live in scratch memory)
+        const auto get_lo = [&](uint32_t i) { i &= 3u; return i == 0u ? blo0 : i == 1u ? blo1 : i == 2u ? blo2 : blo3; };
+        const auto get_hi = [&](uint32_t i) { i &= 3u; return i == 0u ? bhi0 : i == 1u ? bhi1 : i == 2u ? bhi2 : bhi3; };
+        uint32_t top = 0u;     // halfwords of rows laid down
+        uint32_t cells = 0u;   // census of stored M / I / D words (REC_CELLS)
+        bool     overflow = false;
+        uint32_t s_final = 0u;
+        // semi-global end cell: the first score (ascending) with a hit, the upward scan overriding the downward one
+        bool     found = false;
+        uint32_t fs = 0u;
+        int      fk = 0, fh = 0;
+        int      hf = 0;  // extended offset of M[s_final][Ak]
+        uint32_t si0 = 0u;
+        if constexpr (PHASE == 1) {
+            si0 = rfl(ck[1]), top = rfl(ck[2]), cells = rfl(ck[3]), found = rfl(ck[4]) != 0u, fs = rfl(ck[5]), fk = (int)rfl(ck[6]), fh = (int)rfl(ck[7]);
+            blo0 = (int)rfl(ck[8]), blo1 = (int)rfl(ck[9]), blo2 = (int)rfl(ck[10]), blo3 = (int)rfl(ck[11]);
+            bhi0 = (int)rfl(ck[12]), bhi1 = (int)rfl(ck[13]), bhi2 = (int)rfl(ck[14]), bhi3 = (int)rfl(ck[15]);
+            plo = (int)rfl(ck[16]), phi = (int)rfl(ck[17]);
+        }
+
+        for (uint32_t si = si0;; si++) {
+            const uint32_t s = si * g;
+            // ---- the range of next(s) (wfa.go:557-563) and of the seeds
+            int lo = BIG, hi = -BIG;
+            if (si != 0u) {
+                const auto take = [&](int l, int h_) {
+                    if (h_ >= l) lo = imin2(lo, l - 1), hi = imax2(hi, h_ + 1);
+                };
+                if (si >= (uint32_t)DX) take(get_lo(si - DX), get_hi(si - DX));
+                if (si >= (uint32_t)DOE) take(get_lo(si - DOE), get_hi(si - DOE));
+                take(plo, phi);
+                lo = imax2(lo, -(n - 1)), hi = imin2(hi, m - 1);
+            }
+            const bool seeded = s == 0u || s == x;
+            if (seeded) {
+                if (glob) lo = imin2(lo, 0), hi = imax2(hi, 0);
+                else lo = -(n - 1), hi = m - 1;
+            }
+            // what has to be rewritten: the range, and what the slots hold of older rows (M[s-4g] in the new M row's slot, the previous I / D rows)
+            const uint32_t slot = si & 3u;
+            const int ulo = imin2(lo, imin2(get_lo(slot), plo)), uhi = imax2(hi, imax2(get_hi(slot), phi));
+            const int W = hi >= lo ? hi - lo + 1 : 0;
+            if ((uint64_t)(top + (uint32_t)W + 1u) / 2u + 4ull * (si + 2u) > cap) {
+                overflow = true;
+                break;
+            }
+            if (PHASE == 1 && uhi >= ulo && uhi - ulo + 1 > WIDE_RW - 4) {  // the band has outgrown this phase's rings: the ladder takes the pair
+                overflow = true;
+                break;
+            }
+            uint16_t *const Mn = rowM(si), *const Mo = Mn /* M[s-o-e]: the same slot when DOE == 4 */, *const Mx = rowM(si - (uint32_t)DX);
+            uint16_t *const Moe = rowM(si - (uint32_t)DOE);
+            (void)Mo;
+            const bool hasX = si >= (uint32_t)DX, hasO = si >= (uint32_t)DOE, hasE = si >= 1u;
+            const bool inplace = (DOE & 3) == 0;  // the new row's slot IS M[s-o-e]'s: its k-1 cell travels in a register
+
+            // ---- pass 1: next + seeds + extend, tile by tile
+            int      mlo = BIG, mhi = -BIG, mind = BIG, maxd = -BIG;
+            bool     term = false;
+            uint32_t ncell = 0u;
+            uint32_t carryM = 0u, carryI = 0u;  // M[s-o-e][t0 - 1], I[s-e][t0 - 1] as they were before the previous tile overwrote them
+            if (uhi >= ulo) {
+                // U tiles of 64 diagonals per round (the wide rows: four): the LDS reads of all of them go out before the first is consumed --
+                // a wave with 25 KB of rings has one neighbour on its SIMD to hide a round trip behind
+                constexpr int U = PHASE ? 1 : 4;
+                const int t_first = ulo;
+                carryM = hasO ? Moe[RI(t_first - 1)] : 0u;
+                carryI = hasE ? rowI[RI(t_first - 1)] : 0u;
+                for (int t0 = t_first; t0 <= uhi; t0 += 64 * U) {
+                    uint32_t a0[U], b0[U], c0[U], d0[U], x0[U], ownI[U], ownM[U];
+                    bool     in[U], act[U];
+                    // sources (bare offsets, 0 = absent)
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        const int      k  = t0 + 64 * u + lane;
+                        const uint32_t ri = RI(k), rim = RI(k - 1), rip = RI(k + 1);
+                        in[u]  = k <= uhi;
+                        act[u] = in[u] && k >= lo && k <= hi;
+                        a0[u] = b0[u] = c0[u] = d0[u] = x0[u] = ownI[u] = ownM[u] = 0u;
+                        if (in[u]) {
+                            // (the first lane of the round's first tile: what the previous round overwrote travels in carryM / carryI)
+                            if (hasO) a0[u] = (u == 0 && lane == 0 && inplace) ? carryM : Moe[rim], c0[u] = Moe[rip], ownM[u] = Moe[ri];
+                            if (hasE) b0[u] = (u == 0 && lane == 0) ? carryI : rowI[rim], d0[u] = rowD[rip], ownI[u] = rowI[ri];
+                            if (hasX) x0[u] = Mx[ri];
+                        }
+                    }
+                    carryM = rfl((uint32_t)__builtin_amdgcn_readlane((int)ownM[U - 1], 63));
+                    carryI = rfl((uint32_t)__builtin_amdgcn_readlane((int)ownI[U - 1], 63));
+                    lds_sync();  // (every read of the round before its first write: the rows are updated in place)
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        const int      k  = t0 + 64 * u + lane;
+                        const uint32_t ri = RI(k);
+                        uint32_t nM = 0u, nI = 0u, nD = 0u, wd = 0u;
+                        if (act[u] && si != 0u) {
+                            // rejections: > m (not >=) for I and X sources, offset - k > n for D and X sources (wfa.go:581-588,616-623,651-654)
+                            const uint32_t a = (int)a0[u] > m ? 0u : a0[u], b = (int)b0[u] > m ? 0u : b0[u];
+                            const uint32_t c = (int)c0[u] - k > n ? 0u : c0[u], d = (int)d0[u] - k > n ? 0u : d0[u];
+                            const uint32_t xx = ((int)x0[u] > m || (int)x0[u] - k > n) ? 0u : x0[u];
+                            const uint32_t mi = umax2(a, b), Isk = mi + umin2(mi, 1u);
+                            const uint32_t Dsk = umax2(c, d);
+                            const uint32_t x1  = xx + umin2(xx, 1u);
+                            const uint32_t Msk = umax2(umax2(Isk, Dsk), x1);
+                            const bool fromX = xx != 0u && Msk == x1;  // wfa.go:657-693: the mismatch wins a tie, then the insertion
+                            const bool fromI = !fromX && Msk == Isk;
+                            // backTrace recomputes the pre-extension offset from the un-rejected sources (wfa.go:766-817)
+                            const uint32_t mu = umax2(a0[u], b0[u]), Iu = mu + umin2(mu, 1u), Du = umax2(c0[u], d0[u]);
+                            const uint32_t Xu = x0[u] + umin2(x0[u], 1u);
+                            const bool     iext = a < b, dext = c < d;
+                            const uint32_t o0   = (fromI && iext) ? Iu : ((!fromX && !fromI && dext) ? Du : umax2(umax2(Iu, Du), Xu));
+                            nM = Msk, nI = Isk, nD = Dsk;
+                            wd = Msk != 0u ? blk_word(o0, iext, dext, fromX, fromI) : 0u;
+                        }
+                        if (act[u] && seeded && nM == 0u) {  // seeds of initComponents that belong to this score (Set = last write wins: next()'s cell stays)
+                            const uint32_t sw = seed_word<0>(sv, k, s, x, glob);
+                            if (sw != 0u) nM = sw >> TAG_BITS, wd = (sw & TAG_MASK) == TAG_MATCH ? BLK_SEED_MATCH : BLK_SEED_MISMATCH;
+                        }
+                        // WF_EXTEND (wfa.go:394-455): only cells with 0 < v < n and h < m
+                        if (nM != 0u) {
+                            const int h = (int)nM, v = h - k;
+                            if (v > 0 && v < n && h < m) nM += (uint32_t)sv.lcp(v, h);
+                        }
+                        if (in[u]) Mn[ri] = (uint16_t)nM, rowI[ri] = (uint16_t)nI, rowD[ri] = (uint16_t)nD;
+                        if (act[u]) arow[top + (uint32_t)(k - lo)] = (uint16_t)wd;
+                        if (nM != 0u) {
+                            mlo = imin2(mlo, k), mhi = imax2(mhi, k);
+                            const int h = (int)nM, v = h - k;
+                            if (k == Ak && h >= m) term = true, hf = h;  // wfa.go:235-239
+                            if (!(v < 0 || v >= n || h >= m)) {          // wfa.go:474-494
+                                const int dd = imax2(m - h, n - v);
+                                mind = imin2(mind, dd), maxd = imax2(maxd, dd);
+                            }
+                        }
+                        ncell += (nM != 0u ? 1u : 0u) + (nI != 0u ? 1u : 0u) + (nD != 0u ? 1u : 0u);
+                    }
+                    lds_sync();
+                }
+            }
+            mlo = wave_min(mlo), mhi = wave_max(mhi), mind = wave_min(mind), maxd = wave_max(maxd);
+            term = __ballot(term) != 0ull;
+            if (term) hf = wave_max(hf);
+            int nlo = mlo, nhi = mhi;  // the surviving band (I and D only hold cells where M does)
+            if (!term && adaptive && mhi >= mlo && (mhi - mlo + 1) >= minwf && mind != BIG && maxd - mind > mdd) {
+                // ---- reduce (wfa.go:496-537): some distance fails
+                const int thr = mind + mdd;
+                int first_ok = BIG, last_ok = -BIG;
+                for (int t0 = mlo; t0 <= mhi; t0 += 64) {
+                    const int k = t0 + lane;
+                    if (k <= mhi) {
+                        const int h = (int)Mn[RI(k)], v = h - k;
+                        if (h != 0 && !(v < 0 || v >= n || h >= m) && imax2(m - h, n - v) <= thr) first_ok = imin2(first_ok, k), last_ok = imax2(last_ok, k);
+                    }
+                }
+                first_ok = wave_min(first_ok), last_ok = wave_max(last_ok);
+                int lead = -BIG;  // _lo: one past the last valid entry before the first non-failing one (wfa.go:503-516)
+                for (int t0 = mlo; t0 < first_ok && t0 <= mhi; t0 += 64) {
+                    const int k = t0 + lane;
+                    if (k < first_ok && k <= mhi) {
+                        const int h = (int)Mn[RI(k)], v = h - k;
+                        if (h != 0 && !(v < 0 || v >= n || h >= m)) lead = imax2(lead, k);
+                    }
+                }
+                lead = wave_max(lead);
+                nlo  = lead != -BIG ? lead + 1 : mlo;
+                nhi  = last_ok;  // wfa.go:517-524
+                // wfa.go:526-535 deletes k outside [_lo, _hi] in M, I and D
+                for (int t0 = mlo; t0 <= mhi; t0 += 64) {
+                    const int k = t0 + lane;
+                    if (k <= mhi && (k < nlo || k > nhi)) {
+                        const uint32_t ri = RI(k);
+                        ncell -= (Mn[ri] != 0 ? 1u : 0u) + (rowI[ri] != 0 ? 1u : 0u) + (rowD[ri] != 0 ? 1u : 0u);
+                        Mn[ri] = 0, rowI[ri] = 0, rowD[ri] = 0;
+                    }
+                }
+                lds_sync();
+            }
+            // ---- semi-global end cell (wfa.go:270-375) of this score, on the row as it stays
+            if (!glob && !found && nhi >= nlo) {
+                uint32_t keyD = 0xFFFFFFFFu, keyU = 0xFFFFFFFFu;
+                int      hD = 0, hU = 0;
+                for (int t0 = nlo; t0 <= nhi; t0 += 64) {
+                    const int k = t0 + lane;
+                    if (k <= nhi) {
+                        const int h = (int)Mn[RI(k)], v = h - k;
+                        if (h != 0) {
+                            const bool stop = v <= 0 || v > n || h > m;
+                            const bool hit  = !stop && ((v == n && h >= n) || (h == m && v >= m));
+                            if (stop || hit) {
+                                if (k <= Ak) {
+                                    const uint32_t key = ((uint32_t)(Ak - k) << 1) | (hit ? 0u : 1u);
+                                    if (key < keyD) keyD = key, hD = h;
+                                } else {
+                                    const uint32_t key = ((uint32_t)(k - Ak - 1) << 1) | (hit ? 0u : 1u);
+                                    if (key < keyU) keyU = key, hU = h;
+                                }
+                            }
+                        }
+                    }
+                }
+                const uint32_t kD = (uint32_t)wave_min((int)(keyD ^ 0x80000000u)) ^ 0x80000000u;  // unsigned min via signed min
+                const uint32_t kU = (uint32_t)wave_min((int)(keyU ^ 0x80000000u)) ^ 0x80000000u;
+                // (the offset of the winning cell: the lane that holds the winning key)
+                const int wD = wave_max(keyD == kD && kD != 0xFFFFFFFFu ? hD : 0), wU = wave_max(keyU == kU && kU != 0xFFFFFFFFu ? hU : 0);
+                if (kD != 0xFFFFFFFFu && (kD & 1u) == 0u) found = true, fs = s, fk = Ak - (int)(kD >> 1), fh = wD;
+                if (kU != 0xFFFFFFFFu && (kU & 1u) == 0u) found = true, fs = s, fk = Ak + 1 + (int)(kU >> 1), fh = wU;
+            }
+            // ---- the row's directory entry and census
+            if (lane == 0) {
+                const bool any = nhi >= nlo;
+                *reinterpret_cast<uint4 *>(adir - 4u * (si + 1u)) = make_uint4(any ? top + (uint32_t)(nlo - lo) : 0u, any ? (uint32_t)nlo : 0u, any ? (uint32_t)(nhi - nlo + 1) : 0u, 0u);
+            }
+            {
+                uint32_t c = ncell;  // (a wave sum: 64 lanes x at most 3 x tiles)
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) c += (uint32_t)__shfl_xor((int)c, d, 64);
+                cells += c;
+            }
+            top += ((uint32_t)W + 1u) & ~1u;
+            plo = nhi >= nlo ? nlo : BIG, phi = nhi >= nlo ? nhi : -BIG;
+            if (slot == 0u) blo0 = plo, bhi0 = phi;
+            if (slot == 1u) blo1 = plo, bhi1 = phi;
+            if (slot == 2u) blo2 = plo, bhi2 = phi;
+            if (slot == 3u) blo3 = plo, bhi3 = phi;
+            if (term) {
+                s_final = s;
+                break;
+            }
+            if constexpr (PHASE == 0) {
+                if (P.wide_ckpt_on != 0u && si >= 1u) {
+                    const int clo = imin2(imin2(blo0, blo1), imin2(imin2(blo2, blo3), plo)), chi = imax2(imax2(bhi0, bhi1), imax2(imax2(bhi2, bhi3), phi));
+                    if (chi >= clo && chi - clo + 1 <= WIDE_NARROW) {
+                        // checkpoint: the rings' live part in PHASE 1's layout, then the loop's state
+                        uint16_t *const ch = reinterpret_cast<uint16_t *>(ck + WIDE_CKPT_HDR);
+                        uint4 *const    c4 = reinterpret_cast<uint4 *>(ck + WIDE_CKPT_HDR);
+                        for (uint32_t i = (uint32_t)lane; i < 6u * WIDE_RW / 8u; i += 64u) c4[i] = make_uint4(0u, 0u, 0u, 0u);
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (the zeros before the cells: the same addresses from other lanes)
+                        __builtin_amdgcn_s_waitcnt(0);
+                        for (int t0 = clo; t0 <= chi; t0 += 64) {
+                            const int k = t0 + lane;
+                            if (k <= chi) {
+#pragma unroll
+                                for (uint32_t r = 0; r < 6u; r++) ch[r * WIDE_RW + ((uint32_t)k & (uint32_t)(WIDE_RW - 1))] = ring[r * WH + (uint32_t)(k + KOFF)];
+                            }
+                        }
+                        if (lane == 0) {
+                            ck[1] = si + 1u, ck[2] = top, ck[3] = cells, ck[4] = found ? 1u : 0u, ck[5] = fs, ck[6] = (uint32_t)fk, ck[7] = (uint32_t)fh;
+                            ck[8] = (uint32_t)blo0, ck[9] = (uint32_t)blo1, ck[10] = (uint32_t)blo2, ck[11] = (uint32_t)blo3;
+                            ck[12] = (uint32_t)bhi0, ck[13] = (uint32_t)bhi1, ck[14] = (uint32_t)bhi2, ck[15] = (uint32_t)bhi3;
+                            ck[16] = (uint32_t)plo, ck[17] = (uint32_t)phi;
+                            ck[0] = 1u;
+                            P.pair_meta[idx] = make_uint4(ST_PENDING, 0u, 0u, 0u);  // (the second launch writes the pair's record)
+                        }
+                        return;
+                    }
+                }
+            }
+        }
+        if (overflow) {
+            if (lane == 0) {
+                P.pair_meta[idx] = make_uint4(ST_REDO_ARENA, 0u, 0u, 0u);
+                push_redo(P, pair, ST_REDO_ARENA);
+            }
+            return;
+        }
+        if (lane == 0) {
+            const uint32_t bs = (glob || !found) ? s_final : fs;
+            const int      bk = (glob || !found) ? Ak : fk, bh = (glob || !found) ? hf : fh;
+            P.pair_meta[idx] = make_uint4(ST_OK, bs, (uint32_t)bh | ((uint32_t)(bk + (int)WIDE_KBIAS) << 16), P.census ? cells : 0u);
+        }
+    }
+}
+
+}  // namespace wfa
