@@ -122,7 +122,7 @@ typedef struct {
                                   (sliding sequence windows: reads of any length, 64 / 128 / 256 diagonals), 14 / 15 = wfa_blk_kernel<64, 1, false, 1 / 2, .., LONG>
                                   (a wave per pair, one / two diagonals per lane: batches too small to fill the GPU),
                                   16 = wfa_blk_kernel<64, 1, false, 1, false, false> (wfahip_align_pair: one launch, forward pass and backtrace),
-                                  18 = wfa_wide_kernel (round 6: semi-global short reads, a wave per pair with the rows in 16-bit LDS rings),
+                                  18 = wfa_wide_kernel (round 6: semi-global reads up to 2 047 bases, a workgroup per pair with the rows in 16-bit LDS rings),
                                   17 = wfa_teamc_kernel (wide wavefronts: a team of workgroups per pair, one backtrace word per diagonal) */
     uint32_t ladder_start_level; /* arena level the long-pair ladder of this call started on (0 unless a learned hint applied) */
 } wfahip_timing;
@@ -263,6 +263,11 @@ int  wfahip_last_timing(const wfahip_ctx *ctx, wfahip_timing *out);
  *                          what outgrows that retries on the 16-lane instance                         default 1
  *   "blk_wide"  0|1        pairs whose band leaves the 64-diagonal window retry on the same kernel with a
  *                          wave per pair (256 diagonals) before the generic kernel takes them       default 1
+ *   "wide"  0|1|3          semi-global batches of reads up to "wide_max_len" bases (default 2 047, the kernel's limit) and at least
+ *                          "wide_min_pairs" pairs (default 64) start on wfa_wide_kernel (round 6: a workgroup per pair, the
+ *                          rows in 16-bit LDS rings of any width; two launches per chunk under wf-adaptive -- wide rows, then
+ *                          the narrow tail from a checkpoint); 3: one launch per chunk; 0: on the generic ladder     default 1
+ *   "wide_waves"  0|1|4    waves per pair in its first launch: 0 = by the rings' size (four above 12 KB)          default 0
  *   "arena_bytes_per_slot", "slots", "threads_per_pair"   generic kernel (one workgroup per pair)
  *   "prepack"  0|1         the sequences of a chunk are 2-bit packed by a kernel of their own before the 16-lane forward
  *                          kernel, whose refill then is one round of loads (forward pass -2 %, packing kernel +4 %)   default 0

@@ -1718,11 +1718,13 @@ def test_wide_kernel_semi_global_shapes(built, pen, ad):
     want = O.align_batch(_oracle_params(False, ad, pen), *data, n_threads=max(8, (os.cpu_count() or 8) // 2))
     al = _aligner(False, ad, pen)
     al.set_option("arena_poison", 1)
-    al.set_option("wide_max_len", 2047)  # (by default batches of reads beyond 512 bases stay on the ladder's kernels)
     for rep in range(2):
         got = al.align_arrays(*data)
         assert al.last_timing().main_kernel_kind == 18
         assert_batch_equal(got, want, f"wide kernel pen={pen} ad={ad} rep={rep}")
+    al.set_option("wide_waves", 1)  # (rings of this size get four waves per pair by default)
+    assert_batch_equal(al.align_arrays(*data), want, f"wide kernel, a wave per pair, pen={pen} ad={ad}")
+    al.set_option("wide_waves", 0)
     if ad is not None:  # one launch per chunk: every pair runs to its end in the wide rings (no hand-over to the narrow phase)
         al.set_option("wide", 3)
         assert_batch_equal(al.align_arrays(*data), want, f"wide kernel, one phase, pen={pen} ad={ad}")
@@ -1742,7 +1744,6 @@ def test_wide_kernel_semi_global_1kbp(built, ad):
     data = w.generate_pairs(seed=63, n_pairs=n, length=1000, error_rate=0.05, n_threads=32)
     want = O.align_batch(_oracle_params(False, ad), *data, n_threads=max(8, (os.cpu_count() or 8) // 2))
     al = _aligner(False, ad)
-    al.set_option("wide_max_len", 2047)
     got = al.align_arrays(*data)
     assert al.last_timing().main_kernel_kind == 18
     assert_batch_equal(got, want, f"1 kbp semi-global ad={ad}")
@@ -1755,11 +1756,11 @@ def test_wide_kernel_semi_global_1kbp(built, ad):
 
 
 def test_wide_kernel_is_the_default_for_short_semi_global_reads(built):
-    """Batches of semi-global reads of at most 512 bases start on wfa_wide_kernel without any option; longer ones on the ladder."""
+    """Batches of semi-global reads of at most 2 047 bases start on wfa_wide_kernel without any option; longer ones on the ladder."""
     import wfa_amd as w
     from oracle import oracle as O
-    for length, kind in ((300, 18), (800, 0)):
-        data = w.generate_pairs(seed=64, n_pairs=4000, length=length, error_rate=0.06, n_threads=8)
+    for length, n_pairs, kind in ((300, 4000, 18), (1000, 2000, 18), (2300, 200, 0)):
+        data = w.generate_pairs(seed=64, n_pairs=n_pairs, length=length, error_rate=0.06, n_threads=8)
         want = O.align_batch(_oracle_params(False, (10, 50, 1)), *data, n_threads=8)
         al = _aligner(False, (10, 50, 1))
         got = al.align_arrays(*data)

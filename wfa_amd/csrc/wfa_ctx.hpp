@@ -172,11 +172,13 @@ struct wfahip_ctx {
                                                   // (measured: forward 19.96 -> 19.54 ms per 1e6 x 1 kbp pairs, but the packing kernel takes 0.9 ms: off)
     int64_t       opt_narrow_long          = 0;   // experiment: reads of any length start on the 8-lanes-per-pair instance (32-diagonal windows)
     DevBuf        wide_ckpt;                      // wfa_wide_kernel: what its first launch hands its second, per pair of the chunk
-    int64_t       opt_wide                 = 1;   // (3: one launch per chunk, every pair runs to its end in the wide rings) semi-global batches of short reads (at most 2 047 bases, penalties of one of the sub-wave shapes) start on
-                                                  // wfa_wide_kernel (round 6: a wave per pair, rows in 16-bit LDS rings of any width); 0: on the generic ladder
-    int64_t       opt_wide_max_len         = 512; // ... of reads up to this length: its rings take 6 x (n + m) x 2 bytes of LDS per wave -- at 300 bases it is 1.5 times
-                                                  // as fast as the one-workgroup-per-pair kernel (1e5 pairs: 8.5 against 12.8 ms), at 1 kbp six waves per CU are left
-                                                  // and the two are level (1e6 pairs: 434 against 403 ms)
+    int64_t       opt_wide                 = 1;   // semi-global batches of reads up to 2 047 bases (penalties of one of the sub-wave shapes) start on wfa_wide_kernel (round 6: a workgroup per
+                                                  // pair, the rows in 16-bit LDS rings of any width, two launches per chunk under wf-adaptive); 3: one launch per chunk, every pair
+                                                  // runs to its end in the wide rings; 0: on the generic ladder
+    int64_t       opt_wide_max_len         = 2047;// ... of reads up to this length.  1e6 x 1 kbp: 250 ms against the generic kernel's 403; 1e5 x 300 bp: 8.0 against 12.7;
+                                                  // 2e4 x 1 kbp without wf-adaptive: 30 against 71
+    int           opt_wide_waves           = 0;   // ... waves per pair in its first phase: 0 = by the rings' size (four above 12 KB: a 1 kbp pair's 25 KB leave a SIMD a wave and a
+                                                  // half otherwise), 1 or 4 forced (tests)
     int64_t       opt_wide_min_pairs       = 64;  // ... from this many pairs on (fewer: the one-workgroup-per-pair kernel, whose workgroup is larger than a wave)
     int64_t       opt_duo                  = 1;   // reads of 240+ bases start on wfa_duo_kernel (8 or 16 lanes per pair, changing while the pair runs):
                                                   // 0 never, 1 for batches of at least opt_duo_min_pairs (below that its start-up -- a wave takes one new pair

@@ -3,6 +3,7 @@
 //
 // There is NO CPU fallback here: every alignment is produced by the HIP kernels.  Without a GPU the
 // entry points return WFAHIP_ERR_NO_DEVICE.
+#include <map>
 #include "wfa_ctx.hpp"
 // (the kernels' headers for their constants and device functions; the forward kernels are instantiated per penalty shape in
 // wfa_fwd_s*.hip, wfa_duo_kernel in wfa_duo.hip, the long-pair kernels in wfa_long.hip: this unit keeps the router, the
@@ -47,30 +48,29 @@ hipError_t wfa_launch_pair(int shape, bool lds_arena, const KParams &P, size_t l
     }
     return hipErrorInvalidValue;
 }
-// wfa_wide_kernel of penalty shape `shape` (wfa_fwd.hpp: fwd_shape())
-hipError_t wfa_launch_wide(int shape, int phase, const KParams &P, uint32_t grid, size_t lds_bytes, hipStream_t st) {
-    const auto go = [&](auto kern) -> hipError_t {
+// wfa_wide_kernel of penalty shape `shape` (wfa_fwd.hpp: fwd_shape()); phase 0 with `waves` waves per pair (1 or 4), phase 1 with one
+hipError_t wfa_launch_wide(int shape, int phase, int waves, const KParams &P, uint32_t grid, size_t lds_bytes, hipStream_t st) {
+    const auto go = [&](auto kern, int nw) -> hipError_t {
         if (lds_bytes > 64 * 1024) {  // (per device: the attribute belongs to the kernel as loaded there)
             const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds_bytes, st, P);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nw), lds_bytes, st, P);
         return hipGetLastError();
     };
-    switch (shape * 2 + (phase ? 1 : 0)) {
-    case 0: return go(wfa_wide_kernel<2, 4, 0>);
-    case 1: return go(wfa_wide_kernel<2, 4, 1>);
-    case 2: return go(wfa_wide_kernel<1, 3, 0>);
-    case 3: return go(wfa_wide_kernel<1, 3, 1>);
-    case 4: return go(wfa_wide_kernel<1, 2, 0>);
-    case 5: return go(wfa_wide_kernel<1, 2, 1>);
-    case 6: return go(wfa_wide_kernel<2, 3, 0>);
-    case 7: return go(wfa_wide_kernel<2, 3, 1>);
-    case 8: return go(wfa_wide_kernel<2, 2, 0>);
-    case 9: return go(wfa_wide_kernel<2, 2, 1>);
-    case 10: return go(wfa_wide_kernel<3, 3, 0>);
-    case 11: return go(wfa_wide_kernel<3, 3, 1>);
+#define WFA_WIDE_SHAPE(I, DX_, DOE_)                                                                            \
+    case 3 * I: return go(wfa_wide_kernel<DX_, DOE_, 0, 1>, 1);                                                 \
+    case 3 * I + 1: return go(wfa_wide_kernel<DX_, DOE_, 0, 4>, 4);                                             \
+    case 3 * I + 2: return go(wfa_wide_kernel<DX_, DOE_, 1, 1>, 1);
+    switch (shape * 3 + (phase ? 2 : (waves > 1 ? 1 : 0))) {
+        WFA_WIDE_SHAPE(0, 2, 4)
+        WFA_WIDE_SHAPE(1, 1, 3)
+        WFA_WIDE_SHAPE(2, 1, 2)
+        WFA_WIDE_SHAPE(3, 2, 3)
+        WFA_WIDE_SHAPE(4, 2, 2)
+        WFA_WIDE_SHAPE(5, 3, 3)
     }
+#undef WFA_WIDE_SHAPE
     return hipErrorInvalidValue;
 }
 }  // namespace wfa
@@ -453,6 +453,8 @@ static int set_option_impl(wfahip_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_wide_min_pairs = value;
     else if (k == "wide_max_len")
         ctx->opt_wide_max_len = value;
+    else if (k == "wide_waves")
+        ctx->opt_wide_waves = (value == 1 || value == 4) ? (int)value : 0;
     else if (k == "duo")
         ctx->opt_duo = value;
     else if (k == "duo_min_pairs")
@@ -654,6 +656,8 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             if (two_phase && (rc = ensure(ctx, ctx->wide_ckpt, (size_t)chunk * WIDE_CKPT_WORDS * 4))) return rc;
             P.wide_ckpt = static_cast<uint32_t *>(ctx->wide_ckpt.p), P.wide_ckpt_on = two_phase ? 1u : 0u;
             const size_t lds_narrow = (size_t)wide_lds_words_narrow(seq_words) * 4;
+            // waves per pair in the first phase: rings above 12 KB leave a SIMD fewer than three one-wave workgroups -- four waves share them
+            const int wide_waves = ctx->opt_wide_waves > 0 ? ctx->opt_wide_waves : (lds_bytes > 12 * 1024 ? 4 : 1);
             ctx->timing.arena_bytes = std::max<uint64_t>(ctx->timing.arena_bytes, words * 4ull * chunk);
             P.dx = dx, P.doe = doe, P.de = de, P.dm = std::max(dx, doe) + 1, P.di = de + 1;
             P.lds_seq_words = seq_words, P.sub_lds_words = row_hw, P.min_xe = std::min(P.x, P.e);
@@ -674,8 +678,8 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                 if (ctx->opt_arena_poison) HIP_TRY(hipMemsetAsync(P.arena, 0xA5, (size_t)(words * 4ull * cn), st));
                 const uint32_t grid = (uint32_t)cn;  // (a workgroup -- one wave -- per pair)
                 HIP_TRY(hipEventRecord(ctx->evpool[4 * c], st));
-                HIP_TRY(wfa_launch_wide(shape, 0, P, grid, lds_bytes, st));
-                if (two_phase) HIP_TRY(wfa_launch_wide(shape, 1, P, grid, lds_narrow, st));
+                HIP_TRY(wfa_launch_wide(shape, 0, wide_waves, P, grid, lds_bytes, st));
+                if (two_phase) HIP_TRY(wfa_launch_wide(shape, 1, 1, P, grid, lds_narrow, st));
                 HIP_TRY(hipEventRecord(ctx->evpool[4 * c + 1], st));
                 hipLaunchKernelGGL(wfa_backtrace_kernel, dim3((uint32_t)((cn + BT_THREADS - 1) / BT_THREADS)), dim3(BT_THREADS), 0, st, P);
                 HIP_TRY(hipGetLastError());
@@ -691,6 +695,19 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
                 HIP_TRY(hipEventElapsedTime(&msF, ctx->evpool[4 * c], ctx->evpool[4 * c + 1]));
                 HIP_TRY(hipEventElapsedTime(&msB, ctx->evpool[4 * c + 1], ctx->evpool[4 * c + 3]));
                 ctx->timing.kernel_ms += msF + msB, ctx->timing.main_kernel_ms += msF, ctx->timing.n_main_launches++, ctx->timing.n_launches += 2;
+            }
+            if (std::getenv("WFAHIP_WIDE_TRACE")) {  // (debug aid: why the pairs of the last chunk were handed on -- the kernel leaves {status, score index, reason, span})
+                const uint64_t cn = n_pairs - (n_chunks - 1) * chunk;
+                std::vector<uint32_t> hm(4 * cn);
+                HIP_TRY(hipMemcpy(hm.data(), ctx->meta.p, 16 * cn, hipMemcpyDeviceToHost));
+                std::map<uint64_t, uint32_t> tally;
+                uint32_t shown = 0;
+                for (uint64_t i = 0; i < cn; i++)
+                    if (hm[4 * i] >= ST_REDO_BYTES) {
+                        tally[((uint64_t)hm[4 * i] << 32) | hm[4 * i + 2]]++;
+                        if (shown++ < 12) std::fprintf(stderr, "[wfahip] wide: slot %llu status %u si %u reason %u span %u\n", (unsigned long long)i, hm[4 * i], hm[4 * i + 1], hm[4 * i + 2], hm[4 * i + 3]);
+                    }
+                for (const auto &kv : tally) std::fprintf(stderr, "[wfahip] wide: status %u reason %u: %u pairs of %llu\n", (uint32_t)(kv.first >> 32), (uint32_t)kv.first, kv.second, (unsigned long long)cn);
             }
             ctx->timing.main_kernel_kind = 18;
             ctx->timing.n_packed_pairs   = (uint32_t)(n_pairs - redo.size());

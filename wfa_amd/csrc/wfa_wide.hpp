@@ -38,7 +38,7 @@ constexpr uint32_t WIDE_FMT     = 11u;   // CompactView: rows of 16-bit blk_word
 __host__ __device__ inline uint32_t wide_row_hw(uint32_t max_len) { return (2u * max_len + 96u + 63u) & ~63u; }
 // LDS words of a wave: the two packed sequences, then the six rows
 __host__ __device__ inline uint32_t wide_lds_words(uint32_t seq_words, uint32_t max_len) {
-    return ((2u * seq_words + 3u) & ~3u) + 6u * wide_row_hw(max_len) / 2u;
+    return ((2u * seq_words + 3u) & ~3u) + 6u * wide_row_hw(max_len) / 2u + 80u;
 }
 // pair_meta of a finished pair: {ST_OK, score of the walk's start, its extended offset | (its diagonal + WIDE_KBIAS) << 16, cells}
 constexpr uint32_t WIDE_KBIAS = 32768u;
@@ -48,16 +48,22 @@ constexpr uint32_t WIDE_KBIAS = 32768u;
 // in PHASE 1's layout, + the loop's state, WIDE_CKPT_WORDS words per pair.  PHASE 1 picks the pair up with rings of
 // WIDE_RW diagonals indexed modulo (3 KB: the CU's full complement of waves) and runs it to its end; same code, same arena,
 // same directory -- the backtrace sees one pair.  A pair that never narrows (wf-adaptive off) finishes in PHASE 0.
-constexpr int      WIDE_RW = 256, WIDE_NARROW = 200;
+constexpr int      WIDE_RW = 512, WIDE_NARROW = 200;
+constexpr uint32_t WIDE_SCR_WORDS = 80u;  // LDS words behind the rings: what the waves of a workgroup hand one another
 constexpr uint32_t WIDE_CKPT_HDR = 24u, WIDE_CKPT_WORDS = WIDE_CKPT_HDR + 6u * WIDE_RW / 2u;
-__host__ __device__ inline uint32_t wide_lds_words_narrow(uint32_t seq_words) { return ((2u * seq_words + 3u) & ~3u) + 6u * WIDE_RW / 2u; }
+__host__ __device__ inline uint32_t wide_lds_words_narrow(uint32_t seq_words) { return ((2u * seq_words + 3u) & ~3u) + 6u * WIDE_RW / 2u + WIDE_SCR_WORDS; }
 
 // DX / DOE: the penalty shape x/g : (o+e)/g (e/g == 1), as in the sub-wave kernels (wfa_fwd.hpp)
-template <int DX = 2, int DOE = 4, int PHASE = 0>
-__global__ __launch_bounds__(64) void wfa_wide_kernel(const KParams P) {
+// NW: waves of the pair's workgroup (PHASE 0: the rings of a 1 kbp pair are 25 KB, six workgroups a CU -- with one wave each the SIMDs would
+// hold a wave and a half; the waves of a workgroup take a row's rounds side by side)
+template <int DX = 2, int DOE = 4, int PHASE = 0, int NW = 1>
+__global__ __launch_bounds__(64 * NW) void wfa_wide_kernel(const KParams P) {
     static_assert(DX >= 1 && DOE >= 1 && DX <= 4 && DOE <= 4, "ring depths of one to four score steps");
+    static_assert(NW == 1 || (PHASE == 0 && (NW == 2 || NW == 4)), "the narrow phase is one wave");
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const int       lane = threadIdx.x;
+    const int       tid  = (int)threadIdx.x;
+    const int       lane = tid & 63;
+    const int       wv   = NW > 1 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;
     const uint32_t  SW   = P.lds_seq_words;
     const uint32_t  WH   = PHASE ? (uint32_t)WIDE_RW : P.sub_lds_words;  // halfwords of a ring row (PHASE 0: wide_row_hw of the launch's longest pair)
     uint32_t *const lq   = lds;
@@ -66,11 +72,28 @@ __global__ __launch_bounds__(64) void wfa_wide_kernel(const KParams P) {
     uint16_t *const rowI = ring + 4u * WH, *const rowD = ring + 5u * WH;
     const auto      rowM = [&](uint32_t i) -> uint16_t * { return ring + (i & 3u) * WH; };
     const auto      rfl  = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
-    const auto      lds_sync = [] {  // what one lane of the wave stored, another lane reads: in order, and not from a stale register
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    uint32_t *const scr  = reinterpret_cast<uint32_t *>(ring + 6u * WH);  // WIDE_SCR_WORDS: two exchange buffers of 32 words, the carries' four
+    const auto      lds_sync = [] {  // what one lane of the workgroup stored, another lane reads: in order, and not from a stale register
+        if constexpr (NW > 1) {
+            __syncthreads();
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
     };
+    // every wave hands in CNT values; afterwards every wave holds all of them (all[w * CNT + i]).  Two buffers in turn: a wave that is
+    // one exchange ahead writes the other one
+    uint32_t   xcount = 0u;
+    const auto xchg   = [&](const int *mine, int *all, const int CNT) {
+        uint32_t *const b = scr + (xcount & 1u) * 32u;
+        xcount++;
+        if (lane == 0)
+            for (int i = 0; i < CNT; i++) b[wv * CNT + i] = (uint32_t)mine[i];
+        __syncthreads();
+        for (int i = 0; i < NW * CNT; i++) all[i] = __builtin_amdgcn_readfirstlane((int)b[i]);
+    };
+    (void)xchg, (void)scr;
 
     const uint32_t x = P.x, g = P.g;
     const uint64_t cap      = P.arena_words;  // 32-bit words of a pair's slot
@@ -89,7 +112,7 @@ __global__ __launch_bounds__(64) void wfa_wide_kernel(const KParams P) {
         if constexpr (PHASE == 1) {
             if (rfl(ck[0]) != 1u) return;  // finished, or handed on, by the first launch
         } else {
-            if (P.wide_ckpt_on != 0u && lane == 0) ck[0] = 0u;
+            if (P.wide_ckpt_on != 0u && tid == 0) ck[0] = 0u;
         }
         const uint32_t pair = rfl(P.work ? P.work[idx] : P.chunk_first + idx);
         const uint32_t nq = rfl(P.q_len[pair]), mt = rfl(P.t_len[pair]);
@@ -101,12 +124,15 @@ __global__ __launch_bounds__(64) void wfa_wide_kernel(const KParams P) {
         else if ((nq > mt ? nq : mt) > WIDE_MAX_LEN || ((nq > mt ? nq : mt) + 15u) / 16u + 1u > SW || (PHASE == 0 && wide_row_hw(nq > mt ? nq : mt) > WH))
             status = ST_REDO_LDS;
         if (status == ST_PENDING) {
-            bool bad = stage_pack<64>(P.blob, P.q_off[pair], nq, lq, lane);
-            bad |= stage_pack<64>(P.blob, P.t_off[pair], mt, lt, lane);
-            if (__ballot(bad) != 0ull) status = ST_REDO_BYTES;  // a byte outside ACGT: the byte-compare path takes the pair
+            bool bad = stage_pack<64 * NW>(P.blob, P.q_off[pair], nq, lq, tid);
+            bad |= stage_pack<64 * NW>(P.blob, P.t_off[pair], mt, lt, tid);
+            bool anybad;
+            if constexpr (NW > 1) anybad = __syncthreads_or(bad ? 1 : 0) != 0;
+            else anybad = __ballot(bad) != 0ull;
+            if (anybad) status = ST_REDO_BYTES;  // a byte outside ACGT: the byte-compare path takes the pair
         }
         if (status != ST_PENDING) {
-            if (lane == 0) {
+            if (tid == 0) {
                 P.pair_meta[idx] = make_uint4(status, 0u, 0u, 0u);
                 if (status >= ST_REDO_BYTES) push_redo(P, pair, status);
             }
@@ -121,7 +147,7 @@ __global__ __launch_bounds__(64) void wfa_wide_kernel(const KParams P) {
             for (uint32_t i = (uint32_t)lane; i < 6u * WIDE_RW / 8u; i += 64u) r4[i] = c4[i];
         } else {  // rings: all absent
             uint4 *const r4 = reinterpret_cast<uint4 *>(ring);
-            for (uint32_t i = (uint32_t)lane; i < 6u * WH / 8u; i += 64u) r4[i] = make_uint4(0u, 0u, 0u, 0u);
+            for (uint32_t i = (uint32_t)tid; i < 6u * WH / 8u; i += 64u * NW) r4[i] = make_uint4(0u, 0u, 0u, 0u);
         }
         lds_sync();
         const int KOFF = n - 1 + 32;  // PHASE 0: ring index of diagonal k = k + KOFF (guards of 32 below and above); PHASE 1: k modulo WIDE_RW
@@ -138,6 +164,7 @@ __global__ __launch_bounds__(64) void wfa_wide_kernel(const KParams P) {
         uint32_t top = 0u;     // halfwords of rows laid down
         uint32_t cells = 0u;   // census of stored M / I / D words (REC_CELLS)
         bool     overflow = false;
+        uint32_t ovf_si = 0u, ovf_why = 0u, ovf_span = 0u;  // (what WFAHIP_WIDE_TRACE prints)
         uint32_t s_final = 0u;
         // semi-global end cell: the first score (ascending) with a hit, the upward scan overriding the downward one
         bool     found = false;
@@ -174,12 +201,12 @@ __global__ __launch_bounds__(64) void wfa_wide_kernel(const KParams P) {
             const uint32_t slot = si & 3u;
             const int ulo = imin2(lo, imin2(get_lo(slot), plo)), uhi = imax2(hi, imax2(get_hi(slot), phi));
             const int W = hi >= lo ? hi - lo + 1 : 0;
-            if ((uint64_t)(top + (uint32_t)W + 1u) / 2u + 4ull * (si + 2u) > cap) {
-                overflow = true;
+            if ((uint64_t)(top + (uint32_t)W + 4u) / 2u + 4ull * (si + 2u) > cap) {
+                overflow = true, ovf_si = si, ovf_why = 1u, ovf_span = (uint32_t)W;
                 break;
             }
             if (PHASE == 1 && uhi >= ulo && uhi - ulo + 1 > WIDE_RW - 4) {  // the band has outgrown this phase's rings: the ladder takes the pair
-                overflow = true;
+                overflow = true, ovf_si = si, ovf_why = 2u, ovf_span = (uint32_t)(uhi - ulo + 1);
                 break;
             }
             uint16_t *const Mn = rowM(si), *const Mo = Mn /* M[s-o-e]: the same slot when DOE == 4 */, *const Mx = rowM(si - (uint32_t)DX);
@@ -193,92 +220,234 @@ __global__ __launch_bounds__(64) void wfa_wide_kernel(const KParams P) {
             bool     term = false;
             uint32_t ncell = 0u;
             uint32_t carryM = 0u, carryI = 0u;  // M[s-o-e][t0 - 1], I[s-e][t0 - 1] as they were before the previous tile overwrote them
-            if (uhi >= ulo) {
-                // U tiles of 64 diagonals per round (the wide rows: four): the LDS reads of all of them go out before the first is consumed --
-                // a wave with 25 KB of rings has one neighbour on its SIMD to hide a round trip behind
-                constexpr int U = PHASE ? 1 : 4;
+            const bool ecs = !glob && !found;   // the end-cell search is on: the wide rows note its candidates while they are computed
+            int        cdn = -BIG, cup = BIG;
+            bool     single = false;            // the row is one tile of 64 diagonals (PHASE 1): sM / sI / sD = the lane's cells of it
+            uint32_t sM = 0u, sI = 0u, sD = 0u;
+            // one cell: WF_NEXT from the raw sources (0 = absent), the seeds, WF_EXTEND
+            const auto cell = [&](const int k, const bool act, const uint32_t a0, const uint32_t b0, const uint32_t c0, const uint32_t d0, const uint32_t x0,
+                                  uint32_t &nM, uint32_t &nI, uint32_t &nD, uint32_t &wd) {
+                nM = nI = nD = wd = 0u;
+                if (act && si != 0u) {
+                    // rejections: > m (not >=) for I and X sources, offset - k > n for D and X sources (wfa.go:581-588,616-623,651-654)
+                    const uint32_t a = (int)a0 > m ? 0u : a0, b = (int)b0 > m ? 0u : b0;
+                    const uint32_t c = (int)c0 - k > n ? 0u : c0, d = (int)d0 - k > n ? 0u : d0;
+                    const uint32_t xx = ((int)x0 > m || (int)x0 - k > n) ? 0u : x0;
+                    const uint32_t mi = umax2(a, b), Isk = mi + umin2(mi, 1u);
+                    const uint32_t Dsk = umax2(c, d);
+                    const uint32_t x1  = xx + umin2(xx, 1u);
+                    const uint32_t Msk = umax2(umax2(Isk, Dsk), x1);
+                    const bool fromX = xx != 0u && Msk == x1;  // wfa.go:657-693: the mismatch wins a tie, then the insertion
+                    const bool fromI = !fromX && Msk == Isk;
+                    // backTrace recomputes the pre-extension offset from the un-rejected sources (wfa.go:766-817)
+                    const uint32_t mu = umax2(a0, b0), Iu = mu + umin2(mu, 1u), Du = umax2(c0, d0);
+                    const uint32_t Xu = x0 + umin2(x0, 1u);
+                    const bool     iext = a < b, dext = c < d;
+                    const uint32_t o0   = (fromI && iext) ? Iu : ((!fromX && !fromI && dext) ? Du : umax2(umax2(Iu, Du), Xu));
+                    nM = Msk, nI = Isk, nD = Dsk;
+                    wd = Msk != 0u ? blk_word(o0, iext, dext, fromX, fromI) : 0u;
+                }
+                if (act && seeded && nM == 0u) {  // seeds of initComponents that belong to this score (Set = last write wins: next()'s cell stays)
+                    const uint32_t sw = seed_word<0>(sv, k, s, x, glob);
+                    if (sw != 0u) nM = sw >> TAG_BITS, wd = (sw & TAG_MASK) == TAG_MATCH ? BLK_SEED_MATCH : BLK_SEED_MISMATCH;
+                }
+                // WF_EXTEND (wfa.go:394-455): only cells with 0 < v < n and h < m
+                if (nM != 0u) {
+                    const int h = (int)nM, v = h - k;
+                    if (v > 0 && v < n && h < m) nM += (uint32_t)sv.lcp(v, h);
+                }
+            };
+            // ... and what the row's reductions take from a cell (rows of more than one tile; a row of one tile answers them with ballots below)
+            const auto cell_stats = [&](const int k, const uint32_t nM, const uint32_t nI, const uint32_t nD) {
+                if (nM != 0u) {
+                    mlo = imin2(mlo, k), mhi = imax2(mhi, k);
+                    const int h = (int)nM, v = h - k;
+                    if (k == Ak && h >= m) term = true, hf = h;  // wfa.go:235-239
+                    if (!(v < 0 || v >= n || h >= m)) {          // wfa.go:474-494
+                        const int dd = imax2(m - h, n - v);
+                        mind = imin2(mind, dd), maxd = imax2(maxd, dd);
+                    }
+                    if (PHASE == 0 && ecs) {  // the cells the end-cell scans stop at or hit (wfa.go:270-375): the nearest one to diagonal Ak on either side
+                        if (v <= 0 || v > n || h > m || (v == n && h >= n) || (h == m && v >= m)) {
+                            if (k <= Ak) cdn = imax2(cdn, k);
+                            else cup = imin2(cup, k);
+                        }
+                    }
+                }
+                ncell += (nM != 0u ? 1u : 0u) + (nI != 0u ? 1u : 0u) + (nD != 0u ? 1u : 0u);
+            };
+            if (uhi >= ulo && PHASE == 0) {
+                // ---- the wide rows: rounds of 256 diagonals, FOUR CONSECUTIVE DIAGONALS PER LANE.  A lane's cells of a row are one 8-byte LDS word
+                // (the round starts on a ring index that is a multiple of four), three of a cell's five sources are the lane's own registers, and the
+                // row's halfwords go to the arena eight bytes at a time (the row's first halfword is laid so that a lane's four are aligned)
+                const int t_first = ulo - (int)(RI(ulo) & 3u);
+                {
+                    const uint32_t want = (uint32_t)(lo - t_first) & 3u;  // top + (k0 - lo) a multiple of four for every lane's first diagonal k0
+                    top += (want - top) & 3u;
+                }
+                carryM = hasO ? Moe[RI(t_first - 1)] : 0u;
+                carryI = hasE ? rowI[RI(t_first - 1)] : 0u;
+                const auto ld4 = [](const uint16_t *row, uint32_t r0, uint32_t (&v)[4]) {
+                    const uint2 w = *reinterpret_cast<const uint2 *>(row + r0);
+                    v[0] = w.x & 0xFFFFu, v[1] = w.x >> 16, v[2] = w.y & 0xFFFFu, v[3] = w.y >> 16;
+                };
+                const auto st4 = [](uint16_t *row, uint32_t r0, const uint32_t (&v)[4]) {
+                    *reinterpret_cast<uint2 *>(row + r0) = make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16));
+                };
+                // (NW waves: a round of each side by side; the one cell a round overwrites that the next one sources -- its last M[s-o-e] and
+                // I[s-e] -- goes from the last wave to the first through the scratch words, two slots in turn)
+                uint32_t rnd = 0u;
+                for (int t0 = t_first; t0 <= uhi; t0 += 256 * NW) {
+                    const int      k0  = t0 + 256 * wv + 4 * lane;
+                    const uint32_t r0  = RI(k0);
+                    const bool     lin = k0 <= uhi;  // (diagonals of the lane's four beyond uhi, or below ulo in the first round: no cell in any row)
+                    uint32_t oM[4] = {0u, 0u, 0u, 0u}, oI[4] = {0u, 0u, 0u, 0u}, oD[4] = {0u, 0u, 0u, 0u}, oX[4] = {0u, 0u, 0u, 0u};
+                    uint32_t aL = 0u, bL = 0u, cR = 0u, dR = 0u;
+                    if (lin) {
+                        if (hasO) ld4(Moe, r0, oM), aL = Moe[r0 - 1u], cR = Moe[r0 + 4u];
+                        if (hasE) ld4(rowI, r0, oI), ld4(rowD, r0, oD), bL = rowI[r0 - 1u], dR = rowD[r0 + 4u];
+                        if (hasX) ld4(Mx, r0, oX);
+                    }
+                    if (lane == 0 && wv == 0) aL = carryM, bL = carryI;  // (what the previous round overwrote)
+                    if constexpr (NW == 1) {
+                        carryM = rfl((uint32_t)__builtin_amdgcn_readlane((int)oM[3], 63));
+                        carryI = rfl((uint32_t)__builtin_amdgcn_readlane((int)oI[3], 63));
+                    } else if (wv == NW - 1 && lane == 63) {
+                        scr[64u + 2u * (rnd & 1u)] = oM[3], scr[65u + 2u * (rnd & 1u)] = oI[3];
+                    }
+                    lds_sync();  // (every read of the round before its first write: the rows are updated in place)
+                    if constexpr (NW > 1) carryM = rfl(scr[64u + 2u * (rnd & 1u)]), carryI = rfl(scr[65u + 2u * (rnd & 1u)]);
+                    rnd++;
+                    uint32_t nM[4], nI[4], nD[4], wd[4];
+                    bool     act[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int k = k0 + u;
+                        act[u] = k >= lo && k <= hi;
+                        cell(k, act[u], u == 0 ? aL : oM[u - 1], u == 0 ? bL : oI[u - 1], u == 3 ? cR : oM[u + 1], u == 3 ? dR : oD[u + 1], oX[u], nM[u], nI[u], nD[u], wd[u]);
+                        cell_stats(k, nM[u], nI[u], nD[u]);
+                    }
+                    if (lin) {
+                        st4(Mn, r0, nM), st4(rowI, r0, nI), st4(rowD, r0, nD);
+                        uint16_t *const ap = arow + ((int64_t)top + (int64_t)(k0 - lo));  // (only dereferenced where act)
+                        if (act[0] && act[3]) {
+                            *reinterpret_cast<uint2 *>(ap) = make_uint2(wd[0] | (wd[1] << 16), wd[2] | (wd[3] << 16));
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < 4; u++)
+                                if (act[u]) ap[u] = (uint16_t)wd[u];
+                        }
+                    }
+                    if constexpr (NW == 1) lds_sync();  // (several waves: the next round touches other diagonals, and the carry has its own slots)
+                }
+                if constexpr (NW > 1) lds_sync();
+            } else if (uhi >= ulo) {
+                // ---- the narrow rows (PHASE 1): tiles of 64 diagonals, a lane per diagonal; a row of ONE tile -- nearly all of them -- stays in
+                // registers for what follows
+                single = uhi - ulo < 64;
                 const int t_first = ulo;
                 carryM = hasO ? Moe[RI(t_first - 1)] : 0u;
                 carryI = hasE ? rowI[RI(t_first - 1)] : 0u;
-                for (int t0 = t_first; t0 <= uhi; t0 += 64 * U) {
-                    uint32_t a0[U], b0[U], c0[U], d0[U], x0[U], ownI[U], ownM[U];
-                    bool     in[U], act[U];
-                    // sources (bare offsets, 0 = absent)
-#pragma unroll
-                    for (int u = 0; u < U; u++) {
-                        const int      k  = t0 + 64 * u + lane;
-                        const uint32_t ri = RI(k), rim = RI(k - 1), rip = RI(k + 1);
-                        in[u]  = k <= uhi;
-                        act[u] = in[u] && k >= lo && k <= hi;
-                        a0[u] = b0[u] = c0[u] = d0[u] = x0[u] = ownI[u] = ownM[u] = 0u;
-                        if (in[u]) {
-                            // (the first lane of the round's first tile: what the previous round overwrote travels in carryM / carryI)
-                            if (hasO) a0[u] = (u == 0 && lane == 0 && inplace) ? carryM : Moe[rim], c0[u] = Moe[rip], ownM[u] = Moe[ri];
-                            if (hasE) b0[u] = (u == 0 && lane == 0) ? carryI : rowI[rim], d0[u] = rowD[rip], ownI[u] = rowI[ri];
-                            if (hasX) x0[u] = Mx[ri];
-                        }
+                for (int t0 = t_first; t0 <= uhi; t0 += 64) {
+                    const int      k  = t0 + lane;
+                    const uint32_t ri = RI(k), rim = RI(k - 1), rip = RI(k + 1);
+                    const bool     in = k <= uhi, act = in && k >= lo && k <= hi;
+                    uint32_t       a0 = 0u, b0 = 0u, c0 = 0u, d0 = 0u, x0 = 0u, ownI = 0u, ownM = 0u;
+                    if (in) {
+                        // (the first lane: what the previous tile overwrote travels in carryM / carryI)
+                        if (hasO) a0 = (lane == 0 && inplace) ? carryM : Moe[rim], c0 = Moe[rip], ownM = Moe[ri];
+                        if (hasE) b0 = lane == 0 ? carryI : rowI[rim], d0 = rowD[rip], ownI = rowI[ri];
+                        if (hasX) x0 = Mx[ri];
                     }
-                    carryM = rfl((uint32_t)__builtin_amdgcn_readlane((int)ownM[U - 1], 63));
-                    carryI = rfl((uint32_t)__builtin_amdgcn_readlane((int)ownI[U - 1], 63));
-                    lds_sync();  // (every read of the round before its first write: the rows are updated in place)
-#pragma unroll
-                    for (int u = 0; u < U; u++) {
-                        const int      k  = t0 + 64 * u + lane;
-                        const uint32_t ri = RI(k);
-                        uint32_t nM = 0u, nI = 0u, nD = 0u, wd = 0u;
-                        if (act[u] && si != 0u) {
-                            // rejections: > m (not >=) for I and X sources, offset - k > n for D and X sources (wfa.go:581-588,616-623,651-654)
-                            const uint32_t a = (int)a0[u] > m ? 0u : a0[u], b = (int)b0[u] > m ? 0u : b0[u];
-                            const uint32_t c = (int)c0[u] - k > n ? 0u : c0[u], d = (int)d0[u] - k > n ? 0u : d0[u];
-                            const uint32_t xx = ((int)x0[u] > m || (int)x0[u] - k > n) ? 0u : x0[u];
-                            const uint32_t mi = umax2(a, b), Isk = mi + umin2(mi, 1u);
-                            const uint32_t Dsk = umax2(c, d);
-                            const uint32_t x1  = xx + umin2(xx, 1u);
-                            const uint32_t Msk = umax2(umax2(Isk, Dsk), x1);
-                            const bool fromX = xx != 0u && Msk == x1;  // wfa.go:657-693: the mismatch wins a tie, then the insertion
-                            const bool fromI = !fromX && Msk == Isk;
-                            // backTrace recomputes the pre-extension offset from the un-rejected sources (wfa.go:766-817)
-                            const uint32_t mu = umax2(a0[u], b0[u]), Iu = mu + umin2(mu, 1u), Du = umax2(c0[u], d0[u]);
-                            const uint32_t Xu = x0[u] + umin2(x0[u], 1u);
-                            const bool     iext = a < b, dext = c < d;
-                            const uint32_t o0   = (fromI && iext) ? Iu : ((!fromX && !fromI && dext) ? Du : umax2(umax2(Iu, Du), Xu));
-                            nM = Msk, nI = Isk, nD = Dsk;
-                            wd = Msk != 0u ? blk_word(o0, iext, dext, fromX, fromI) : 0u;
-                        }
-                        if (act[u] && seeded && nM == 0u) {  // seeds of initComponents that belong to this score (Set = last write wins: next()'s cell stays)
-                            const uint32_t sw = seed_word<0>(sv, k, s, x, glob);
-                            if (sw != 0u) nM = sw >> TAG_BITS, wd = (sw & TAG_MASK) == TAG_MATCH ? BLK_SEED_MATCH : BLK_SEED_MISMATCH;
-                        }
-                        // WF_EXTEND (wfa.go:394-455): only cells with 0 < v < n and h < m
-                        if (nM != 0u) {
-                            const int h = (int)nM, v = h - k;
-                            if (v > 0 && v < n && h < m) nM += (uint32_t)sv.lcp(v, h);
-                        }
-                        if (in[u]) Mn[ri] = (uint16_t)nM, rowI[ri] = (uint16_t)nI, rowD[ri] = (uint16_t)nD;
-                        if (act[u]) arow[top + (uint32_t)(k - lo)] = (uint16_t)wd;
-                        if (nM != 0u) {
-                            mlo = imin2(mlo, k), mhi = imax2(mhi, k);
-                            const int h = (int)nM, v = h - k;
-                            if (k == Ak && h >= m) term = true, hf = h;  // wfa.go:235-239
-                            if (!(v < 0 || v >= n || h >= m)) {          // wfa.go:474-494
-                                const int dd = imax2(m - h, n - v);
-                                mind = imin2(mind, dd), maxd = imax2(maxd, dd);
-                            }
-                        }
-                        ncell += (nM != 0u ? 1u : 0u) + (nI != 0u ? 1u : 0u) + (nD != 0u ? 1u : 0u);
+                    if (!single) {
+                        carryM = rfl((uint32_t)__builtin_amdgcn_readlane((int)ownM, 63));
+                        carryI = rfl((uint32_t)__builtin_amdgcn_readlane((int)ownI, 63));
                     }
+                    lds_sync();  // (every read of the tile before its first write: the rows are updated in place)
+                    uint32_t nM, nI, nD, wd;
+                    cell(k, act, a0, b0, c0, d0, x0, nM, nI, nD, wd);
+                    if (single) sM = nM, sI = nI, sD = nD;
+                    else cell_stats(k, nM, nI, nD);
+                    if (in) Mn[ri] = (uint16_t)nM, rowI[ri] = (uint16_t)nI, rowD[ri] = (uint16_t)nD;
+                    if (act) arow[top + (uint32_t)(k - lo)] = (uint16_t)wd;
                     lds_sync();
                 }
             }
+            int nlo, nhi;  // the surviving band (I and D only hold cells where M does)
+            if (single) {
+                // ---- a row of one tile: the lane of diagonal ulo + lane holds its cells; every reduction is a ballot and a scalar bit scan
+                const auto ctz64 = [](uint64_t b) { return (int)__builtin_ctzll(b); };
+                const auto top64 = [](uint64_t b) { return 63 - (int)__builtin_clzll(b); };
+                const int  k = ulo + lane;
+                const int  h = (int)sM, v = h - k;
+                const uint64_t bm = __ballot(sM != 0u);
+                if (bm != 0ull) mlo = ulo + ctz64(bm), mhi = ulo + top64(bm);
+                term = __ballot(sM != 0u && k == Ak && h >= m) != 0ull;  // wfa.go:235-239
+                if (term) hf = __builtin_amdgcn_readlane((int)sM, (int)rfl((uint32_t)(Ak - ulo)));
+                nlo = mlo, nhi = mhi;
+                uint32_t cnt = (uint32_t)__popcll(bm) + (uint32_t)__popcll(__ballot(sI != 0u)) + (uint32_t)__popcll(__ballot(sD != 0u));
+                const bool     valid = sM != 0u && !(v < 0 || v >= n || h >= m);  // wfa.go:474-494
+                const int      dd    = imax2(m - h, n - v);
+                const uint64_t bv    = __ballot(valid);
+                if (!term && adaptive && bm != 0ull && (mhi - mlo + 1) >= minwf && bv != 0ull) {
+                    const int      thr = wave_min(valid ? dd : BIG) + mdd;
+                    const uint64_t bo  = __ballot(valid && dd <= thr);
+                    if (bo != bv) {  // ---- reduce (wfa.go:496-537): some distance fails
+                        const int      f     = ctz64(bo);
+                        const uint64_t below = bv & ((1ull << f) - 1ull);  // _lo: one past the last valid entry before the first non-failing one (wfa.go:503-516)
+                        nlo = below != 0ull ? ulo + top64(below) + 1 : mlo;
+                        nhi = ulo + top64(bo);  // wfa.go:517-524
+                        const bool del = k >= mlo && k <= mhi && (k < nlo || k > nhi);  // wfa.go:526-535
+                        cnt -= (uint32_t)__popcll(__ballot(del && sM != 0u)) + (uint32_t)__popcll(__ballot(del && sI != 0u)) + (uint32_t)__popcll(__ballot(del && sD != 0u));
+                        if (del) {
+                            const uint32_t ri = RI(k);
+                            Mn[ri] = 0, rowI[ri] = 0, rowD[ri] = 0, sM = 0u;
+                        }
+                        lds_sync();
+                    }
+                }
+                cells += cnt;
+                // ---- semi-global end cell (wfa.go:270-375) of this score, on the row as it stays
+                if (!glob && !found && nhi >= nlo) {
+                    const bool     inb  = sM != 0u && k >= nlo && k <= nhi;
+                    const bool     stop = v <= 0 || v > n || h > m;
+                    const bool     hit  = !stop && ((v == n && h >= n) || (h == m && v >= m));
+                    const uint64_t bs = __ballot(inb && (stop || hit)), bh = __ballot(inb && hit);
+                    const int      a  = Ak - ulo;  // the lane of diagonal Ak: the scan down starts there, the scan up one above
+                    const uint64_t mD = a >= 63 ? ~0ull : (a < 0 ? 0ull : ((2ull << a) - 1ull));
+                    const uint64_t cd = bs & mD, cu = bs & ~mD;
+                    if (cd != 0ull) {
+                        const int l = top64(cd);
+                        if ((bh >> l) & 1ull) found = true, fs = s, fk = ulo + l, fh = __builtin_amdgcn_readlane((int)sM, (int)rfl((uint32_t)l));
+                    }
+                    if (cu != 0ull) {
+                        const int l = ctz64(cu);
+                        if ((bh >> l) & 1ull) found = true, fs = s, fk = ulo + l, fh = __builtin_amdgcn_readlane((int)sM, (int)rfl((uint32_t)l));
+                    }
+                }
+            } else {
             mlo = wave_min(mlo), mhi = wave_max(mhi), mind = wave_min(mind), maxd = wave_max(maxd);
             term = __ballot(term) != 0ull;
             if (term) hf = wave_max(hf);
-            int nlo = mlo, nhi = mhi;  // the surviving band (I and D only hold cells where M does)
+            if (PHASE == 0 && ecs) cdn = wave_max(cdn), cup = wave_min(cup);
+            if constexpr (NW > 1) {
+                const int mine[7] = {mlo, mhi, mind, maxd, term ? hf : 0, cdn, cup};
+                int       all[NW * 7];
+                xchg(mine, all, 7);
+                mlo = BIG, mhi = -BIG, mind = BIG, maxd = -BIG, hf = 0, cdn = -BIG, cup = BIG;
+#pragma unroll
+                for (int w = 0; w < NW; w++) {
+                    mlo = imin2(mlo, all[7 * w]), mhi = imax2(mhi, all[7 * w + 1]), mind = imin2(mind, all[7 * w + 2]), maxd = imax2(maxd, all[7 * w + 3]), hf = imax2(hf, all[7 * w + 4]);
+                    cdn = imax2(cdn, all[7 * w + 5]), cup = imin2(cup, all[7 * w + 6]);
+                }
+                term = hf != 0;
+            }
+            nlo = mlo, nhi = mhi;
             if (!term && adaptive && mhi >= mlo && (mhi - mlo + 1) >= minwf && mind != BIG && maxd - mind > mdd) {
                 // ---- reduce (wfa.go:496-537): some distance fails
                 const int thr = mind + mdd;
                 int first_ok = BIG, last_ok = -BIG;
-                for (int t0 = mlo; t0 <= mhi; t0 += 64) {
+                for (int t0 = mlo + 64 * wv; t0 <= mhi; t0 += 64 * NW) {
                     const int k = t0 + lane;
                     if (k <= mhi) {
                         const int h = (int)Mn[RI(k)], v = h - k;
@@ -286,8 +455,15 @@ __global__ __launch_bounds__(64) void wfa_wide_kernel(const KParams P) {
                     }
                 }
                 first_ok = wave_min(first_ok), last_ok = wave_max(last_ok);
+                if constexpr (NW > 1) {
+                    const int mine[2] = {first_ok, last_ok};
+                    int       all[NW * 2];
+                    xchg(mine, all, 2);
+#pragma unroll
+                    for (int w = 0; w < NW; w++) first_ok = imin2(first_ok, all[2 * w]), last_ok = imax2(last_ok, all[2 * w + 1]);
+                }
                 int lead = -BIG;  // _lo: one past the last valid entry before the first non-failing one (wfa.go:503-516)
-                for (int t0 = mlo; t0 < first_ok && t0 <= mhi; t0 += 64) {
+                for (int t0 = mlo + 64 * wv; t0 < first_ok && t0 <= mhi; t0 += 64 * NW) {
                     const int k = t0 + lane;
                     if (k < first_ok && k <= mhi) {
                         const int h = (int)Mn[RI(k)], v = h - k;
@@ -295,10 +471,17 @@ __global__ __launch_bounds__(64) void wfa_wide_kernel(const KParams P) {
                     }
                 }
                 lead = wave_max(lead);
+                if constexpr (NW > 1) {
+                    const int mine[1] = {lead};
+                    int       all[NW];
+                    xchg(mine, all, 1);
+#pragma unroll
+                    for (int w = 0; w < NW; w++) lead = imax2(lead, all[w]);
+                }
                 nlo  = lead != -BIG ? lead + 1 : mlo;
                 nhi  = last_ok;  // wfa.go:517-524
                 // wfa.go:526-535 deletes k outside [_lo, _hi] in M, I and D
-                for (int t0 = mlo; t0 <= mhi; t0 += 64) {
+                for (int t0 = mlo + 64 * wv; t0 <= mhi; t0 += 64 * NW) {
                     const int k = t0 + lane;
                     if (k <= mhi && (k < nlo || k > nhi)) {
                         const uint32_t ri = RI(k);
@@ -309,10 +492,23 @@ __global__ __launch_bounds__(64) void wfa_wide_kernel(const KParams P) {
                 lds_sync();
             }
             // ---- semi-global end cell (wfa.go:270-375) of this score, on the row as it stays
-            if (!glob && !found && nhi >= nlo) {
+            bool scan = !glob && !found && nhi >= nlo;
+            if (PHASE == 0 && scan && cdn <= nhi && cup >= nlo) {
+                // the wide rows noted the nearest candidate on either side of Ak while they were computed; unless wf-adaptive has just cut it off
+                // (then the row is scanned as below) it is the cell the reference's scan ends at
+                scan = false;
+                const auto at = [&](const int k) {
+                    const int h = (int)rfl((uint32_t)Mn[RI(k)]), v = h - k;
+                    const bool stop = v <= 0 || v > n || h > m;
+                    if (!stop && ((v == n && h >= n) || (h == m && v >= m))) found = true, fs = s, fk = k, fh = h;
+                };
+                if (cdn >= nlo) at(cdn);
+                if (cup <= nhi) at(cup);  // (the scan up overrides the scan down)
+            }
+            if (scan) {
                 uint32_t keyD = 0xFFFFFFFFu, keyU = 0xFFFFFFFFu;
                 int      hD = 0, hU = 0;
-                for (int t0 = nlo; t0 <= nhi; t0 += 64) {
+                for (int t0 = nlo + 64 * wv; t0 <= nhi; t0 += 64 * NW) {
                     const int k = t0 + lane;
                     if (k <= nhi) {
                         const int h = (int)Mn[RI(k)], v = h - k;
@@ -331,23 +527,43 @@ __global__ __launch_bounds__(64) void wfa_wide_kernel(const KParams P) {
                         }
                     }
                 }
-                const uint32_t kD = (uint32_t)wave_min((int)(keyD ^ 0x80000000u)) ^ 0x80000000u;  // unsigned min via signed min
-                const uint32_t kU = (uint32_t)wave_min((int)(keyU ^ 0x80000000u)) ^ 0x80000000u;
+                uint32_t kD = (uint32_t)wave_min((int)(keyD ^ 0x80000000u)) ^ 0x80000000u;  // unsigned min via signed min
+                uint32_t kU = (uint32_t)wave_min((int)(keyU ^ 0x80000000u)) ^ 0x80000000u;
                 // (the offset of the winning cell: the lane that holds the winning key)
-                const int wD = wave_max(keyD == kD && kD != 0xFFFFFFFFu ? hD : 0), wU = wave_max(keyU == kU && kU != 0xFFFFFFFFu ? hU : 0);
+                int wD = wave_max(keyD == kD && kD != 0xFFFFFFFFu ? hD : 0), wU = wave_max(keyU == kU && kU != 0xFFFFFFFFu ? hU : 0);
+                if constexpr (NW > 1) {
+                    const int mine[4] = {(int)kD, wD, (int)kU, wU};
+                    int       all[NW * 4];
+                    xchg(mine, all, 4);
+                    kD = kU = 0xFFFFFFFFu, wD = wU = 0;
+#pragma unroll
+                    for (int w = 0; w < NW; w++) {  // (a key is a diagonal: no two waves hold the same one, save the empty key)
+                        if ((uint32_t)all[4 * w] < kD) kD = (uint32_t)all[4 * w], wD = all[4 * w + 1];
+                        if ((uint32_t)all[4 * w + 2] < kU) kU = (uint32_t)all[4 * w + 2], wU = all[4 * w + 3];
+                    }
+                }
                 if (kD != 0xFFFFFFFFu && (kD & 1u) == 0u) found = true, fs = s, fk = Ak - (int)(kD >> 1), fh = wD;
                 if (kU != 0xFFFFFFFFu && (kU & 1u) == 0u) found = true, fs = s, fk = Ak + 1 + (int)(kU >> 1), fh = wU;
-            }
-            // ---- the row's directory entry and census
-            if (lane == 0) {
-                const bool any = nhi >= nlo;
-                *reinterpret_cast<uint4 *>(adir - 4u * (si + 1u)) = make_uint4(any ? top + (uint32_t)(nlo - lo) : 0u, any ? (uint32_t)nlo : 0u, any ? (uint32_t)(nhi - nlo + 1) : 0u, 0u);
             }
             {
                 uint32_t c = ncell;  // (a wave sum: 64 lanes x at most 3 x tiles)
 #pragma unroll
                 for (int d = 32; d >= 1; d >>= 1) c += (uint32_t)__shfl_xor((int)c, d, 64);
+                if constexpr (NW > 1) {
+                    const int mine[1] = {(int)c};
+                    int       all[NW];
+                    xchg(mine, all, 1);
+                    c = 0u;
+#pragma unroll
+                    for (int w = 0; w < NW; w++) c += (uint32_t)all[w];
+                }
                 cells += c;
+            }
+            }  // (rows of more than one tile)
+            // ---- the row's directory entry
+            if (tid == 0) {
+                const bool any = nhi >= nlo;
+                *reinterpret_cast<uint4 *>(adir - 4u * (si + 1u)) = make_uint4(any ? top + (uint32_t)(nlo - lo) : 0u, any ? (uint32_t)nlo : 0u, any ? (uint32_t)(nhi - nlo + 1) : 0u, 0u);
             }
             top += ((uint32_t)W + 1u) & ~1u;
             plo = nhi >= nlo ? nlo : BIG, phi = nhi >= nlo ? nhi : -BIG;
@@ -360,23 +576,23 @@ __global__ __launch_bounds__(64) void wfa_wide_kernel(const KParams P) {
                 break;
             }
             if constexpr (PHASE == 0) {
-                if (P.wide_ckpt_on != 0u && si >= 1u) {
+                if (P.wide_ckpt_on != 0u && s >= x) {  // (score x seeds every diagonal once more, wfa.go:163-183 -- however narrow an early cut left the rows)
                     const int clo = imin2(imin2(blo0, blo1), imin2(imin2(blo2, blo3), plo)), chi = imax2(imax2(bhi0, bhi1), imax2(imax2(bhi2, bhi3), phi));
                     if (chi >= clo && chi - clo + 1 <= WIDE_NARROW) {
-                        // checkpoint: the rings' live part in PHASE 1's layout, then the loop's state
-                        uint16_t *const ch = reinterpret_cast<uint16_t *>(ck + WIDE_CKPT_HDR);
-                        uint4 *const    c4 = reinterpret_cast<uint4 *>(ck + WIDE_CKPT_HDR);
-                        for (uint32_t i = (uint32_t)lane; i < 6u * WIDE_RW / 8u; i += 64u) c4[i] = make_uint4(0u, 0u, 0u, 0u);
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (the zeros before the cells: the same addresses from other lanes)
-                        __builtin_amdgcn_s_waitcnt(0);
-                        for (int t0 = clo; t0 <= chi; t0 += 64) {
-                            const int k = t0 + lane;
-                            if (k <= chi) {
+                        // checkpoint: the rings' live part in PHASE 1's layout (slot = diagonal modulo WIDE_RW; a thread writes 16 bytes: the eight
+                        // slots' diagonals of the live span, absent elsewhere), then the loop's state
+                        uint4 *const c4 = reinterpret_cast<uint4 *>(ck + WIDE_CKPT_HDR);
+                        for (uint32_t i = (uint32_t)tid; i < 6u * WIDE_RW / 8u; i += 64u * NW) {
+                            const uint32_t r = i / (uint32_t)(WIDE_RW / 8), p0 = (i % (uint32_t)(WIDE_RW / 8)) * 8u;
+                            uint32_t       hw[8];
 #pragma unroll
-                                for (uint32_t r = 0; r < 6u; r++) ch[r * WIDE_RW + ((uint32_t)k & (uint32_t)(WIDE_RW - 1))] = ring[r * WH + (uint32_t)(k + KOFF)];
+                            for (uint32_t j = 0; j < 8u; j++) {
+                                const int k = clo + (int)((p0 + j - (uint32_t)clo) & (uint32_t)(WIDE_RW - 1));  // the diagonal of slot p0 + j at or above clo
+                                hw[j] = k <= chi ? (uint32_t)ring[r * WH + (uint32_t)(k + KOFF)] : 0u;
                             }
+                            c4[i] = make_uint4(hw[0] | (hw[1] << 16), hw[2] | (hw[3] << 16), hw[4] | (hw[5] << 16), hw[6] | (hw[7] << 16));
                         }
-                        if (lane == 0) {
+                        if (tid == 0) {
                             ck[1] = si + 1u, ck[2] = top, ck[3] = cells, ck[4] = found ? 1u : 0u, ck[5] = fs, ck[6] = (uint32_t)fk, ck[7] = (uint32_t)fh;
                             ck[8] = (uint32_t)blo0, ck[9] = (uint32_t)blo1, ck[10] = (uint32_t)blo2, ck[11] = (uint32_t)blo3;
                             ck[12] = (uint32_t)bhi0, ck[13] = (uint32_t)bhi1, ck[14] = (uint32_t)bhi2, ck[15] = (uint32_t)bhi3;
@@ -390,13 +606,13 @@ __global__ __launch_bounds__(64) void wfa_wide_kernel(const KParams P) {
             }
         }
         if (overflow) {
-            if (lane == 0) {
-                P.pair_meta[idx] = make_uint4(ST_REDO_ARENA, 0u, 0u, 0u);
+            if (tid == 0) {
+                P.pair_meta[idx] = make_uint4(ST_REDO_ARENA, ovf_si, ovf_why + 10u * (uint32_t)PHASE, ovf_span);
                 push_redo(P, pair, ST_REDO_ARENA);
             }
             return;
         }
-        if (lane == 0) {
+        if (tid == 0) {
             const uint32_t bs = (glob || !found) ? s_final : fs;
             const int      bk = (glob || !found) ? Ak : fk, bh = (glob || !found) ? hf : fh;
             P.pair_meta[idx] = make_uint4(ST_OK, bs, (uint32_t)bh | ((uint32_t)(bk + (int)WIDE_KBIAS) << 16), P.census ? cells : 0u);
