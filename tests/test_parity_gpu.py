@@ -657,10 +657,10 @@ def test_team_kernel_wave_mode(built, penalties):
     solo -> wave), global and semi-global; the same batch with wave mode off must store the same number of cells."""
     import wfa_amd as w
     from oracle import oracle as O
-    a = w.generate_pairs(seed=21, n_pairs=24, length=600, error_rate=0.08)
+    a = w.generate_pairs(seed=21, n_pairs=16 if max(penalties) >= 20 else 24, length=600, error_rate=0.08)
     # (the two sets with a 20 / 40 gap open reach scores -- rows, and oracle seconds -- several times the others': a smaller second batch)
     heavy = max(penalties) >= 20
-    b = w.generate_pairs(seed=22, n_pairs=2 if heavy else 4, length=2500 if heavy else 4000, error_rate=0.12)
+    b = w.generate_pairs(seed=22, n_pairs=2 if heavy else 4, length=1800 if heavy else 4000, error_rate=0.12)
     for data in (a, b):
         for glob, ad in ((True, (10, 50, 1)), (False, (10, 50, 1)), (True, None), (False, (4, 5, 1))):
             want = O.align_batch(_oracle_params(glob, ad, penalties), *data, n_threads=8)
@@ -750,15 +750,14 @@ def test_teamc_kernel_words_and_results(built, slack):
     then the results of 9 kbp pairs through three and five workgroups per team against wfa_team_kernel's and the oracle's."""
     import wfa_amd as w
     from oracle import oracle as O
-    blob, qo, ql, to, tl = w.generate_pairs(seed=41, n_pairs=2, length=2600, error_rate=0.08)
-    blob, qo, ql, to, tl = w.generate_pairs(seed=41, n_pairs=1, length=2600 if slack == 3 else 1500, error_rate=0.08)
+    blob, qo, ql, to, tl = w.generate_pairs(seed=41, n_pairs=1, length=2100 if slack == 3 else 1300, error_rate=0.08)
     for pen in ((4, 6, 2), (2, 4, 2), (6, 4, 2)):
         for glob, ad in ((False, (10, 50, 1)), (True, None), (False, None), (True, (10, 50, 1))):
             oa = O.Aligner(_oracle_params(glob, ad, pen))
             # (the default penalties see every shape of team; the others the two that differ most)
             # (fast = 0: every step of the stripe modes takes the general step instead of the short one of their steady state)
             # (fast = 2: the short steps without the pipelined ones, which are the default and need wf-adaptive, a team and e/g = 1, x/g >= 2)
-            # (slack = 3, the 2 600-base pair: the other penalties see one shape of team -- the run is bound by the word-for-word
+            # (slack = 3, the 2 100-base pair: the other penalties see one shape of team -- the run is bound by the word-for-word
             # comparison in Python, and the moving axis does not depend on the penalties)
             for wgs, solo_max, wave, fast in ((((2, 64, 1, 1), (3, 0, 1, 1), (3, 0, 1, 2)) if slack == 3 else
                                                ((2, 64, 1, 1), (2, 4096, 1, 1), (1, 4096, 0, 1), (3, 0, 1, 1), (2, 64, 1, 0), (3, 0, 1, 2))) if pen == (4, 6, 2)

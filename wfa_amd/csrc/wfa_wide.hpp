@@ -1,32 +1,34 @@
-// wfa_wide.hpp -- kernel W (round 6): a WAVE per pair with the last rows in 16-bit LDS rings of ANY width.
+// wfa_wide.hpp -- kernel W (round 6): a WORKGROUP per pair with the last rows in 16-bit LDS rings of ANY width.
 //
-// For what the register-window kernels cannot hold: semi-global alignments of short reads (wfa.go:163-183 seeds every one
-// of the n + m - 1 diagonals, and wf-adaptive cuts nothing until the leading diagonal is MaxDistDiff bases ahead: a 1 kbp
-// pair keeps ~2 000 diagonals for its first dozen score steps, eight times the cells of its global alignment), with
-// wf-adaptive on or off.  Until round 6 those batches went to wfa_generic_kernel -- one workgroup per pair, the sources of
-// WF_NEXT read back from the arena in global memory, three 32-bit words per diagonal stored: 2.5e6 pairs/s on 1e6 x 1 kbp,
-// a 23-fold cliff behind the same pairs aligned globally.
+// For what the register-window kernels cannot hold: semi-global alignments of reads up to 2 047 bases (wfa.go:163-183 seeds every
+// one of the n + m - 1 diagonals, at score 0 and again at score x, and wf-adaptive cuts nothing until the leading diagonal is
+// MaxDistDiff bases ahead: a 1 kbp pair keeps ~2 000 diagonals for its first dozen score steps, eight times the cells of its global
+// alignment), with wf-adaptive on or off.  Until round 6 those batches went to wfa_generic_kernel -- one workgroup per pair, the
+// sources of WF_NEXT read back from the arena in global memory, three 32-bit words per diagonal stored: 2.5e6 pairs/s on
+// 1e6 x 1 kbp, a 23-fold cliff behind the same pairs aligned globally.
 //
-// Here a wave owns a pair from its first score to its last:
-//   * a workgroup of ONE wave per pair (the hardware dispatcher is the pair queue); both sequences 2-bit packed in LDS
-//     (packed by the wave itself, stage_pack), and the rows the next scores source as
-//     BARE 16-bit offsets in LDS rings indexed by diagonal: four M rows (slot = score index & 3), one I and one D row
-//     (penalties with e / g == 1: the sub-wave kernels' shapes).  6 x (n + m) x 2 bytes -- 25 KB for a 1 kbp pair;
-//   * a row is computed in tiles of 64 diagonals, a lane per diagonal: the exact WF_NEXT (wfa.go:549-700, rejections
-//     included: a semi-global row always has cells at sequence ends), the seeds (wfa.go:155-183), WF_EXTEND on the packed
-//     LDS words (wfa.go:381-458).  The new M row overwrites the slot of M[s-o-e] and the I / D rows are updated in place:
-//     the cells a tile overwrites that the next tile still sources (M[s-o-e][k-1], I[s-e][k-1] at the tile's first
-//     diagonal) travel in registers;
-//   * wf-adaptive (wfa.go:461-540) as wave reductions over the tiles' partial results; a row that cuts cells is swept
-//     once more to delete them from the rings;
+// Here a workgroup owns a pair (the hardware dispatcher is the pair queue):
+//   * both sequences 2-bit packed in LDS (packed by the workgroup itself, stage_pack), and the rows the next scores source as BARE
+//     16-bit offsets in LDS rings indexed by diagonal: four M rows (slot = score index & 3), one I and one D row (penalties with
+//     e / g == 1: the sub-wave kernels' shapes).  6 x (n + m) x 2 bytes -- 25 KB for a 1 kbp pair;
+//   * wide rows (PHASE 0) are computed in rounds of 256 diagonals, FOUR CONSECUTIVE DIAGONALS PER LANE -- a lane's cells of a row are
+//     one 8-byte LDS word, three of a cell's five sources its own registers -- by NW waves side by side (four when the rings take more
+//     than 12 KB: with one, six workgroups a CU would leave a SIMD a wave and a half); narrow rows (PHASE 1) in tiles of 64, a lane
+//     per diagonal.  Per cell the exact WF_NEXT (wfa.go:549-700, rejections included: a semi-global row always has cells at
+//     sequence ends), the seeds (wfa.go:155-183), WF_EXTEND on the packed LDS words (wfa.go:381-458).  The new M row overwrites the
+//     slot of M[s-o-e] and the I / D rows are updated in place: every read of a round goes out before its first write, and the one
+//     cell a round overwrites that the next one sources (M[s-o-e][k-1], I[s-e][k-1] at its first diagonal) travels in a register
+//     (several waves: through two LDS words in turn);
+//   * wf-adaptive (wfa.go:461-540) as wave reductions over the rounds' partial results (several waves: + an exchange through LDS);
+//     a row that cuts cells is swept once more to delete them from the rings.  A narrow row of one tile stays in registers: every
+//     reduction on it is a ballot and a scalar bit scan;
 //   * the semi-global end cell (wfa.go:270-375) is found while the rows are in LDS: the reference scans every score from
 //     the last down to 0 and keeps the LOWEST score with a hit -- the first one in ascending order;
 //   * per diagonal and score ONE 16-bit word goes to the arena -- the blocked kernels' blk_word(): the pre-extension
 //     offset backTrace recomputes (wfa.go:766-817) over the four decisions of next() -- in rows laid back to back with a
 //     16-byte directory entry {first halfword, lo, width} per score index growing down from the end of the pair's slot
 //     (CompactView fmt 11); wfa_backtrace_kernel walks it with back_trace_compact().
-// Everything is per pair and per wave: no workgroup barrier, no second pass of another kernel; what the wave cannot hold
-// (an arena that overflows) is handed to the generic ladder like every sub-wave kernel does.
+// What the workgroup cannot hold (an arena that overflows) is handed to the generic ladder like every sub-wave kernel does.
 #pragma once
 #include "wfa_device.hpp"
 
@@ -42,12 +44,13 @@ __host__ __device__ inline uint32_t wide_lds_words(uint32_t seq_words, uint32_t 
 }
 // pair_meta of a finished pair: {ST_OK, score of the walk's start, its extended offset | (its diagonal + WIDE_KBIAS) << 16, cells}
 constexpr uint32_t WIDE_KBIAS = 32768u;
-// Two launches per chunk.  PHASE 0 runs a pair from its seeds while its rows are wide -- 25 KB of rings per wave: six waves per
-// CU -- and leaves as soon as every row in the rings spans at most WIDE_NARROW diagonals (a score step or four after
-// wf-adaptive's first cut: the older rows leave the rings); it hands the pair on as a CHECKPOINT: the rings' live part, already
-// in PHASE 1's layout, + the loop's state, WIDE_CKPT_WORDS words per pair.  PHASE 1 picks the pair up with rings of
-// WIDE_RW diagonals indexed modulo (3 KB: the CU's full complement of waves) and runs it to its end; same code, same arena,
+// Two launches per chunk.  PHASE 0 runs a pair from its seeds while its rows are wide -- 25 KB of rings per workgroup at 1 kbp: six
+// per CU -- and leaves as soon as every row in the rings spans at most WIDE_NARROW diagonals (a score step or four after
+// wf-adaptive's first cut: the older rows leave the rings) and score x has been seeded; it hands the pair on as a CHECKPOINT: the
+// rings' live part, already in PHASE 1's layout, + the loop's state, WIDE_CKPT_WORDS words per pair.  PHASE 1 picks the pair up with
+// rings of WIDE_RW diagonals indexed modulo (6 KB: the CU's full complement of waves) and runs it to its end; same code, same arena,
 // same directory -- the backtrace sees one pair.  A pair that never narrows (wf-adaptive off) finishes in PHASE 0.
+// (WIDE_RW 256 was too few: after the first cut a band is still 100-200 wide and widens by two a step until the leader pulls away.)
 constexpr int      WIDE_RW = 512, WIDE_NARROW = 200;
 constexpr uint32_t WIDE_SCR_WORDS = 80u;  // LDS words behind the rings: what the waves of a workgroup hand one another
 constexpr uint32_t WIDE_CKPT_HDR = 24u, WIDE_CKPT_WORDS = WIDE_CKPT_HDR + 6u * WIDE_RW / 2u;
