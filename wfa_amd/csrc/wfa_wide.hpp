@@ -222,6 +222,7 @@ __global__ __launch_bounds__(64 * NW) void wfa_wide_kernel(const KParams P) {
             int      mlo = BIG, mhi = -BIG, mind = BIG, maxd = -BIG;
             bool     term = false;
             uint32_t ncell = 0u;
+            const bool census = P.census != 0u;  // (REC_CELLS: the stored words are only counted when somebody asks)
             uint32_t carryM = 0u, carryI = 0u;  // M[s-o-e][t0 - 1], I[s-e][t0 - 1] as they were before the previous tile overwrote them
             const bool ecs = !glob && !found;   // the end-cell search is on: the wide rows note its candidates while they are computed
             int        cdn = -BIG, cup = BIG;
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(64 * NW) void wfa_wide_kernel(const KParams P) {
                         }
                     }
                 }
-                ncell += (nM != 0u ? 1u : 0u) + (nI != 0u ? 1u : 0u) + (nD != 0u ? 1u : 0u);
+                if (census) ncell += (nM != 0u ? 1u : 0u) + (nI != 0u ? 1u : 0u) + (nD != 0u ? 1u : 0u);
             };
             if (uhi >= ulo && PHASE == 0) {
                 // ---- the wide rows: rounds of 256 diagonals, FOUR CONSECUTIVE DIAGONALS PER LANE.  A lane's cells of a row are one 8-byte LDS word
@@ -388,7 +389,8 @@ __global__ __launch_bounds__(64 * NW) void wfa_wide_kernel(const KParams P) {
                 term = __ballot(sM != 0u && k == Ak && h >= m) != 0ull;  // wfa.go:235-239
                 if (term) hf = __builtin_amdgcn_readlane((int)sM, (int)rfl((uint32_t)(Ak - ulo)));
                 nlo = mlo, nhi = mhi;
-                uint32_t cnt = (uint32_t)__popcll(bm) + (uint32_t)__popcll(__ballot(sI != 0u)) + (uint32_t)__popcll(__ballot(sD != 0u));
+                uint32_t cnt = 0u;
+                if (census) cnt = (uint32_t)__popcll(bm) + (uint32_t)__popcll(__ballot(sI != 0u)) + (uint32_t)__popcll(__ballot(sD != 0u));
                 const bool     valid = sM != 0u && !(v < 0 || v >= n || h >= m);  // wfa.go:474-494
                 const int      dd    = imax2(m - h, n - v);
                 const uint64_t bv    = __ballot(valid);
@@ -401,7 +403,7 @@ __global__ __launch_bounds__(64 * NW) void wfa_wide_kernel(const KParams P) {
                         nlo = below != 0ull ? ulo + top64(below) + 1 : mlo;
                         nhi = ulo + top64(bo);  // wfa.go:517-524
                         const bool del = k >= mlo && k <= mhi && (k < nlo || k > nhi);  // wfa.go:526-535
-                        cnt -= (uint32_t)__popcll(__ballot(del && sM != 0u)) + (uint32_t)__popcll(__ballot(del && sI != 0u)) + (uint32_t)__popcll(__ballot(del && sD != 0u));
+                        if (census) cnt -= (uint32_t)__popcll(__ballot(del && sM != 0u)) + (uint32_t)__popcll(__ballot(del && sI != 0u)) + (uint32_t)__popcll(__ballot(del && sD != 0u));
                         if (del) {
                             const uint32_t ri = RI(k);
                             Mn[ri] = 0, rowI[ri] = 0, rowD[ri] = 0, sM = 0u;
@@ -411,7 +413,8 @@ __global__ __launch_bounds__(64 * NW) void wfa_wide_kernel(const KParams P) {
                 }
                 cells += cnt;
                 // ---- semi-global end cell (wfa.go:270-375) of this score, on the row as it stays
-                if (!glob && !found && nhi >= nlo) {
+                // (a stop or a hit is a cell at an end of a sequence: v <= 0, v >= n or h >= m -- none for most of a narrow phase's rows)
+                if (!glob && !found && nhi >= nlo && __ballot(sM != 0u && (v <= 0 || v >= n || h >= m)) != 0ull) {
                     const bool     inb  = sM != 0u && k >= nlo && k <= nhi;
                     const bool     stop = v <= 0 || v > n || h > m;
                     const bool     hit  = !stop && ((v == n && h >= n) || (h == m && v >= m));
@@ -488,7 +491,7 @@ __global__ __launch_bounds__(64 * NW) void wfa_wide_kernel(const KParams P) {
                     const int k = t0 + lane;
                     if (k <= mhi && (k < nlo || k > nhi)) {
                         const uint32_t ri = RI(k);
-                        ncell -= (Mn[ri] != 0 ? 1u : 0u) + (rowI[ri] != 0 ? 1u : 0u) + (rowD[ri] != 0 ? 1u : 0u);
+                        if (census) ncell -= (Mn[ri] != 0 ? 1u : 0u) + (rowI[ri] != 0 ? 1u : 0u) + (rowD[ri] != 0 ? 1u : 0u);
                         Mn[ri] = 0, rowI[ri] = 0, rowD[ri] = 0;
                     }
                 }
@@ -548,7 +551,7 @@ __global__ __launch_bounds__(64 * NW) void wfa_wide_kernel(const KParams P) {
                 if (kD != 0xFFFFFFFFu && (kD & 1u) == 0u) found = true, fs = s, fk = Ak - (int)(kD >> 1), fh = wD;
                 if (kU != 0xFFFFFFFFu && (kU & 1u) == 0u) found = true, fs = s, fk = Ak + 1 + (int)(kU >> 1), fh = wU;
             }
-            {
+            if (census) {
                 uint32_t c = ncell;  // (a wave sum: 64 lanes x at most 3 x tiles)
 #pragma unroll
                 for (int d = 32; d >= 1; d >>= 1) c += (uint32_t)__shfl_xor((int)c, d, 64);
