@@ -546,10 +546,10 @@ KNAMES = ["wfa_generic_kernel", "wfa_packed_kernel", "wfa_reg_kernel<2, 4, 1>", 
           "wfa_blk_kernel<64, 1, false, 2, false, true, false>",
           "wfa_blk_kernel<64, 1, false, 1, false, false",  # 16: the lone-pair instance of wfahip_align_pair
           "wfa_teamc_kernel",                              # 17: wide wavefronts, one backtrace word per diagonal (round 5)
-          "wfa_wide_kernel"]                               # 18: semi-global short reads, a wave per pair with the rows in LDS rings (round 6)
+          "wfa_wide_kernel"]                               # 18: semi-global reads up to 2 047 bases, a workgroup per pair with the rows in LDS rings (round 6)
 # legs of config.other_configs: (config, timed steps, warm-up steps)
 # (round 5: every configuration that had a line only under profiles/ now has a driver-observed leg -- about two minutes in all)
-OTHER_LEGS = [("c2", 300, 5), ("c2m", 100, 3), ("p242", 12, 3), ("k10", 30, 4), ("k20", 12, 3), ("l5", 12, 3), ("l20", 5, 2), ("L5", 4, 2),
+OTHER_LEGS = [("c2", 300, 5), ("c2m", 100, 3), ("p242", 12, 3), ("g3", 3, 1), ("k10", 30, 4), ("k20", 12, 3), ("l5", 12, 3), ("l20", 5, 2), ("L5", 4, 2),
               ("c4", 3, 1), ("c5s", 2, 1), ("c5s32", 1, 1)]
 
 

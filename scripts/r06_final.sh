@@ -35,6 +35,7 @@ fi
 if has profiles; then
   timeout 900 bash scripts/profile_bench.sh ${TAG}_c3 > $OUT/prof_c3.log 2>&1
   timeout 900 bash scripts/profile_bench.sh ${TAG}_p242 --config p242 > $OUT/prof_p242.log 2>&1
+  timeout 900 bash scripts/profile_bench.sh ${TAG}_g3 --config g3 > $OUT/prof_g3.log 2>&1
   timeout 900 bash scripts/profile_bench.sh ${TAG}_c2 --config c2 > $OUT/prof_c2.log 2>&1
   timeout 900 bash scripts/profile_bench.sh ${TAG}_c2m --config c2m > $OUT/prof_c2m.log 2>&1
   timeout 900 bash scripts/profile_bench.sh ${TAG}_l5 --config l5 > $OUT/prof_l5.log 2>&1

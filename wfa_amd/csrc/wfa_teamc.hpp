@@ -932,7 +932,7 @@ __global__ __launch_bounds__(TC_THREADS) void wfa_teamc_kernel(const KParams P, 
                         // ---- the full pass over row S (wfa.go:497-524), everybody, out of the rings; then the row's deletions, keys, entry and halo
                         const uint32_t siS = si - 1u;
                         const int thr = (int)rfl((uint32_t)pf[14]) + (int)P.max_dist_diff;
-                        const int amlo = (int)rfl((uint32_t)pf[12]), amhi = (int)rfl((uint32_t)pf[13]);
+                        const int amlo = (int)rfl((uint32_t)pf[12]);
                         int f_ok = INT32_MAX, l_ok = INT32_MIN;
                         if (!syncw) {
 #pragma unroll

@@ -307,7 +307,10 @@ __global__ __launch_bounds__(64 * NW) void wfa_wide_kernel(const KParams P) {
                     const bool     lin = k0 <= uhi;  // (diagonals of the lane's four beyond uhi, or below ulo in the first round: no cell in any row)
                     uint32_t oM[4] = {0u, 0u, 0u, 0u}, oI[4] = {0u, 0u, 0u, 0u}, oD[4] = {0u, 0u, 0u, 0u}, oX[4] = {0u, 0u, 0u, 0u};
                     uint32_t aL = 0u, bL = 0u, cR = 0u, dR = 0u;
-                    if (lin) {
+                    // a round wholly outside the new row's range only clears what the new M row's slot still holds of M[s-4g] (the steps after
+                    // wf-adaptive's first cut: the wide old rows leave the rings one slot a step) -- every source row is empty there
+                    const bool ract = t0 + 256 * wv + 255 >= lo && t0 + 256 * wv <= hi;
+                    if (lin && ract) {
                         if (hasO) ld4(Moe, r0, oM), aL = Moe[r0 - 1u], cR = Moe[r0 + 4u];
                         if (hasE) ld4(rowI, r0, oI), ld4(rowD, r0, oD), bL = rowI[r0 - 1u], dR = rowD[r0 + 4u];
                         if (hasX) ld4(Mx, r0, oX);
@@ -322,6 +325,10 @@ __global__ __launch_bounds__(64 * NW) void wfa_wide_kernel(const KParams P) {
                     lds_sync();  // (every read of the round before its first write: the rows are updated in place)
                     if constexpr (NW > 1) carryM = rfl(scr[64u + 2u * (rnd & 1u)]), carryI = rfl(scr[65u + 2u * (rnd & 1u)]);
                     rnd++;
+                    if (!ract) {
+                        if (lin) *reinterpret_cast<uint2 *>(Mn + r0) = make_uint2(0u, 0u);
+                        continue;
+                    }
                     uint32_t nM[4], nI[4], nD[4], wd[4];
                     bool     act[4];
 #pragma unroll
