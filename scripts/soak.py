@@ -24,21 +24,28 @@ for seed, length, err, ad in ((101, 1000, 0.05, (10, 50, 1)), (102, 1000, 0.08, 
                               (116, 150, 0.02, (10, 50, 1)), (117, 60, 0.05, None), (118, 200, 0.05, (10, 50, 1)),
                               # round 4: the sliding-window instances (wfa_blk_kernel<.., LONG>): GPU-filling batches of 5-50 kbp reads
                               (119, 8000, 0.05, (10, 50, 1)), (120, 20000, 0.03, (10, 50, 1)), (121, 50000, 0.05, (10, 50, 1)),
-                              (122, 5000, 0.10, (10, 50, 1))):
+                              (122, 5000, 0.10, (10, 50, 1)),
+                              # round 6: semi-global batches on wfa_wide_kernel (negative seed = semi-global): one and four waves per pair, two launches and one
+                              (-123, 1000, 0.05, (10, 50, 1)), (-124, 300, 0.08, (10, 50, 1)), (-125, 600, 0.05, (10, 50, 1)), (-126, 450, 0.04, None),
+                              (-127, 1800, 0.06, (10, 50, 1)), (-128, 150, 0.05, (10, 50, 1))):
+    glob = seed > 0
+    seed = abs(seed)
     if os.environ.get("SOAK_SEEDS") and str(seed) not in os.environ["SOAK_SEEDS"].split(","):
         continue  # (SOAK_SEEDS=107,108,...: only those shapes)
     nn = n * 1000 // length if length > 1000 else n
+    if not glob:
+        nn = nn // 10 if ad is not None else nn // 50  # (eight times the cells of the global pair; without wf-adaptive every row is n + m - 1 wide)
     data = w.generate_pairs(seed=seed, n_pairs=nn, length=length, error_rate=err, n_threads=32)
     t0 = time.perf_counter()
-    want = O.align_batch(T._oracle_params(True, ad), *data, n_threads=thr)
+    want = O.align_batch(T._oracle_params(glob, ad), *data, n_threads=thr)
     t1 = time.perf_counter()
-    al = T._aligner(True, ad)
+    al = T._aligner(glob, ad)
     for rep in range(3):  # (the context learns rows / windows from the first call: the later ones take other passes)
         got = al.align_arrays(*data)
         t = al.last_timing()
         try:
-            T.assert_batch_equal(got, want, f"seed={seed} L={length} err={err} ad={ad} rep={rep}")
-            print(f"ok   seed={seed} n={nn} L={length} err={err} ad={ad} rep={rep}: lib {t.total_ms:.1f} ms, kind {t.main_kernel_kind}, "
+            T.assert_batch_equal(got, want, f"seed={seed} glob={glob} L={length} err={err} ad={ad} rep={rep}")
+            print(f"ok   seed={seed} {'global' if glob else 'semi-global'} n={nn} L={length} err={err} ad={ad} rep={rep}: lib {t.total_ms:.1f} ms, kind {t.main_kernel_kind}, "
                   f"retried {t.n_retried_pairs}, oracle {t1 - t0:.1f} s on {thr} threads", flush=True)
         except AssertionError as e:
             bad += 1

@@ -1758,7 +1758,7 @@ def test_wide_kernel_is_the_default_for_short_semi_global_reads(built):
     """Batches of semi-global reads of at most 2 047 bases start on wfa_wide_kernel without any option; longer ones on the ladder."""
     import wfa_amd as w
     from oracle import oracle as O
-    for length, n_pairs, kind in ((300, 4000, 18), (1000, 2000, 18), (2300, 200, 0)):
+    for length, n_pairs, kind in ((300, 4000, 18), (1000, 2000, 18), (1900, 300, 18), (2300, 200, 0)):  # (1 900: rings of 48 KB, offsets near the 16-bit words' 2 047)
         data = w.generate_pairs(seed=64, n_pairs=n_pairs, length=length, error_rate=0.06, n_threads=8)
         want = O.align_batch(_oracle_params(False, (10, 50, 1)), *data, n_threads=8)
         al = _aligner(False, (10, 50, 1))
