@@ -38,7 +38,7 @@ T = {
 }
 table = subprocess.run([sys.executable, os.path.join(R, "scripts", "r06_table.py")], capture_output=True, text=True, check=True).stdout
 ktable = subprocess.run([sys.executable, os.path.join(R, "scripts", "r06_table.py"), "--kernels"], capture_output=True, text=True, check=True).stdout
-for f in ("DESIGN.md", "BASELINE.md", "README.md"):
+for f in ("DESIGN.md", "BASELINE.md", "README.md", "KERNELS.md"):
     p = os.path.join(R, f)
     s = open(p).read()
     for k, v in T.items():
