@@ -1724,6 +1724,9 @@ def test_wide_kernel_semi_global_shapes(built, pen, ad):
     al.set_option("wide_waves", 1)  # (rings of this size get four waves per pair by default)
     assert_batch_equal(al.align_arrays(*data), want, f"wide kernel, a wave per pair, pen={pen} ad={ad}")
     al.set_option("wide_waves", 0)
+    al.set_option("wide_exact", 1)  # (the interior of a wide row is computed two diagonals per register by default: here every round takes the exact per-cell path)
+    assert_batch_equal(al.align_arrays(*data), want, f"wide kernel, exact path only, pen={pen} ad={ad}")
+    al.set_option("wide_exact", 0)
     if ad is not None:  # one launch per chunk: every pair runs to its end in the wide rings (no hand-over to the narrow phase)
         al.set_option("wide", 3)
         assert_batch_equal(al.align_arrays(*data), want, f"wide kernel, one phase, pen={pen} ad={ad}")

@@ -123,6 +123,7 @@ struct KParams {
                                      // them, so that neither the refill nor the walk fetches them from the host's mapped block (a PCIe round trip each)
     uint32_t *wide_ckpt;             // wfa_wide_kernel: WIDE_CKPT_WORDS words per pair of the chunk -- what its first launch hands its second (wfa_wide.hpp)
     uint32_t  wide_ckpt_on;          // ... 1: the first launch hands pairs on once their rows are narrow; 0: it runs every pair to its end
+    uint32_t  wide_exact;            // ... 1: every round of the wide rows takes the exact per-cell path (tests: the packed two-diagonals-per-register path against it)
     uint32_t  compact_fmt;           // compact arena layout (CompactView): 0 = rows + directory; no directory: 1 = 64 words
                                      // per score, diagonal k at slot k & 63; 3 = tiles of 8 scores x 64 diagonals;
                                      // 4 = 256 words per score, slot k & 255; 5 = 32 words per score, slot k & 31

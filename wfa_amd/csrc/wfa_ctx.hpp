@@ -179,6 +179,7 @@ struct wfahip_ctx {
                                                   // 2e4 x 1 kbp without wf-adaptive: 30 against 71
     int           opt_wide_waves           = 0;   // ... waves per pair in its first phase: 0 = by the rings' size (four above 12 KB: a 1 kbp pair's 25 KB leave a SIMD a wave and a
                                                   // half otherwise), 1 or 4 forced (tests)
+    bool          opt_wide_exact           = false; // ... 1: no packed fast path in the wide rows (tests)
     int64_t       opt_wide_min_pairs       = 64;  // ... from this many pairs on (fewer: the one-workgroup-per-pair kernel, whose workgroup is larger than a wave)
     int64_t       opt_duo                  = 1;   // reads of 240+ bases start on wfa_duo_kernel (8 or 16 lanes per pair, changing while the pair runs):
                                                   // 0 never, 1 for batches of at least opt_duo_min_pairs (below that its start-up -- a wave takes one new pair

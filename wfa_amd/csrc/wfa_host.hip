@@ -453,6 +453,8 @@ static int set_option_impl(wfahip_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_wide_min_pairs = value;
     else if (k == "wide_max_len")
         ctx->opt_wide_max_len = value;
+    else if (k == "wide_exact")
+        ctx->opt_wide_exact = value != 0;
     else if (k == "wide_waves")
         ctx->opt_wide_waves = (value == 1 || value == 4) ? (int)value : 0;
     else if (k == "duo")
@@ -654,7 +656,7 @@ static int align_device_impl(wfahip_ctx *ctx, const wfahip_params *p, const void
             // diagonals, the CU's full complement of waves -- the rest (wfa_wide.hpp)
             const bool two_phase = P.adaptive != 0 && ctx->opt_wide >= 1 && ctx->opt_wide != 3;
             if (two_phase && (rc = ensure(ctx, ctx->wide_ckpt, (size_t)chunk * WIDE_CKPT_WORDS * 4))) return rc;
-            P.wide_ckpt = static_cast<uint32_t *>(ctx->wide_ckpt.p), P.wide_ckpt_on = two_phase ? 1u : 0u;
+            P.wide_ckpt = static_cast<uint32_t *>(ctx->wide_ckpt.p), P.wide_ckpt_on = two_phase ? 1u : 0u, P.wide_exact = ctx->opt_wide_exact ? 1u : 0u;
             const size_t lds_narrow = (size_t)wide_lds_words_narrow(seq_words) * 4;
             // waves per pair in the first phase: rings above 12 KB leave a SIMD fewer than three one-wave workgroups -- four waves share them
             const int wide_waves = ctx->opt_wide_waves > 0 ? ctx->opt_wide_waves : (lds_bytes > 12 * 1024 ? 4 : 1);

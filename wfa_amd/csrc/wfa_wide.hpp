@@ -57,10 +57,38 @@ constexpr uint32_t WIDE_CKPT_HDR = 24u, WIDE_CKPT_WORDS = WIDE_CKPT_HDR + 6u * W
 __host__ __device__ inline uint32_t wide_lds_words_narrow(uint32_t seq_words) { return ((2u * seq_words + 3u) & ~3u) + 6u * WIDE_RW / 2u + WIDE_SCR_WORDS; }
 
 // DX / DOE: the penalty shape x/g : (o+e)/g (e/g == 1), as in the sub-wave kernels (wfa_fwd.hpp)
+// Two 16-bit offsets per register (the wide rows' interior: v_pk_max_u16 / v_pk_add_u16 / v_pk_sub_u16 with clamp / v_pk_min_u16)
+typedef unsigned short wide_us2 __attribute__((ext_vector_type(2)));
+WFA_DEV wide_us2 wide_pk(uint32_t x) { return __builtin_bit_cast(wide_us2, x); }
+WFA_DEV uint32_t wide_u32(wide_us2 x) { return __builtin_bit_cast(uint32_t, x); }
+WFA_DEV wide_us2 wide_max(wide_us2 a, wide_us2 b) { return __builtin_elementwise_max(a, b); }
+// (`one` = (1, 1) from a register the compiler cannot see through: it turns min(a, 1) into two compares, two selects and a permute otherwise)
+WFA_DEV wide_us2 wide_ind(wide_us2 a, wide_us2 one) { return __builtin_elementwise_min(a, one); }                             // 1 where a != 0
+WFA_DEV wide_us2 wide_lt(wide_us2 a, wide_us2 b, wide_us2 one) { return wide_ind(__builtin_elementwise_sub_sat(b, a), one); }  // 1 where a < b
+// WF_NEXT of two neighbouring diagonals whose sources need no rejection (wfa.go:572-699; the decisions as blk_word_asm() takes them: the mismatch
+// wins iff x1 >= max(Isk, Dsk), else the insertion iff Isk >= Dsk; backTrace's recomputed pre-extension offset is the M offset itself)
+WFA_DEV void wide_next2(wide_us2 a, wide_us2 b, wide_us2 c, wide_us2 d, wide_us2 x, wide_us2 one, uint32_t &M2, uint32_t &I2, uint32_t &D2, uint32_t &W2) {
+    const wide_us2 mi = wide_max(a, b), Isk = mi + wide_ind(mi, one), Dsk = wide_max(c, d), x1 = x + wide_ind(x, one);
+    const wide_us2 t = wide_max(Isk, Dsk), Msk = wide_max(t, x1);
+    const wide_us2 iext = wide_lt(a, b, one), dext = wide_lt(c, d, one), fx = one - wide_lt(x1, t, one), fi = one - wide_lt(Isk, Dsk, one);
+    wide_us2 w = Msk + Msk + iext;
+    w = w + w + dext, w = w + w + fx, w = w + w + fi;
+    w &= (wide_us2)(0) - wide_ind(Msk, one);  // (no cell: no word)
+    M2 = wide_u32(Msk), I2 = wide_u32(Isk), D2 = wide_u32(Dsk), W2 = wide_u32(w);
+}
+
+#ifndef WFA_WIDE_EU
+#define WFA_WIDE_EU 5  // waves per SIMD the register allocation aims at (0: the compiler's choice -- 110 registers with the packed path: four waves, 8 % slower on g3)
+#endif
+#if WFA_WIDE_EU
+#define WFA_WIDE_EU_ATTR __attribute__((amdgpu_waves_per_eu(WFA_WIDE_EU, WFA_WIDE_EU)))
+#else
+#define WFA_WIDE_EU_ATTR
+#endif
 // NW: waves of the pair's workgroup (PHASE 0: the rings of a 1 kbp pair are 25 KB, six workgroups a CU -- with one wave each the SIMDs would
 // hold a wave and a half; the waves of a workgroup take a row's rounds side by side)
 template <int DX = 2, int DOE = 4, int PHASE = 0, int NW = 1>
-__global__ __launch_bounds__(64 * NW) void wfa_wide_kernel(const KParams P) {
+__global__ __launch_bounds__(64 * NW) WFA_WIDE_EU_ATTR void wfa_wide_kernel(const KParams P) {
     static_assert(DX >= 1 && DOE >= 1 && DX <= 4 && DOE <= 4, "ring depths of one to four score steps");
     static_assert(NW == 1 || (PHASE == 0 && (NW == 2 || NW == 4)), "the narrow phase is one wave");
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -261,6 +289,12 @@ __global__ __launch_bounds__(64 * NW) void wfa_wide_kernel(const KParams P) {
                     if (v > 0 && v < n && h < m) nM += (uint32_t)sv.lcp(v, h);
                 }
             };
+            const auto cell_extend = [&](const int k, uint32_t &nM) {
+                if (nM != 0u) {
+                    const int h = (int)nM, v = h - k;
+                    if (v > 0 && v < n && h < m) nM += (uint32_t)sv.lcp(v, h);
+                }
+            };
             // ... and what the row's reductions take from a cell (rows of more than one tile; a row of one tile answers them with ballots below)
             const auto cell_stats = [&](const int k, const uint32_t nM, const uint32_t nI, const uint32_t nD) {
                 if (nM != 0u) {
@@ -284,7 +318,10 @@ __global__ __launch_bounds__(64 * NW) void wfa_wide_kernel(const KParams P) {
                 // ---- the wide rows: rounds of 256 diagonals, FOUR CONSECUTIVE DIAGONALS PER LANE.  A lane's cells of a row are one 8-byte LDS word
                 // (the round starts on a ring index that is a multiple of four), three of a cell's five sources are the lane's own registers, and the
                 // row's halfwords go to the arena eight bytes at a time (the row's first halfword is laid so that a lane's four are aligned)
-                const int t_first = ulo - (int)(RI(ulo) & 3u);
+                const int  t_first = ulo - (int)(RI(ulo) & 3u);
+                const bool pk_ok   = !seeded && si != 0u && !census && P.wide_exact == 0u;
+                uint32_t   pk_one  = 0x00010001u;
+                asm volatile("" : "+v"(pk_one));
                 {
                     const uint32_t want = (uint32_t)(lo - t_first) & 3u;  // top + (k0 - lo) a multiple of four for every lane's first diagonal k0
                     top += (want - top) & 3u;
@@ -301,25 +338,26 @@ __global__ __launch_bounds__(64 * NW) void wfa_wide_kernel(const KParams P) {
                 // (NW waves: a round of each side by side; the one cell a round overwrites that the next one sources -- its last M[s-o-e] and
                 // I[s-e] -- goes from the last wave to the first through the scratch words, two slots in turn)
                 uint32_t rnd = 0u;
+                const int wr = wv;  // the quarter of a round this wave takes (rotating it with the score, so that the exact-path quarters at the row's two ends move from SIMD to SIMD, changed nothing: 159.5 against 158.3 ms)
                 for (int t0 = t_first; t0 <= uhi; t0 += 256 * NW) {
-                    const int      k0  = t0 + 256 * wv + 4 * lane;
+                    const int      k0  = t0 + 256 * wr + 4 * lane;
                     const uint32_t r0  = RI(k0);
                     const bool     lin = k0 <= uhi;  // (diagonals of the lane's four beyond uhi, or below ulo in the first round: no cell in any row)
                     uint32_t oM[4] = {0u, 0u, 0u, 0u}, oI[4] = {0u, 0u, 0u, 0u}, oD[4] = {0u, 0u, 0u, 0u}, oX[4] = {0u, 0u, 0u, 0u};
                     uint32_t aL = 0u, bL = 0u, cR = 0u, dR = 0u;
                     // a round wholly outside the new row's range only clears what the new M row's slot still holds of M[s-4g] (the steps after
                     // wf-adaptive's first cut: the wide old rows leave the rings one slot a step) -- every source row is empty there
-                    const bool ract = t0 + 256 * wv + 255 >= lo && t0 + 256 * wv <= hi;
+                    const bool ract = t0 + 256 * wr + 255 >= lo && t0 + 256 * wr <= hi;
                     if (lin && ract) {
                         if (hasO) ld4(Moe, r0, oM), aL = Moe[r0 - 1u], cR = Moe[r0 + 4u];
                         if (hasE) ld4(rowI, r0, oI), ld4(rowD, r0, oD), bL = rowI[r0 - 1u], dR = rowD[r0 + 4u];
                         if (hasX) ld4(Mx, r0, oX);
                     }
-                    if (lane == 0 && wv == 0) aL = carryM, bL = carryI;  // (what the previous round overwrote)
+                    if (lane == 0 && wr == 0) aL = carryM, bL = carryI;  // (what the previous round overwrote)
                     if constexpr (NW == 1) {
                         carryM = rfl((uint32_t)__builtin_amdgcn_readlane((int)oM[3], 63));
                         carryI = rfl((uint32_t)__builtin_amdgcn_readlane((int)oI[3], 63));
-                    } else if (wv == NW - 1 && lane == 63) {
+                    } else if (wr == NW - 1 && lane == 63) {
                         scr[64u + 2u * (rnd & 1u)] = oM[3], scr[65u + 2u * (rnd & 1u)] = oI[3];
                     }
                     lds_sync();  // (every read of the round before its first write: the rows are updated in place)
@@ -328,6 +366,88 @@ __global__ __launch_bounds__(64 * NW) void wfa_wide_kernel(const KParams P) {
                     if (!ract) {
                         if (lin) *reinterpret_cast<uint2 *>(Mn + r0) = make_uint2(0u, 0u);
                         continue;
+                    }
+                    // ---- the interior of a wide row: every diagonal of the wave's round inside [lo, hi], no seeds, no source that next() would
+                    // reject -- WF_NEXT on two diagonals per register; the I / D rows and the backtrace words are stored as they come out
+                    if (pk_ok && t0 + 256 * wr >= lo && t0 + 256 * wr + 255 <= hi) {
+                        const uint32_t pM0 = oM[0] | (oM[1] << 16), pM1 = oM[2] | (oM[3] << 16), pI0 = oI[0] | (oI[1] << 16), pI1 = oI[2] | (oI[3] << 16);
+                        const uint32_t pD0 = oD[0] | (oD[1] << 16), pD1 = oD[2] | (oD[3] << 16), pX0 = oX[0] | (oX[1] << 16), pX1 = oX[2] | (oX[3] << 16);
+                        // the sources of diagonals (k0, k0+1) and (k0+2, k0+3): k-1 of the M[s-o-e] / I rows, k+1 of the M[s-o-e] / D rows
+                        const uint32_t a0p = (pM0 << 16) | aL, a1p = __builtin_amdgcn_alignbit(pM1, pM0, 16), c1p = (pM1 >> 16) | (cR << 16);
+                        const uint32_t b0p = (pI0 << 16) | bL, b1p = __builtin_amdgcn_alignbit(pI1, pI0, 16);
+                        const uint32_t d0p = __builtin_amdgcn_alignbit(pD1, pD0, 16), d1p = (pD1 >> 16) | (dR << 16);
+                        // rejections (wfa.go:581-588,616-623,651-654): an offset > m, an offset - k > n -- none in the whole round, or the round takes the exact path
+                        const wide_us2 hi_m = wide_max(wide_max(wide_max(wide_pk(a0p), wide_pk(a1p)), wide_max(wide_pk(b0p), wide_pk(b1p))), wide_max(wide_pk(pX0), wide_pk(pX1)));
+                        const uint32_t nk0 = (uint32_t)(n + k0) | ((uint32_t)(n + k0 + 1) << 16), nk1 = (uint32_t)(n + k0 + 2) | ((uint32_t)(n + k0 + 3) << 16);
+                        const wide_us2 over = __builtin_elementwise_sub_sat(hi_m, wide_pk((uint32_t)m * 0x10001u)) |
+                                              __builtin_elementwise_sub_sat(wide_max(wide_max(wide_pk(a1p), wide_pk(d0p)), wide_pk(pX0)), wide_pk(nk0)) |
+                                              __builtin_elementwise_sub_sat(wide_max(wide_max(wide_pk(c1p), wide_pk(d1p)), wide_pk(pX1)), wide_pk(nk1));
+                        if (__ballot(lin && wide_u32(over) != 0u) == 0ull) {
+                            uint32_t M0, M1, I0, I1, D0, D1, W0, W1;
+                            wide_next2(wide_pk(a0p), wide_pk(b0p), wide_pk(a1p) /* = (M[k0+1], M[k0+2]) */, wide_pk(d0p), wide_pk(pX0), wide_pk(pk_one), M0, I0, D0, W0);
+                            wide_next2(wide_pk(a1p), wide_pk(b1p), wide_pk(c1p), wide_pk(d1p), wide_pk(pX1), wide_pk(pk_one), M1, I1, D1, W1);
+                            uint32_t nM[4] = {M0 & 0xFFFFu, M0 >> 16, M1 & 0xFFFFu, M1 >> 16};
+                            // WF_EXTEND (wfa.go:394-455), the first 16-base window of the lane's four cells side by side and without a branch; the
+                            // few cells whose window matches throughout go on in the loop
+                            uint32_t more = 0u;
+#pragma unroll
+                            for (int u = 0; u < 4; u++) {
+                                const int  k = k0 + u, h = (int)nM[u], v = h - k;
+                                const bool ext = h != 0 && v > 0 && v < n && h < m;
+                                const int  vv = ext ? v : 0, hh = ext ? h : 0;  // (a cell that does not extend reads the sequences' first words)
+                                const uint32_t xw  = SeqView<0>::win16(lq, vv) ^ SeqView<0>::win16(lt, hh);
+                                const int      rem = imin2(n - vv, m - hh), tot = xw != 0u ? (int)(__builtin_ctz(xw) >> 1) : 16;
+                                nM[u] = (uint32_t)(h + (ext ? imin2(tot, rem) : 0));
+                                more |= (ext && xw == 0u && rem > 16) ? (1u << u) : 0u;
+                            }
+                            if (__ballot(more != 0u) != 0ull) {
+#pragma unroll
+                                for (int u = 0; u < 4; u++)
+                                    if ((more >> u) & 1u) {
+                                        const int h = (int)nM[u], v = h - (k0 + u);
+                                        nM[u] += (uint32_t)sv.lcp(v, h);
+                                    }
+                            }
+                            // what the row's reductions take from the four cells (cell_stats(), per lane instead of per cell where the cells' order allows)
+                            {
+                                const bool z0 = nM[0] != 0u, z1 = nM[1] != 0u, z2 = nM[2] != 0u, z3 = nM[3] != 0u;
+                                mlo = imin2(mlo, z0 ? k0 : (z1 ? k0 + 1 : (z2 ? k0 + 2 : (z3 ? k0 + 3 : BIG))));
+                                mhi = imax2(mhi, z3 ? k0 + 3 : (z2 ? k0 + 2 : (z1 ? k0 + 1 : (z0 ? k0 : -BIG))));
+                                const int ua = Ak - k0;  // the lane that holds the final diagonal (wfa.go:235-239)
+                                if (ua >= 0 && ua < 4) {
+                                    const int hA = (int)(ua == 0 ? nM[0] : (ua == 1 ? nM[1] : (ua == 2 ? nM[2] : nM[3])));
+                                    if (hA >= m) term = true, hf = hA;
+                                }
+                                bool edge = false;
+#pragma unroll
+                                for (int u = 0; u < 4; u++) {
+                                    const int  h = (int)nM[u], v = h - (k0 + u);
+                                    const bool valid = h != 0 && (uint32_t)v < (uint32_t)n && h < m;  // wfa.go:474-494 (v < 0 wraps)
+                                    const int  dd = imax2(m - h, n - v);
+                                    mind = imin2(mind, valid ? dd : BIG), maxd = imax2(maxd, valid ? dd : -BIG);
+                                    edge |= h != 0 && (!valid || v == 0);
+                                }
+                                // a stop or a hit of the end-cell scans is a cell at an end of a sequence: none in the interior of most rows
+                                if (ecs && __ballot(edge) != 0ull) {
+#pragma unroll
+                                    for (int u = 0; u < 4; u++) {
+                                        const int k = k0 + u, h = (int)nM[u], v = h - k;
+                                        if (h != 0 && (v <= 0 || v > n || h > m || (v == n && h >= n) || (h == m && v >= m))) {
+                                            if (k <= Ak) cdn = imax2(cdn, k);
+                                            else cup = imin2(cup, k);
+                                        }
+                                    }
+                                }
+                            }
+                            if (lin) {
+                                st4(Mn, r0, nM);
+                                *reinterpret_cast<uint2 *>(rowI + r0) = make_uint2(I0, I1);
+                                *reinterpret_cast<uint2 *>(rowD + r0) = make_uint2(D0, D1);
+                                *reinterpret_cast<uint2 *>(arow + ((int64_t)top + (int64_t)(k0 - lo))) = make_uint2(W0, W1);
+                            }
+                            if constexpr (NW == 1) lds_sync();
+                            continue;
+                        }
                     }
                     uint32_t nM[4], nI[4], nD[4], wd[4];
                     bool     act[4];
