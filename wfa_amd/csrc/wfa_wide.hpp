@@ -258,7 +258,7 @@ __global__ __launch_bounds__(64 * NW) WFA_WIDE_EU_ATTR void wfa_wide_kernel(cons
             uint32_t sM = 0u, sI = 0u, sD = 0u;
             // one cell: WF_NEXT from the raw sources (0 = absent), the seeds, WF_EXTEND
             const auto cell = [&](const int k, const bool act, const uint32_t a0, const uint32_t b0, const uint32_t c0, const uint32_t d0, const uint32_t x0,
-                                  uint32_t &nM, uint32_t &nI, uint32_t &nD, uint32_t &wd) {
+                                  uint32_t &nM, uint32_t &nI, uint32_t &nD, uint32_t &wd, const bool with_extend = true) {
                 nM = nI = nD = wd = 0u;
                 if (act && si != 0u) {
                     // rejections: > m (not >=) for I and X sources, offset - k > n for D and X sources (wfa.go:581-588,616-623,651-654)
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(64 * NW) WFA_WIDE_EU_ATTR void wfa_wide_kernel(cons
                     if (sw != 0u) nM = sw >> TAG_BITS, wd = (sw & TAG_MASK) == TAG_MATCH ? BLK_SEED_MATCH : BLK_SEED_MISMATCH;
                 }
                 // WF_EXTEND (wfa.go:394-455): only cells with 0 < v < n and h < m
-                if (nM != 0u) {
+                if (with_extend && nM != 0u) {
                     const int h = (int)nM, v = h - k;
                     if (v > 0 && v < n && h < m) nM += (uint32_t)sv.lcp(v, h);
                 }
@@ -313,6 +313,62 @@ __global__ __launch_bounds__(64 * NW) WFA_WIDE_EU_ATTR void wfa_wide_kernel(cons
                     }
                 }
                 if (census) ncell += (nM != 0u ? 1u : 0u) + (nI != 0u ? 1u : 0u) + (nD != 0u ? 1u : 0u);
+            };
+            // the lane's four consecutive cells of a wide row after WF_NEXT: WF_EXTEND and what the row's reductions take from them (cell_stats(), per lane
+            // instead of per cell where the cells' order allows) -- shared by the packed and the exact path of the rounds
+            const auto finish4 = [&](const int k0, uint32_t (&nM)[4]) {
+                // WF_EXTEND (wfa.go:394-455), the first 16-base window of the lane's four cells side by side and without a branch; the
+                // few cells whose window matches throughout go on in the loop
+                uint32_t more = 0u;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int  k = k0 + u, h = (int)nM[u], v = h - k;
+                    const bool ext = h != 0 && v > 0 && v < n && h < m;
+                    const int  vv = ext ? v : 0, hh = ext ? h : 0;  // (a cell that does not extend reads the sequences' first words)
+                    const uint32_t xw  = SeqView<0>::win16(lq, vv) ^ SeqView<0>::win16(lt, hh);
+                    const int      rem = imin2(n - vv, m - hh), tot = xw != 0u ? (int)(__builtin_ctz(xw) >> 1) : 16;
+                    nM[u] = (uint32_t)(h + (ext ? imin2(tot, rem) : 0));
+                    more |= (ext && xw == 0u && rem > 16) ? (1u << u) : 0u;
+                }
+                if (__ballot(more != 0u) != 0ull) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        if ((more >> u) & 1u) {
+                            const int h = (int)nM[u], v = h - (k0 + u);
+                            nM[u] += (uint32_t)sv.lcp(v, h);
+                        }
+                }
+                // what the row's reductions take from the four cells (cell_stats(), per lane instead of per cell where the cells' order allows)
+                {
+                    const bool z0 = nM[0] != 0u, z1 = nM[1] != 0u, z2 = nM[2] != 0u, z3 = nM[3] != 0u;
+                    mlo = imin2(mlo, z0 ? k0 : (z1 ? k0 + 1 : (z2 ? k0 + 2 : (z3 ? k0 + 3 : BIG))));
+                    mhi = imax2(mhi, z3 ? k0 + 3 : (z2 ? k0 + 2 : (z1 ? k0 + 1 : (z0 ? k0 : -BIG))));
+                    const int ua = Ak - k0;  // the lane that holds the final diagonal (wfa.go:235-239)
+                    if (ua >= 0 && ua < 4) {
+                        const int hA = (int)(ua == 0 ? nM[0] : (ua == 1 ? nM[1] : (ua == 2 ? nM[2] : nM[3])));
+                        if (hA >= m) term = true, hf = hA;
+                    }
+                    bool edge = false;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int  h = (int)nM[u], v = h - (k0 + u);
+                        const bool valid = h != 0 && (uint32_t)v < (uint32_t)n && h < m;  // wfa.go:474-494 (v < 0 wraps)
+                        const int  dd = imax2(m - h, n - v);
+                        mind = imin2(mind, valid ? dd : BIG), maxd = imax2(maxd, valid ? dd : -BIG);
+                        edge |= h != 0 && (!valid || v == 0);
+                    }
+                    // a stop or a hit of the end-cell scans is a cell at an end of a sequence: none in the interior of most rows
+                    if (ecs && __ballot(edge) != 0ull) {
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const int k = k0 + u, h = (int)nM[u], v = h - k;
+                            if (h != 0 && (v <= 0 || v > n || h > m || (v == n && h >= n) || (h == m && v >= m))) {
+                                if (k <= Ak) cdn = imax2(cdn, k);
+                                else cup = imin2(cup, k);
+                            }
+                        }
+                    }
+                }
             };
             if (uhi >= ulo && PHASE == 0) {
                 // ---- the wide rows: rounds of 256 diagonals, FOUR CONSECUTIVE DIAGONALS PER LANE.  A lane's cells of a row are one 8-byte LDS word
@@ -387,58 +443,7 @@ __global__ __launch_bounds__(64 * NW) WFA_WIDE_EU_ATTR void wfa_wide_kernel(cons
                             wide_next2(wide_pk(a0p), wide_pk(b0p), wide_pk(a1p) /* = (M[k0+1], M[k0+2]) */, wide_pk(d0p), wide_pk(pX0), wide_pk(pk_one), M0, I0, D0, W0);
                             wide_next2(wide_pk(a1p), wide_pk(b1p), wide_pk(c1p), wide_pk(d1p), wide_pk(pX1), wide_pk(pk_one), M1, I1, D1, W1);
                             uint32_t nM[4] = {M0 & 0xFFFFu, M0 >> 16, M1 & 0xFFFFu, M1 >> 16};
-                            // WF_EXTEND (wfa.go:394-455), the first 16-base window of the lane's four cells side by side and without a branch; the
-                            // few cells whose window matches throughout go on in the loop
-                            uint32_t more = 0u;
-#pragma unroll
-                            for (int u = 0; u < 4; u++) {
-                                const int  k = k0 + u, h = (int)nM[u], v = h - k;
-                                const bool ext = h != 0 && v > 0 && v < n && h < m;
-                                const int  vv = ext ? v : 0, hh = ext ? h : 0;  // (a cell that does not extend reads the sequences' first words)
-                                const uint32_t xw  = SeqView<0>::win16(lq, vv) ^ SeqView<0>::win16(lt, hh);
-                                const int      rem = imin2(n - vv, m - hh), tot = xw != 0u ? (int)(__builtin_ctz(xw) >> 1) : 16;
-                                nM[u] = (uint32_t)(h + (ext ? imin2(tot, rem) : 0));
-                                more |= (ext && xw == 0u && rem > 16) ? (1u << u) : 0u;
-                            }
-                            if (__ballot(more != 0u) != 0ull) {
-#pragma unroll
-                                for (int u = 0; u < 4; u++)
-                                    if ((more >> u) & 1u) {
-                                        const int h = (int)nM[u], v = h - (k0 + u);
-                                        nM[u] += (uint32_t)sv.lcp(v, h);
-                                    }
-                            }
-                            // what the row's reductions take from the four cells (cell_stats(), per lane instead of per cell where the cells' order allows)
-                            {
-                                const bool z0 = nM[0] != 0u, z1 = nM[1] != 0u, z2 = nM[2] != 0u, z3 = nM[3] != 0u;
-                                mlo = imin2(mlo, z0 ? k0 : (z1 ? k0 + 1 : (z2 ? k0 + 2 : (z3 ? k0 + 3 : BIG))));
-                                mhi = imax2(mhi, z3 ? k0 + 3 : (z2 ? k0 + 2 : (z1 ? k0 + 1 : (z0 ? k0 : -BIG))));
-                                const int ua = Ak - k0;  // the lane that holds the final diagonal (wfa.go:235-239)
-                                if (ua >= 0 && ua < 4) {
-                                    const int hA = (int)(ua == 0 ? nM[0] : (ua == 1 ? nM[1] : (ua == 2 ? nM[2] : nM[3])));
-                                    if (hA >= m) term = true, hf = hA;
-                                }
-                                bool edge = false;
-#pragma unroll
-                                for (int u = 0; u < 4; u++) {
-                                    const int  h = (int)nM[u], v = h - (k0 + u);
-                                    const bool valid = h != 0 && (uint32_t)v < (uint32_t)n && h < m;  // wfa.go:474-494 (v < 0 wraps)
-                                    const int  dd = imax2(m - h, n - v);
-                                    mind = imin2(mind, valid ? dd : BIG), maxd = imax2(maxd, valid ? dd : -BIG);
-                                    edge |= h != 0 && (!valid || v == 0);
-                                }
-                                // a stop or a hit of the end-cell scans is a cell at an end of a sequence: none in the interior of most rows
-                                if (ecs && __ballot(edge) != 0ull) {
-#pragma unroll
-                                    for (int u = 0; u < 4; u++) {
-                                        const int k = k0 + u, h = (int)nM[u], v = h - k;
-                                        if (h != 0 && (v <= 0 || v > n || h > m || (v == n && h >= n) || (h == m && v >= m))) {
-                                            if (k <= Ak) cdn = imax2(cdn, k);
-                                            else cup = imin2(cup, k);
-                                        }
-                                    }
-                                }
-                            }
+                            finish4(k0, nM);
                             if (lin) {
                                 st4(Mn, r0, nM);
                                 *reinterpret_cast<uint2 *>(rowI + r0) = make_uint2(I0, I1);
@@ -455,9 +460,10 @@ __global__ __launch_bounds__(64 * NW) WFA_WIDE_EU_ATTR void wfa_wide_kernel(cons
                     for (int u = 0; u < 4; u++) {
                         const int k = k0 + u;
                         act[u] = k >= lo && k <= hi;
-                        cell(k, act[u], u == 0 ? aL : oM[u - 1], u == 0 ? bL : oI[u - 1], u == 3 ? cR : oM[u + 1], u == 3 ? dR : oD[u + 1], oX[u], nM[u], nI[u], nD[u], wd[u]);
-                        cell_stats(k, nM[u], nI[u], nD[u]);
+                        cell(k, act[u], u == 0 ? aL : oM[u - 1], u == 0 ? bL : oI[u - 1], u == 3 ? cR : oM[u + 1], u == 3 ? dR : oD[u + 1], oX[u], nM[u], nI[u], nD[u], wd[u], false);
+                        if (census) ncell += (nM[u] != 0u ? 1u : 0u) + (nI[u] != 0u ? 1u : 0u) + (nD[u] != 0u ? 1u : 0u);
                     }
+                    finish4(k0, nM);
                     if (lin) {
                         st4(Mn, r0, nM), st4(rowI, r0, nI), st4(rowD, r0, nD);
                         uint16_t *const ap = arow + ((int64_t)top + (int64_t)(k0 - lo));  // (only dereferenced where act)
