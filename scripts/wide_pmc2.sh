@@ -1,3 +1,6 @@
+#!/bin/bash
+# Instruction counters of wfa_wide_kernel's two launches on g3: the default build against option wide_exact=1 (no packed path in the wide rows).
+# Three passes over the 1e6 pairs per run (warm-up, step, census; the census pass takes the exact path in both).  Usage (through gpurun): bash scripts/wide_pmc2.sh
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 R=$(pwd); OUT=gpurun_out/widepmc; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 B="--cpu-sample 0 --host-entry 0 --latency 0 --other-configs 0 --config g3 --steps 1 --warmup 1"
