@@ -40,7 +40,7 @@ constexpr uint32_t WIDE_FMT     = 11u;   // CompactView: rows of 16-bit blk_word
 __host__ __device__ inline uint32_t wide_row_hw(uint32_t max_len) { return (2u * max_len + 96u + 63u) & ~63u; }
 // LDS words of a wave: the two packed sequences, then the six rows
 __host__ __device__ inline uint32_t wide_lds_words(uint32_t seq_words, uint32_t max_len) {
-    return ((2u * seq_words + 3u) & ~3u) + 6u * wide_row_hw(max_len) / 2u + 80u;
+    return ((2u * seq_words + 3u) & ~3u) + 6u * wide_row_hw(max_len) / 2u + 144u;
 }
 // pair_meta of a finished pair: {ST_OK, score of the walk's start, its extended offset | (its diagonal + WIDE_KBIAS) << 16, cells}
 constexpr uint32_t WIDE_KBIAS = 32768u;
@@ -52,7 +52,7 @@ constexpr uint32_t WIDE_KBIAS = 32768u;
 // same directory -- the backtrace sees one pair.  A pair that never narrows (wf-adaptive off) finishes in PHASE 0.
 // (WIDE_RW 256 was too few: after the first cut a band is still 100-200 wide and widens by two a step until the leader pulls away.)
 constexpr int      WIDE_RW = 512, WIDE_NARROW = 200;
-constexpr uint32_t WIDE_SCR_WORDS = 80u;  // LDS words behind the rings: what the waves of a workgroup hand one another
+constexpr uint32_t WIDE_SCR_WORDS = 144u;  // LDS words behind the rings: what the waves of a workgroup hand one another (two exchange buffers of 32, the boundary cells of up to 17 quarters)
 constexpr uint32_t WIDE_CKPT_HDR = 24u, WIDE_CKPT_WORDS = WIDE_CKPT_HDR + 6u * WIDE_RW / 2u;
 __host__ __device__ inline uint32_t wide_lds_words_narrow(uint32_t seq_words) { return ((2u * seq_words + 3u) & ~3u) + 6u * WIDE_RW / 2u + WIDE_SCR_WORDS; }
 
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(64 * NW) WFA_WIDE_EU_ATTR void wfa_wide_kernel(cons
     uint16_t *const rowI = ring + 4u * WH, *const rowD = ring + 5u * WH;
     const auto      rowM = [&](uint32_t i) -> uint16_t * { return ring + (i & 3u) * WH; };
     const auto      rfl  = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
-    uint32_t *const scr  = reinterpret_cast<uint32_t *>(ring + 6u * WH);  // WIDE_SCR_WORDS: two exchange buffers of 32 words, the carries' four
+    uint32_t *const scr  = reinterpret_cast<uint32_t *>(ring + 6u * WH);  // WIDE_SCR_WORDS: two exchange buffers of 32 words, then the quarters' boundary cells
     const auto      lds_sync = [] {  // what one lane of the workgroup stored, another lane reads: in order, and not from a stale register
         if constexpr (NW > 1) {
             __syncthreads();
@@ -391,9 +391,24 @@ __global__ __launch_bounds__(64 * NW) WFA_WIDE_EU_ATTR void wfa_wide_kernel(cons
                 const auto st4 = [](uint16_t *row, uint32_t r0, const uint32_t (&v)[4]) {
                     *reinterpret_cast<uint2 *>(row + r0) = make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16));
                 };
-                // (NW waves: a round of each side by side; the one cell a round overwrites that the next one sources -- its last M[s-o-e] and
-                // I[s-e] -- goes from the last wave to the first through the scratch words, two slots in turn)
-                uint32_t rnd = 0u;
+                // NW waves: each takes a quarter (256 diagonals) of every round.  The rows are updated in place, and the only cells one wave reads that another
+                // overwrites are the two on either side of a quarter's edge: they are saved before the row, one barrier, and the waves run their quarters without
+                // waiting for one another (with a barrier per round the row took as long as the SUM of every round's slowest wave -- the exact-path quarters at its two ends)
+                uint32_t *const bnd = scr + 64;  // per quarter q: {M[s-o-e], I[s-e] at its first diagonal - 1; M[s-o-e], D[s-e] at its first diagonal}
+                if constexpr (NW > 1) {
+                    const int nq = (uhi - t_first) / 256 + 1;
+                    if (tid <= nq) {
+                        const int kf = t_first + 256 * tid;
+                        bnd[4 * tid + 0] = (hasO && kf - 1 <= uhi) ? Moe[RI(kf - 1)] : 0u, bnd[4 * tid + 1] = (hasE && kf - 1 <= uhi) ? rowI[RI(kf - 1)] : 0u;
+                        bnd[4 * tid + 2] = (hasO && kf <= uhi) ? Moe[RI(kf)] : 0u, bnd[4 * tid + 3] = (hasE && kf <= uhi) ? rowD[RI(kf)] : 0u;
+                    }
+                    lds_sync();
+                }
+                const auto wave_sync = [] {  // (the wave's own reads before its own writes)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                };
                 const int wr = wv;  // the quarter of a round this wave takes (rotating it with the score, so that the exact-path quarters at the row's two ends move from SIMD to SIMD, changed nothing: 159.5 against 158.3 ms)
                 for (int t0 = t_first; t0 <= uhi; t0 += 256 * NW) {
                     const int      k0  = t0 + 256 * wr + 4 * lane;
@@ -409,16 +424,16 @@ __global__ __launch_bounds__(64 * NW) WFA_WIDE_EU_ATTR void wfa_wide_kernel(cons
                         if (hasE) ld4(rowI, r0, oI), ld4(rowD, r0, oD), bL = rowI[r0 - 1u], dR = rowD[r0 + 4u];
                         if (hasX) ld4(Mx, r0, oX);
                     }
-                    if (lane == 0 && wr == 0) aL = carryM, bL = carryI;  // (what the previous round overwrote)
                     if constexpr (NW == 1) {
+                        if (lane == 0) aL = carryM, bL = carryI;  // (what the previous round overwrote)
                         carryM = rfl((uint32_t)__builtin_amdgcn_readlane((int)oM[3], 63));
                         carryI = rfl((uint32_t)__builtin_amdgcn_readlane((int)oI[3], 63));
-                    } else if (wr == NW - 1 && lane == 63) {
-                        scr[64u + 2u * (rnd & 1u)] = oM[3], scr[65u + 2u * (rnd & 1u)] = oI[3];
+                    } else {
+                        const int q = (t0 - t_first) / 256 + wr;
+                        if (lane == 0) aL = bnd[4 * q], bL = bnd[4 * q + 1];
+                        if (lane == 63) cR = bnd[4 * q + 6], dR = bnd[4 * q + 7];
                     }
-                    lds_sync();  // (every read of the round before its first write: the rows are updated in place)
-                    if constexpr (NW > 1) carryM = rfl(scr[64u + 2u * (rnd & 1u)]), carryI = rfl(scr[65u + 2u * (rnd & 1u)]);
-                    rnd++;
+                    wave_sync();  // (every read of the round before its first write: the rows are updated in place)
                     if (!ract) {
                         if (lin) *reinterpret_cast<uint2 *>(Mn + r0) = make_uint2(0u, 0u);
                         continue;
