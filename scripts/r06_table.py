@@ -16,7 +16,7 @@ def sig(v, n=3):
 BOUND = {  # what bounds the dominant kernel of a configuration (DESIGN.md sections 4-6, KERNELS.md)
     "c3": "vector-instruction issue (0.64e12 wave-instructions/s; DPP / select / compare work of WF_NEXT and the band)",
     "p242": "as c3 (a shallower ring, fewer scores)",
-    "g3": "first launch (wide rows, 148 ms): the slowest of a pair's four waves in every row; second launch (narrow tail, 77 ms): vector + scalar issue, a pair per wave",
+    "g3": "first launch (wide rows, 143 ms): the slowest of a pair's four waves in every row; second launch (narrow tail, 77 ms): vector + scalar issue, a pair per wave",
     "c4": "as c3, five chunks",
     "c2": "latency of a wave and a half per SIMD, each as long as the slowest of its 64 pairs",
     "c2m": "vector issue; lanes wait for the slowest pair of their generation",
